@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the CenterNet hot path (forward + gather_detection2d [+ RCCL all-gather]) on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
+`python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+  step      = one pass of the hot path over one synthetic batch per GPU:
+              CenterNet.forward (ResNet-34 -> neck -> heads, sigmoid) + gather_detection2d (k=100, nms 3)
+              [+ all-gather of the packed detections when N > 1].  Inputs are resident in HBM.
+  workload  = BASELINE.json configs[1] (C1): ResNet34 + simple upsample neck, batch 32 per GPU, 512x512, 80 classes
+              (`--config fpn --batch 64` = C2/C3, `--config tracking --batch 32 --height 608 --width 1088` = C4).
+  value     = total images / max-over-ranks wall time of the K timed steps (weak scaling: batch per GPU fixed).
+  roofline  = the dominant kernel (fp32 MFMA implicit-GEMM conv): algorithmic conv FLOPs of one step / the sum of
+              that kernel's launch durations in one step, measured with HIP events on the launch stream.
+  cpu_baseline = the CPU oracle (oracle/ref_cpu.py + oracle/decode_ref.py: the plain PyTorch restatement of the
+              reference path — kind "port") timed on this box's host cores on a bounded sample; rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "centernet-lightning_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import centernet_lightning_amd as cl  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
+
+
+def synthetic_weights_(model, seed=0):
+    """Random-init weights of the named architecture (no checkpoints offline).  Convs: Kaiming fan_out (reference
+    layers.py:77).  BN affine/stats randomised so folding is exercised; the residual-branch BN (bn2) gets a small gamma
+    so activations stay O(1) through 16 residual blocks without a calibration pass.  out_conv: N(0, 0.01^2), biases
+    keep init_bias (-2.19 / 10 / 0)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = model.state_dict()
+    for k, v in sd.items():
+        if k.endswith("running_var"):
+            base = k[: -len("running_var")]
+            lo, hi = (0.15, 0.35) if base.endswith("bn2.") else (0.7, 1.3)
+            sd[base + "weight"].copy_(torch.rand(v.shape, generator=g) * (hi - lo) + lo)
+            sd[base + "bias"].copy_(torch.randn(v.shape, generator=g) * 0.1)
+            sd[base + "running_mean"].copy_(torch.randn(v.shape, generator=g) * 0.1)
+            v.copy_(torch.rand(v.shape, generator=g) * 0.4 + 0.8)
+        elif k.endswith("out_conv.weight"):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.01)
+        elif v.dim() == 4:
+            fan_out = v.shape[0] * v.shape[2] * v.shape[3]
+            v.copy_(torch.randn(v.shape, generator=g) * (2.0 / fan_out) ** 0.5)
+    model.load_state_dict(sd)
+    return model
+
+
+def step(model, x, tracking, k):
+    out = model(x)
+    dets = model.gather_tracking2d(out, num_detections=k) if tracking else model.gather_detection2d(out, num_detections=k)
+    return model.collate(dets)
+
+
+def conv_kernel_profile(model, x, reps=3):
+    """HIP-event timing of every conv launch of one forward (events on torch's current stream == the launch
+    stream).  Returns (sum of conv durations per step [ms], conv flops per step, launches per step, per-layer rows)."""
+    import ctypes
+    eng = model._engine
+    model(x)                                            # make sure the plan exists
+    plan = eng.plans[(x.shape[0], x.shape[2], x.shape[3], True)]
+    lib = plan.lib
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    convs = [L for L in plan.launches if not isinstance(L.fn, str)]
+    acc = [0.0] * len(convs)
+    for _ in range(reps):
+        model(x)                                        # refresh inputs of every layer
+        torch.cuda.synchronize()
+        evs = []
+        for L in convs:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = L.fn(ctypes.byref(L.args), stream)
+            e1.record()
+            assert rc == 0, L.what
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        for i, (e0, e1) in enumerate(evs):
+            acc[i] += e0.elapsed_time(e1)
+    rows = [(L.what, L.flops, acc[i] / reps) for i, L in enumerate(convs)]
+    return sum(r[2] for r in rows), sum(r[1] for r in rows), len(rows), rows
+
+
+def cpu_baseline(model, tracking, k, H, W, budget_s=20.0):
+    """Oracle leg: CPU restatement of forward + decode on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import decode_ref
+    import ref_cpu
+    sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
+    n = 2
+    x = torch.rand(n, 3, H, W, generator=torch.Generator().manual_seed(1234))
+    cores = torch.get_num_threads()
+
+    def one():
+        o = ref_cpu.forward(sd, x, sigmoid=True)
+        d = decode_ref.decode_detections(o["heatmap"].numpy(), o["box_2d"].numpy(), k, 3,
+                                         reid=o["reid"].numpy() if tracking else None)
+        return o, d
+
+    t0 = time.perf_counter()
+    o, d = one()                                        # warm-up (also used as the checker below)
+    warm = time.perf_counter() - t0
+    iters, spent = 0, 0.0
+    while iters < 1 or (spent + warm < budget_s and iters < 5):
+        t0 = time.perf_counter()
+        one()
+        spent += time.perf_counter() - t0
+        iters += 1
+    # checker: the HIP path on the same sample
+    with torch.no_grad():
+        out = model(x.cuda())
+    err = float((out[0].cpu() - o["heatmap"]).abs().max())
+    return {"value": round(n * iters / spent, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} timed passes of oracle/ref_cpu.forward + decode_ref on {n}x3x{H}x{W} (same weights), "
+                      f"torch {torch.__version__} CPU fp32, {cores} threads; max |heatmap_gpu - heatmap_cpu| = {err:.2e}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="simple")
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="also print the per-layer conv table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))     # RCCL over xGMI
+
+    tracking = args.config == "tracking"
+    torch.manual_seed(0)
+    model = synthetic_weights_(cl.build_centernet(os.path.join(ROOT, "centernet-lightning_amd", "configs", CONFIGS[args.config]))).cuda()
+    B, H, W = args.batch, args.height, args.width
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1234 + rank)).cuda()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step(model, x, tracking, args.k)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(model, x, tracking, args.k)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        with torch.no_grad():
+            conv_ms, conv_flops, n_launch, rows = conv_kernel_profile(model, x)
+            # decode-only latency (p50) on the forward's own outputs
+            out = model(x)
+            lat = []
+            for _ in range(30):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                (model.gather_tracking2d if tracking else model.gather_detection2d)(out, num_detections=args.k)
+                e1.record()
+                torch.cuda.synchronize()
+                lat.append(e0.elapsed_time(e1))
+            lat.sort()
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        ms_per_step = elapsed / args.steps * 1e3
+        result = {
+            "metric": "images/sec @512x512 ResNet34 CenterNet forward + gather_detection2d",
+            "value": round(world * B * args.steps / elapsed, 2),
+            "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (seeded rand images; random-init weights of the named architecture)",
+            "config": {"workload": f"BASELINE C{'1' if args.config == 'simple' else ('4' if tracking else '2/3')}: ResNet34 + {args.config} neck, "
+                                   f"{B} img/GPU x {H}x{W}, heads {'2+4+reid64' if tracking else '80+4'} (w256), k={args.k}, nms 3",
+                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of detections" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "cnl_conv::conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
+                         "launches_per_step": n_launch, "kernel_ms_per_step": round(conv_ms, 3),
+                         "algorithmic_gflop_per_step": round(conv_flops / 1e9, 2),
+                         "avg_launch_us": round(conv_ms * 1e3 / n_launch, 2)},
+            "decode_p50_ms": round(lat[len(lat) // 2], 4),
+        }
+        if args.layers:
+            for what, fl, ms in rows:
+                print(f"{what:44s} {fl / 1e9:10.2f} GFLOP {ms * 1e3:10.1f} us {fl / (ms * 1e-3) / 1e12 if ms else 0:8.1f} TF", file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(model, tracking, args.k, H, W)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+"""ctypes binding of libcenternet_gfx950.so (C ABI: include/centernet_gfx950.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, the product path
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p)
+
+_LIB_NAME = "libcenternet_gfx950.so"
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
+
+CNL_RELU = 1 << 0
+CNL_SIGMOID = 1 << 1
+CNL_UPSAMPLE_IN = 1 << 2
+CNL_UPSAMPLE_OUT_ADD = 1 << 3
+
+CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4
+
+
+class ConvParams(Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("y", c_void_p),
+                ("N", c_int32), ("H_in", c_int32), ("W_in", c_int32), ("Cin", c_int32), ("Cout", c_int32),
+                ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
+                ("ldx", c_int32), ("ldy", c_int32), ("ldr", c_int32), ("flags", c_uint32)]
+
+
+class DecodeParams(Structure):
+    _fields_ = [("heat", c_void_p), ("heat_sn", c_int64), ("heat_sc", c_int64), ("heat_sh", c_int64), ("heat_sw", c_int64),
+                ("box", c_void_p), ("box_sn", c_int64), ("box_sc", c_int64), ("box_sh", c_int64), ("box_sw", c_int64),
+                ("reid", c_void_p), ("reid_sn", c_int64), ("reid_sc", c_int64), ("reid_sh", c_int64), ("reid_sw", c_int64),
+                ("N", c_int32), ("C", c_int32), ("H", c_int32), ("W", c_int32), ("E", c_int32),
+                ("k", c_int32), ("nms_kernel", c_int32), ("normalize_boxes", c_int32), ("box_log", c_int32),
+                ("box_multiplier", c_float), ("stride", c_float),
+                ("scores", c_void_p), ("indices", c_void_p), ("labels", c_void_p), ("boxes", c_void_p), ("emb", c_void_p),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
+_SIGNATURES = {
+    "cnl_version": (ctypes.c_int, []),
+    "cnl_last_error": (c_size_t, [c_char_p, c_size_t]),
+    "cnl_conv2d_nhwc_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
+    "cnl_conv2d_out_hw": (ctypes.c_int, [POINTER(ConvParams), POINTER(c_int32), POINTER(c_int32)]),
+    "cnl_stem_conv7x7_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                            c_int32, c_int32, c_int32, c_void_p]),
+    "cnl_maxpool3x3s2_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "cnl_decode_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "cnl_decode_f32": (ctypes.c_int, [POINTER(DecodeParams), c_void_p]),
+    "cnl_gather_boxes_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                            c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
+    "cnl_gather_embeddings_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                                 c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "cnl_pack_detections_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "cnl_unpack_detections_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.environ.get("CENTERNET_GFX950_LIB", _LIB_PATH)
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises HipLibraryError when the .so is missing —
+    build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C csrc`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise HipLibraryError(f"{_LIB_NAME} not found at {path}; the HIP extension is required (no CPU fallback). "
+                              "Build it with __graft_entry__.build().")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:
+        raise HipLibraryError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    load().cnl_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc, what=""):
+    """Map the C ABI's error convention onto Python exceptions (reference: bare asserts / exceptions)."""
+    if rc == 0:
+        return
+    msg = f"{what}: {last_error()}" if what else last_error()
+    if rc in (CNL_E_BAD_ARG, CNL_E_UNSUPPORTED):
+        raise ValueError(msg)
+    raise RuntimeError(msg)

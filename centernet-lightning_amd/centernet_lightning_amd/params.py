@@ -1,0 +1,162 @@
+"""Parameter containers for the CenterNet hot path: ResNet-34 backbone, simple / FPN neck, GenericHead.
+
+These nn.Modules only HOLD parameters (so `state_dict()` / `load_state_dict()` / `.to()` behave like the
+reference's modules and torchvision ResNet checkpoints load by key name); they are never *called* — the
+forward pass is the HIP launch plan in engine.py.
+
+Structure restated from (the Gen-A sources are missing from the reference tree):
+  backbone  public torchvision ResNet-34 topology — conv1 7x7/2, bn1, maxpool 3x3/2, BasicBlock x [3,4,6,3],
+            channels 64/128/256/512, 1x1/2 downsample — feature contract tests/test_backbones.py:60-70
+  neck      models/layers.py:40-101 (make_conv, make_upsample), :138-177 (Fuse); contract tests/test_necks.py:23-56
+  heads     models/meta.py:21-30 (GenericHead), models/fairmot.py:20 (reid defaults)
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+RESNET_LAYERS = {"resnet18": [2, 2, 2, 2], "resnet34": [3, 4, 6, 3]}
+BACKBONE_CHANNELS = [64, 64, 128, 256, 512]          # strides 2, 4, 8, 16, 32 (tests/test_necks.py:7-8)
+
+
+class ConvBn(nn.Module):
+    """conv (no bias) + BatchNorm2d (+ ReLU at run time): make_conv "normal" (layers.py:72-77) / ConvBnAct."""
+
+    def __init__(self, cin, cout, k=3, stride=1, names=("conv", "bn")):
+        super().__init__()
+        self._names = names
+        self.k, self.stride = k, stride
+        self.add_module(names[0], nn.Conv2d(cin, cout, k, stride=stride, padding=(k - 1) // 2, bias=False))
+        self.add_module(names[1], nn.BatchNorm2d(cout))
+        nn.init.kaiming_normal_(self.conv_module.weight, mode="fan_out", nonlinearity="relu")   # layers.py:77
+
+    @property
+    def conv_module(self):
+        return getattr(self, self._names[0])
+
+    @property
+    def bn_module(self):
+        return getattr(self, self._names[1])
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.stride = stride
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
+        for m in (self.conv1, self.conv2) + ((self.downsample[0],) if self.downsample is not None else ()):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+
+class ResNetBackbone(nn.Module):
+    """Parameter layout of torchvision `resnet34` (keys conv1, bn1, layer{1..4}.{i}.conv{1,2}, bn{1,2}, downsample.{0,1})."""
+
+    def __init__(self, name="resnet34", pretrained=False, frozen_stages=0, **ignored):
+        super().__init__()
+        if name not in RESNET_LAYERS:
+            raise ValueError(f"backbone '{name}' is outside the MI355X hot-path scope (supported: {sorted(RESNET_LAYERS)})")
+        self.name = name
+        self.out_channels = list(BACKBONE_CHANNELS)
+        self.output_stride = 32
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        nn.init.kaiming_normal_(self.conv1.weight, mode="fan_out", nonlinearity="relu")
+        cin = 64
+        for li, (n_blocks, cout) in enumerate(zip(RESNET_LAYERS[name], [64, 128, 256, 512])):
+            blocks = []
+            for b in range(n_blocks):
+                blocks.append(BasicBlock(cin, cout, stride=2 if (b == 0 and li > 0) else 1))
+                cin = cout
+            setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
+        # `pretrained: True` (configs/base_resnet34.yaml:5) cannot be honoured offline; weights arrive through
+        # load_state_dict().  Recorded so callers can see the request.
+        self.pretrained_requested = bool(pretrained)
+
+
+class SimpleNeck(nn.Module):
+    """3 x [conv3x3+BN+ReLU -> x2 nearest upsample] on the last backbone feature (docs/implementation.md:40-48;
+    tests/test_necks.py:23-39)."""
+
+    def __init__(self, backbone_channels, upsample_channels=(256, 128, 64), upsample_type="nearest", conv_type="normal", **ignored):
+        super().__init__()
+        _check_neck_options(upsample_type, conv_type, False)
+        self.out_channels = upsample_channels[-1]
+        self.upsample_stride = 2 ** len(upsample_channels)
+        layers = []
+        cin = backbone_channels[-1]
+        for c in upsample_channels:
+            layers.append(ConvBn(cin, c, 3, names=("0", "1")))
+            cin = c
+        self.layers = nn.Sequential(*layers)
+
+
+class FuseParams(nn.Module):
+    """Parameters of layers.py:138-177 `Fuse(in_channels=[skip_c, top_c], out, resize="up")`: optional 1x1
+    projections WITH bias where channels differ (:152) and the 3x3 output conv+BN (:158)."""
+
+    def __init__(self, skip_c, top_c, out):
+        super().__init__()
+        self.project = nn.ModuleList([nn.Conv2d(skip_c, out, 1) if skip_c != out else nn.Identity(),
+                                      nn.Conv2d(top_c, out, 1) if top_c != out else nn.Identity()])
+        self.output_conv = ConvBn(out, out, 3, names=("0", "1"))
+
+
+class FPNNeck(nn.Module):
+    """top = 1x1(c5 -> up[0]); level i: Fuse([skip_{/16,/8,/4}, top] -> up[i]) (SURVEY.md §8c decision (i);
+    docs/implementation.md:49-52; tests/test_necks.py:41-56)."""
+
+    def __init__(self, backbone_channels, upsample_channels=(256, 128, 64), upsample_type="nearest", conv_type="normal",
+                 weighted_fusion=False, **ignored):
+        super().__init__()
+        _check_neck_options(upsample_type, conv_type, weighted_fusion)
+        if len(upsample_channels) > len(backbone_channels) - 1:
+            raise ValueError("FPN neck needs one backbone skip feature per upsample stage")
+        self.out_channels = upsample_channels[-1]
+        self.upsample_stride = 2 ** len(upsample_channels)
+        self.top_conv = nn.Conv2d(backbone_channels[-1], upsample_channels[0], 1)
+        fuse = []
+        top_c = upsample_channels[0]
+        for i, c in enumerate(upsample_channels):
+            skip_c = backbone_channels[-2 - i]
+            fuse.append(FuseParams(skip_c, top_c, c))
+            top_c = c
+        self.fuse = nn.ModuleList(fuse)
+
+
+def _check_neck_options(upsample_type, conv_type, weighted_fusion):
+    if upsample_type != "nearest" or conv_type != "normal" or weighted_fusion:
+        raise ValueError("only upsample_type='nearest', conv_type='normal', weighted_fusion=False are on the MI355X hot path "
+                         f"(got {upsample_type!r}, {conv_type!r}, {weighted_fusion!r}); see DESIGN.md 'out of scope'")
+
+
+class GenericHead(nn.Module):
+    """models/meta.py:21-30: depth x (3x3 conv + BN + ReLU, `width` channels) then a 1x1 conv with bias, the bias
+    filled with init_bias."""
+
+    def __init__(self, in_channels, out_channels, width=256, depth=3, init_bias=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.width, self.depth = in_channels, out_channels, width, depth
+        for i in range(depth):
+            self.add_module(f"block_{i + 1}", ConvBn(in_channels if i == 0 else width, width, 3))
+        self.out_conv = nn.Conv2d(width if depth > 0 else in_channels, out_channels, 1)
+        if init_bias is not None:
+            self.out_conv.bias.data.fill_(init_bias)
+
+    def blocks(self):
+        return [getattr(self, f"block_{i + 1}") for i in range(self.depth)]
+
+
+def build_neck(cfg, backbone_channels):
+    cfg = dict(cfg)
+    name = cfg.pop("name")
+    if name == "simple":
+        return SimpleNeck(backbone_channels, **cfg)
+    if name == "fpn":
+        return FPNNeck(backbone_channels, **cfg)
+    raise ValueError(f"neck '{name}' is outside the MI355X hot-path scope (supported: simple, fpn)")

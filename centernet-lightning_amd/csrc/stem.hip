@@ -1,0 +1,178 @@
+// stem.hip — ResNet stem for gfx950: Conv2d(3,64,7,s2,p3)+BN(folded)+ReLU on the matrix cores, and
+// MaxPool2d(3,s2,p1) on NHWC.
+//
+// Replaces torchvision resnet.conv1/bn1/relu/maxpool reached through backbone.forward_features
+// (reference models/meta.py:42; contract tests/test_backbones.py:60-70: stride-2 feature with 64 ch).
+//
+// conv: implicit GEMM with K = 7*7*3 = 147 (padded to 148 with a zero weight row).  Cin = 3 makes a
+// global-memory im2col hopeless (12-byte pixels), so the im2col happens on the LDS side: a workgroup
+// stages the (2*8+5) x (2*32+5) x 3 input patch of its 8x32 output tile and the whole 148x64 weight
+// matrix in LDS; each MFMA A operand is a per-lane ds_read_b32 at  row(ky) * RS + 6*px + (k % 21)
+// (kx and c are contiguous in the patch row, so k % 21 is a plain offset).  Each wave computes two
+// output rows (2 x 32 pixels) x 64 channels = four 32x32 accumulators with v_mfma_f32_32x32x2_f32.
+// The input is read through explicit element strides, so NCHW and channels_last callers are zero-copy.
+#include "cnl_common.h"
+
+namespace cnl_stem {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ST_TH = 8, ST_TW = 32;                  // output tile
+constexpr int ST_PR = 2 * ST_TH + 5 + 1;              // patch rows (+1 zero row for the k=147 pad tap)
+constexpr int ST_PC = 2 * ST_TW + 5;                  // patch cols
+constexpr int ST_RS = ST_PC * 3 + 1;                  // patch row stride in floats (208)
+constexpr int ST_KP = 148;                            // padded K
+constexpr int ST_LDS_FLOATS = ST_PR * ST_RS + ST_KP * 64;
+
+__global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restrict__ x, long sn, long sc, long sh, long sw,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ y, int N, int H, int W, int Ho, int Wo,
+                                                           int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* patch = reinterpret_cast<float*>(smem);
+    float* wl = patch + ST_PR * ST_RS;                // [148][64], k-major
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5, px = lane & 31;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+
+    // weights: global OHWI [64][147] -> LDS [k][co]; row 147 = 0
+    for (int e = tid; e < ST_KP * 64; e += 256) {
+        const int k = e >> 6, co = e & 63;
+        wl[e] = k < 147 ? w[co * 147 + k] : 0.f;
+    }
+    // input patch -> LDS [row][col*3 + c]; channel-minor or plane-major traversal for coalescing
+    const float* xn = x + (long)n * sn;
+    if (sc == 1) {
+        for (int e = tid; e < ST_PR * ST_PC * 3; e += 256) {
+            const int r = e / (ST_PC * 3), cc = e - r * (ST_PC * 3);
+            const int col = cc / 3, c = cc - col * 3;
+            const int iy = iy0 + r, ix = ix0 + col;
+            float v = 0.f;
+            if (r < ST_PR - 1 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xn[iy * sh + ix * sw + c];
+            patch[r * ST_RS + cc] = v;
+        }
+    } else {
+        for (int e = tid; e < 3 * ST_PR * ST_PC; e += 256) {
+            const int c = e / (ST_PR * ST_PC), rem = e - c * (ST_PR * ST_PC);
+            const int r = rem / ST_PC, col = rem - r * ST_PC;
+            const int iy = iy0 + r, ix = ix0 + col;
+            float v = 0.f;
+            if (r < ST_PR - 1 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xn[c * sc + iy * sh + ix * sw];
+            patch[r * ST_RS + col * 3 + c] = v;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // lane's A base: output row (wave*2 + i), column px -> patch row 2*(wave*2+i) + ky, col 2*px + kx
+    const float* pa = patch + (wave * 4) * ST_RS + px * 6;       // i adds 2*ST_RS
+    const float* pb = wl + hi * 64 + px;                         // k = 2s + hi
+    int kr = hi, rowoff = 0;                                     // k % 21 and (k / 21) * RS
+    for (int s = 0; s < ST_KP / 2; ++s) {
+        const float a0 = pa[rowoff + kr];
+        const float a1 = pa[rowoff + kr + 2 * ST_RS];
+        const float b0 = pb[s * 128];
+        const float b1 = pb[s * 128 + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        kr += 2;
+        if (kr >= 21) { kr -= 21; rowoff += ST_RS; }
+    }
+
+    // epilogue: bias + ReLU, NHWC store (col = lane&31 -> channel, rows -> pixels of the row)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = j * 32 + px;
+        const float bv = bias[co];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = oy0 + wave * 2 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (oy < Ho && ox < Wo) {
+                    const float v = fmaxf(acc[i][j][r] + bv, 0.f);
+                    y[(((size_t)n * Ho + oy) * Wo + ox) * 64 + co] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int N, int H, int W,
+                                                      int C4, int Ho, int Wo, long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C4);
+        long p = e / C4;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const float ninf = -__builtin_inff();
+        f32x4 m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = x[(((long)n * H + iy) * W + ix) * C4 + c];
+                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+            }
+        }
+        y[e] = m;
+    }
+}
+
+}  // namespace cnl_stem
+using namespace cnl_stem;
+
+extern "C" int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
+                                    const float* bias, float* y, int32_t N, int32_t H, int32_t W, void* stream) {
+    CNL_REQUIRE(x && w && bias && y, CNL_E_BAD_ARG, "cnl_stem_conv7x7_f32: null tensor pointer");
+    CNL_REQUIRE(N > 0 && H > 0 && W > 0, CNL_E_BAD_ARG, "cnl_stem_conv7x7_f32: non-positive dimension");
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    const int tiles_x = (Wo + ST_TW - 1) / ST_TW, tiles_y = (Ho + ST_TH - 1) / ST_TH;
+    const long long blocks = (long long)N * tiles_x * tiles_y;
+    CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_stem_conv7x7_f32: grid too large");
+    static bool attr_done = false;
+    const int lds = ST_LDS_FLOATS * 4;
+    if (!attr_done) {
+        CNL_HIP(hipFuncSetAttribute((const void*)stem_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, (long)sn, (long)sc,
+                       (long)sh, (long)sw, w, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y);
+    return cnl::check_launch("stem_conv_kernel");
+}
+
+extern "C" int cnl_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    CNL_REQUIRE(x && y, CNL_E_BAD_ARG, "cnl_maxpool3x3s2_nhwc_f32: null tensor pointer");
+    CNL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, CNL_E_BAD_ARG, "cnl_maxpool3x3s2_nhwc_f32: non-positive dimension");
+    CNL_REQUIRE(C % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, CNL_E_UNSUPPORTED,
+                "cnl_maxpool3x3s2_nhwc_f32: C %% 4 != 0 or unaligned pointers");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)N * Ho * Wo * (C / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, (f32x4*)y, N, H,
+                       W, C / 4, Ho, Wo, total);
+    return cnl::check_launch("maxpool_kernel");
+}

@@ -1,0 +1,149 @@
+/*
+ * centernet_gfx950.h — C ABI of libcenternet_gfx950.so
+ *
+ * MI355X-native (gfx950 / CDNA4) replacement for the CenterNet inference hot path of
+ * gau-nernst/centernet-lightning.  The reference is pure Python dispatching to ATen/cuDNN ops; every
+ * entry point below replaces the ATen call sites listed beside it (paths relative to the reference
+ * root).  The reference-side binding is a ctypes stub.
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers (HBM); all tensors are fp32 unless stated;
+ *   - activations are NHWC ("channels_last"): element (n,y,x,c) lives at ((n*H+y)*W+x)*ld + c where
+ *     ld >= C is the pixel stride in elements (lets several heads share one buffer);
+ *   - conv weights are OHWI: w[co][ky][kx][ci], K = KH*KW*Cin contiguous per output channel, with the
+ *     eval-mode BatchNorm already folded in (scale into w, shift into bias);
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (void* to keep HIP headers out
+ *     of the binding), allocates nothing, and is re-entrant;
+ *   - return value: 0 = CNL_OK, negative = CNL_E_*; cnl_last_error() returns the message of the last
+ *     failure on the calling thread.  No C++ exception crosses this boundary.
+ */
+#ifndef CENTERNET_GFX950_H
+#define CENTERNET_GFX950_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNL_ABI_VERSION 1
+
+enum {
+    CNL_OK = 0,
+    CNL_E_BAD_ARG = -1,      /* null pointer, non-positive dimension, inconsistent shapes            */
+    CNL_E_UNSUPPORTED = -2,  /* shape outside what the gfx950 kernels cover (e.g. Cin % 32 != 0)     */
+    CNL_E_WORKSPACE = -3,    /* workspace pointer null / too small (see cnl_decode_workspace_bytes)  */
+    CNL_E_HIP = -4           /* a HIP runtime call failed; text in cnl_last_error()                  */
+};
+
+/* epilogue / gather flags of cnl_conv2d_nhwc_f32 */
+enum {
+    CNL_RELU = 1u << 0,          /* y = max(y, 0)                      nn.ReLU      (layers.py:75)        */
+    CNL_SIGMOID = 1u << 1,       /* y = 1/(1+exp(-y))                  .sigmoid()   (centernet.py:205)    */
+    CNL_UPSAMPLE_IN = 1u << 2,   /* read x through nn.Upsample(scale_factor=2, mode="nearest")
+                                    (layers.py:99): logical input is (2*H_in, 2*W_in)                   */
+    CNL_UPSAMPLE_OUT_ADD = 1u << 3 /* write y at 2x resolution and add `residual` there:
+                                    y[n,2oy+dy,2ox+dx,:] = conv(x)[n,oy,ox,:] + bias + residual[...]
+                                    = Fuse.forward's project -> resize("up") -> sum (layers.py:160-174) */
+};
+
+/*
+ * One fused convolution layer: Conv2d (+ folded BatchNorm2d) (+ residual add) (+ ReLU | sigmoid).
+ * Replaces, per call site:
+ *   - ResNet BasicBlock conv3x3/BN/ReLU and the 1x1 stride-2 downsample (torchvision, reached through
+ *     backbone.forward_features, models/meta.py:42);
+ *   - make_conv(..., conv_type="normal")            models/layers.py:72-77
+ *   - Fuse.project 1x1 conv with bias               models/layers.py:152
+ *   - GenericHead block_i (ConvBnAct) and out_conv  models/meta.py:24-30
+ * Implementation: fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM, M = N*Ho*Wo, N = Cout,
+ * K = KH*KW*Cin, LDS-staged via buffer_load ... lds.
+ */
+typedef struct cnl_conv_params {
+    const float* x;         /* input  [N, H_in, W_in, ldx]                                           */
+    const float* w;         /* weight [Cout, KH, KW, Cin]                                            */
+    const float* bias;      /* [Cout] (never null; zeros when the layer has none)                    */
+    const float* residual;  /* null, or same geometry as y with pixel stride ldr                      */
+    float* y;               /* output [N, H_out, W_out, ldy]                                         */
+    int32_t N, H_in, W_in, Cin, Cout;
+    int32_t KH, KW, stride, pad;
+    int32_t ldx, ldy, ldr;  /* pixel strides in elements                                             */
+    uint32_t flags;         /* CNL_RELU | CNL_SIGMOID | CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD        */
+} cnl_conv_params;
+
+int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream);
+
+/* Output spatial size of the conv itself (before CNL_UPSAMPLE_OUT_ADD doubles it). */
+int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);
+
+/*
+ * ResNet stem: Conv2d(3,64,7,stride=2,padding=3,bias=False)+BN+ReLU (torchvision resnet.conv1/bn1/relu).
+ * x is read through explicit element strides (sn,sc,sh,sw) so NCHW-contiguous and channels_last
+ * callers are both zero-copy (models/meta.py:97-98 precedent); y is NHWC [N, H/2, W/2, 64].
+ * w: [64][7][7][3] (OHWI, BN folded), bias: [64].
+ */
+int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                         const float* w, const float* bias, float* y,
+                         int32_t N, int32_t H, int32_t W, void* stream);
+
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC (torchvision resnet.maxpool). C % 4 == 0. */
+int cnl_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C,
+                              void* stream);
+
+/*
+ * Fused decode = CenterNet.decode_detections (models/centernet.py:229-304)
+ *              + EmbeddingHead.gather_at_indices (models/fairmot.py:63-73) when reid != null:
+ *   3x3 (nms_kernel) max-pool pseudo-NMS with equality mask, per-pixel max/argmax over classes,
+ *   per-image sorted top-k (ties: score desc, flat index asc), label / ltrb-box / embedding gather,
+ *   box decode to x1y1x2y2.
+ * heat/box/reid element (n,c,y,x) at n*s_n + c*s_c + y*s_h + x*s_w (elements): any NCHW or NHWC view.
+ * Outputs: scores [N,k] f32, indices [N,k] i64 (flat y*W+x), labels [N,k] i64, boxes [N,k,4] f32,
+ * emb [N,k,E] f32 (may be null when reid is null).
+ */
+typedef struct cnl_decode_params {
+    const float* heat; int64_t heat_sn, heat_sc, heat_sh, heat_sw;
+    const float* box;  int64_t box_sn, box_sc, box_sh, box_sw;
+    const float* reid; int64_t reid_sn, reid_sc, reid_sh, reid_sw;   /* reid may be null */
+    int32_t N, C, H, W, E;
+    int32_t k;               /* num_detections, 1 <= k <= min(1024, H*W)                              */
+    int32_t nms_kernel;      /* odd, 1..7 (reference default 3, centernet.py:93)                      */
+    int32_t normalize_boxes; /* !=0: divide by (W,H) (centernet.py:299-301) else multiply by stride    */
+    int32_t box_log;         /* !=0: exp() the offsets first (centernet.py:283-284)                   */
+    float box_multiplier;    /* centernet.py:285                                                      */
+    float stride;            /* output stride (centernet.py:303), e.g. 4                              */
+    float* scores; int64_t* indices; int64_t* labels; float* boxes; float* emb;
+    void* workspace; size_t workspace_bytes;
+} cnl_decode_params;
+
+size_t cnl_decode_workspace_bytes(int32_t N, int32_t H, int32_t W);
+int cnl_decode_f32(const cnl_decode_params* p, void* stream);
+
+/*
+ * Standalone gathers at caller-supplied flat indices [N,k] (i64), for the Gen-A per-head calls
+ * heads["box_2d"].gather_at_indices / EmbeddingHead.gather_at_indices (models/fairmot.py:141-143, 63-73;
+ * arithmetic of CenterNet.gather_and_decode_boxes, models/centernet.py:263-304).  Strides in elements.
+ */
+int cnl_gather_boxes_f32(const float* box, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const int64_t* indices,
+                         float* boxes, int32_t N, int32_t H, int32_t W, int32_t k, int32_t normalize_boxes,
+                         int32_t box_log, float box_multiplier, float stride, void* stream);
+int cnl_gather_embeddings_f32(const float* reid, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                              const int64_t* indices, float* emb, int32_t N, int32_t E, int32_t H, int32_t W,
+                              int32_t k, void* stream);
+
+/*
+ * All-gather record (replaces the pickled all_gather_object of eval/coco.py:10-18):
+ * rec[n][j][0:4] = box, [4] = score, [5] = bit pattern of (int32)label, [6:6+E] = embedding.
+ */
+int cnl_pack_detections_f32(const float* boxes, const float* scores, const int64_t* labels, const float* emb,
+                            float* rec, int32_t N, int32_t k, int32_t E, void* stream);
+int cnl_unpack_detections_f32(const float* rec, float* boxes, float* scores, int64_t* labels, float* emb,
+                              int32_t N, int32_t k, int32_t E, void* stream);
+
+int cnl_version(void);
+/* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
+size_t cnl_last_error(char* buf, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CENTERNET_GFX950_H */

@@ -1,0 +1,138 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY. Never imported by the product package.
+
+CPU (numpy) restatement of the reference's detection decode:
+
+  * get_topk_from_heatmap   <- centernet_lightning/models/centernet.py:243-261
+  * gather_and_decode_boxes <- centernet_lightning/models/centernet.py:263-304
+  * decode_detections       <- centernet_lightning/models/centernet.py:229-241
+  * gather_at_indices       <- centernet_lightning/models/fairmot.py:63-73
+  * gather_tracking2d       <- centernet_lightning/models/fairmot.py:138-151
+  * pack / unpack of the all-gather record (the build's own wire format; the reference uses
+    pickled objects, eval/coco.py:10-18)
+
+Parity status: PINNED.  tests/golden/decode_*.npz hold outputs produced by the reference's own code
+(imported in the build container by oracle/make_golden.py); tests/test_oracle_golden.py checks this
+restatement against them bit-for-bit, and — when /root/reference is present — against the live
+reference on fresh random inputs.
+
+Tie rule.  torch.topk leaves the order of equal scores unspecified (SURVEY.md §7 "hard parts").
+This oracle (and the HIP kernel) define the canonical order **(score descending, flat index
+ascending)**; `canonicalize()` re-orders any reference output into that order so that tie groups
+(e.g. the all-zero tail when an image has fewer than k peaks) compare equal.
+"""
+import numpy as np
+
+
+def pseudo_nms(heat: np.ndarray, nms_kernel: int = 3) -> np.ndarray:
+    """heat * (max_pool2d(heat, k, stride=1, pad=(k-1)//2) == heat); -inf padding, plateaus survive.
+    centernet.py:249-253.  heat: (N, C, H, W) float32."""
+    assert nms_kernel % 2 == 1, "reference breaks (shape mismatch) for even kernels"
+    heat = np.asarray(heat, dtype=np.float32)
+    p = (nms_kernel - 1) // 2
+    H, W = heat.shape[-2:]
+    padded = np.pad(heat, ((0, 0), (0, 0), (p, p), (p, p)), constant_values=-np.inf)
+    m = np.full_like(heat, -np.inf)
+    for dy in range(nms_kernel):
+        for dx in range(nms_kernel):
+            m = np.maximum(m, padded[..., dy:dy + H, dx:dx + W])
+    mask = (m == heat)
+    return heat * mask.astype(np.float32)
+
+
+def get_topk_from_heatmap(heat: np.ndarray, num_detections: int = 100, nms_kernel: int = 3,
+                          pseudo: bool = True):
+    """centernet.py:243-261.  Returns scores (N,k) f32, indices (N,k) i64, labels (N,k) i64 in the
+    canonical tie order."""
+    heat = np.asarray(heat, dtype=np.float32)
+    N = heat.shape[0]
+    h = pseudo_nms(heat, nms_kernel) if pseudo else heat
+    score = h.max(axis=1).reshape(N, -1)                 # torch.max(dim=1): values
+    label = h.argmax(axis=1).reshape(N, -1)              # first maximal class (centernet.py:254)
+    order = np.argsort(-score, axis=1, kind="stable")[:, :num_detections]   # (score desc, idx asc)
+    scores = np.take_along_axis(score, order, axis=1)
+    labels = np.take_along_axis(label, order, axis=1).astype(np.int64)
+    return scores, order.astype(np.int64), labels
+
+
+def gather_and_decode_boxes(box_offsets: np.ndarray, indices: np.ndarray, normalize_boxes: bool = False,
+                            box_log: bool = False, box_multiplier: float = 1.0, stride: int = 4):
+    """centernet.py:263-304.  box_offsets (N,4,H,W) ltrb in feature-map units -> (N,k,4) x1y1x2y2.
+    All arithmetic in float32, one rounding per op (no fma contraction), like ATen."""
+    box = np.asarray(box_offsets, dtype=np.float32)
+    N, _, H, W = box.shape
+    idx = np.asarray(indices, dtype=np.int64)
+    cx = (idx % W).astype(np.float32) + np.float32(0.5)             # :278
+    cy = (idx // W).astype(np.float32) + np.float32(0.5)            # :279
+    flat = box.reshape(N, 4, H * W)
+    g = np.stack([np.take_along_axis(flat[:, j], idx, axis=1) for j in range(4)], axis=-1)   # (N,k,4)
+    if box_log:
+        g = np.exp(g).astype(np.float32)                            # :283-284
+    g = (g * np.float32(box_multiplier)).astype(np.float32)         # :285
+    g = np.maximum(g, np.float32(0))                                # :286 clamp_min(0)
+    x1 = cx - g[..., 0]
+    y1 = cy - g[..., 1]
+    x2 = cx + g[..., 2]
+    y2 = cy + g[..., 3]
+    boxes = np.stack([x1, y1, x2, y2], axis=-1).astype(np.float32)
+    if normalize_boxes:
+        boxes[..., [0, 2]] /= np.float32(W)                         # :299-301
+        boxes[..., [1, 3]] /= np.float32(H)
+    else:
+        boxes *= np.float32(stride)                                 # :303
+    return boxes
+
+
+def gather_at_indices(reid: np.ndarray, indices: np.ndarray):
+    """fairmot.py:63-73.  reid (N,E,H,W), indices (N,k) -> (N,k,E)."""
+    reid = np.asarray(reid, dtype=np.float32)
+    N, E = reid.shape[:2]
+    flat = reid.reshape(N, E, -1)
+    idx = np.broadcast_to(np.asarray(indices)[:, None, :], (N, E, indices.shape[1]))
+    return np.take_along_axis(flat, idx, axis=2).swapaxes(1, 2).copy()
+
+
+def decode_detections(heat, box_offsets, num_detections=100, nms_kernel=3, normalize_boxes=False,
+                      box_log=False, box_multiplier=1.0, stride=4, reid=None):
+    """centernet.py:229-241 (+ fairmot.py:138-151 when `reid` is given)."""
+    scores, indices, labels = get_topk_from_heatmap(heat, num_detections, nms_kernel)
+    boxes = gather_and_decode_boxes(box_offsets, indices, normalize_boxes, box_log, box_multiplier, stride)
+    out = {"boxes": boxes, "scores": scores, "labels": labels, "indices": indices}
+    if reid is not None:
+        out["embeddings"] = gather_at_indices(reid, indices)
+    return out
+
+
+def canonicalize(scores, indices, *others):
+    """Re-order each image's detections into (score desc, index asc).  Only permutes inside groups of
+    equal score, so it is the identity on tie-free outputs."""
+    scores = np.asarray(scores)
+    indices = np.asarray(indices)
+    order = np.lexsort((indices, -scores.astype(np.float64)), axis=1)
+    take = lambda a: np.take_along_axis(a, order.reshape(order.shape + (1,) * (a.ndim - 2)), axis=1)
+    return (take(scores), take(indices)) + tuple(take(np.asarray(o)) for o in others)
+
+
+# ----------------------------------------------------------------------------------------------
+# all-gather record: one float32 row per detection  [x1, y1, x2, y2, score, label(bits), emb...]
+# ----------------------------------------------------------------------------------------------
+def pack_detections(boxes, scores, labels, embeddings=None):
+    """(N,k,4) f32, (N,k) f32, (N,k) i64 [, (N,k,E) f32] -> (N,k,6[+E]) f32.  The label travels as the
+    bit pattern of its low 32 bits (int32), not as a converted float, so it round-trips exactly."""
+    N, k = scores.shape
+    E = 0 if embeddings is None else embeddings.shape[-1]
+    rec = np.empty((N, k, 6 + E), dtype=np.float32)
+    rec[..., 0:4] = boxes
+    rec[..., 4] = scores
+    rec[..., 5] = labels.astype(np.int32).view(np.float32)
+    if E:
+        rec[..., 6:] = embeddings
+    return rec
+
+
+def unpack_detections(rec):
+    rec = np.ascontiguousarray(rec, dtype=np.float32)
+    out = {"boxes": rec[..., 0:4].copy(), "scores": rec[..., 4].copy(),
+           "labels": rec[..., 5].copy().view(np.int32).astype(np.int64)}
+    if rec.shape[-1] > 6:
+        out["embeddings"] = rec[..., 6:].copy()
+    return out

@@ -1,0 +1,152 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY. Never imported by the product package.
+
+Plain PyTorch CPU fp32 restatement of the CenterNet forward that the HIP path must match:
+  GenericModel.forward            <- centernet_lightning/models/meta.py:41-47
+  GenericHead                     <- centernet_lightning/models/meta.py:21-30 (block = conv3x3 no-bias + BN + ReLU)
+  make_conv / make_upsample / Fuse <- centernet_lightning/models/layers.py:72-77, :99, :160-177
+  ResNet-34 backbone              <- public torchvision topology (absent from the reference tree; contract
+                                     tests/test_backbones.py:60-70)
+  .sigmoid() at the forward boundary <- centernet_lightning/models/centernet.py:205
+
+It is op-per-layer and unfused on purpose (F.conv2d, F.batch_norm in eval mode, F.relu, F.max_pool2d,
+F.interpolate(nearest), explicit adds): exactly the ATen call sequence of the reference, so BN folding,
+upsample folding, head fusion and the MFMA summation order of the product are all exercised by the
+comparison.  The structure is read from the state_dict's key names, so this file does not import the
+product's model code.
+
+Parity status: heads/wiring PINNED by tests/golden/head_wiring.npz (outputs of the reference's
+GenericHead / GenericModel); backbone + neck "parity unpinned" by the reference (its sources and tests
+for them are missing — SURVEY.md §8c) and defined against this restatement.
+"""
+import re
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-5
+
+
+def _bn(x, sd, prefix, stats=None):
+    if stats is not None:                      # calibration: measure batch stats, store them, use them
+        mean = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        sd[prefix + ".running_mean"].copy_(mean)
+        sd[prefix + ".running_var"].copy_(var.clamp_min(1e-3))
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                        sd[prefix + ".bias"], training=False, eps=EPS)
+
+
+def _conv_bn_relu(x, sd, conv, bn, stride=1, relu=True, stats=None):
+    w = sd[conv + ".weight"]
+    y = F.conv2d(x, w, None, stride=stride, padding=(w.shape[-1] - 1) // 2)
+    y = _bn(y, sd, bn, stats)
+    return F.relu(y) if relu else y
+
+
+def backbone_features(sd, x, stats=None):
+    """-> [f/2, f/4, f/8, f/16, f/32] with channels [64,64,128,256,512]."""
+    p = "backbone."
+    x = _conv_bn_relu(x, sd, p + "conv1", p + "bn1", stride=2, stats=stats)
+    feats = [x]
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li in range(1, 5):
+        bi = 0
+        while f"{p}layer{li}.{bi}.conv1.weight" in sd:
+            q = f"{p}layer{li}.{bi}."
+            stride = 2 if (bi == 0 and li > 1) else 1
+            out = _conv_bn_relu(x, sd, q + "conv1", q + "bn1", stride=stride, stats=stats)
+            out = _conv_bn_relu(out, sd, q + "conv2", q + "bn2", relu=False, stats=stats)
+            if q + "downsample.0.weight" in sd:
+                idn = F.conv2d(x, sd[q + "downsample.0.weight"], None, stride=stride)
+                idn = _bn(idn, sd, q + "downsample.1", stats)
+            else:
+                idn = x
+            x = F.relu(out + idn)
+            bi += 1
+        feats.append(x)
+    return feats
+
+
+def neck_forward(sd, feats, stats=None):
+    if "neck.top_conv.weight" in sd:                           # FPN
+        top = F.conv2d(feats[-1], sd["neck.top_conv.weight"], sd["neck.top_conv.bias"])
+        i = 0
+        while f"neck.fuse.{i}.output_conv.0.weight" in sd:
+            q = f"neck.fuse.{i}."
+            skip = feats[-2 - i]
+            if q + "project.0.weight" in sd:                   # Fuse.forward (layers.py:160-177)
+                skip = F.conv2d(skip, sd[q + "project.0.weight"], sd[q + "project.0.bias"])
+            if q + "project.1.weight" in sd:
+                top = F.conv2d(top, sd[q + "project.1.weight"], sd[q + "project.1.bias"])
+            top = F.interpolate(top, scale_factor=2, mode="nearest")
+            out = torch.stack([skip, top], dim=-1).sum(dim=-1)
+            top = _conv_bn_relu(out, sd, q + "output_conv.0", q + "output_conv.1", stats=stats)
+            i += 1
+        return top
+    x = feats[-1]                                              # simple neck: conv -> upsample per stage
+    i = 0
+    while f"neck.layers.{i}.0.weight" in sd:
+        x = _conv_bn_relu(x, sd, f"neck.layers.{i}.0", f"neck.layers.{i}.1", stats=stats)
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        i += 1
+    return x
+
+
+def head_names(sd):
+    names = []
+    for k in sd:
+        m = re.match(r"heads\.([^.]+)\.out_conv\.weight", k)
+        if m:
+            names.append(m.group(1))
+    return names
+
+
+def head_forward(sd, name, x, stats=None, prefix="heads."):
+    q = f"{prefix}{name}."
+    i = 1
+    while f"{q}block_{i}.conv.weight" in sd:
+        x = _conv_bn_relu(x, sd, f"{q}block_{i}.conv", f"{q}block_{i}.bn", stats=stats)
+        i += 1
+    return F.conv2d(x, sd[q + "out_conv.weight"], sd[q + "out_conv.bias"])
+
+
+@torch.no_grad()
+def forward(sd, x, sigmoid=True, stats=None, return_intermediates=False):
+    """sd: state_dict (CPU fp32 tensors) with the key layout of centernet_lightning_amd.CenterNet;
+    x: [N,3,H,W] CPU fp32.  Returns OrderedDict(heatmap, box_2d[, reid]) in NCHW."""
+    feats = backbone_features(sd, x, stats)
+    neck = neck_forward(sd, feats, stats)
+    out = OrderedDict()
+    for name in head_names(sd):
+        y = head_forward(sd, name, neck, stats)
+        out[name] = y.sigmoid() if (name == "heatmap" and sigmoid) else y
+    if return_intermediates:
+        return out, feats, neck
+    return out
+
+
+@torch.no_grad()
+def synth_state_dict(model_state_dict, seed=0, calib_shape=(2, 3, 256, 256), calib_seed=1234):
+    """Synthetic weights per BASELINE.md §5 / SURVEY.md §8(d): convs keep their Kaiming init; BN gamma~U(0.5,1.5),
+    beta~N(0,0.1); running stats CALIBRATED by one CPU forward on a seeded batch so activations stay O(1);
+    out_conv.weight ~ N(0, 0.01^2); out_conv.bias keeps init_bias.  Returns a new CPU state_dict."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict((k, v.detach().clone().float().cpu() if v.is_floating_point() else v.detach().clone().cpu())
+                     for k, v in model_state_dict.items())
+    for k, v in sd.items():
+        if k.endswith("running_var"):
+            base = k[: -len("running_var")]
+            sd[base + "weight"].copy_(torch.rand(v.shape, generator=g) + 0.5)
+            sd[base + "bias"].copy_(torch.randn(v.shape, generator=g) * 0.1)
+        elif k.endswith("out_conv.weight"):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.01)
+        elif k.endswith("weight") and v.dim() == 4:
+            fan_out = v.shape[0] * v.shape[2] * v.shape[3]
+            v.copy_(torch.randn(v.shape, generator=g) * (2.0 / fan_out) ** 0.5)       # kaiming_normal_(fan_out, relu)
+        elif k.endswith(("top_conv.bias", "project.0.bias", "project.1.bias")):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.05)
+    xg = torch.Generator().manual_seed(calib_seed)
+    x = torch.rand(*calib_shape, generator=xg)
+    forward(sd, x, stats=True)
+    return sd

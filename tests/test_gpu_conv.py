@@ -1,0 +1,172 @@
+"""GPU: layer-level parity of the HIP conv / stem / max-pool kernels (called through the C ABI) against plain
+PyTorch CPU fp32 ops — the ATen calls of the reference's forward (F.conv2d, F.relu, F.max_pool2d,
+F.interpolate(nearest), add, sigmoid).  Tolerance: |d| <= 1e-4 + 1e-4*|ref| (north star: 1e-4 fp32); the
+only difference is fp32 summation order (MFMA k-order vs oneDNN)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from centernet_lightning_amd import _lib
+from centernet_lightning_amd._lib import CNL_RELU, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD, ConvParams
+
+pytestmark = pytest.mark.gpu
+RTOL = ATOL = 1e-4
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0, x_off=0):
+    """x_nchw: CPU tensor. Returns NCHW CPU output of cnl_conv2d_nhwc_f32."""
+    lib = _lib.load()
+    N, Cin, H, W = x_nchw.shape
+    Cout, _, KH, KW = w_oihw.shape
+    ldx = Cin + ldx_extra
+    xb = torch.full((N, H, W, ldx), float("nan"))          # poison the padding channels
+    xb[..., x_off:x_off + Cin] = x_nchw.permute(0, 2, 3, 1)
+    xd = xb.cuda()
+    wd = w_oihw.permute(0, 2, 3, 1).contiguous().cuda()
+    bd = bias.cuda()
+    p = ConvParams()
+    p.x, p.w, p.bias = xd.data_ptr() + 4 * x_off, wd.data_ptr(), bd.data_ptr()
+    p.N, p.H_in, p.W_in, p.Cin, p.Cout = N, H, W, Cin, Cout
+    p.KH, p.KW, p.stride, p.pad = KH, KW, stride, (KH - 1) // 2
+    p.ldx, p.flags = ldx, flags
+    ho, wo = ctypes.c_int32(), ctypes.c_int32()
+    _lib.check(lib.cnl_conv2d_out_hw(ctypes.byref(p), ctypes.byref(ho), ctypes.byref(wo)))
+    oh, ow = ho.value, wo.value
+    if flags & CNL_UPSAMPLE_OUT_ADD:
+        oh, ow = 2 * oh, 2 * ow
+    y = torch.full((N, oh, ow, Cout), float("nan"), device="cuda")
+    p.y, p.ldy = y.data_ptr(), Cout
+    rd = None
+    if residual is not None:
+        rd = residual.permute(0, 2, 3, 1).contiguous().cuda()
+        p.residual, p.ldr = rd.data_ptr(), Cout
+    _lib.check(lib.cnl_conv2d_nhwc_f32(ctypes.byref(p), _stream()), "conv")
+    torch.cuda.synchronize()
+    return y.cpu().permute(0, 3, 1, 2)
+
+
+def ref_conv(x, w, b, stride=1, flags=0, residual=None):
+    if flags & CNL_UPSAMPLE_IN:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    y = F.conv2d(x, w, b, stride=stride, padding=(w.shape[-1] - 1) // 2)
+    if flags & CNL_UPSAMPLE_OUT_ADD:
+        y = F.interpolate(y, scale_factor=2, mode="nearest") + residual
+    elif residual is not None:
+        y = y + residual
+    if flags & CNL_RELU:
+        y = F.relu(y)
+    if flags & CNL_SIGMOID:
+        y = y.sigmoid()
+    return y
+
+
+def mk(N, Cin, H, W, Cout, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    return x, w, b
+
+
+CASES = [
+    # N, Cin, H, W, Cout, k, stride, flags, residual
+    (2, 64, 16, 16, 64, 3, 1, CNL_RELU, False),            # 256x64 tile, layer1 shape
+    (2, 64, 16, 16, 128, 3, 2, CNL_RELU, False),           # stride 2
+    (2, 64, 16, 16, 128, 1, 2, 0, False),                  # 1x1 stride-2 downsample
+    (1, 256, 8, 8, 256, 3, 1, CNL_RELU, True),             # K = 2304, residual + relu
+    (2, 512, 4, 4, 512, 3, 1, CNL_RELU, True),             # K = 4608 (layer4), 64x128 tile
+    (1, 256, 16, 16, 80, 1, 1, CNL_SIGMOID, False),        # heatmap out_conv + sigmoid (N tail 80 < 128)
+    (1, 256, 16, 16, 4, 1, 1, 0, False),                   # box out_conv, 256x32 tile
+    (1, 64, 5, 7, 64, 3, 1, CNL_RELU, False),              # ragged M (35 rows) and odd spatial size
+    (3, 32, 9, 11, 160, 3, 1, 0, False),                   # Cin = 32, Cout tail over two N tiles
+    (1, 128, 8, 8, 64, 3, 1, CNL_RELU | CNL_UPSAMPLE_IN, False),   # conv on nearest-2x upsampled input
+    (2, 64, 6, 6, 256, 3, 1, CNL_RELU | CNL_UPSAMPLE_IN, False),
+    (1, 256, 4, 4, 128, 1, 1, CNL_UPSAMPLE_OUT_ADD, True),         # Fuse: project -> up -> + skip
+    (2, 512, 2, 2, 256, 1, 1, CNL_UPSAMPLE_OUT_ADD, True),
+    (2, 64, 40, 40, 256, 3, 1, CNL_RELU, False),           # > 512 tiles -> 128x128 config, many K chunks
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "N{}c{}_{}x{}_o{}k{}s{}f{}r{}".format(*[int(v) for v in c]))
+def test_conv_matches_cpu(case):
+    N, Cin, H, W, Cout, k, stride, flags, use_res = case
+    x, w, b = mk(N, Cin, H, W, Cout, k, seed=Cin * 7 + Cout + H)
+    ref_nores = ref_conv(x, w, b, stride, flags & ~(CNL_RELU | CNL_SIGMOID | CNL_UPSAMPLE_OUT_ADD))
+    res = None
+    if use_res:
+        shape = list(ref_nores.shape)
+        if flags & CNL_UPSAMPLE_OUT_ADD:
+            shape[2] *= 2
+            shape[3] *= 2
+        res = torch.randn(shape, generator=torch.Generator().manual_seed(5))
+    ref = ref_conv(x, w, b, stride, flags, res)
+    out = run_conv(x, w, b, stride, flags, res)
+    assert out.shape == ref.shape
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out, ref, rtol=RTOL, atol=ATOL)
+
+
+def test_conv_reads_channel_slice_of_wider_buffer():
+    """heads read their 256-channel slice out of the fused 512-channel first-block buffer (ldx > Cin, x offset)."""
+    x, w, b = mk(1, 64, 8, 8, 64, 3, seed=3)
+    out = run_conv(x, w, b, 1, CNL_RELU, ldx_extra=64, x_off=32)
+    torch.testing.assert_close(out, ref_conv(x, w, b, 1, CNL_RELU), rtol=RTOL, atol=ATOL)
+
+
+def test_conv_is_deterministic():
+    x, w, b = mk(2, 128, 12, 12, 128, 3, seed=9)
+    a = run_conv(x, w, b, 1, CNL_RELU)
+    for _ in range(2):
+        assert torch.equal(a, run_conv(x, w, b, 1, CNL_RELU))
+
+
+def test_conv_exact_on_integers():
+    """Small-integer operands make every product and partial sum exact in fp32: any indexing / padding / swizzle
+    mistake shows up as a hard mismatch, independent of summation order (asymmetric weights catch transposes)."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(-3, 4, (2, 64, 10, 9), generator=g).float()
+    w = torch.randint(-2, 3, (96, 64, 3, 3), generator=g).float()
+    b = torch.randint(-5, 6, (96,), generator=g).float()
+    assert torch.equal(run_conv(x, w, b, 1, 0), ref_conv(x, w, b, 1, 0))
+    assert torch.equal(run_conv(x, w, b, 2, CNL_RELU), ref_conv(x, w, b, 2, CNL_RELU))
+
+
+@pytest.mark.parametrize("shape,channels_last", [((2, 3, 64, 64), False), ((2, 3, 64, 64), True), ((1, 3, 96, 160), False),
+                                                 ((1, 3, 70, 50), True)])
+def test_stem_matches_cpu(shape, channels_last):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(*shape, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    b = torch.randn(64, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, b, stride=2, padding=3))
+    xd = x.cuda()
+    if channels_last:
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+    bd = b.cuda()
+    N, _, H, W = shape
+    y = torch.full((N, ref.shape[2], ref.shape[3], 64), float("nan"), device="cuda")
+    sn, sc, sh, sw = xd.stride()
+    _lib.check(lib.cnl_stem_conv7x7_f32(xd.data_ptr(), sn, sc, sh, sw, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), N, H, W, _stream()))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.cpu().permute(0, 3, 1, 2), ref, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 32, 32), (1, 64, 17, 23), (1, 8, 6, 6)])
+def test_maxpool_matches_cpu_bit_exact(shape):
+    lib = _lib.load()
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(2))
+    ref = F.max_pool2d(x, 3, 2, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    N, C, H, W = shape
+    y = torch.empty((N, ref.shape[2], ref.shape[3], C), device="cuda")
+    _lib.check(lib.cnl_maxpool3x3s2_nhwc_f32(xd.data_ptr(), y.data_ptr(), N, H, W, C, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu().permute(0, 3, 1, 2), ref)

@@ -1,0 +1,161 @@
+"""GPU: parity of the fused HIP decode (through the C ABI) with the oracle and the reference-generated golden
+vectors.  Bar: scores / indices / labels / boxes / embeddings BIT-EXACT (compare-select and one-rounding fp32
+arithmetic); only box_log=True (exp) is compared with a tolerance."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import decode_ref
+import recipes
+import centernet_lightning_amd as cl
+from centernet_lightning_amd import decode as hip_decode
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _np(d):
+    return {k: v.cpu().numpy() for k, v in d.items()}
+
+
+def _check(o, ref, box_tol=False):
+    for key in ("scores", "indices", "labels"):
+        assert np.array_equal(o[key], ref[key]), key
+    if box_tol:
+        np.testing.assert_allclose(o["boxes"], ref["boxes"], rtol=2e-6, atol=1e-5)
+    else:
+        assert np.array_equal(o["boxes"].view(np.uint32), ref["boxes"].view(np.uint32))
+    if "embeddings" in ref and ref["embeddings"] is not None:
+        assert np.array_equal(o["embeddings"], ref["embeddings"])
+
+
+def _layouts(t):
+    """same logical NCHW tensor as (a) contiguous NCHW, (b) channels_last / NHWC storage."""
+    return [t.cuda().contiguous(), t.cuda().contiguous(memory_format=torch.channels_last)]
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "decode_*.npz"))), ids=lambda p: os.path.basename(p)[7:-4])
+def test_decode_matches_reference_golden(path):
+    g = dict(np.load(path))
+    shape = tuple(int(v) for v in g["shape"])
+    ins = recipes.decode_inputs(int(g["seed"]), shape, int(g["emb"]))
+    assert recipes.sha256(*ins) == str(g["sha"])
+    for li in range(2):
+        heat, box = _layouts(ins[0])[li], _layouts(ins[1])[li]
+        reid = _layouts(ins[2])[li] if len(ins) > 2 else None
+        o = _np(hip_decode.decode(heat, box, reid, int(g["k"]), int(g["nms"]), bool(g["normalize"]), bool(g["box_log"]),
+                                  float(g["mult"]), int(g["stride"])))
+        _check(o, {k: g[k] for k in ("scores", "indices", "labels", "boxes")}, box_tol=bool(g["box_log"]))
+        if reid is not None:
+            assert recipes.sha256(o["embeddings"]) == str(g["embeddings_sha"])
+
+
+@pytest.mark.parametrize("name", ["plateau", "allequal", "signed", "kfull"])
+def test_decode_kats(name):
+    g = dict(np.load(os.path.join(GOLDEN, f"kat_{name}.npz")))
+    for heat, box in zip(_layouts(torch.from_numpy(g["heat"])), _layouts(torch.from_numpy(g["box"]))):
+        o = _np(hip_decode.decode(heat, box, None, int(g["k"]), int(g["nms"])))
+        _check(o, g)
+
+
+@pytest.mark.parametrize("shape,k,nms,emb", [((3, 80, 128, 128), 100, 3, 0), ((2, 2, 152, 272), 300, 3, 64), ((2, 5, 33, 47), 77, 5, 3),
+                                            ((1, 1, 8, 200), 9, 7, 0), ((2, 6, 16, 16), 256, 1, 0), ((1, 81, 20, 20), 50, 3, 0),
+                                            ((1, 130, 12, 12), 20, 3, 0)])
+def test_decode_random_vs_oracle(shape, k, nms, emb):
+    ins = recipes.decode_inputs(sum(shape) + k, shape, emb)
+    ref = decode_ref.decode_detections(ins[0].numpy(), ins[1].numpy(), k, nms, reid=ins[2].numpy() if emb else None)
+    for li in range(2):
+        heat, box = _layouts(ins[0])[li], _layouts(ins[1])[li]
+        reid = _layouts(ins[2])[li] if emb else None
+        o = _np(hip_decode.decode(heat, box, reid, k, nms))
+        _check(o, ref)
+
+
+def test_decode_quantised_scores_many_ties():
+    """Scores on a coarse grid produce large tie groups everywhere, including across the k boundary."""
+    g = torch.Generator().manual_seed(3)
+    heat = (torch.rand(2, 4, 24, 24, generator=g) * 8).floor() / 8
+    box = torch.rand(2, 4, 24, 24, generator=g) * 5
+    ref = decode_ref.decode_detections(heat.numpy(), box.numpy(), 60, 3)
+    for h, b in zip(_layouts(heat), _layouts(box)):
+        _check(_np(hip_decode.decode(h, b, None, 60, 3)), ref)
+
+
+def test_decode_full_size_properties():
+    """BASELINE C1 size (32x80x128x128): properties that need no oracle run — sortedness, peak-ness, top-k-ness."""
+    N, C, H, W, k = 32, 80, 128, 128, 100
+    g = torch.Generator(device="cuda").manual_seed(0)
+    heat = torch.randn(N, H, W, C, device="cuda", generator=g).sub_(2.19).sigmoid_().permute(0, 3, 1, 2)
+    box = (torch.rand(N, H, W, 4, device="cuda", generator=g) * 16).permute(0, 3, 1, 2)
+    o = hip_decode.decode(heat, box, None, k, 3)
+    s, i, l, b = o["scores"], o["indices"], o["labels"], o["boxes"]
+    assert bool((s[:, :-1] >= s[:, 1:]).all())
+    flat = heat.reshape(N, C, H * W)
+    got = torch.gather(flat, 2, i.unsqueeze(1).expand(-1, C, -1))                       # values at winners: N,C,k
+    assert torch.equal(got.gather(1, l.unsqueeze(1)).squeeze(1), s)                     # score == heat[label, idx]
+    pooled = torch.nn.functional.max_pool2d(heat, 3, 1, 1)
+    assert bool((pooled.reshape(N, C, -1).gather(2, i.unsqueeze(1).expand(-1, C, -1)).gather(1, l.unsqueeze(1)).squeeze(1) == s).all())
+    masked = (heat * (pooled == heat)).amax(dim=1).reshape(N, -1)
+    kth = masked.topk(k, dim=1).values
+    assert torch.equal(kth, s)                                                          # same score multiset as torch
+    cx = (i % W).float() + 0.5
+    ltrb = torch.gather(box.reshape(N, 4, -1), 2, i.unsqueeze(1).expand(-1, 4, -1)).clamp_min(0)
+    assert torch.equal(b[..., 0], (cx - ltrb[:, 0]) * 4) and torch.equal(b[..., 2], (cx + ltrb[:, 2]) * 4)
+    # idempotence / determinism
+    o2 = hip_decode.decode(heat, box, None, k, 3)
+    assert all(torch.equal(o[key], o2[key]) for key in o)
+
+
+def test_standalone_gathers_and_model_surface():
+    ins = recipes.decode_inputs(8, (2, 3, 24, 32), 16)
+    heat, box, reid = [t.cuda() for t in ins]
+    m = cl.CenterNet({"name": "resnet34"}, {"name": "fpn"}, {"heatmap": {"num_classes": 3}, "box_2d": {}, "reid": {}}, "tracking")
+    ref = decode_ref.decode_detections(ins[0].numpy(), ins[1].numpy(), 40, 3, reid=ins[2].numpy())
+    d = m.gather_tracking2d(heat, box, reid, num_detections=40)
+    assert set(d) == {"bboxes", "labels", "scores", "embeddings"} and d["labels"].dtype == torch.int64
+    _check({"scores": d["scores"].cpu().numpy(), "indices": ref["indices"], "labels": d["labels"].cpu().numpy(),
+            "boxes": d["bboxes"].cpu().numpy(), "embeddings": d["embeddings"].cpu().numpy()}, ref)
+    # Gen-A per-head calls (fairmot.py:141-143)
+    s, i, l = m.heads["heatmap"].gather_topk(heat, nms_kernel=3, num_detections=40)
+    assert np.array_equal(i.cpu().numpy(), ref["indices"]) and np.array_equal(l.cpu().numpy(), ref["labels"])
+    bb = m.heads["box_2d"].gather_at_indices(box, i, normalize_bbox=False, stride=4)
+    assert np.array_equal(bb.cpu().numpy().view(np.uint32), ref["boxes"].view(np.uint32))
+    ee = m.heads["reid"].gather_at_indices(reid, i)
+    assert np.array_equal(ee.cpu().numpy(), ref["embeddings"])
+    # Gen-B names (centernet.py:229-304); namedtuple accepted as the single argument (README.md:97-98)
+    d2 = m.gather_detection2d((heat, box), num_detections=40)
+    assert torch.equal(d2["bboxes"], d["bboxes"])
+    m.num_detections = 40
+    d3 = m.decode_detections(heat, box)
+    assert set(d3) == {"boxes", "scores", "labels"} and torch.equal(d3["boxes"], d["bboxes"])
+    bn = cl.CenterNet.gather_and_decode_boxes(box, i, normalize_boxes=True)
+    refn = decode_ref.gather_and_decode_boxes(ins[1].numpy(), ref["indices"], normalize_boxes=True)
+    assert np.array_equal(bn.cpu().numpy().view(np.uint32), refn.view(np.uint32))
+
+
+def test_decode_argument_errors():
+    heat = torch.rand(1, 2, 8, 8, device="cuda")
+    box = torch.rand(1, 4, 8, 8, device="cuda")
+    with pytest.raises(ValueError):
+        hip_decode.decode(heat, box, None, 65, 3)            # k > H*W
+    with pytest.raises(ValueError):
+        hip_decode.decode(heat, box, None, 10, 4)            # even kernel (reference breaks too)
+    with pytest.raises(ValueError):
+        hip_decode.decode(heat, box[:, :3], None, 10, 3)
+
+
+def test_pack_unpack_and_collate_single_process():
+    ins = recipes.decode_inputs(2, (2, 3, 16, 16), 8)
+    o = hip_decode.decode(*[t.cuda() for t in ins], 20, 3)
+    dets = {"bboxes": o["boxes"], "scores": o["scores"], "labels": o["labels"], "embeddings": o["embeddings"]}
+    rec = cl.pack_detections(dets)
+    ref = decode_ref.pack_detections(o["boxes"].cpu().numpy(), o["scores"].cpu().numpy(), o["labels"].cpu().numpy(),
+                                     o["embeddings"].cpu().numpy())
+    assert np.array_equal(rec.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    u = cl.unpack_detections(rec)
+    for key in dets:
+        assert torch.equal(u[key], dets[key])
+    assert cl.collate_detections(dets) is dets               # world size 1: no-op (eval/coco.py:11-13)

@@ -1,0 +1,122 @@
+"""GPU: end-to-end parity of CenterNet.forward / get_encoded_outputs / gather_detection2d with the CPU oracle
+(oracle/ref_cpu.py + oracle/decode_ref.py) on the BASELINE configs at sizes the CPU finishes in seconds.
+
+Level A (decode on identical tensors): bit-exact — test_gpu_decode.py.
+Level B (this file): conv accumulation order differs from oneDNN, so logits / scores / boxes must agree within
+rtol = atol = 1e-4 and top-k indices wherever the oracle's neighbouring score gap exceeds that tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import decode_ref
+import recipes
+import ref_cpu
+import centernet_lightning_amd as cl
+
+pytestmark = pytest.mark.gpu
+CONFIGS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "centernet-lightning_amd", "configs")
+TOL = 1e-4
+
+
+def build(cfg_name):
+    torch.manual_seed(0)
+    model = cl.build_centernet(os.path.join(CONFIGS, cfg_name))
+    sd = ref_cpu.synth_state_dict(model.state_dict(), seed=0, calib_shape=(2, 3, 128, 128))
+    model.load_state_dict(sd)
+    return model.cuda(), sd
+
+
+def compare_detections(dets, ref, k):
+    s, l, b = dets["scores"].cpu().numpy(), dets["labels"].cpu().numpy(), dets["bboxes"].cpu().numpy()
+    np.testing.assert_allclose(s, ref["scores"], rtol=TOL, atol=TOL)
+    # indices are only well-defined where neighbouring oracle scores are further apart than the tolerance
+    gap_prev = np.abs(np.diff(ref["scores"], axis=1, prepend=np.inf))
+    gap_next = np.abs(np.diff(ref["scores"], axis=1, append=-np.inf))
+    safe = (gap_prev > 4 * TOL) & (gap_next > 4 * TOL)
+    safe[:, -1] = False                       # the k-th may swap with the (k+1)-th
+    assert safe.mean() > 0.5
+    assert np.array_equal(l[safe], ref["labels"][safe])
+    np.testing.assert_allclose(b[safe], ref["boxes"][safe], rtol=TOL, atol=TOL * 4)     # boxes are in pixels (x stride 4)
+    return safe
+
+
+@pytest.mark.parametrize("cfg,shape", [("resnet34_simple.yaml", (2, 3, 128, 160)), ("resnet34_fpn.yaml", (2, 3, 160, 128)),
+                                       ("tracking_resnet34_fpn.yaml", (1, 3, 96, 160))])
+def test_forward_and_decode_match_cpu_oracle(cfg, shape):
+    model, sd = build(cfg)
+    x = recipes.images(1234, shape)
+    ref_logits = ref_cpu.forward(sd, x, sigmoid=False)
+    ref_sig = ref_cpu.forward(sd, x, sigmoid=True)
+    xd = x.cuda()
+    enc = model.get_encoded_outputs(xd)
+    assert list(enc.keys()) == list(ref_logits.keys())
+    for name, r in ref_logits.items():
+        o = enc[name]
+        assert tuple(o.shape) == tuple(r.shape) and o.shape[2] == shape[2] // model.output_stride
+        torch.testing.assert_close(o.cpu(), r, rtol=TOL, atol=TOL)
+    out = model(xd)                                           # namedtuple, heatmap post-sigmoid
+    heat, box = out[0], out[1]
+    assert float(heat.min()) >= 0 and float(heat.max()) <= 1                  # tests/test_models.py:93-95
+    torch.testing.assert_close(heat.cpu(), ref_sig["heatmap"], rtol=TOL, atol=TOL)
+    heat_std = float(ref_sig["heatmap"].std())
+    assert heat_std > 1e-3, "degenerate synthetic heatmap: the comparison would be meaningless"
+    k = 50
+    if model.task == "tracking":
+        dets = model.gather_tracking2d(out, num_detections=k)
+        ref = decode_ref.decode_detections(ref_sig["heatmap"].numpy(), ref_sig["box_2d"].numpy(), k, 3, reid=ref_sig["reid"].numpy())
+    else:
+        dets = model.gather_detection2d(out, num_detections=k)
+        ref = decode_ref.decode_detections(ref_sig["heatmap"].numpy(), ref_sig["box_2d"].numpy(), k, 3)
+    safe = compare_detections(dets, ref, k)
+    # Level A on the GPU's own tensors: indices bit-exact against the oracle decode of the same bytes
+    refA = decode_ref.decode_detections(heat.cpu().numpy(), box.cpu().numpy(), k, 3,
+                                        reid=out[2].cpu().numpy() if model.task == "tracking" else None)
+    assert np.array_equal(dets["scores"].cpu().numpy(), refA["scores"])
+    assert np.array_equal(dets["labels"].cpu().numpy(), refA["labels"])
+    assert np.array_equal(dets["bboxes"].cpu().numpy().view(np.uint32), refA["boxes"].view(np.uint32))
+    if model.task == "tracking":
+        assert np.array_equal(dets["embeddings"].cpu().numpy(), refA["embeddings"])
+        np.testing.assert_allclose(dets["embeddings"].cpu().numpy()[safe], ref["embeddings"][safe], rtol=TOL, atol=TOL)
+
+
+def test_c0_config_512(request):
+    """BASELINE C0: configs/base_resnet34.yaml-equivalent, 1x3x512x512."""
+    model, sd = build("resnet34_simple.yaml")
+    x = recipes.images(1234, (1, 3, 512, 512))
+    ref = ref_cpu.forward(sd, x, sigmoid=True)
+    heat, box = model(x.cuda())
+    assert tuple(heat.shape) == (1, 80, 128, 128) and tuple(box.shape) == (1, 4, 128, 128)
+    torch.testing.assert_close(heat.cpu(), ref["heatmap"], rtol=TOL, atol=TOL)
+    torch.testing.assert_close(box.cpu(), ref["box_2d"], rtol=TOL, atol=TOL)
+    dets = model.gather_detection2d(heat, box)
+    assert tuple(dets["bboxes"].shape) == (1, 100, 4) and dets["labels"].dtype == torch.int64
+    compare_detections(dets, decode_ref.decode_detections(ref["heatmap"].numpy(), ref["box_2d"].numpy(), 100, 3), 100)
+
+
+def test_batch_shard_equals_full_batch():
+    """The N>1 partitioning: running each contiguous shard separately gives the same bytes as the
+    full batch (images are independent; kernels are batch-invariant)."""
+    model, _ = build("resnet34_fpn.yaml")
+    x = recipes.images(7, (4, 3, 128, 128)).cuda()
+    full = model.gather_detection2d(model(x), num_detections=30)
+    parts = []
+    for r in range(2):
+        lo, hi = cl.shard_range(4, r, 2)
+        parts.append(model.gather_detection2d(model(x[lo:hi]), num_detections=30))
+    for key in full:
+        assert torch.equal(full[key], torch.cat([p[key] for p in parts], dim=0)), key
+
+
+def test_channels_last_input_and_weight_reload():
+    model, sd = build("resnet34_simple.yaml")
+    x = recipes.images(3, (1, 3, 128, 128)).cuda()
+    a = model.get_encoded_outputs(x)
+    b = model.get_encoded_outputs(x.contiguous(memory_format=torch.channels_last))
+    for key in a:
+        assert torch.equal(a[key], b[key])
+    sd2 = {k: (v * 1.5 if k == "heads.box_2d.out_conv.bias" else v) for k, v in sd.items()}
+    model.load_state_dict(sd2)
+    c = model.get_encoded_outputs(x)
+    assert not torch.equal(a["box_2d"], c["box_2d"]) and torch.equal(a["heatmap"], c["heatmap"])

@@ -1,0 +1,193 @@
+"""CPU: host logic of the product package — config surface, model contract (re-stated from the reference's
+tests/test_models.py, test_necks.py, test_backbones.py), C-ABI library load / exported symbols / argument
+validation (no compute without a GPU), and the N>1 collate protocol over gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import centernet_lightning_amd as cl
+from centernet_lightning_amd import _lib
+from centernet_lightning_amd.config import load_config, model_section
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------- C ABI
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "centernet_gfx950.h")).read()
+    declared = set(re.findall(r"\b(cnl_[a-z0-9_]+)\s*\(", header))
+    declared -= {"cnl_conv_params", "cnl_decode_params"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/centernet_gfx950.h but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    assert lib.cnl_version() == 1
+
+
+def test_abi_error_convention_without_gpu():
+    lib = _lib.load()
+    assert lib.cnl_conv2d_nhwc_f32(None, None) == _lib.CNL_E_BAD_ARG
+    assert "null" in _lib.last_error()
+    p = _lib.ConvParams()
+    p.x = p.w = p.bias = p.y = 0x1000
+    p.N, p.H_in, p.W_in, p.Cin, p.Cout = 1, 8, 8, 3, 64
+    p.KH = p.KW = 3
+    p.stride, p.pad, p.ldx, p.ldy = 1, 1, 4, 64
+    assert lib.cnl_conv2d_nhwc_f32(ctypes.byref(p), None) == _lib.CNL_E_UNSUPPORTED      # Cin % 32 != 0
+    assert "multiple of 32" in _lib.last_error()
+    with pytest.raises(ValueError):
+        _lib.check(_lib.CNL_E_UNSUPPORTED, "x")
+    d = _lib.DecodeParams()
+    assert lib.cnl_decode_f32(ctypes.byref(d), None) == _lib.CNL_E_BAD_ARG
+    assert lib.cnl_decode_workspace_bytes(2, 128, 128) >= 2 * 128 * 128 * 8
+    ho, wo = ctypes.c_int32(), ctypes.c_int32()
+    p.Cin = 64
+    p.stride = 2
+    assert lib.cnl_conv2d_out_hw(ctypes.byref(p), ctypes.byref(ho), ctypes.byref(wo)) == 0 and (ho.value, wo.value) == (4, 4)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("CENTERNET_GFX950_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.load()
+    monkeypatch.undo()
+    _lib.load()
+
+
+# ----------------------------------------------------------------------------- config surface
+def test_configs_build(configs_dir):
+    m = cl.build_centernet(os.path.join(configs_dir, "resnet34_simple.yaml"))
+    assert type(m.neck).__name__ == "SimpleNeck" and m.num_classes == 80 and m.task == "detection"
+    m = cl.build_centernet(os.path.join(configs_dir, "resnet34_fpn.yaml"))
+    assert type(m.neck).__name__ == "FPNNeck"
+    m = cl.build_centernet(os.path.join(configs_dir, "tracking_resnet34_fpn.yaml"))      # __base__ inheritance
+    assert m.task == "tracking" and list(m.heads.keys()) == ["heatmap", "box_2d", "reid"] and m.num_classes == 2
+    assert m.heads["reid"].depth == 1 and m.heads["reid"].out_channels == 64             # fairmot.py:20
+    assert m.heads["heatmap"].out_conv.bias.data.eq(-2.19).all() and m.heads["box_2d"].out_conv.bias.data.eq(10).all()
+
+
+def test_neck_params_nesting_and_ignored_sections():
+    cfg = {"model": {"task": "detection", "backbone": {"name": "resnet34", "pretrained": True, "input_channels": 3},
+                     "neck": {"name": "simple", "params": {"upsample_channels": [128, 64, 32], "upsample_type": "nearest",
+                                                           "conv_type": "normal", "skip_kernel": 3}},
+                     "output_heads": {"heatmap": {"num_classes": 20, "loss_function": "cornernet_focal"}, "box_2d": {}},
+                     "optimizer": {"name": "SGD"}},
+           "data": {"train": {}}, "trainer": {"gpus": 2}}
+    m = cl.build_centernet(cfg)
+    assert m.neck.out_channels == 32 and m.num_classes == 20
+    assert model_section(cfg)["neck"]["upsample_channels"] == [128, 64, 32]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="reference tree only in the build container")
+@pytest.mark.parametrize("name", ["base_resnet34.yaml", "base_resnet34_fpn.yaml", "base_tracking_resnet34_fpn.yaml"])
+def test_reference_yaml_files_build(name):
+    m = cl.build_centernet(os.path.join("/root/reference/configs", name))
+    assert m.output_stride == 4
+
+
+def test_out_of_scope_options_raise():
+    base = {"backbone": {"name": "resnet34"}, "neck": {"name": "fpn"}, "output_heads": {"heatmap": {"num_classes": 3}, "box_2d": {}}}
+    for bad in ({"backbone": {"name": "mobilenet_v2"}}, {"neck": {"name": "bifpn"}}, {"neck": {"name": "fpn", "conv_type": "separable"}},
+                {"neck": {"name": "simple", "upsample_type": "conv_transpose"}}):
+        cfg = dict(base, **bad)
+        with pytest.raises(ValueError):
+            cl.CenterNet(cfg["backbone"], cfg["neck"], cfg["output_heads"], "detection")
+
+
+# ----------------------------------------------------------------------------- model contract
+@pytest.mark.parametrize("neck", ["simple", "fpn"])
+def test_model_attributes_contract(neck):
+    m = cl.CenterNet({"name": "resnet34"}, {"name": neck}, {"heatmap": {"num_classes": 20}, "box_2d": {}}, "detection")
+    assert isinstance(m.output_stride, int) and m.output_stride == 4 and m.stride == 4       # tests/test_models.py:64
+    assert m.task == "detection" and m.num_classes == 20
+    assert m.backbone.out_channels == [64, 64, 128, 256, 512] and m.backbone.output_stride == 32
+    assert m.neck.out_channels == 64 and m.neck.upsample_stride == 8                         # tests/test_necks.py:27-28
+    assert not m.training
+    with pytest.raises(RuntimeError):
+        m.train()
+
+
+def test_state_dict_uses_torchvision_and_generic_head_key_names():
+    m = cl.build_centernet({"model": {"backbone": {"name": "resnet34"}, "neck": {"name": "fpn"},
+                                      "output_heads": {"heatmap": {"num_classes": 80}, "box_2d": {}}}})
+    keys = set(m.state_dict())
+    for k in ("backbone.conv1.weight", "backbone.bn1.running_var", "backbone.layer1.0.conv1.weight", "backbone.layer2.0.downsample.0.weight",
+              "backbone.layer2.0.downsample.1.running_mean", "backbone.layer4.2.bn2.bias", "neck.top_conv.bias",
+              "neck.fuse.1.project.1.weight", "neck.fuse.0.output_conv.0.weight", "neck.fuse.2.output_conv.1.running_var",
+              "heads.heatmap.block_1.conv.weight", "heads.heatmap.block_3.bn.weight", "heads.box_2d.out_conv.bias"):
+        assert k in keys, k
+    assert "neck.fuse.0.project.1.weight" not in keys                 # 256 -> 256: no projection (layers.py:152)
+    n_backbone = sum(v.numel() for k, v in m.state_dict().items() if k.startswith("backbone.") and v.dim() == 4)
+    assert abs(n_backbone - 21.26e6) < 0.1e6                          # ResNet-34 conv params (docs/experiments.md:24-27)
+    n_heads = sum(p.numel() for p in m.heads.parameters())
+    conv = lambda cin, cout: 9 * cin * cout + 2 * cout                # 3x3 no-bias conv + BN affine (meta.py:24-26)
+    expect = 2 * (conv(64, 256) + 2 * conv(256, 256)) + (256 * 80 + 80) + (256 * 4 + 4)
+    assert n_heads == expect                                          # with a 256-ch neck this is the 3.6 M of docs/experiments.md:27
+
+
+def test_cpu_input_raises_no_fallback():
+    m = cl.build_centernet({"model": {"backbone": {"name": "resnet34"}, "neck": {"name": "simple"},
+                                      "output_heads": {"heatmap": {"num_classes": 4}, "box_2d": {}}}})
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(1, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.gather_detection2d(torch.rand(1, 4, 16, 16), torch.rand(1, 4, 16, 16))
+    with pytest.raises(RuntimeError):
+        cl.pack_detections({"bboxes": torch.zeros(1, 2, 4), "scores": torch.zeros(1, 2), "labels": torch.zeros(1, 2, dtype=torch.int64)})
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "centernet-lightning_amd", "centernet_lightning_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+(oracle|decode_ref|ref_cpu|recipes)\b", src, re.M), fn
+
+
+# ----------------------------------------------------------------------------- N>1 protocol (gloo, world_size 2)
+def _collate_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "centernet-lightning_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import decode_ref
+    import recipes
+    from centernet_lightning_amd import all_gather_records, shard_range
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        n_total, k, E = 6, 10, 4
+        h, b, r = [t.numpy() for t in recipes.decode_inputs(21, (n_total, 3, 16, 16), E)]
+        lo, hi = shard_range(n_total, rank, world)
+        o = decode_ref.decode_detections(h[lo:hi], b[lo:hi], k, reid=r[lo:hi])
+        rec = torch.from_numpy(decode_ref.pack_detections(o["boxes"], o["scores"], o["labels"], o["embeddings"]))
+        full = all_gather_records(rec).numpy()
+        g = decode_ref.decode_detections(h, b, k, reid=r)
+        u = decode_ref.unpack_detections(full)
+        ok = all(np.array_equal(u[key], g[key]) for key in ("boxes", "scores", "labels", "embeddings"))
+        ret[rank] = bool(ok and full.shape == (n_total, k, 6 + E))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collate_protocol_gloo_world2():
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_collate_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret.get(0) is True and ret.get(1) is True
+
+
+def test_collate_is_noop_at_world_size_one():
+    dets = {"bboxes": torch.zeros(1, 2, 4), "scores": torch.zeros(1, 2), "labels": torch.zeros(1, 2, dtype=torch.int64)}
+    assert cl.collate_detections(dets) is dets                       # eval/coco.py:11-13 behaviour
+    assert cl.shard_range(512, 3, 8) == (192, 256)
+    with pytest.raises(ValueError):
+        cl.shard_range(10, 0, 4)
