@@ -17,7 +17,8 @@ import centernet_lightning_amd as cl
 
 pytestmark = pytest.mark.gpu
 CONFIGS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "centernet-lightning_amd", "configs")
-TOL = 1e-4
+TOL = 1e-4          # north star: outputs within 1e-4 fp32
+GAP = 2e-5          # an oracle top-k position is "well separated" when both neighbouring score gaps exceed this
 
 
 def build(cfg_name):
@@ -28,16 +29,19 @@ def build(cfg_name):
     return model.cuda(), sd
 
 
-def compare_detections(dets, ref, k):
+def compare_detections(dets, ref, k, indices=None):
     s, l, b = dets["scores"].cpu().numpy(), dets["labels"].cpu().numpy(), dets["bboxes"].cpu().numpy()
     np.testing.assert_allclose(s, ref["scores"], rtol=TOL, atol=TOL)
-    # indices are only well-defined where neighbouring oracle scores are further apart than the tolerance
+    # Across two different fp32 summation orders a rank is only well-defined where the oracle's neighbouring scores
+    # are further apart than the conv round-off (observed ~3e-7); everywhere else positions may legitimately swap.
     gap_prev = np.abs(np.diff(ref["scores"], axis=1, prepend=np.inf))
     gap_next = np.abs(np.diff(ref["scores"], axis=1, append=-np.inf))
-    safe = (gap_prev > 4 * TOL) & (gap_next > 4 * TOL)
+    safe = (gap_prev > GAP) & (gap_next > GAP)
     safe[:, -1] = False                       # the k-th may swap with the (k+1)-th
-    assert safe.mean() > 0.5
+    assert safe.mean() > 0.5, safe.mean()
     assert np.array_equal(l[safe], ref["labels"][safe])
+    if indices is not None:                   # top-k indices bit-exact
+        assert np.array_equal(indices.cpu().numpy()[safe], ref["indices"][safe])
     np.testing.assert_allclose(b[safe], ref["boxes"][safe], rtol=TOL, atol=TOL * 4)     # boxes are in pixels (x stride 4)
     return safe
 
@@ -69,10 +73,12 @@ def test_forward_and_decode_match_cpu_oracle(cfg, shape):
     else:
         dets = model.gather_detection2d(out, num_detections=k)
         ref = decode_ref.decode_detections(ref_sig["heatmap"].numpy(), ref_sig["box_2d"].numpy(), k, 3)
-    safe = compare_detections(dets, ref, k)
+    idx = cl.decode.decode(heat, box, None, k, 3, stride=model.output_stride)["indices"]
+    safe = compare_detections(dets, ref, k, idx)
     # Level A on the GPU's own tensors: indices bit-exact against the oracle decode of the same bytes
     refA = decode_ref.decode_detections(heat.cpu().numpy(), box.cpu().numpy(), k, 3,
                                         reid=out[2].cpu().numpy() if model.task == "tracking" else None)
+    assert np.array_equal(idx.cpu().numpy(), refA["indices"])                  # indices bit-exact on identical bytes
     assert np.array_equal(dets["scores"].cpu().numpy(), refA["scores"])
     assert np.array_equal(dets["labels"].cpu().numpy(), refA["labels"])
     assert np.array_equal(dets["bboxes"].cpu().numpy().view(np.uint32), refA["boxes"].view(np.uint32))
