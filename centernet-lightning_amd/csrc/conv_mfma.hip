@@ -9,7 +9,7 @@
 //   A[m][k]  = x[n, oy*s+ky-p, ox*s+kx-p, ci]   (zero outside the image; optional nearest-2x source)
 //   B[co][k] = w[co][ky][kx][ci]                (OHWI, K contiguous)
 // Tiling: workgroup tile BM x BN, BK = 32 floats (one 128-byte row per pixel / output channel);
-// each wave owns TM x TN accumulator tiles of 32x32 (v_mfma_f32_32x32x2_f32, 64-wide wavefront).
+// 4 waves, each owning TM x TN accumulator tiles of 32x32 (v_mfma_f32_32x32x2_f32, 64-wide wavefront).
 // Staging: buffer_load_dwordx4 ... lds (LDS-DMA, no VGPR round trip).  The DMA writes LDS
 // lane-linearly, so the bank-conflict swizzle is applied on the SOURCE address (which 16-byte slot of
 // the 128-byte row a lane fetches) and again on the ds_read_b128 address; out-of-image taps and
@@ -17,9 +17,18 @@
 // K order inside a BK chunk is permuted (lanes 0-31 take floats 8j..8j+3, lanes 32-63 take 8j+4..8j+7
 // of read j) so one ds_read_b128 feeds four MFMAs; A and B use the same permutation, so the sum is
 // unchanged up to fp32 summation order.
-// Pipeline: 2 LDS stages, one barrier per K chunk, 2 workgroups per CU so one group's DMA wait
-// overlaps the other's MFMAs.  Block ids are remapped so each XCD works on a contiguous run of tiles.
+// Pipeline: 2 LDS stages, one barrier per K chunk, the next chunk's DMA (address math included) issued
+// under the current chunk's MFMAs, fragments for read j+1 prefetched while read j's MFMAs run,
+// 2 workgroups per CU.  Block ids are remapped so each XCD works on a contiguous run of tiles.
+//
+// Instruction budget outside the MFMA stream.  A workgroup's tile prologue / epilogue runs beside the
+// co-resident workgroup's MFMA stream and only gets the issue slots that stream leaves free: measured,
+// a ~3000-instruction prologue took 20-35 us there (5.6 us alone) — a quarter of a K=576 tile.  So the
+// prologue is kept to a few hundred instructions: magic-number division for (n,oy,ox), compile-time tap
+// loops (KS template), accumulators zeroed by 4 MFMAs instead of 64 v_mov, and the epilogue addresses
+// ride on the buffer instructions' scalar offset (no per-store VALU address math).
 #include "cnl_common.h"
+#include <cstdlib>
 
 namespace cnl_conv {
 
@@ -38,12 +47,14 @@ struct ConvArgs {
     int HL, WL;        // logical input size (2x when CNL_UPSAMPLE_IN)
     int Ho, Wo, M;     // conv output size, M = N*Ho*Wo
     int CC, KT, K;     // Cin/32, KH*KW*CC, KH*KW*Cin
-    unsigned x_bytes, w_bytes;
+    unsigned x_bytes, w_bytes, y_bytes, r_bytes;
     unsigned flags;
     int tiles_n, tiles;
+    unsigned mg_hw, sh_hw, mg_w, sh_w;   // magic division by Ho*Wo and by Wo (exact for n < 2^31)
+    long long* trace;                    // CNL_TRACE builds only: per-workgroup phase timestamps
 };
 
-constexpr unsigned OOB = 0xFFFFFFF0u;   // voffset that is always >= num_records -> DMA writes zeros
+constexpr unsigned OOB = 0xFFFFFFF0u;   // voffset that is always >= num_records -> DMA writes zeros / store dropped
 
 template <int WM, int WN, int TM, int TN>
 struct Cfg {
@@ -55,23 +66,76 @@ struct Cfg {
     static constexpr int B_INSTR = BN / (NW * 8);
     static constexpr int STAGE_BYTES = (BM + BN) * 128;
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static_assert(NW == 4, "kernel is declared __launch_bounds__(256, 2)");
     static_assert(BM % (NW * 8) == 0 && BN % (NW * 8) == 0, "tile rows must split evenly over waves");
-    static_assert(THREADS == 256, "kernel is declared __launch_bounds__(256, 2)");
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
 
 // amdgcn builtins are wrapped in NON-template device functions: called with template-dependent arguments
 // directly inside the kernel template they make hipcc's host pass silently drop the kernel's host stub.
-__device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* lds_dst, unsigned voffset) {
+__device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* lds_dst, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 0, 0);
+}
+__device__ __forceinline__ float buf_load(const float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset, soffset, 0));
+}
+__device__ __forceinline__ void buf_store(float v, float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voffset, soffset, 0);
 }
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x16 mfma_zero() {        // 16 zeroed accumulator registers from ONE instruction
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, z, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 lds_read16(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
+// n / d for n < 2^31 with host-computed (magic, shift); shift == 0xFF encodes d == 1
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, unsigned shift) {
+    return shift == 0xFFu ? n : (__umulhi(n, magic) >> shift);
+}
 
-template <int WM, int WN, int TM, int TN, bool UP_IN>
+// Epilogue for one 32x32 accumulator tile: + bias (+ residual) -> max(.,lo) -> (sigmoid) -> NHWC store.
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+// `voff` = byte offset of (row 0 of this lane, col); the row's r-dependent part goes in the scalar offset.
+template <bool CHECK, bool RES>
+__device__ __forceinline__ void store_tile(const f32x16& acc, float bv, float lo, bool sigm, const ConvArgs& a, unsigned y_voff,
+                                           unsigned r_voff, int m_base, bool col_ok) {
+    float v[16];
+    if constexpr (RES) {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            const bool ok = !CHECK || (col_ok && m_base + ro < a.M);
+            rv[r] = buf_load(a.res, a.r_bytes, ok ? r_voff : OOB, (unsigned)(ro * a.ldr * 4));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r] + bv + rv[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r] + bv;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], lo);
+    if (sigm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ro = (r & 3) + 8 * (r >> 2);
+        const bool ok = !CHECK || (col_ok && m_base + ro < a.M);
+        buf_store(v[r], a.y, a.y_bytes, ok ? y_voff : OOB, (unsigned)(ro * a.ldy * 4));
+    }
+}
+
+// KS: compile-time square kernel size (1 or 3), or 0 = run-time KH x KW (<= 32 taps).
+template <int WM, int WN, int TM, int TN, int KS, bool UP_IN>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     using C = Cfg<WM, WN, TM, TN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -80,35 +144,57 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int hi = lane >> 5;
+#ifdef CNL_TRACE
+    const long long t_start = wall_clock64();
+#endif
 
     const unsigned tile = cnl::xcd_remap(blockIdx.x, (unsigned)a.tiles);
     const int n_tile = tile % a.tiles_n;
     const int m_tile = tile / a.tiles_n;
     const int m0 = m_tile * C::BM;
     const int n0 = n_tile * C::BN;
+    const int KH = KS ? KS : a.KH, KW = KS ? KS : a.KW;
 
-    // ---- per-lane staging bookkeeping: which rows this lane fetches, and which 16-B slot ----
+    // ---- per-lane staging bookkeeping (once per tile) ----
+    // Row r of the A tile is output pixel m0+r; this lane fetches rows (j*NW+wave)*8 + lane/8, j < A_INSTR, always the
+    // same 16-byte slot.  a_mask bit t: tap t=(ky*KW+kx) of that row lies inside the image (and m < M); a_base: byte
+    // offset of tap (0,0), channel 0 (+ swizzled slot).  Per chunk a wave-uniform delta is added — in the VECTOR
+    // offset: a_base is "negative" (wrapped) for border pixels and the bounds check looks at the vector offset alone.
     const int lrow = lane >> 3;      // row within the 8-row group one DMA instruction covers
     const int pslot = lane & 7;      // physical 16-B slot inside the 128-B LDS row
-    int a_iy0[C::A_INSTR], a_ix0[C::A_INSTR], a_pix[C::A_INSTR], a_q[C::A_INSTR];
+    unsigned a_mask[C::A_INSTR], a_base[C::A_INSTR];
+    int a_iy0[UP_IN ? C::A_INSTR : 1], a_ix0[UP_IN ? C::A_INSTR : 1];
 #pragma unroll
     for (int j = 0; j < C::A_INSTR; ++j) {
         const int r = (j * C::NW + wave) * 8 + lrow;
         const int m = m0 + r;
-        a_q[j] = (pslot ^ ((r >> 1) & 7)) * 4;          // logical slot (in floats) fetched into pslot
-        if (m < a.M) {
-            const int hw = a.Ho * a.Wo;
-            const int n = m / hw;
-            const int rem = m - n * hw;
-            const int oy = rem / a.Wo;
-            const int ox = rem - oy * a.Wo;
-            a_iy0[j] = oy * a.stride - a.pad;
-            a_ix0[j] = ox * a.stride - a.pad;
-            a_pix[j] = n * a.Hin * a.Win;
+        const int q = (pslot ^ ((r >> 1) & 7)) * 4;          // logical slot (in floats) fetched into pslot
+        const unsigned n = fast_div((unsigned)m, a.mg_hw, a.sh_hw);
+        const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
+        const unsigned oy = fast_div(rem, a.mg_w, a.sh_w);
+        const unsigned ox = rem - oy * (unsigned)a.Wo;
+        const int iy0 = (int)oy * a.stride - a.pad;
+        const int ix0 = (int)ox * a.stride - a.pad;
+        unsigned mask = 0;
+        if constexpr (KS != 0) {
+            unsigned xb = 0;
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) xb |= ((unsigned)(ix0 + kx) < (unsigned)a.WL) ? (1u << kx) : 0u;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) mask |= ((unsigned)(iy0 + ky) < (unsigned)a.HL) ? (xb << (ky * KS)) : 0u;
         } else {
-            a_iy0[j] = -0x40000000;                     // never valid
-            a_ix0[j] = 0;
-            a_pix[j] = 0;
+            for (int ky = 0; ky < KH; ++ky)
+                for (int kx = 0; kx < KW; ++kx)
+                    if ((unsigned)(iy0 + ky) < (unsigned)a.HL && (unsigned)(ix0 + kx) < (unsigned)a.WL) mask |= 1u << (ky * KW + kx);
+        }
+        a_mask[j] = m < a.M ? mask : 0u;
+        const int pix = (int)n * a.Hin * a.Win;
+        if constexpr (UP_IN) {
+            a_iy0[j] = iy0;
+            a_ix0[j] = ix0;
+            a_base[j] = (unsigned)((pix * a.ldx + q) * 4);
+        } else {
+            a_base[j] = (unsigned)(((pix + iy0 * a.Win + ix0) * a.ldx + q) * 4);   // may wrap; used only when the tap is valid
         }
     }
     unsigned b_off[C::B_INSTR];
@@ -119,126 +205,208 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         b_off[j] = (unsigned)(((n0 + r) * a.K + q) * 4);   // rows >= Cout land beyond w_bytes -> zeros
     }
 
-    // LDS-DMA of K chunk (ky,kx,c0) / kbase into `stage`.  (A macro, not a lambda: a lambda holding amdgcn
-    // builtins inside a kernel template silently blocks hipcc's host-side instantiation of the kernel stub.)
-#define CNL_ISSUE(stage_, ky_, kx_, c0_, kbase_)                                                                 \
-    do {                                                                                                         \
-        char* sA_ = smem + (stage_) * C::STAGE_BYTES;                                                            \
-        char* sB_ = sA_ + C::BM * 128;                                                                           \
-        _Pragma("unroll") for (int j = 0; j < C::A_INSTR; ++j) {                                                 \
-            const int iy = a_iy0[j] + (ky_);                                                                     \
-            const int ix = a_ix0[j] + (kx_);                                                                     \
-            const bool ok = (unsigned)iy < (unsigned)a.HL && (unsigned)ix < (unsigned)a.WL;                      \
-            const int sy = UP_IN ? (iy >> 1) : iy;                                                               \
-            const int sx = UP_IN ? (ix >> 1) : ix;                                                               \
-            const unsigned off = (unsigned)(((a_pix[j] + sy * a.Win + sx) * a.ldx + (c0_) + a_q[j]) * 4);        \
-            dma16(a.x, a.x_bytes, sA_ + (j * C::NW + wave) * 1024, ok ? off : OOB);                              \
-        }                                                                                                        \
-        _Pragma("unroll") for (int j = 0; j < C::B_INSTR; ++j) {                                                 \
-            dma16(a.w, a.w_bytes, sB_ + (j * C::NW + wave) * 1024, b_off[j] + (unsigned)((kbase_) * 4));         \
-        }                                                                                                        \
+    // LDS-DMA of K chunk (tap_, ky_, kx_, c0_) into `stage_`.  (A macro, not a lambda: see the note above.)
+#define CNL_ISSUE(stage_, tap_, ky_, kx_, c0_, kbase_)                                                            \
+    do {                                                                                                          \
+        char* sA_ = smem + (stage_) * C::STAGE_BYTES;                                                             \
+        char* sB_ = sA_ + C::BM * 128;                                                                            \
+        const unsigned bit_ = 1u << (tap_);                                                                       \
+        const unsigned delta_ = UP_IN ? (unsigned)((c0_) * 4) : (unsigned)((((ky_) * a.Win + (kx_)) * a.ldx + (c0_)) * 4); \
+        _Pragma("unroll") for (int j = 0; j < C::A_INSTR; ++j) {                                                  \
+            unsigned off_ = a_base[j] + delta_;                                                                   \
+            if constexpr (UP_IN)                                                                                  \
+                off_ += (unsigned)(((((a_iy0[j] + (ky_)) >> 1) * a.Win + ((a_ix0[j] + (kx_)) >> 1)) * a.ldx) * 4); \
+            dma16(a.x, a.x_bytes, sA_ + (j * C::NW + wave) * 1024, (a_mask[j] & bit_) ? off_ : OOB, 0);           \
+        }                                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < C::B_INSTR; ++j)                                                    \
+            dma16(a.w, a.w_bytes, sB_ + (j * C::NW + wave) * 1024, b_off[j], (unsigned)((kbase_) * 4));           \
     } while (0)
+
+    int tap = 0, ky = 0, kx = 0, cc = 0;     // position of the chunk being ISSUED
+#define CNL_ADVANCE()                                   \
+    do {                                                \
+        if (++cc == a.CC) {                             \
+            cc = 0;                                     \
+            ++tap;                                      \
+            if (++kx == KW) { kx = 0; ++ky; }           \
+        }                                               \
+    } while (0)
+#ifdef CNL_TRACE
+    const long long t_pro = wall_clock64();
+    const long long c_pro = clock64();
+#endif
+    CNL_ISSUE(0, 0, 0, 0, 0, 0);             // first chunk in flight before anything else
 
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_zero();
 
     // fragment read addresses (bytes inside a stage): row * 128 + ((2*jj + hi) ^ swz) * 16
     const int swz = (lane >> 1) & 7;
     const int a_row_byte = (wm * TM * 32 + (lane & 31)) * 128;
     const int b_row_byte = C::BM * 128 + (wn * TN * 32 + (lane & 31)) * 128;
+    f32x4 af[2][TM], bf[2][TN];
 
-    int ky = 0, kx = 0, cc = 0;     // position of the chunk being ISSUED
-    CNL_ISSUE(0, 0, 0, 0, 0);
-    for (int kt = 0; kt < a.KT; ++kt) {
-        const int stage = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for chunk kt has landed
-        __syncthreads();                                    // everyone's has; stage^1 is free again
-        if (kt + 1 < a.KT) {
-            if (++cc == a.CC) {
-                cc = 0;
-                if (++kx == a.KW) { kx = 0; ++ky; }
-            }
-            CNL_ISSUE(stage ^ 1, ky, kx, cc * 32, (kt + 1) * 32);
-        }
-        const char* sS = smem + stage * C::STAGE_BYTES;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int slot_byte = (((2 * jj + hi) ^ swz) << 4);
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(sS + a_row_byte + i * 32 * 128 + slot_byte);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(sS + b_row_byte + j * 32 * 128 + slot_byte);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = mfma32(af[i][c], bf[j][c], acc[i][j]);
-        }
+#define CNL_READ(buf_, stage_ptr_, jj_)                                                                           \
+    do {                                                                                                          \
+        const int sb_ = (((2 * (jj_) + hi) ^ swz) << 4);                                                          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) af[buf_][i] = lds_read16((stage_ptr_) + a_row_byte + i * 32 * 128 + sb_); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[buf_][j] = lds_read16((stage_ptr_) + b_row_byte + j * 32 * 128 + sb_); \
+    } while (0)
+#define CNL_MFMA(buf_)                                                                                            \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                             \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                        \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                    \
+                    acc[i][j] = mfma32(af[buf_][i][c], bf[buf_][j][c], acc[i][j]);                                \
+    } while (0)
+    // scheduling pin for "issue the next group's fragment reads right after the first MFMA of this group": hipcc otherwise
+    // sinks the ds_reads to just before their first use and exposes the LDS latency four times per chunk
+#define CNL_SCHED_RM()                                                     \
+    do {                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN - 1, 0);   \
+    } while (0)
+    // One K chunk (64 MFMAs per wave).  Fragments are always read one 16-MFMA group ahead of their use, and the
+    // hand-over to the next chunk (DMA wait + barrier + first fragment read of chunk kt+1 + DMA issue of chunk kt+2)
+    // happens BEFORE the last MFMA group of chunk kt, so neither the barrier nor LDS latency is exposed:
+    //   barrier B_kt guarantees (a) every wave has finished reading chunk kt's stage -> it may be refilled with chunk kt+2,
+    //                           (b) every wave's DMA of chunk kt+1 has landed        -> it may be read.
+#define CNL_CHUNK(kt_, SYNC_, ISSUE_)                                                                             \
+    do {                                                                                                          \
+        const char* sS = smem + ((kt_) & 1) * C::STAGE_BYTES;                                                     \
+        const char* sN = smem + (((kt_) + 1) & 1) * C::STAGE_BYTES;                                               \
+        CNL_READ(1, sS, 1);                                                                                       \
+        CNL_MFMA(0);                                                                                              \
+        CNL_SCHED_RM();                                                                                           \
+        CNL_READ(0, sS, 2);                                                                                       \
+        CNL_MFMA(1);                                                                                              \
+        CNL_SCHED_RM();                                                                                           \
+        CNL_READ(1, sS, 3);                                                                                       \
+        CNL_MFMA(0);                                                                                              \
+        CNL_SCHED_RM();                                                                                           \
+        if (SYNC_) {                                                                                              \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+            __syncthreads();                                                                                      \
+            if (ISSUE_) {                                                                                         \
+                CNL_ADVANCE();                                                                                    \
+                CNL_ISSUE((kt_) & 1, tap, ky, kx, cc * 32, ((kt_) + 2) * 32);                                     \
+            }                                                                                                     \
+            CNL_READ(0, sN, 0);                                                                                   \
+        }                                                                                                         \
+        CNL_MFMA(1);                                                                                              \
+        if (SYNC_) {                                                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   /* next chunk's first fragments at once */ \
+            if (ISSUE_) {                                                                                         \
+                _Pragma("unroll") for (int g = 0; g < C::A_INSTR + C::B_INSTR; ++g) {                             \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  /* one LDS-DMA per MFMA */                \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+    } while (0)
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk 0 landed (this wave) ...
+    __syncthreads();                                    // ... and everyone's
+    if (a.KT > 1) {
+        CNL_ADVANCE();
+        CNL_ISSUE(1, tap, ky, kx, cc * 32, 32);
     }
-
+    CNL_READ(0, smem, 0);
+    int kt = 0;
+    for (; kt + 2 < a.KT; ++kt) CNL_CHUNK(kt, true, true);
+    if (kt + 1 < a.KT) {
+        CNL_CHUNK(kt, true, false);
+        ++kt;
+    }
+    CNL_CHUNK(kt, false, false);
+#undef CNL_CHUNK
+#undef CNL_SCHED_RM
+#undef CNL_ADVANCE
 #undef CNL_ISSUE
-    // ---- epilogue: + bias (+ residual) (ReLU | sigmoid), NHWC store ----
-    // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const bool relu = a.flags & CNL_RELU;
+#undef CNL_READ
+#undef CNL_MFMA
+#ifdef CNL_TRACE
+    const long long t_loop = wall_clock64();
+    const long long c_loop = clock64();
+#endif
+
+    // ---- epilogue ----
+    const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
     const bool sigm = a.flags & CNL_SIGMOID;
-    const bool up_out = a.flags & CNL_UPSAMPLE_OUT_ADD;
+    const bool full = (m0 + C::BM <= a.M) && (n0 + C::BN <= a.Cout);
+    if (!(a.flags & CNL_UPSAMPLE_OUT_ADD)) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-        const bool col_ok = col < a.Cout;
-        const float bv = col_ok ? a.bias[col] : 0.f;
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+            const bool col_ok = col < a.Cout;
+            const float bv = col_ok ? a.bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + (wm * TM + i) * 32 + 4 * hi;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (!(col_ok && m < a.M)) continue;
-                float v = acc[i][j][r] + bv;
-                if (!up_out) {
-                    if (a.res) v += a.res[(size_t)m * a.ldr + col];
-                    if (relu) v = fmaxf(v, 0.f);
-                    if (sigm) v = 1.0f / (1.0f + expf(-v));
-                    a.y[(size_t)m * a.ldy + col] = v;
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + (wm * TM + i) * 32 + 4 * hi;
+                const unsigned y_voff = (unsigned)((mb * a.ldy + col) * 4);
+                const unsigned r_voff = (unsigned)((mb * a.ldr + col) * 4);
+                if (full) {
+                    if (a.res) store_tile<false, true>(acc[i][j], bv, lo, sigm, a, y_voff, r_voff, mb, true);
+                    else store_tile<false, false>(acc[i][j], bv, lo, sigm, a, y_voff, r_voff, mb, true);
                 } else {
-                    const int hw = a.Ho * a.Wo;
-                    const int n = m / hw;
-                    const int rem = m - n * hw;
-                    const int oy = rem / a.Wo;
-                    const int ox = rem - oy * a.Wo;
+                    if (a.res) store_tile<true, true>(acc[i][j], bv, lo, sigm, a, y_voff, r_voff, mb, col_ok);
+                    else store_tile<true, false>(acc[i][j], bv, lo, sigm, a, y_voff, r_voff, mb, col_ok);
+                }
+            }
+        }
+    } else {
+        // FPN Fuse: write the four 2x-upsampled positions, adding the skip tensor there (layers.py:160-174)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+            const bool col_ok = col < a.Cout;
+            const float bv = col_ok ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + (wm * TM + i) * 32 + 4 * hi;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (!(col_ok && m < a.M)) continue;
+                    const float v = acc[i][j][r] + bv;
+                    const unsigned n = fast_div((unsigned)m, a.mg_hw, a.sh_hw);
+                    const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
+                    const unsigned oy = fast_div(rem, a.mg_w, a.sh_w);
+                    const unsigned ox = rem - oy * (unsigned)a.Wo;
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const size_t pix = ((size_t)n * (2 * a.Ho) + 2 * oy + (d >> 1)) * (2 * a.Wo) + 2 * ox + (d & 1);
-                        float u = v + a.res[pix * a.ldr + col];
-                        if (relu) u = fmaxf(u, 0.f);
-                        a.y[pix * a.ldy + col] = u;
+                        a.y[pix * a.ldy + col] = fmaxf(v + a.res[pix * a.ldr + col], lo);
                     }
                 }
             }
         }
     }
+#ifdef CNL_TRACE
+    if (a.trace && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* t = a.trace + (long)blockIdx.x * 8;
+        t[0] = t_start; t[1] = t_pro; t[2] = t_pro; t[3] = t_loop; t[4] = wall_clock64();
+        t[5] = c_loop - c_pro;
+        t[6] = tile;
+    }
+#endif
 }
 
-template <int WM, int WN, int TM, int TN, bool UP_IN>
+template <int WM, int WN, int TM, int TN, int KS, bool UP_IN>
 int launch_one(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<WM, WN, TM, TN>;
     static bool attr_done = false;
     if (!attr_done) {
-        CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, UP_IN>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, KS, UP_IN>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, UP_IN>), dim3(a.tiles), dim3(C::THREADS), C::LDS_BYTES, stream, a);
+    static const int lds_extra = getenv("CNL_LDS_EXTRA") ? atoi(getenv("CNL_LDS_EXTRA")) : 0;   // experiments: force 1 workgroup/CU
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, KS, UP_IN>), dim3(a.tiles), dim3(C::THREADS), C::LDS_BYTES + lds_extra, stream, a);
     return cnl::check_launch("conv_mfma_kernel");
 }
 
@@ -249,8 +417,20 @@ int launch_cfg(const ConvArgs& in, hipStream_t stream) {
     const int tiles_m = (a.M + C::BM - 1) / C::BM;
     a.tiles_n = (a.Cout + C::BN - 1) / C::BN;
     a.tiles = tiles_m * a.tiles_n;
-    if (a.flags & CNL_UPSAMPLE_IN) return launch_one<WM, WN, TM, TN, true>(a, stream);
-    return launch_one<WM, WN, TM, TN, false>(a, stream);
+    const bool up = a.flags & CNL_UPSAMPLE_IN;
+    const int ks = (a.KH == a.KW && (a.KH == 1 || a.KH == 3)) ? a.KH : 0;
+    if (ks == 3) return up ? launch_one<WM, WN, TM, TN, 3, true>(a, stream) : launch_one<WM, WN, TM, TN, 3, false>(a, stream);
+    if (ks == 1 && !up) return launch_one<WM, WN, TM, TN, 1, false>(a, stream);
+    return up ? launch_one<WM, WN, TM, TN, 0, true>(a, stream) : launch_one<WM, WN, TM, TN, 0, false>(a, stream);
+}
+
+// (magic, shift) with  n / d == umulhi(n, magic) >> shift  for every n < 2^31 (d >= 2); d == 1 -> shift 0xFF.
+static void magic_u31(unsigned d, unsigned* magic, unsigned* shift) {
+    if (d <= 1) { *magic = 0; *shift = 0xFFu; return; }
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;                       // ceil(log2 d)
+    *magic = (unsigned)(((1ull << (31 + s)) / d) + 1);
+    *shift = s - 1;
 }
 
 }  // namespace cnl_conv
@@ -272,6 +452,7 @@ extern "C" int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream) {
                 "cnl_conv2d_nhwc_f32: non-positive dimension");
     CNL_REQUIRE(p->KH > 0 && p->KW > 0 && p->stride > 0 && p->pad >= 0, CNL_E_BAD_ARG,
                 "cnl_conv2d_nhwc_f32: bad kernel/stride/pad");
+    CNL_REQUIRE(p->KH * p->KW <= 32, CNL_E_UNSUPPORTED, "cnl_conv2d_nhwc_f32: KH*KW = %d > 32 taps", p->KH * p->KW);
     CNL_REQUIRE(p->Cin % 32 == 0, CNL_E_UNSUPPORTED,
                 "cnl_conv2d_nhwc_f32: Cin=%d is not a multiple of 32 (use cnl_stem_conv7x7_f32 for the RGB stem)", p->Cin);
     CNL_REQUIRE(p->ldx >= p->Cin && p->ldy >= p->Cout && p->ldx % 4 == 0, CNL_E_BAD_ARG,
@@ -298,13 +479,23 @@ extern "C" int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream) {
     CNL_REQUIRE(M < (1ll << 31) - 512, CNL_E_UNSUPPORTED, "cnl_conv2d_nhwc_f32: N*Ho*Wo too large");
     a.M = (int)M;
     a.CC = p->Cin / 32; a.KT = p->KH * p->KW * a.CC; a.K = p->KH * p->KW * p->Cin;
+    const unsigned long long lim = 0xFFFFFF00ull;
     const unsigned long long xb = (((unsigned long long)p->N * p->H_in * p->W_in - 1) * p->ldx + p->Cin) * 4ull;
     const unsigned long long wb = (unsigned long long)p->Cout * a.K * 4ull;
-    CNL_REQUIRE(xb < 0xFFFFFF00ull, CNL_E_UNSUPPORTED,
-                "cnl_conv2d_nhwc_f32: input spans %llu bytes; split the batch so it stays below 4 GiB", xb);
-    CNL_REQUIRE(wb + (unsigned long long)256 * a.K * 4ull < 0xFFFFFF00ull, CNL_E_UNSUPPORTED, "cnl_conv2d_nhwc_f32: weight too large");
-    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+    const unsigned long long Mo = up_out ? 4ull * M : (unsigned long long)M;
+    const unsigned long long yb = ((Mo - 1) * p->ldy + p->Cout) * 4ull;
+    const unsigned long long rb = p->residual ? ((Mo - 1) * p->ldr + p->Cout) * 4ull : 0ull;
+    CNL_REQUIRE(xb < lim && yb + 512ull * p->ldy * 4 < lim && rb + 512ull * p->ldr * 4 < lim, CNL_E_UNSUPPORTED,
+                "cnl_conv2d_nhwc_f32: a tensor spans >= 4 GiB (x %llu, y %llu bytes); split the batch", xb, yb);
+    CNL_REQUIRE(wb + (unsigned long long)256 * a.K * 4ull < lim, CNL_E_UNSUPPORTED, "cnl_conv2d_nhwc_f32: weight too large");
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.tiles_n = a.tiles = 0;
+    magic_u31((unsigned)(a.Ho * a.Wo), &a.mg_hw, &a.sh_hw);
+    magic_u31((unsigned)a.Wo, &a.mg_w, &a.sh_w);
+    a.trace = nullptr;
+#ifdef CNL_TRACE
+    if (const char* e = getenv("CNL_TRACE_PTR")) a.trace = (long long*)strtoull(e, nullptr, 0);
+#endif
 
     hipStream_t s = (hipStream_t)stream;
     // Tile choice: BN follows Cout; shrink BM when the grid would not fill 256 CUs x 2 workgroups.

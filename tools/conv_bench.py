@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Micro-benchmark of cnl_conv2d_nhwc_f32 on one layer shape (HIP events on the launch stream), for rocprofv3
+--pmc passes and A/B work on the conv kernel.  Usage: python tools/conv_bench.py [name ...] [--reps R]"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "centernet-lightning_amd"))
+import torch  # noqa: E402
+from centernet_lightning_amd import _lib  # noqa: E402
+from centernet_lightning_amd._lib import CNL_RELU, CNL_SIGMOID, CNL_UPSAMPLE_IN, ConvParams  # noqa: E402
+
+# name: (N, H, W, Cin, Cout, k, stride, flags, residual)
+SHAPES = {
+    "head256": (32, 128, 128, 256, 256, 3, 1, CNL_RELU, False),
+    "headfirst": (32, 64, 64, 64, 512, 3, 1, CNL_RELU | CNL_UPSAMPLE_IN, False),
+    "layer1": (32, 128, 128, 64, 64, 3, 1, CNL_RELU, False),
+    "layer1res": (32, 128, 128, 64, 64, 3, 1, CNL_RELU, True),
+    "layer2": (32, 64, 64, 128, 128, 3, 1, CNL_RELU, True),
+    "layer3": (32, 32, 32, 256, 256, 3, 1, CNL_RELU, True),
+    "layer4": (32, 16, 16, 512, 512, 3, 1, CNL_RELU, True),
+    "out80": (32, 128, 128, 256, 80, 1, 1, CNL_SIGMOID, False),
+    "out4": (32, 128, 128, 256, 4, 1, 1, 0, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("names", nargs="*", default=["head256"])
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for name in args.names:
+        N, H, W, Cin, Cout, k, stride, flags, res = SHAPES[name]
+        up = 2 if flags & CNL_UPSAMPLE_IN else 1
+        Ho, Wo = (H * up + 2 * ((k - 1) // 2) - k) // stride + 1, (W * up + 2 * ((k - 1) // 2) - k) // stride + 1
+        x = torch.randn(N, H, W, Cin, device="cuda")
+        w = torch.randn(Cout, k, k, Cin, device="cuda") * (1.0 / (Cin * k * k)) ** 0.5
+        b = torch.randn(Cout, device="cuda")
+        y = torch.empty(N, Ho, Wo, Cout, device="cuda")
+        r = torch.randn(N, Ho, Wo, Cout, device="cuda") if res else None
+        p = ConvParams()
+        p.x, p.w, p.bias, p.y = x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr()
+        p.residual = r.data_ptr() if res else None
+        p.N, p.H_in, p.W_in, p.Cin, p.Cout = N, H, W, Cin, Cout
+        p.KH, p.KW, p.stride, p.pad = k, k, stride, (k - 1) // 2
+        p.ldx, p.ldy, p.ldr, p.flags = Cin, Cout, Cout, flags | (int(os.environ.get("CNL_DEBUG_FLAGS", "0")))
+        for _ in range(2):
+            _lib.check(lib.cnl_conv2d_nhwc_f32(ctypes.byref(p), stream))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            lib.cnl_conv2d_nhwc_f32(ctypes.byref(p), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.reps
+        flops = 2.0 * N * Ho * Wo * Cout * k * k * Cin
+        print(f"{name:10s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s  ({flops / 1e9:.1f} GFLOP)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
