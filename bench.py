@@ -30,6 +30,10 @@ import torch.distributed as dist  # noqa: E402
 import centernet_lightning_amd as cl  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+# HBM bytes per conv launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_fetch_size.txt,
+# r01_pmc_write_size.txt): mean FETCH_SIZE 209.0 MB x 2 (gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md
+# §HBM) + mean WRITE_SIZE 115.4 MB, averaged over the 45 conv launches of a C1 step.  Other configs: not profiled -> null.
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("simple", 32, 512, 512): 533.3e6}
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 
 
@@ -89,7 +93,18 @@ def conv_kernel_profile(model, x, reps=3):
         for i, (e0, e1) in enumerate(evs):
             acc[i] += e0.elapsed_time(e1)
     rows = [(L.what, L.flops, acc[i] / reps) for i, L in enumerate(convs)]
-    return sum(r[2] for r in rows), sum(r[1] for r in rows), len(rows), rows
+    # algorithmic HBM bytes of a conv launch: input + weights + bias + output (+ residual), each touched once
+    nbytes = 0
+    for L in convs:
+        p = L.args
+        up_in = 2 if p.flags & 4 else 1
+        ho = (p.H_in * up_in + 2 * p.pad - p.KH) // p.stride + 1
+        wo = (p.W_in * up_in + 2 * p.pad - p.KW) // p.stride + 1
+        up_out = 4 if p.flags & 8 else 1
+        out_px = p.N * ho * wo * up_out
+        nbytes += 4 * (p.N * p.H_in * p.W_in * p.Cin + p.Cout * p.KH * p.KW * p.Cin + p.Cout + out_px * p.Cout
+                       + (out_px * p.Cout if p.residual else 0))
+    return sum(r[2] for r in rows), sum(r[1] for r in rows), len(rows), rows, nbytes
 
 
 def cpu_baseline(model, tracking, k, H, W, budget_s=20.0):
@@ -179,7 +194,7 @@ def main():
     result = None
     if rank == 0:
         with torch.no_grad():
-            conv_ms, conv_flops, n_launch, rows = conv_kernel_profile(model, x)
+            conv_ms, conv_flops, n_launch, rows, conv_bytes = conv_kernel_profile(model, x)
             # decode-only latency (p50) on the forward's own outputs
             out = model(x)
             lat = []
@@ -205,7 +220,10 @@ def main():
                                    f"{B} img/GPU x {H}x{W}, heads {'2+4+reid64' if tracking else '80+4'} (w256), k={args.k}, nms 3",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of detections" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": MEASURED_TRAFFIC_BYTES_PER_LAUNCH.get((args.config, B, H, W)),
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, see profiles/)",
+                         "algorithmic_bytes_per_launch": round(conv_bytes / n_launch),
                          "kernel": "cnl_conv::conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
                          "launches_per_step": n_launch, "kernel_ms_per_step": round(conv_ms, 3),
                          "algorithmic_gflop_per_step": round(conv_flops / 1e9, 2),
