@@ -72,14 +72,14 @@ def unpack_detections(rec: torch.Tensor, box_key="bboxes") -> dict:
     return out
 
 
-def all_gather_records(rec: torch.Tensor, group=None) -> torch.Tensor:
+def all_gather_records(rec: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
     """[N_local,k,R] on every rank -> [world*N_local,k,R] in rank order.  Device-agnostic torch.distributed call
     (RCCL for HIP tensors, gloo for the CPU protocol tests).  No-op without an initialised process group or at
-    world size 1."""
+    world size 1 (unless `force`, which runs the collective anyway — used to exercise the RCCL path on one GPU)."""
     if not (dist.is_available() and dist.is_initialized()):
         return rec
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return rec
     rec = rec.contiguous()
     out = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), device=rec.device, dtype=rec.dtype)
@@ -87,9 +87,9 @@ def all_gather_records(rec: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
-def collate_detections(dets: dict, group=None) -> dict:
+def collate_detections(dets: dict, group=None, force: bool = False) -> dict:
     """All ranks call this with their local detections; every rank gets the global, rank-ordered detections."""
     box_key = "bboxes" if "bboxes" in dets else "boxes"
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return dets
-    return unpack_detections(all_gather_records(pack_detections(dets), group), box_key=box_key)
+    return unpack_detections(all_gather_records(pack_detections(dets), group, force), box_key=box_key)

@@ -159,3 +159,24 @@ def test_pack_unpack_and_collate_single_process():
     for key in dets:
         assert torch.equal(u[key], dets[key])
     assert cl.collate_detections(dets) is dets               # world size 1: no-op (eval/coco.py:11-13)
+
+
+def test_collate_through_rccl_single_rank():
+    """The real collective path (pack kernel -> RCCL all_gather_into_tensor on HIP memory -> unpack kernel) on the one GPU
+    this box has: a world-size-1 "nccl" group with the gather forced.  The multi-rank ordering is covered on CPU (gloo)."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        ins = recipes.decode_inputs(4, (3, 2, 16, 24), 8)
+        o = hip_decode.decode(*[t.cuda() for t in ins], 25, 3)
+        dets = {"bboxes": o["boxes"], "scores": o["scores"], "labels": o["labels"], "embeddings": o["embeddings"]}
+        g = cl.collate_detections(dets, force=True)
+        torch.cuda.synchronize()
+        assert g is not dets
+        for key in dets:
+            assert torch.equal(g[key], dets[key]), key
+    finally:
+        dist.destroy_process_group()
