@@ -77,6 +77,16 @@ int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream);
 int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);
 
 /*
+ * The same fused layer for 3x3 / stride 1 / pad 1 (ResNet BasicBlock convs, make_conv, GenericHead blocks) computed by
+ * Winograd F(2x2,3x3): 2.25x fewer matrix-core multiplies, same result up to fp32 rounding (see csrc/winograd.hip).
+ * `p->w` must point to the PRE-TRANSFORMED weights produced by cnl_winograd_transform_weights_f32 from the OHWI
+ * (BN-folded) weights; flags: CNL_RELU only (upsample / sigmoid variants stay on cnl_conv2d_nhwc_f32). Cin % 8 == 0.
+ */
+int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream);
+size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout);        /* elements of the transformed weight buffer */
+int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream);
+
+/*
  * ResNet stem: Conv2d(3,64,7,stride=2,padding=3,bias=False)+BN+ReLU (torchvision resnet.conv1/bn1/relu).
  * x is read through explicit element strides (sn,sc,sh,sw) so NCHW-contiguous and channels_last
  * callers are both zero-copy (models/meta.py:97-98 precedent); y is NHWC [N, H/2, W/2, 64].

@@ -170,3 +170,65 @@ def test_maxpool_matches_cpu_bit_exact(shape):
     _lib.check(lib.cnl_maxpool3x3s2_nhwc_f32(xd.data_ptr(), y.data_ptr(), N, H, W, C, _stream()))
     torch.cuda.synchronize()
     assert torch.equal(y.cpu().permute(0, 3, 1, 2), ref)
+
+
+# ----------------------------------------------------------------------------- Winograd F(2x2,3x3) path
+def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None):
+    lib = _lib.load()
+    N, Cin, H, W = x_nchw.shape
+    Cout = w_oihw.shape[0]
+    xd = x_nchw.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = w_oihw.permute(0, 2, 3, 1).contiguous().cuda()
+    u = torch.full((lib.cnl_winograd_weight_floats(Cin, Cout),), float("nan"), device="cuda")
+    _lib.check(lib.cnl_winograd_transform_weights_f32(wd.data_ptr(), u.data_ptr(), Cin, Cout, _stream()))
+    bd = bias.cuda()
+    y = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    p = ConvParams()
+    p.x, p.w, p.bias, p.y = xd.data_ptr(), u.data_ptr(), bd.data_ptr(), y.data_ptr()
+    p.N, p.H_in, p.W_in, p.Cin, p.Cout = N, H, W, Cin, Cout
+    p.KH = p.KW = 3
+    p.stride, p.pad, p.ldx, p.ldy, p.flags = 1, 1, Cin, Cout, flags
+    rd = None
+    if residual is not None:
+        rd = residual.permute(0, 2, 3, 1).contiguous().cuda()
+        p.residual, p.ldr = rd.data_ptr(), Cout
+    _lib.check(lib.cnl_conv3x3_winograd_f32(ctypes.byref(p), _stream()), "winograd")
+    torch.cuda.synchronize()
+    return y.cpu().permute(0, 3, 1, 2)
+
+
+WINO_CASES = [
+    # N, Cin, H, W, Cout, relu, residual
+    (2, 64, 16, 16, 64, True, False),
+    (1, 256, 32, 32, 256, True, True),         # K = 2304, residual
+    (2, 64, 128, 128, 64, True, True),         # layer1 shape (many blocks)
+    (1, 512, 16, 16, 512, True, True),         # layer4
+    (1, 8, 6, 10, 40, False, False),           # tiny, Cout tail (40 -> padded 64), partial 16x16 block
+    (2, 24, 19, 34, 96, True, False),          # odd height (608x1088 /32 grid), ragged blocks
+    (1, 128, 40, 24, 128, False, True),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "N{}c{}_{}x{}_o{}relu{}res{}".format(*[int(v) for v in c]))
+def test_winograd_matches_cpu(case):
+    N, Cin, H, W, Cout, relu, use_res = case
+    x, w, b = mk(N, Cin, H, W, Cout, 3, seed=Cin + Cout + H + W)
+    res = torch.randn(N, Cout, H, W, generator=torch.Generator().manual_seed(6)) if use_res else None
+    flags = CNL_RELU if relu else 0
+    ref = ref_conv(x, w, b, 1, flags, res)
+    out = run_winograd(x, w, b, flags, res)
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out, ref, rtol=RTOL, atol=ATOL)
+    # and against the direct MFMA kernel: both are fp32-rounding-level restatements of the same sum
+    if Cin % 32 == 0:
+        torch.testing.assert_close(out, run_conv(x, w, b, 1, flags, res), rtol=1e-5, atol=2e-5)
+
+
+def test_winograd_exact_on_small_integers():
+    """With small-integer inputs and weights in multiples of 4 every Winograd intermediate (the 1/2 and 1/4 factors of G g G^T
+    included) is an exact fp32 integer, so layout / index mistakes show up as hard mismatches."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(-3, 4, (2, 16, 12, 20), generator=g).float()
+    w = torch.randint(-2, 3, (48, 16, 3, 3), generator=g).float() * 4
+    b = torch.randint(-5, 6, (48,), generator=g).float()
+    assert torch.equal(run_winograd(x, w, b, 0), ref_conv(x, w, b, 1, 0))

@@ -30,6 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("names", nargs="*", default=["head256"])
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--winograd", action="store_true")
     args = ap.parse_args()
     lib = _lib.load()
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -48,13 +49,22 @@ def main():
         p.N, p.H_in, p.W_in, p.Cin, p.Cout = N, H, W, Cin, Cout
         p.KH, p.KW, p.stride, p.pad = k, k, stride, (k - 1) // 2
         p.ldx, p.ldy, p.ldr, p.flags = Cin, Cout, Cout, flags | (int(os.environ.get("CNL_DEBUG_FLAGS", "0")))
+        fn = lib.cnl_conv2d_nhwc_f32
+        if args.winograd:
+            if k != 3 or stride != 1 or flags & CNL_UPSAMPLE_IN:
+                continue
+            u = torch.empty(lib.cnl_winograd_weight_floats(Cin, Cout), device="cuda")
+            _lib.check(lib.cnl_winograd_transform_weights_f32(w.data_ptr(), u.data_ptr(), Cin, Cout, stream))
+            p.w = u.data_ptr()
+            p.flags = flags & 1
+            fn = lib.cnl_conv3x3_winograd_f32
         for _ in range(2):
-            _lib.check(lib.cnl_conv2d_nhwc_f32(ctypes.byref(p), stream))
+            _lib.check(fn(ctypes.byref(p), stream))
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
-            lib.cnl_conv2d_nhwc_f32(ctypes.byref(p), stream)
+            fn(ctypes.byref(p), stream)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
