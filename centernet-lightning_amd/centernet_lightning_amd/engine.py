@@ -13,6 +13,7 @@ Fusions relative to the reference's op-per-layer graph (results identical up to 
   * heatmap .sigmoid() (centernet.py:205)                 -> epilogue of the heatmap out_conv
 """
 import ctypes
+import os
 from collections import OrderedDict
 
 import torch
@@ -36,14 +37,30 @@ def fold_conv_bn(conv_w, conv_b, bn=None):
     return w.permute(0, 2, 3, 1).contiguous(), b.contiguous()
 
 
+def winograd_enabled():
+    """3x3 / stride-1 layers run through the Winograd F(2x2,3x3) kernel unless CNL_WINOGRAD=0 (then every conv takes the
+    direct implicit-GEMM kernel; same results up to fp32 rounding)."""
+    return os.environ.get("CNL_WINOGRAD", "1") != "0"
+
+
 class _Layer:
-    """One packed conv layer: folded OHWI weight + bias on the device."""
+    """One packed conv layer: folded OHWI weight + bias on the device (+ the Winograd-transformed weight for
+    3x3 / stride-1 layers, produced once by cnl_winograd_transform_weights_f32)."""
 
     def __init__(self, w_ohwi, bias, stride=1):
         self.w, self.b = w_ohwi, bias
         self.cout, self.kh, self.kw, self.cin = w_ohwi.shape
         self.stride = stride
         self.pad = (self.kh - 1) // 2
+        self.u = None
+        if self.kh == 3 and self.kw == 3 and stride == 1 and self.cin % 8 == 0 and w_ohwi.is_cuda and winograd_enabled():
+            lib = _lib.load()
+            n = lib.cnl_winograd_weight_floats(self.cin, self.cout)
+            with torch.cuda.device(w_ohwi.device):
+                self.u = torch.empty((n,), device=w_ohwi.device, dtype=torch.float32)
+                stream = ctypes.c_void_p(torch.cuda.current_stream(w_ohwi.device).cuda_stream)
+                _lib.check(lib.cnl_winograd_transform_weights_f32(w_ohwi.data_ptr(), self.u.data_ptr(), self.cin, self.cout, stream),
+                           "cnl_winograd_transform_weights_f32")
 
 
 class PackedWeights:
@@ -130,8 +147,13 @@ class Plan:
         p.flags = flags
         ho, wo = ctypes.c_int32(), ctypes.c_int32()
         _lib.check(self.lib.cnl_conv2d_out_hw(ctypes.byref(p), ctypes.byref(ho), ctypes.byref(wo)), what)
-        flops = 2 * self.N * ho.value * wo.value * layer.cout * layer.kh * layer.kw * layer.cin
-        self.launches.append(_Launch(self.lib.cnl_conv2d_nhwc_f32, p, what, flops, keep=(x, y, residual, layer)))
+        flops = 2 * self.N * ho.value * wo.value * layer.cout * layer.kh * layer.kw * layer.cin   # direct-conv (algorithmic) flops
+        fn = self.lib.cnl_conv2d_nhwc_f32
+        if layer.u is not None and not (flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD | CNL_SIGMOID)) and (4 * x_off) % 16 == 0:
+            p.w = layer.u.data_ptr()
+            fn = self.lib.cnl_conv3x3_winograd_f32
+            what += " [winograd]"
+        self.launches.append(_Launch(fn, p, what, flops, keep=(x, y, residual, layer)))
         return p, ho.value, wo.value
 
     def _build(self, Wt):

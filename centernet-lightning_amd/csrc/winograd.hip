@@ -22,6 +22,7 @@
 // LDS: V 32 KB + U 2 x 16 KB + patch 12 KB = 76 KB -> 2 workgroups per CU: one group's transform phase (VALU + LDS)
 // runs under the other's MFMA phase.
 #include "cnl_common.h"
+#include <cstdlib>
 
 namespace cnl_wino {
 
@@ -42,15 +43,18 @@ struct WinoArgs {
     int blocks;
     unsigned x_bytes, u_bytes;
     unsigned flags;
+    long long* trace;             // CNL_TRACE builds only
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
-constexpr int T = 64;                       // tiles per workgroup (8 x 8)
+constexpr int T = 64;                       // tiles per workgroup (8 x 8 -> 16 x 16 output pixels)
+constexpr int BN = 64;                      // output channels per workgroup
 constexpr int PW = 18;                      // patch width / height in pixels
-constexpr int V_BYTES = 16 * T * 32;        // 32768
-constexpr int U_BYTES = 16 * 32 * 32;       // 16384 per buffer
-constexpr int P_BYTES = 3 * 256 * 16;       // 12288 (648 slots used)
-constexpr int LDS_BYTES = V_BYTES + 2 * U_BYTES + P_BYTES;   // 77824
+constexpr int V_BYTES = 16 * T * 32;        // 32768 per buffer
+constexpr int U_BYTES = 16 * BN * 32;       // 32768 per buffer
+constexpr int P_SLOTS = 704;                // 648 used; 512 (all waves) + 192 (waves 0-2)
+constexpr int P_BYTES = P_SLOTS * 16;       // 11264 per buffer
+constexpr int LDS_BYTES = 2 * V_BYTES + 2 * U_BYTES + 2 * P_BYTES;   // 153600 -> one 8-wave workgroup per CU
 
 __device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* lds_dst, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
@@ -63,17 +67,23 @@ __device__ __forceinline__ f32x16 mfma_zero() {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     return __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, z, 0, 0, 0);
 }
+__device__ __forceinline__ float lds_f(const char* p) { return *reinterpret_cast<const float*>(p); }
+__device__ __forceinline__ f32x4 lds_f4(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-__global__ __launch_bounds__(256, 2) void winograd_conv_kernel(const WinoArgs a) {
+// 8 waves: wave w owns transform positions xi = 2w, 2w+1, for all 64 tiles (2 groups of 32) x 64 couts (2 groups of 32).
+__global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sV = smem;
-    char* sU = smem + V_BYTES;
-    char* sP = smem + V_BYTES + 2 * U_BYTES;
+    char* sV = smem;                                  // [2][16 xi][64 tiles][8 ci]
+    char* sU = smem + 2 * V_BYTES;                    // [2][16 xi][64 co][8 ci]
+    char* sP = smem + 2 * V_BYTES + 2 * U_BYTES;      // [2][18*18 px][8 ci] (+ slack)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
+#ifdef CNL_TRACE
+    const long long t_start = wall_clock64();
+#endif
 
     // block -> (image n, tile-block row/col, cout block); cout fastest so the blocks sharing a patch are neighbours
     unsigned b = cnl::xcd_remap(blockIdx.x, (unsigned)a.blocks);
@@ -81,156 +91,238 @@ __global__ __launch_bounds__(256, 2) void winograd_conv_kernel(const WinoArgs a)
     const int bxi = b % a.bx; b /= a.bx;
     const int byi = b % a.by;
     const int n = b / a.by;
-    const int y0 = byi * 16, x0 = bxi * 16, n0 = nbi * 32;
+    const int y0 = byi * 16, x0 = bxi * 16, n0 = nbi * BN;
 
     // ---- per-lane DMA bookkeeping ----
-    unsigned p_off[3];
+    unsigned p_off[2];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int s = i * 256 + tid;                  // 16-byte slot of the patch: pixel s>>1, channel half s&1
+    for (int i = 0; i < 2; ++i) {
+        const int s = i * 512 + tid;                  // 16-byte slot of the patch: pixel s>>1, channel half s&1
         const int px = s >> 1, half = s & 1;
         const int py = px / PW, pxx = px - py * PW;
         const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
         const bool ok = s < PW * PW * 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         p_off[i] = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.ldx + half * 4) * 4) : OOB;
     }
-    unsigned u_off[4];
+    unsigned u_off[2];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) u_off[p] = (unsigned)((((wave * 4 + p) * a.CoutP + n0) * 8) * 4 + lane * 16);
+    for (int p = 0; p < 2; ++p) u_off[p] = (unsigned)((((wave * 2 + p) * a.CoutP + n0) * 8) * 4 + lane * 16);
     const unsigned u_chunk = (unsigned)(16 * a.CoutP * 8 * 4);          // bytes per channel chunk of U
 
-#define WINO_ISSUE(cc_)                                                                                          \
+#define WINO_ISSUE_P(cc_)                                                                                        \
     do {                                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                            \
-            dma16(a.x, a.x_bytes, sP + (i * 256 + wave * 64) * 16, p_off[i] == OOB ? OOB : p_off[i] + (unsigned)((cc_) * 32), 0); \
-        _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                            \
-            dma16(a.u, a.u_bytes, sU + ((cc_) & 1) * U_BYTES + (wave * 4 + p) * 1024, u_off[p], (unsigned)(cc_) * u_chunk); \
+        char* d_ = sP + ((cc_) & 1) * P_BYTES;                                                                   \
+        const bool live_ = (cc_) < a.CC;                   /* prefetch past the end: all lanes out of bounds -> zeros */ \
+        dma16(a.x, a.x_bytes, d_ + (wave * 64) * 16, (p_off[0] == OOB || !live_) ? OOB : p_off[0] + (unsigned)((cc_) * 32), 0); \
+        if (wave < 3) dma16(a.x, a.x_bytes, d_ + (512 + wave * 64) * 16, (p_off[1] == OOB || !live_) ? OOB : p_off[1] + (unsigned)((cc_) * 32), 0); \
+    } while (0)
+#define WINO_ISSUE_U(cc_)                                                                                        \
+    do {                                                                                                         \
+        char* d_ = sU + ((cc_) & 1) * U_BYTES;                                                                   \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                          \
+            dma16(a.u, a.u_bytes, d_ + (wave * 2 + p) * 2048, u_off[p], (unsigned)(cc_) * u_chunk);              \
+            dma16(a.u, a.u_bytes, d_ + (wave * 2 + p) * 2048 + 1024, u_off[p] + 1024u, (unsigned)(cc_) * u_chunk); \
+        }                                                                                                        \
     } while (0)
 
-    WINO_ISSUE(0);
+    // transform item: thread -> (tile = tid >> 3, ch = tid & 7)
+    const int t_ch = tid & 7, t_tile = tid >> 3;
+    const int t_src = (((2 * (t_tile >> 3)) * PW + 2 * (t_tile & 7)) * 8 + t_ch) * 4;
+    const int t_dst = (t_tile * 8 + t_ch) * 4;
+    // input transform of one chunk: patch buffer pb_ -> V buffer vb_ (B^T d B, 16 reads / 32 adds / 16 writes per thread)
+#define WINO_TRANSFORM(pb_, vb_)                                                                                 \
+    do {                                                                                                         \
+        const char* src_ = sP + (pb_) * P_BYTES + t_src;                                                         \
+        float d_[4][4], t_[4][4];                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) d_[i][j] = lds_f(src_ + (i * PW + j) * 32);            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+            t_[0][j] = d_[0][j] - d_[2][j];                                                                      \
+            t_[1][j] = d_[1][j] + d_[2][j];                                                                      \
+            t_[2][j] = d_[2][j] - d_[1][j];                                                                      \
+            t_[3][j] = d_[1][j] - d_[3][j];                                                                      \
+        }                                                                                                        \
+        char* dst_ = sV + (vb_) * V_BYTES + t_dst;                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+            *reinterpret_cast<float*>(dst_ + (i * 4 + 0) * (T * 32)) = t_[i][0] - t_[i][2];                      \
+            *reinterpret_cast<float*>(dst_ + (i * 4 + 1) * (T * 32)) = t_[i][1] + t_[i][2];                      \
+            *reinterpret_cast<float*>(dst_ + (i * 4 + 2) * (T * 32)) = t_[i][2] - t_[i][1];                      \
+            *reinterpret_cast<float*>(dst_ + (i * 4 + 3) * (T * 32)) = t_[i][1] - t_[i][3];                      \
+        }                                                                                                        \
+    } while (0)
 
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) acc[p][g] = mfma_zero();
+    WINO_ISSUE_P(0);
+    WINO_ISSUE_U(0);
 
-    // transform item addresses (two items per thread): item idx = tid + 256*it -> (tile = idx >> 3, ch = idx & 7)
-    int t_src[2], t_dst[2];
+    f32x16 acc[2][2][2];     // [position][tile group][cout group]
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int idx = tid + 256 * it;
-        const int ch = idx & 7, tile = idx >> 3;
-        const int ty = tile >> 3, tx = tile & 7;
-        t_src[it] = (((2 * ty) * PW + 2 * tx) * 8 + ch) * 4;
-        t_dst[it] = (tile * 8 + ch) * 4;
-    }
-    // fragment addresses
-    const int a_frag = ((lane & 31) * 8 + hi * 4) * 4;      // + (xi*64 + g*32) * 32
-    const int b_frag = ((lane & 31) * 8 + hi * 4) * 4;      // + xi * 1024
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[p][g][h] = mfma_zero();
 
-    for (int cc = 0; cc < a.CC; ++cc) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    WINO_TRANSFORM(0, 0);
+    if (a.CC > 1) WINO_ISSUE_P(1);
+
+#ifdef CNL_TRACE
+    const long long t_pro = wall_clock64();
+#endif
+    const int frag = ((lane & 31) * 8 + hi * 4) * 4;      // + (xi*64 + group*32) * 32
+    // 16 position GEMMs of one chunk (this wave: 2 positions x 2 x 2 accumulator tiles, 32 MFMAs)
+#define WINO_MFMA(cc_)                                                                                           \
+    do {                                                                                                         \
+        const char* vB = sV + ((cc_) & 1) * V_BYTES + frag;                                                      \
+        const char* uB = sU + ((cc_) & 1) * U_BYTES + frag;                                                      \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                          \
+            const int xi = wave * 2 + p;                                                                         \
+            const f32x4 a0 = lds_f4(vB + (xi * 64) * 32), a1 = lds_f4(vB + (xi * 64 + 32) * 32);                 \
+            const f32x4 b0 = lds_f4(uB + (xi * 64) * 32), b1 = lds_f4(uB + (xi * 64 + 32) * 32);                 \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                      \
+                acc[p][0][0] = mfma32(a0[c], b0[c], acc[p][0][0]);                                               \
+                acc[p][0][1] = mfma32(a0[c], b1[c], acc[p][0][1]);                                               \
+                acc[p][1][0] = mfma32(a1[c], b0[c], acc[p][1][0]);                                               \
+                acc[p][1][1] = mfma32(a1[c], b1[c], acc[p][1][1]);                                               \
+            }                                                                                                    \
+        }                                                                                                        \
+    } while (0)
+
+    // steady state: ONE barrier per chunk; the transform of chunk cc+1 is straight-line code in the same block as the MFMAs
+    // of chunk cc so that its VALU / LDS instructions issue in the shadow of the matrix pipe
+    int cc = 0;
+    for (; cc + 1 < a.CC; ++cc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                   // chunk cc landed everywhere; MFMA phase cc-1 finished -> V free
-        // ---- input transform: patch -> V = B^T d B ----
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const char* src = sP + t_src[it];
-            float d[4][4];
+        __syncthreads();     // V[cc&1] complete, U[cc&1] + patch cc+1 landed; MFMA phase cc-1 and transform cc done everywhere
+        WINO_ISSUE_U(cc + 1);
+        WINO_ISSUE_P(cc + 2);                              // past the last chunk this DMA is all-OOB (see p_lim)
+        // MFMAs of chunk cc with the input transform of chunk cc+1 hand-interleaved, one slice = {1 MFMA, 2 VALU | 1 LDS write},
+        // slices fenced by sched_barrier(0): left to itself hipcc emits the whole transform after the last MFMA, where both waves
+        // of a SIMD reach it together and the matrix pipe idles (sched_group_barrier patterns were not honoured here).
+        {
+            const char* vB = sV + (cc & 1) * V_BYTES + frag;
+            const char* uB = sU + (cc & 1) * U_BYTES + frag;
+            const char* src_ = sP + ((cc + 1) & 1) * P_BYTES + t_src;
+            char* dst_ = sV + ((cc + 1) & 1) * V_BYTES + t_dst;
+            const int xi0 = wave * 2;
+            f32x4 fa[2], fb[2];
+            fa[0] = lds_f4(vB + (xi0 * 64) * 32); fa[1] = lds_f4(vB + (xi0 * 64 + 32) * 32);
+            fb[0] = lds_f4(uB + (xi0 * 64) * 32); fb[1] = lds_f4(uB + (xi0 * 64 + 32) * 32);
+            float d_[4][4], t_[4][4], v_[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const float*>(src + (i * PW + j) * 32);
-            float t[4][4];
+                for (int j = 0; j < 4; ++j) d_[i][j] = lds_f(src_ + (i * PW + j) * 32);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 ga[2], gb[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t[0][j] = d[0][j] - d[2][j];
-                t[1][j] = d[1][j] + d[2][j];
-                t[2][j] = d[2][j] - d[1][j];
-                t[3][j] = d[1][j] - d[3][j];
+            for (int k = 0; k < 16; ++k) {
+                const int c = k >> 2, g = (k >> 1) & 1, h = k & 1;
+                acc[0][g][h] = mfma32(fa[g][c], fb[h][c], acc[0][g][h]);
+#pragma unroll
+                for (int e = 2 * k; e < 2 * k + 2; ++e) {
+                    if (e < 16) {                                   // t = B^T d   (column j of d)
+                        const int i = e & 3, j = e >> 2;
+                        t_[i][j] = i == 0 ? d_[0][j] - d_[2][j] : i == 1 ? d_[1][j] + d_[2][j] : i == 2 ? d_[2][j] - d_[1][j] : d_[1][j] - d_[3][j];
+                    } else {                                        // V = t B     (row i of t)
+                        const int i = (e - 16) >> 2, jj = (e - 16) & 3;
+                        v_[i][jj] = jj == 0 ? t_[i][0] - t_[i][2] : jj == 1 ? t_[i][1] + t_[i][2] : jj == 2 ? t_[i][2] - t_[i][1] : t_[i][1] - t_[i][3];
+                    }
+                }
+                if (k == 11) {                                      // fragments of the second position, 4 MFMAs ahead of use
+                    ga[0] = lds_f4(vB + ((xi0 + 1) * 64) * 32); ga[1] = lds_f4(vB + ((xi0 + 1) * 64 + 32) * 32);
+                    gb[0] = lds_f4(uB + ((xi0 + 1) * 64) * 32); gb[1] = lds_f4(uB + ((xi0 + 1) * 64 + 32) * 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            char* dst = sV + t_dst[it];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<float*>(dst + (i * 4 + 0) * (T * 32)) = t[i][0] - t[i][2];
-                *reinterpret_cast<float*>(dst + (i * 4 + 1) * (T * 32)) = t[i][1] + t[i][2];
-                *reinterpret_cast<float*>(dst + (i * 4 + 2) * (T * 32)) = t[i][2] - t[i][1];
-                *reinterpret_cast<float*>(dst + (i * 4 + 3) * (T * 32)) = t[i][1] - t[i][3];
-            }
-        }
-        __syncthreads();                                   // V complete; patch buffer free
-        if (cc + 1 < a.CC) WINO_ISSUE(cc + 1);
-        // ---- 16 position GEMMs: wave owns positions 4*wave .. 4*wave+3 ----
-        const char* uB = sU + (cc & 1) * U_BYTES;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int xi = wave * 4 + p;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sV + (xi * T) * 32 + a_frag);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sV + (xi * T + 32) * 32 + a_frag);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(uB + xi * 1024 + b_frag);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc[p][0] = mfma32(a0[c], bb[c], acc[p][0]);
-                acc[p][1] = mfma32(a1[c], bb[c], acc[p][1]);
+            for (int k = 0; k < 16; ++k) {
+                const int c = k >> 2, g = (k >> 1) & 1, h = k & 1;
+                acc[1][g][h] = mfma32(ga[g][c], gb[h][c], acc[1][g][h]);
+                *reinterpret_cast<float*>(dst_ + k * (T * 32)) = v_[k >> 2][k & 3];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-#undef WINO_ISSUE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    WINO_MFMA(cc);
+#undef WINO_MFMA
+#undef WINO_ISSUE_P
+#undef WINO_ISSUE_U
+#undef WINO_TRANSFORM
 
+#ifdef CNL_TRACE
+    const long long t_loop = wall_clock64();
+#endif
     // ---- epilogue: M (16 positions) -> LDS -> Y = A^T M A -> + bias (+ residual) (ReLU) -> NHWC ----
     const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
     float* sM = reinterpret_cast<float*>(smem);            // [16][32 tiles][32 co] = 64 KB
     const int co = tid & 31;
-    const int col = n0 + co;
-    const bool col_ok = col < a.Cout;
-    const float bv = col_ok ? a.bias[col] : 0.f;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        __syncthreads();                                   // everyone is done reading V/U (g=0) or sM of the previous pass
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int xi = wave * 4 + p;
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();                               // done reading V/U (first pass) or sM of the previous pass
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                sM[(xi * 32 + tl) * 32 + (lane & 31)] = acc[p][g][r];
-            }
-        }
-        __syncthreads();
+            for (int p = 0; p < 2; ++p) {
+                const int xi = wave * 2 + p;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int tl = (tid >> 5) + 8 * it;            // tile inside this 32-tile group
-            float m[16];
-#pragma unroll
-            for (int xi = 0; xi < 16; ++xi) m[xi] = sM[(xi * 32 + tl) * 32 + co];
-            float q[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                q[i][0] = m[i * 4 + 0] + m[i * 4 + 1] + m[i * 4 + 2];
-                q[i][1] = m[i * 4 + 1] - m[i * 4 + 2] - m[i * 4 + 3];
-            }
-            float yv[2][2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                yv[0][c] = q[0][c] + q[1][c] + q[2][c];
-                yv[1][c] = q[1][c] - q[2][c] - q[3][c];
-            }
-            const int tile = g * 32 + tl;
-            const int oy = y0 + 2 * (tile >> 3), ox = x0 + 2 * (tile & 7);
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int yy = oy + dy, xx = ox + dx;
-                    if (col_ok && yy < a.H && xx < a.W) {
-                        const size_t pix = ((size_t)n * a.H + yy) * a.W + xx;
-                        float v = yv[dy][dx] + bv;
-                        if (a.res) v += a.res[pix * a.ldr + col];
-                        a.y[pix * a.ldy + col] = fmaxf(v, lo);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int tl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    sM[(xi * 32 + tl) * 32 + (lane & 31)] = acc[p][g][h][r];
                 }
+            }
+            __syncthreads();
+            const int col = n0 + h * 32 + co;
+            const bool col_ok = col < a.Cout;
+            const float bv = col_ok ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int tl = (tid >> 5) + 16 * it;       // tile inside this 32-tile group
+                const int tile = g * 32 + tl;
+                const int oy = y0 + 2 * (tile >> 3), ox = x0 + 2 * (tile & 7);
+                float rv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+                if (a.res) {
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx)
+                            if (col_ok && oy + dy < a.H && ox + dx < a.W)
+                                rv[dy][dx] = a.res[(((size_t)n * a.H + oy + dy) * a.W + ox + dx) * a.ldr + col];
+                }
+                float m[16];
+#pragma unroll
+                for (int xi = 0; xi < 16; ++xi) m[xi] = sM[(xi * 32 + tl) * 32 + co];
+                float q[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    q[i][0] = m[i * 4 + 0] + m[i * 4 + 1] + m[i * 4 + 2];
+                    q[i][1] = m[i * 4 + 1] - m[i * 4 + 2] - m[i * 4 + 3];
+                }
+                float yv[2][2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    yv[0][c] = q[0][c] + q[1][c] + q[2][c];
+                    yv[1][c] = q[1][c] - q[2][c] - q[3][c];
+                }
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx)
+                        if (col_ok && oy + dy < a.H && ox + dx < a.W)
+                            a.y[(((size_t)n * a.H + oy + dy) * a.W + ox + dx) * a.ldy + col] = fmaxf(yv[dy][dx] + bv + rv[dy][dx], lo);
+            }
         }
     }
+#ifdef CNL_TRACE
+    if (a.trace && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* t = a.trace + (long)blockIdx.x * 8;
+        t[0] = t_start; t[1] = t_pro; t[2] = t_pro; t[3] = t_loop; t[4] = wall_clock64(); t[5] = 0;
+    }
+#endif
 }
 
 // U = G g G^T per (co, ci), packed [Cin/8][16][CoutP][8]; rows co >= Cout are zero.
@@ -266,14 +358,14 @@ using namespace cnl_wino;
 
 extern "C" size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8) return 0;
-    const size_t CoutP = (size_t)((Cout + 31) / 32) * 32;
+    const size_t CoutP = (size_t)((Cout + 63) / 64) * 64;
     return (size_t)(Cin / 8) * 16 * CoutP * 8;
 }
 
 extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream) {
     CNL_REQUIRE(w_ohwi && u, CNL_E_BAD_ARG, "cnl_winograd_transform_weights_f32: null pointer");
     CNL_REQUIRE(Cin > 0 && Cout > 0 && Cin % 8 == 0, CNL_E_UNSUPPORTED, "cnl_winograd_transform_weights_f32: Cin %% 8 != 0");
-    const int CoutP = (Cout + 31) / 32 * 32;
+    const int CoutP = (Cout + 63) / 64 * 64;
     const long total = (long)CoutP * Cin;
     hipLaunchKernelGGL(winograd_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_ohwi, u, Cin,
                        Cout, CoutP);
@@ -296,10 +388,10 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
     WinoArgs a;
     a.x = p->x; a.u = p->w; a.bias = p->bias; a.res = p->residual; a.y = p->y;
     a.N = p->N; a.H = p->H_in; a.W = p->W_in; a.Cin = p->Cin; a.Cout = p->Cout;
-    a.CoutP = (p->Cout + 31) / 32 * 32;
+    a.CoutP = (p->Cout + 63) / 64 * 64;
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
     a.CC = p->Cin / 8;
-    a.nb = a.CoutP / 32; a.bx = (p->W_in + 15) / 16; a.by = (p->H_in + 15) / 16;
+    a.nb = a.CoutP / BN; a.bx = (p->W_in + 15) / 16; a.by = (p->H_in + 15) / 16;
     const long long blocks = (long long)p->N * a.by * a.bx * a.nb;
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: grid too large");
     a.blocks = (int)blocks;
@@ -308,12 +400,16 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
     CNL_REQUIRE(xb < 0xFFFFFF00ull && ub < 0xFFFFFF00ull, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub;
     a.flags = p->flags;
+    a.trace = nullptr;
+#ifdef CNL_TRACE
+    if (const char* e = getenv("CNL_TRACE_PTR")) a.trace = (long long*)strtoull(e, nullptr, 0);
+#endif
     static bool attr_done = false;
     if (!attr_done) {
         CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     LDS_BYTES));
         attr_done = true;
     }
-    hipLaunchKernelGGL(winograd_conv_kernel, dim3((unsigned)blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(winograd_conv_kernel, dim3((unsigned)blocks), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
     return cnl::check_launch("winograd_conv_kernel");
 }

@@ -14,6 +14,7 @@ from centernet_lightning_amd import _lib  # noqa: E402
 from centernet_lightning_amd._lib import CNL_UPSAMPLE_IN, ConvParams  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "head256"
+WINO = len(sys.argv) > 2 and sys.argv[2] == "winograd"
 N, H, W, Cin, Cout, k, stride, flags, res = SHAPES[name]
 trace = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")
 lib = _lib.load()
@@ -31,11 +32,18 @@ p.residual = r.data_ptr() if res else None
 p.N, p.H_in, p.W_in, p.Cin, p.Cout = N, H, W, Cin, Cout
 p.KH, p.KW, p.stride, p.pad = k, k, stride, (k - 1) // 2
 p.ldx, p.ldy, p.ldr, p.flags = Cin, Cout, Cout, flags
+fn = lib.cnl_conv2d_nhwc_f32
+if WINO:
+    u = torch.empty(lib.cnl_winograd_weight_floats(Cin, Cout), device="cuda")
+    lib.cnl_winograd_transform_weights_f32(w.data_ptr(), u.data_ptr(), Cin, Cout, stream)
+    p.w = u.data_ptr()
+    p.flags = flags & 1
+    fn = lib.cnl_conv3x3_winograd_f32
 for _ in range(2):
-    lib.cnl_conv2d_nhwc_f32(ctypes.byref(p), stream)
+    fn(ctypes.byref(p), stream)
 torch.cuda.synchronize()
 os.environ["CNL_TRACE_PTR"] = str(trace.data_ptr())
-lib.cnl_conv2d_nhwc_f32(ctypes.byref(p), stream)
+fn(ctypes.byref(p), stream)
 torch.cuda.synchronize()
 t = trace.cpu().numpy().reshape(-1, 8)
 t = t[t[:, 0] > 0]
