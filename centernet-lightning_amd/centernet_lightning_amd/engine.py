@@ -149,7 +149,7 @@ class Plan:
         _lib.check(self.lib.cnl_conv2d_out_hw(ctypes.byref(p), ctypes.byref(ho), ctypes.byref(wo)), what)
         flops = 2 * self.N * ho.value * wo.value * layer.cout * layer.kh * layer.kw * layer.cin   # direct-conv (algorithmic) flops
         fn = self.lib.cnl_conv2d_nhwc_f32
-        if layer.u is not None and not (flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD | CNL_SIGMOID)) and (4 * x_off) % 16 == 0:
+        if layer.u is not None and not (flags & (CNL_UPSAMPLE_OUT_ADD | CNL_SIGMOID)) and (4 * x_off) % 16 == 0:
             p.w = layer.u.data_ptr()
             fn = self.lib.cnl_conv3x3_winograd_f32
             what += " [winograd]"

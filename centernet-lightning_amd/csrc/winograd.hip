@@ -8,19 +8,22 @@
 // rounding (|err| ~2.6e-6 at K=2304 vs 1.2e-6 for the direct sum; tolerance 1e-4).
 //
 //   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A        d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
-// which is 16 independent GEMMs, one per transform position xi:  M_xi[tile][co] = sum_ci V_xi[tile][ci] U_xi[co][ci].
+// which is 16 independent GEMMs, one per transform position xi = 4i+j:  M_xi[tile][co] = sum_ci V_xi[tile][ci] U_xi[co][ci].
 //
-// Workgroup = 4 waves = 8x8 tiles (16x16 output pixels of one image) x 32 output channels x all 16 positions.
-// Per chunk of 8 input channels:
-//   LDS-DMA   the 18x18x8 input patch (zero halo from the buffer bounds check) and the chunk's U slice
-//             ([xi][32 co][8 ci], pre-transformed and pre-packed once per weight load);
-//   transform thread = (tile, channel): 16 ds_read_b32 -> 32 adds (B^T d B) -> 16 ds_write_b32 into V[xi][tile][8 ci];
-//   MFMA      wave w owns positions 4w..4w+3: per position two 32-tile A fragments + one B fragment, each ONE
-//             ds_read_b128 (lanes 0-31 take ci 0-3, lanes 32-63 ci 4-7: four K=2 steps per read), 8 MFMAs.
-// Epilogue: accumulators go through LDS ([xi][tile][co]) so that thread = (tile, co) can apply A^T . A, + bias
-// (+ residual) (+ ReLU) and store the 2x2 outputs NHWC (32 consecutive channels per 128-byte segment).
-// LDS: V 32 KB + U 2 x 16 KB + patch 12 KB = 76 KB -> 2 workgroups per CU: one group's transform phase (VALU + LDS)
-// runs under the other's MFMA phase.
+// Workgroup = 8 waves = 8x8 tiles (16x16 output pixels of one image) x 64 output channels x all 16 positions; one
+// workgroup per CU (150 KB of LDS: V, U and the input patch are all double-buffered), two waves per SIMD.
+// Per chunk of 8 input channels, ONE barrier:
+//   LDS-DMA   the 18x18x8 input patch of chunk cc+2 (zero halo from the buffer bounds check; optional nearest-2x source)
+//             and the U slice of chunk cc+1 ([xi][64 co][8 ci], pre-transformed and pre-packed once per weight load);
+//   MFMA      wave w owns transform row i = w>>1 (positions 4i..4i+3) for cout group h = w&1 and both 32-tile groups:
+//             per position two A fragments + one B fragment, each ONE ds_read_b128 (lanes 0-31 take ci 0-3, lanes
+//             32-63 ci 4-7: four K=2 steps per read), 8 MFMAs; 32 MFMAs per wave per chunk;
+//   transform of chunk cc+1 (thread = (tile, channel): 16 LDS reads, 32 adds, 16 LDS writes) is hand-interleaved with
+//             those MFMAs, one slice = {1 MFMA, 2 adds | 1 write}, fenced by sched_barrier(0).
+// Epilogue: owning a whole transform row lets each wave apply the first half of A^T M A in registers (4 -> 2 matrices);
+// the halves meet through LDS ([i][c][tile][co], two passes) where thread = (tile, co) finishes Y, adds bias
+// (+ residual) (+ ReLU) and stores the 2x2 outputs NHWC with buffer stores (uniform part of the address in the SGPR
+// offset, 64 consecutive channels per 256 bytes).
 #include "cnl_common.h"
 #include <cstdlib>
 
@@ -36,14 +39,15 @@ struct WinoArgs {
     const float* bias;
     const float* res;
     float* y;
-    int N, H, W, Cin, Cout, CoutP;
+    int N, H, W, Cin, Cout, CoutP;   // H, W: output (= logical input) size
+    int Hs, Ws;                       // stored input size (H/2, W/2 with CNL_UPSAMPLE_IN, else H, W)
     int ldx, ldy, ldr;
-    int CC;                       // Cin / 8
-    int nb, bx, by;               // blocks along cout, x, y
+    int CC;                           // Cin / 8
+    int nb, bx, by;                   // blocks along cout, x, y
     int blocks;
-    unsigned x_bytes, u_bytes;
+    unsigned x_bytes, u_bytes, y_bytes, r_bytes;
     unsigned flags;
-    long long* trace;             // CNL_TRACE builds only
+    long long* trace;                 // CNL_TRACE builds only
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -60,6 +64,14 @@ __device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* l
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 0, 0);
 }
+__device__ __forceinline__ float buf_load(const float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset, soffset, 0));
+}
+__device__ __forceinline__ void buf_store(float v, float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voffset, soffset, 0);
+}
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -70,7 +82,6 @@ __device__ __forceinline__ f32x16 mfma_zero() {
 __device__ __forceinline__ float lds_f(const char* p) { return *reinterpret_cast<const float*>(p); }
 __device__ __forceinline__ f32x4 lds_f4(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// 8 waves: wave w owns transform positions xi = 2w, 2w+1, for all 64 tiles (2 groups of 32) x 64 couts (2 groups of 32).
 __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sV = smem;                                  // [2][16 xi][64 tiles][8 ci]
@@ -81,6 +92,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
+    const int wi = wave >> 1, wh = wave & 1;          // transform row and cout group owned by this wave
 #ifdef CNL_TRACE
     const long long t_start = wall_clock64();
 #endif
@@ -92,6 +104,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
     const int byi = b % a.by;
     const int n = b / a.by;
     const int y0 = byi * 16, x0 = bxi * 16, n0 = nbi * BN;
+    const bool up = a.flags & CNL_UPSAMPLE_IN;
 
     // ---- per-lane DMA bookkeeping ----
     unsigned p_off[2];
@@ -102,8 +115,10 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
         const int py = px / PW, pxx = px - py * PW;
         const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
         const bool ok = s < PW * PW * 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        p_off[i] = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.ldx + half * 4) * 4) : OOB;
+        const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;      // nn.Upsample(nearest, x2) folded into the gather
+        p_off[i] = ok ? (unsigned)((((n * a.Hs + sy) * a.Ws + sx) * a.ldx + half * 4) * 4) : OOB;
     }
+    // U: this wave loads its own 4 positions' rows for BOTH cout groups of... no: positions 2*wave, 2*wave+1, all 64 couts
     unsigned u_off[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) u_off[p] = (unsigned)((((wave * 2 + p) * a.CoutP + n0) * 8) * 4 + lane * 16);
@@ -129,190 +144,173 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
     const int t_ch = tid & 7, t_tile = tid >> 3;
     const int t_src = (((2 * (t_tile >> 3)) * PW + 2 * (t_tile & 7)) * 8 + t_ch) * 4;
     const int t_dst = (t_tile * 8 + t_ch) * 4;
-    // input transform of one chunk: patch buffer pb_ -> V buffer vb_ (B^T d B, 16 reads / 32 adds / 16 writes per thread)
-#define WINO_TRANSFORM(pb_, vb_)                                                                                 \
-    do {                                                                                                         \
-        const char* src_ = sP + (pb_) * P_BYTES + t_src;                                                         \
-        float d_[4][4], t_[4][4];                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) d_[i][j] = lds_f(src_ + (i * PW + j) * 32);            \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
-            t_[0][j] = d_[0][j] - d_[2][j];                                                                      \
-            t_[1][j] = d_[1][j] + d_[2][j];                                                                      \
-            t_[2][j] = d_[2][j] - d_[1][j];                                                                      \
-            t_[3][j] = d_[1][j] - d_[3][j];                                                                      \
-        }                                                                                                        \
-        char* dst_ = sV + (vb_) * V_BYTES + t_dst;                                                               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
-            *reinterpret_cast<float*>(dst_ + (i * 4 + 0) * (T * 32)) = t_[i][0] - t_[i][2];                      \
-            *reinterpret_cast<float*>(dst_ + (i * 4 + 1) * (T * 32)) = t_[i][1] + t_[i][2];                      \
-            *reinterpret_cast<float*>(dst_ + (i * 4 + 2) * (T * 32)) = t_[i][2] - t_[i][1];                      \
-            *reinterpret_cast<float*>(dst_ + (i * 4 + 3) * (T * 32)) = t_[i][1] - t_[i][3];                      \
-        }                                                                                                        \
-    } while (0)
 
     WINO_ISSUE_P(0);
     WINO_ISSUE_U(0);
 
-    f32x16 acc[2][2][2];     // [position][tile group][cout group]
+    f32x16 acc[4][2];        // [position j of row wi][tile group]
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) acc[p][g][h] = mfma_zero();
+        for (int g = 0; g < 2; ++g) acc[j][g] = mfma_zero();
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    WINO_TRANSFORM(0, 0);
+    {   // input transform of chunk 0 (not overlapped)
+        const char* src_ = sP + t_src;
+        float d_[4][4], t_[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d_[i][j] = lds_f(src_ + (i * PW + j) * 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t_[0][j] = d_[0][j] - d_[2][j];
+            t_[1][j] = d_[1][j] + d_[2][j];
+            t_[2][j] = d_[2][j] - d_[1][j];
+            t_[3][j] = d_[1][j] - d_[3][j];
+        }
+        char* dst_ = sV + t_dst;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float*>(dst_ + (i * 4 + 0) * (T * 32)) = t_[i][0] - t_[i][2];
+            *reinterpret_cast<float*>(dst_ + (i * 4 + 1) * (T * 32)) = t_[i][1] + t_[i][2];
+            *reinterpret_cast<float*>(dst_ + (i * 4 + 2) * (T * 32)) = t_[i][2] - t_[i][1];
+            *reinterpret_cast<float*>(dst_ + (i * 4 + 3) * (T * 32)) = t_[i][1] - t_[i][3];
+        }
+    }
     if (a.CC > 1) WINO_ISSUE_P(1);
 
 #ifdef CNL_TRACE
     const long long t_pro = wall_clock64();
 #endif
-    const int frag = ((lane & 31) * 8 + hi * 4) * 4;      // + (xi*64 + group*32) * 32
-    // 16 position GEMMs of one chunk (this wave: 2 positions x 2 x 2 accumulator tiles, 32 MFMAs)
-#define WINO_MFMA(cc_)                                                                                           \
-    do {                                                                                                         \
-        const char* vB = sV + ((cc_) & 1) * V_BYTES + frag;                                                      \
-        const char* uB = sU + ((cc_) & 1) * U_BYTES + frag;                                                      \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                          \
-            const int xi = wave * 2 + p;                                                                         \
-            const f32x4 a0 = lds_f4(vB + (xi * 64) * 32), a1 = lds_f4(vB + (xi * 64 + 32) * 32);                 \
-            const f32x4 b0 = lds_f4(uB + (xi * 64) * 32), b1 = lds_f4(uB + (xi * 64 + 32) * 32);                 \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                      \
-                acc[p][0][0] = mfma32(a0[c], b0[c], acc[p][0][0]);                                               \
-                acc[p][0][1] = mfma32(a0[c], b1[c], acc[p][0][1]);                                               \
-                acc[p][1][0] = mfma32(a1[c], b0[c], acc[p][1][0]);                                               \
-                acc[p][1][1] = mfma32(a1[c], b1[c], acc[p][1][1]);                                               \
-            }                                                                                                    \
-        }                                                                                                        \
-    } while (0)
+    const int fragA = ((lane & 31) * 8 + hi * 4) * 4;                  // + (xi*64 + g*32) * 32
+    const int fragB = ((wh * 32 + (lane & 31)) * 8 + hi * 4) * 4;      // + (xi*64) * 32
+    const int xi0 = wi * 4;
+    // the 8 MFMAs of one position: k = 0..7 -> c = k >> 1, g = k & 1
+#define WINO_MFMA8(j_, fa_, fb_, k_) acc[j_][(k_) & 1] = mfma32((fa_)[(k_) & 1][(k_) >> 1], (fb_)[(k_) >> 1], acc[j_][(k_) & 1])
 
-    // steady state: ONE barrier per chunk; the transform of chunk cc+1 is straight-line code in the same block as the MFMAs
-    // of chunk cc so that its VALU / LDS instructions issue in the shadow of the matrix pipe
+    // steady state: ONE barrier per chunk; MFMAs of chunk cc with the input transform of chunk cc+1 hand-interleaved, one
+    // slice = {1 MFMA, 2 VALU | 1 LDS write}, slices fenced by sched_barrier(0): left to itself hipcc emits the whole
+    // transform after the last MFMA, where both waves of a SIMD reach it together and the matrix pipe idles.
     int cc = 0;
     for (; cc + 1 < a.CC; ++cc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();     // V[cc&1] complete, U[cc&1] + patch cc+1 landed; MFMA phase cc-1 and transform cc done everywhere
         WINO_ISSUE_U(cc + 1);
-        WINO_ISSUE_P(cc + 2);                              // past the last chunk this DMA is all-OOB (see p_lim)
-        // MFMAs of chunk cc with the input transform of chunk cc+1 hand-interleaved, one slice = {1 MFMA, 2 VALU | 1 LDS write},
-        // slices fenced by sched_barrier(0): left to itself hipcc emits the whole transform after the last MFMA, where both waves
-        // of a SIMD reach it together and the matrix pipe idles (sched_group_barrier patterns were not honoured here).
-        {
-            const char* vB = sV + (cc & 1) * V_BYTES + frag;
-            const char* uB = sU + (cc & 1) * U_BYTES + frag;
-            const char* src_ = sP + ((cc + 1) & 1) * P_BYTES + t_src;
-            char* dst_ = sV + ((cc + 1) & 1) * V_BYTES + t_dst;
-            const int xi0 = wave * 2;
-            f32x4 fa[2], fb[2];
-            fa[0] = lds_f4(vB + (xi0 * 64) * 32); fa[1] = lds_f4(vB + (xi0 * 64 + 32) * 32);
-            fb[0] = lds_f4(uB + (xi0 * 64) * 32); fb[1] = lds_f4(uB + (xi0 * 64 + 32) * 32);
-            float d_[4][4], t_[4][4], v_[4][4];
+        WINO_ISSUE_P(cc + 2);
+        const char* vB = sV + (cc & 1) * V_BYTES + fragA;
+        const char* uB = sU + (cc & 1) * U_BYTES + fragB;
+        const char* src_ = sP + ((cc + 1) & 1) * P_BYTES + t_src;
+        char* dst_ = sV + ((cc + 1) & 1) * V_BYTES + t_dst;
+        f32x4 fa[2][2], fb[2];      // double-buffered fragments: [buffer][tile group]
+        fa[0][0] = lds_f4(vB + (xi0 * 64) * 32); fa[0][1] = lds_f4(vB + (xi0 * 64 + 32) * 32);
+        fb[0] = lds_f4(uB + (xi0 * 64) * 32);
+        float d_[4][4], t_[4][4], v_[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d_[i][j] = lds_f(src_ + (i * PW + j) * 32);
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 ga[2], gb[2];
+            for (int j = 0; j < 4; ++j) d_[i][j] = lds_f(src_ + (i * PW + j) * 32);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int c = k >> 2, g = (k >> 1) & 1, h = k & 1;
-                acc[0][g][h] = mfma32(fa[g][c], fb[h][c], acc[0][g][h]);
+        for (int k = 0; k < 32; ++k) {
+            const int j = k >> 3, kk = k & 7, buf = j & 1;
+            WINO_MFMA8(j, fa[buf], fb[buf], kk);
+            if (kk == 2 && j < 3) {                                 // next position's fragments, 6 MFMAs ahead of use
+                fa[buf ^ 1][0] = lds_f4(vB + ((xi0 + j + 1) * 64) * 32);
+                fa[buf ^ 1][1] = lds_f4(vB + ((xi0 + j + 1) * 64 + 32) * 32);
+                fb[buf ^ 1] = lds_f4(uB + ((xi0 + j + 1) * 64) * 32);
+            }
+            if (k < 16) {
 #pragma unroll
                 for (int e = 2 * k; e < 2 * k + 2; ++e) {
-                    if (e < 16) {                                   // t = B^T d   (column j of d)
-                        const int i = e & 3, j = e >> 2;
-                        t_[i][j] = i == 0 ? d_[0][j] - d_[2][j] : i == 1 ? d_[1][j] + d_[2][j] : i == 2 ? d_[2][j] - d_[1][j] : d_[1][j] - d_[3][j];
+                    if (e < 16) {                                   // t = B^T d   (column jj of d)
+                        const int i = e & 3, jj = e >> 2;
+                        t_[i][jj] = i == 0 ? d_[0][jj] - d_[2][jj] : i == 1 ? d_[1][jj] + d_[2][jj] : i == 2 ? d_[2][jj] - d_[1][jj] : d_[1][jj] - d_[3][jj];
                     } else {                                        // V = t B     (row i of t)
                         const int i = (e - 16) >> 2, jj = (e - 16) & 3;
                         v_[i][jj] = jj == 0 ? t_[i][0] - t_[i][2] : jj == 1 ? t_[i][1] + t_[i][2] : jj == 2 ? t_[i][2] - t_[i][1] : t_[i][1] - t_[i][3];
                     }
                 }
-                if (k == 11) {                                      // fragments of the second position, 4 MFMAs ahead of use
-                    ga[0] = lds_f4(vB + ((xi0 + 1) * 64) * 32); ga[1] = lds_f4(vB + ((xi0 + 1) * 64 + 32) * 32);
-                    gb[0] = lds_f4(uB + ((xi0 + 1) * 64) * 32); gb[1] = lds_f4(uB + ((xi0 + 1) * 64 + 32) * 32);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                *reinterpret_cast<float*>(dst_ + (k - 16) * (T * 32)) = v_[(k - 16) >> 2][(k - 16) & 3];
             }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int c = k >> 2, g = (k >> 1) & 1, h = k & 1;
-                acc[1][g][h] = mfma32(ga[g][c], gb[h][c], acc[1][g][h]);
-                *reinterpret_cast<float*>(dst_ + k * (T * 32)) = v_[k >> 2][k & 3];
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    WINO_MFMA(cc);
-#undef WINO_MFMA
+    {   // last chunk: MFMAs only
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* vB = sV + (cc & 1) * V_BYTES + fragA;
+        const char* uB = sU + (cc & 1) * U_BYTES + fragB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 fa[1][2], fb[1];
+            fa[0][0] = lds_f4(vB + ((xi0 + j) * 64) * 32); fa[0][1] = lds_f4(vB + ((xi0 + j) * 64 + 32) * 32);
+            fb[0] = lds_f4(uB + ((xi0 + j) * 64) * 32);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) WINO_MFMA8(j, fa[0], fb[0], kk);
+        }
+    }
+#undef WINO_MFMA8
 #undef WINO_ISSUE_P
 #undef WINO_ISSUE_U
-#undef WINO_TRANSFORM
 
 #ifdef CNL_TRACE
     const long long t_loop = wall_clock64();
 #endif
-    // ---- epilogue: M (16 positions) -> LDS -> Y = A^T M A -> + bias (+ residual) (ReLU) -> NHWC ----
+    // ---- epilogue: Y = A^T M A.  Stage 1 (row of positions, in registers): q_c = sum_j A^T[c][j] M[i][j] ----
     const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
-    float* sM = reinterpret_cast<float*>(smem);            // [16][32 tiles][32 co] = 64 KB
-    const int co = tid & 31;
+    float* sQ = reinterpret_cast<float*>(smem);            // [4 i][2 c][32 tiles][64 co] = 64 KB per tile group
+    const int co = tid & 63;
+    const int col = n0 + co;
+    const bool col_ok = col < a.Cout;
+    const float bv = col_ok ? a.bias[col] : 0.f;
+    const bool full = (y0 + 16 <= a.H) && (x0 + 16 <= a.W) && (n0 + BN <= a.Cout);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
+        __syncthreads();                                   // done reading V/U (g = 0) or sQ of the previous pass
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            __syncthreads();                               // done reading V/U (first pass) or sM of the previous pass
+        for (int r = 0; r < 16; ++r) {
+            const int tl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float m0 = acc[0][g][r], m1 = acc[1][g][r], m2 = acc[2][g][r], m3 = acc[3][g][r];
+            sQ[((wi * 2 + 0) * 32 + tl) * 64 + wh * 32 + (lane & 31)] = m0 + m1 + m2;
+            sQ[((wi * 2 + 1) * 32 + tl) * 64 + wh * 32 + (lane & 31)] = m1 - m2 - m3;
+        }
+        __syncthreads();
+        // Stage 2: thread = (tile, co): Y[a][c] = sum_i A^T[a][i] q[i][c]; 4 items per thread
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int xi = wave * 2 + p;
+        for (int it = 0; it < 4; ++it) {
+            const int tl = (tid >> 6) + 8 * it;            // tile inside this 32-tile group
+            const int tile = g * 32 + tl;
+            const int oy = y0 + 2 * (tile >> 3), ox = x0 + 2 * (tile & 7);
+            const unsigned pix = (unsigned)((n * a.H + oy) * a.W + ox);
+            const unsigned y_voff = (pix * (unsigned)a.ldy + (unsigned)col) * 4u;
+            const unsigned r_voff = (pix * (unsigned)a.ldr + (unsigned)col) * 4u;
+            bool ok[2][2];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int tl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    sM[(xi * 32 + tl) * 32 + (lane & 31)] = acc[p][g][h][r];
-                }
-            }
-            __syncthreads();
-            const int col = n0 + h * 32 + co;
-            const bool col_ok = col < a.Cout;
-            const float bv = col_ok ? a.bias[col] : 0.f;
+            for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int tl = (tid >> 5) + 16 * it;       // tile inside this 32-tile group
-                const int tile = g * 32 + tl;
-                const int oy = y0 + 2 * (tile >> 3), ox = x0 + 2 * (tile & 7);
-                float rv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-                if (a.res) {
-#pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                        for (int dx = 0; dx < 2; ++dx)
-                            if (col_ok && oy + dy < a.H && ox + dx < a.W)
-                                rv[dy][dx] = a.res[(((size_t)n * a.H + oy + dy) * a.W + ox + dx) * a.ldr + col];
-                }
-                float m[16];
-#pragma unroll
-                for (int xi = 0; xi < 16; ++xi) m[xi] = sM[(xi * 32 + tl) * 32 + co];
-                float q[4][2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    q[i][0] = m[i * 4 + 0] + m[i * 4 + 1] + m[i * 4 + 2];
-                    q[i][1] = m[i * 4 + 1] - m[i * 4 + 2] - m[i * 4 + 3];
-                }
-                float yv[2][2];
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    yv[0][c] = q[0][c] + q[1][c] + q[2][c];
-                    yv[1][c] = q[1][c] - q[2][c] - q[3][c];
-                }
+                for (int dx = 0; dx < 2; ++dx) ok[dy][dx] = full || (col_ok && oy + dy < a.H && ox + dx < a.W);
+            float rv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+            if (a.res) {
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 2; ++dx)
-                        if (col_ok && oy + dy < a.H && ox + dx < a.W)
-                            a.y[(((size_t)n * a.H + oy + dy) * a.W + ox + dx) * a.ldy + col] = fmaxf(yv[dy][dx] + bv + rv[dy][dx], lo);
+                        rv[dy][dx] = buf_load(a.res, a.r_bytes, ok[dy][dx] ? r_voff : OOB, (unsigned)((dy * a.W + dx) * a.ldr * 4));
+            }
+            float q[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) q[i][c] = sQ[((i * 2 + c) * 32 + tl) * 64 + co];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float ya = q[0][c] + q[1][c] + q[2][c];
+                const float yb = q[1][c] - q[2][c] - q[3][c];
+                buf_store(fmaxf(ya + bv + rv[0][c], lo), a.y, a.y_bytes, ok[0][c] ? y_voff : OOB, (unsigned)(c * a.ldy * 4));
+                buf_store(fmaxf(yb + bv + rv[1][c], lo), a.y, a.y_bytes, ok[1][c] ? y_voff : OOB, (unsigned)((a.W + c) * a.ldy * 4));
             }
         }
     }
@@ -379,26 +377,32 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 "cnl_conv3x3_winograd_f32: non-positive dimension");
     CNL_REQUIRE(p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1, CNL_E_UNSUPPORTED,
                 "cnl_conv3x3_winograd_f32: only 3x3 / stride 1 / pad 1");
-    CNL_REQUIRE(!(p->flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD | CNL_SIGMOID)), CNL_E_UNSUPPORTED,
-                "cnl_conv3x3_winograd_f32: upsample / sigmoid flags are handled by cnl_conv2d_nhwc_f32");
+    CNL_REQUIRE(!(p->flags & (CNL_UPSAMPLE_OUT_ADD | CNL_SIGMOID)), CNL_E_UNSUPPORTED,
+                "cnl_conv3x3_winograd_f32: UPSAMPLE_OUT_ADD / SIGMOID are handled by cnl_conv2d_nhwc_f32");
     CNL_REQUIRE(p->Cin % 8 == 0 && p->ldx % 4 == 0 && p->ldx >= p->Cin && p->ldy >= p->Cout, CNL_E_UNSUPPORTED,
                 "cnl_conv3x3_winograd_f32: Cin %% 8 != 0 or bad pixel stride");
     CNL_REQUIRE(((uintptr_t)p->x & 15) == 0 && ((uintptr_t)p->w & 15) == 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unaligned x / u");
     CNL_REQUIRE(!p->residual || p->ldr >= p->Cout, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: ldr < Cout");
     WinoArgs a;
     a.x = p->x; a.u = p->w; a.bias = p->bias; a.res = p->residual; a.y = p->y;
-    a.N = p->N; a.H = p->H_in; a.W = p->W_in; a.Cin = p->Cin; a.Cout = p->Cout;
+    const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
+    a.N = p->N; a.Hs = p->H_in; a.Ws = p->W_in; a.H = p->H_in * upf; a.W = p->W_in * upf; a.Cin = p->Cin; a.Cout = p->Cout;
     a.CoutP = (p->Cout + 63) / 64 * 64;
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
     a.CC = p->Cin / 8;
-    a.nb = a.CoutP / BN; a.bx = (p->W_in + 15) / 16; a.by = (p->H_in + 15) / 16;
+    a.nb = a.CoutP / BN; a.bx = (a.W + 15) / 16; a.by = (a.H + 15) / 16;
     const long long blocks = (long long)p->N * a.by * a.bx * a.nb;
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: grid too large");
     a.blocks = (int)blocks;
     const unsigned long long xb = (((unsigned long long)p->N * p->H_in * p->W_in - 1) * p->ldx + p->Cin) * 4ull;
     const unsigned long long ub = (unsigned long long)cnl_winograd_weight_floats(p->Cin, p->Cout) * 4ull;
-    CNL_REQUIRE(xb < 0xFFFFFF00ull && ub < 0xFFFFFF00ull, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
-    a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub;
+    const unsigned long long Mo = (unsigned long long)p->N * a.H * a.W;
+    const unsigned long long yb = ((Mo - 1) * p->ldy + p->Cout) * 4ull;
+    const unsigned long long rb = p->residual ? ((Mo - 1) * p->ldr + p->Cout) * 4ull : 0ull;
+    const unsigned long long slack = (unsigned long long)(a.W + 2) * 4ull;     // scalar-offset reach of the epilogue stores
+    CNL_REQUIRE(xb < 0xFFFFFF00ull && ub < 0xFFFFFF00ull && yb + slack * p->ldy < 0xFFFFFF00ull && rb + slack * (p->residual ? p->ldr : 0) < 0xFFFFFF00ull,
+                CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
+    a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.flags = p->flags;
     a.trace = nullptr;
 #ifdef CNL_TRACE

@@ -175,7 +175,9 @@ def test_maxpool_matches_cpu_bit_exact(shape):
 # ----------------------------------------------------------------------------- Winograd F(2x2,3x3) path
 def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None):
     lib = _lib.load()
-    N, Cin, H, W = x_nchw.shape
+    N, Cin, Hs, Ws = x_nchw.shape
+    upf = 2 if flags & CNL_UPSAMPLE_IN else 1
+    H, W = Hs * upf, Ws * upf
     Cout = w_oihw.shape[0]
     xd = x_nchw.permute(0, 2, 3, 1).contiguous().cuda()
     wd = w_oihw.permute(0, 2, 3, 1).contiguous().cuda()
@@ -185,7 +187,7 @@ def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None):
     y = torch.full((N, H, W, Cout), float("nan"), device="cuda")
     p = ConvParams()
     p.x, p.w, p.bias, p.y = xd.data_ptr(), u.data_ptr(), bd.data_ptr(), y.data_ptr()
-    p.N, p.H_in, p.W_in, p.Cin, p.Cout = N, H, W, Cin, Cout
+    p.N, p.H_in, p.W_in, p.Cin, p.Cout = N, Hs, Ws, Cin, Cout
     p.KH = p.KW = 3
     p.stride, p.pad, p.ldx, p.ldy, p.flags = 1, 1, Cin, Cout, flags
     rd = None
@@ -222,6 +224,16 @@ def test_winograd_matches_cpu(case):
     # and against the direct MFMA kernel: both are fp32-rounding-level restatements of the same sum
     if Cin % 32 == 0:
         torch.testing.assert_close(out, run_conv(x, w, b, 1, flags, res), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 8, 8, 128), (1, 128, 16, 24, 64), (1, 32, 5, 9, 32)])
+def test_winograd_upsample_in(shape):
+    """conv3x3 on a nearest-2x upsampled input (simple neck stages and the heads behind it), upsample folded into the gather."""
+    N, Cin, H, W, Cout = shape
+    x, w, b = mk(N, Cin, H, W, Cout, 3, seed=H * W + Cout)
+    flags = CNL_RELU | CNL_UPSAMPLE_IN
+    out = run_winograd(x, w, b, flags)
+    torch.testing.assert_close(out, ref_conv(x, w, b, 1, flags), rtol=RTOL, atol=ATOL)
 
 
 def test_winograd_exact_on_small_integers():
