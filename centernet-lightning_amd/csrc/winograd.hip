@@ -183,6 +183,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
 
 #ifdef CNL_TRACE
     const long long t_pro = wall_clock64();
+    const long long c_pro = clock64();
 #endif
     const int fragA = ((lane & 31) * 8 + hi * 4) * 4;                  // + (xi*64 + g*32) * 32
     const int fragB = ((wh * 32 + (lane & 31)) * 8 + hi * 4) * 4;      // + (xi*64) * 32
@@ -197,8 +198,6 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
     for (; cc + 1 < a.CC; ++cc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();     // V[cc&1] complete, U[cc&1] + patch cc+1 landed; MFMA phase cc-1 and transform cc done everywhere
-        WINO_ISSUE_U(cc + 1);
-        WINO_ISSUE_P(cc + 2);
         const char* vB = sV + (cc & 1) * V_BYTES + fragA;
         const char* uB = sU + (cc & 1) * U_BYTES + fragB;
         const char* src_ = sP + ((cc + 1) & 1) * P_BYTES + t_src;
@@ -207,11 +206,9 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
         fa[0][0] = lds_f4(vB + (xi0 * 64) * 32); fa[0][1] = lds_f4(vB + (xi0 * 64 + 32) * 32);
         fb[0] = lds_f4(uB + (xi0 * 64) * 32);
         float d_[4][4], t_[4][4], v_[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) d_[i][j] = lds_f(src_ + (i * PW + j) * 32);
         __builtin_amdgcn_sched_barrier(0);
+        // slice schedule after the barrier: first MFMA as soon as the first fragments arrive; patch reads in slices 0-3,
+        // DMA issue (next U chunk, patch after next) in slices 4-5, adds in 6-21, LDS writes of V in 16-31.
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             const int j = k >> 3, kk = k & 7, buf = j & 1;
@@ -221,22 +218,31 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
                 fa[buf ^ 1][1] = lds_f4(vB + ((xi0 + j + 1) * 64 + 32) * 32);
                 fb[buf ^ 1] = lds_f4(uB + ((xi0 + j + 1) * 64) * 32);
             }
-            if (k < 16) {
+            if (k < 4) {
 #pragma unroll
-                for (int e = 2 * k; e < 2 * k + 2; ++e) {
-                    if (e < 16) {                                   // t = B^T d   (column jj of d)
-                        const int i = e & 3, jj = e >> 2;
-                        t_[i][jj] = i == 0 ? d_[0][jj] - d_[2][jj] : i == 1 ? d_[1][jj] + d_[2][jj] : i == 2 ? d_[2][jj] - d_[1][jj] : d_[1][jj] - d_[3][jj];
-                    } else {                                        // V = t B     (row i of t)
-                        const int i = (e - 16) >> 2, jj = (e - 16) & 3;
-                        v_[i][jj] = jj == 0 ? t_[i][0] - t_[i][2] : jj == 1 ? t_[i][1] + t_[i][2] : jj == 2 ? t_[i][2] - t_[i][1] : t_[i][1] - t_[i][3];
-                    }
+                for (int jj = 0; jj < 4; ++jj) d_[k][jj] = lds_f(src_ + (k * PW + jj) * 32);
+            }
+            if (k == 4) WINO_ISSUE_U(cc + 1);
+            if (k == 5) WINO_ISSUE_P(cc + 2);
+            if (k >= 6 && k < 14) {                                 // t = B^T d   (two columns' worth per slice)
+#pragma unroll
+                for (int e = 2 * (k - 6); e < 2 * (k - 6) + 2; ++e) {
+                    const int i = e & 3, jj = e >> 2;
+                    t_[i][jj] = i == 0 ? d_[0][jj] - d_[2][jj] : i == 1 ? d_[1][jj] + d_[2][jj] : i == 2 ? d_[2][jj] - d_[1][jj] : d_[1][jj] - d_[3][jj];
                 }
-            } else {
-                *reinterpret_cast<float*>(dst_ + (k - 16) * (T * 32)) = v_[(k - 16) >> 2][(k - 16) & 3];
+            }
+            if (k >= 14 && k < 30) {                                // V = t B (one value per slice) ...
+                const int e = k - 14, i = e >> 2, jj = e & 3;
+                v_[i][jj] = jj == 0 ? t_[i][0] - t_[i][2] : jj == 1 ? t_[i][1] + t_[i][2] : jj == 2 ? t_[i][2] - t_[i][1] : t_[i][1] - t_[i][3];
+            }
+            if (k >= 16) {                                          // ... written two slices after it was computed
+                const int e = k - 16;
+                if (e < 14) *reinterpret_cast<float*>(dst_ + e * (T * 32)) = v_[e >> 2][e & 3];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        *reinterpret_cast<float*>(dst_ + 14 * (T * 32)) = v_[3][2];
+        *reinterpret_cast<float*>(dst_ + 15 * (T * 32)) = v_[3][3];
     }
     {   // last chunk: MFMAs only
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -258,6 +264,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
 
 #ifdef CNL_TRACE
     const long long t_loop = wall_clock64();
+    const long long c_loop = clock64();
 #endif
     // ---- epilogue: Y = A^T M A.  Stage 1 (row of positions, in registers): q_c = sum_j A^T[c][j] M[i][j] ----
     const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
     if (a.trace && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long* t = a.trace + (long)blockIdx.x * 8;
-        t[0] = t_start; t[1] = t_pro; t[2] = t_pro; t[3] = t_loop; t[4] = wall_clock64(); t[5] = 0;
+        t[0] = t_start; t[1] = t_pro; t[2] = t_pro; t[3] = t_loop; t[4] = wall_clock64(); t[5] = c_loop - c_pro;
     }
 #endif
 }
