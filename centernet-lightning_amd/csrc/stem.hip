@@ -8,8 +8,11 @@
 // global-memory im2col hopeless (12-byte pixels), so the im2col happens on the LDS side: a workgroup
 // stages the (2*8+5) x (2*32+5) x 3 input patch of its 8x32 output tile and the whole 148x64 weight
 // matrix in LDS; each MFMA A operand is a per-lane ds_read_b32 at  row(ky) * RS + 6*px + (k % 21)
-// (kx and c are contiguous in the patch row, so k % 21 is a plain offset).  Each wave computes two
-// output rows (2 x 32 pixels) x 64 channels = four 32x32 accumulators with v_mfma_f32_32x32x2_f32.
+// (kx and c are contiguous in the patch row, so k % 21 is a plain offset).  Each wave computes four
+// output rows (4 x 32 pixels) x 64 channels = eight 32x32 accumulators with v_mfma_f32_32x32x2_f32.
+// The weight matrix is copied global -> LDS with coalesced reads (thread e reads w[e]) into a [k][65]
+// image (row stride 65 keeps both the transposing write and the fragment reads bank-conflict-free); the first
+// version read it with a 147-float stride per lane and spent 3/4 of its time there.
 // The input is read through explicit element strides, so NCHW and channels_last callers are zero-copy.
 #include "cnl_common.h"
 
@@ -18,12 +21,13 @@ namespace cnl_stem {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int ST_TH = 8, ST_TW = 32;                  // output tile
+constexpr int ST_TH = 16, ST_TW = 32;                 // output tile (4 rows per wave)
+constexpr int ST_WS = 65;                             // LDS row stride of the weight image [k][co]
 constexpr int ST_PR = 2 * ST_TH + 5 + 1;              // patch rows (+1 zero row for the k=147 pad tap)
 constexpr int ST_PC = 2 * ST_TW + 5;                  // patch cols
 constexpr int ST_RS = ST_PC * 3 + 1;                  // patch row stride in floats (208)
 constexpr int ST_KP = 148;                            // padded K
-constexpr int ST_LDS_FLOATS = ST_PR * ST_RS + ST_KP * 64;
+constexpr int ST_LDS_FLOATS = ST_PR * ST_RS + ST_KP * ST_WS;
 
 __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restrict__ x, long sn, long sc, long sh, long sw,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
@@ -31,7 +35,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
                                                            int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* patch = reinterpret_cast<float*>(smem);
-    float* wl = patch + ST_PR * ST_RS;                // [148][64], k-major
+    float* wl = patch + ST_PR * ST_RS;                // [148][65], k-major
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5, px = lane & 31;
@@ -42,11 +46,12 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
     const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
 
-    // weights: global OHWI [64][147] -> LDS [k][co]; row 147 = 0
-    for (int e = tid; e < ST_KP * 64; e += 256) {
-        const int k = e >> 6, co = e & 63;
-        wl[e] = k < 147 ? w[co * 147 + k] : 0.f;
+    // weights: global OHWI [64][147] (read coalesced) -> LDS [k][co] with row stride 65; row 147 = 0
+    for (int e = tid; e < 64 * 147; e += 256) {
+        const int co = e / 147, k = e - co * 147;
+        wl[k * ST_WS + co] = w[e];
     }
+    if (tid < 64) wl[147 * ST_WS + tid] = 0.f;
     // input patch -> LDS [row][col*3 + c]; channel-minor or plane-major traversal for coalescing
     const float* xn = x + (long)n * sn;
     if (sc == 1) {
@@ -70,27 +75,27 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
     }
     __syncthreads();
 
-    f32x16 acc[2][2];
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // lane's A base: output row (wave*2 + i), column px -> patch row 2*(wave*2+i) + ky, col 2*px + kx
-    const float* pa = patch + (wave * 4) * ST_RS + px * 6;       // i adds 2*ST_RS
-    const float* pb = wl + hi * 64 + px;                         // k = 2s + hi
+    // lane's A base: output row (wave*4 + i), column px -> patch row 2*(wave*4+i) + ky, col 2*px + kx
+    const float* pa = patch + (wave * 8) * ST_RS + px * 6;       // i adds 2*ST_RS
+    const float* pb = wl + hi * ST_WS + px;                      // k = 2s + hi
     int kr = hi, rowoff = 0;                                     // k % 21 and (k / 21) * RS
     for (int s = 0; s < ST_KP / 2; ++s) {
-        const float a0 = pa[rowoff + kr];
-        const float a1 = pa[rowoff + kr + 2 * ST_RS];
-        const float b0 = pb[s * 128];
-        const float b1 = pb[s * 128 + 32];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        const float b0 = pb[s * 2 * ST_WS];
+        const float b1 = pb[s * 2 * ST_WS + 32];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float av = pa[rowoff + kr + i * 2 * ST_RS];
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[i][1], 0, 0, 0);
+        }
         kr += 2;
         if (kr >= 21) { kr -= 21; rowoff += ST_RS; }
     }
@@ -101,8 +106,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
         const int co = j * 32 + px;
         const float bv = bias[co];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int oy = oy0 + wave * 2 + i;
+        for (int i = 0; i < 4; ++i) {
+            const int oy = oy0 + wave * 4 + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;

@@ -20,6 +20,11 @@
 //             32-63 ci 4-7: four K=2 steps per read), 8 MFMAs; 32 MFMAs per wave per chunk;
 //   transform of chunk cc+1 (thread = (tile, channel): 16 LDS reads, 32 adds, 16 LDS writes) is hand-interleaved with
 //             those MFMAs, one slice = {1 MFMA, 2 adds | 1 write}, fenced by sched_barrier(0).
+// Measured and rejected (round 1): a wave-specialised variant (8 matrix waves + 4 producer waves doing all DMA and the
+// transform, 3 waves/SIMD) was correct but 5 % slower (2707 vs 2568 us on the 256->256 @128^2 x32 layer), with or without
+// s_setprio for the producers.  Ablation of this kernel on that layer: 2536 us full; -146 us without the transform's LDS
+// traffic, -51 without the DMA, -36 without the barrier, ~0 without the fragment reads; 2182 us with all four removed,
+// against 2057 us of pure MFMA time at the 2.04 GHz the chip sustains in this loop.
 // Epilogue: owning a whole transform row lets each wave apply the first half of A^T M A in registers (4 -> 2 matrices);
 // the halves meet through LDS ([i][c][tile][co], two passes) where thread = (tile, co) finishes Y, adds bias
 // (+ residual) (+ ReLU) and stores the 2x2 outputs NHWC with buffer stores (uniform part of the address in the SGPR
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
         const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;      // nn.Upsample(nearest, x2) folded into the gather
         p_off[i] = ok ? (unsigned)((((n * a.Hs + sy) * a.Ws + sx) * a.ldx + half * 4) * 4) : OOB;
     }
-    // U: this wave loads its own 4 positions' rows for BOTH cout groups of... no: positions 2*wave, 2*wave+1, all 64 couts
+    // U slice DMA: this wave fetches positions 2*wave, 2*wave+1 for all 64 couts (2 x 1 KB each)
     unsigned u_off[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) u_off[p] = (unsigned)((((wave * 2 + p) * a.CoutP + n0) * 8) * 4 + lane * 16);

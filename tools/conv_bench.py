@@ -51,12 +51,12 @@ def main():
         p.ldx, p.ldy, p.ldr, p.flags = Cin, Cout, Cout, flags | (int(os.environ.get("CNL_DEBUG_FLAGS", "0")))
         fn = lib.cnl_conv2d_nhwc_f32
         if args.winograd:
-            if k != 3 or stride != 1 or flags & CNL_UPSAMPLE_IN:
+            if k != 3 or stride != 1:
                 continue
             u = torch.empty(lib.cnl_winograd_weight_floats(Cin, Cout), device="cuda")
             _lib.check(lib.cnl_winograd_transform_weights_f32(w.data_ptr(), u.data_ptr(), Cin, Cout, stream))
             p.w = u.data_ptr()
-            p.flags = flags & 1
+            p.flags = flags & 5            # RELU | UPSAMPLE_IN
             fn = lib.cnl_conv3x3_winograd_f32
         for _ in range(2):
             _lib.check(fn(ctypes.byref(p), stream))
