@@ -61,7 +61,9 @@ constexpr int BN = 64;                      // output channels per workgroup
 constexpr int PW = 18;                      // patch width / height in pixels
 constexpr int V_BYTES = 16 * T * 32;        // 32768 per buffer
 constexpr int U_BYTES = 16 * BN * 32;       // 32768 per buffer
-constexpr int P_SLOTS = 704;                // 648 used; 512 (all waves) + 192 (waves 0-2)
+constexpr int PWP = 19;                     // padded patch row (pixels) of the LDS image [py][half][PWP][4 floats]: the 76-float
+                                            // half-row stride makes the transform's 4x4 gathers bank-conflict-free
+constexpr int P_SLOTS = 704;                // 684 used; 512 (all waves) + 192 (waves 0-2)
 constexpr int P_BYTES = P_SLOTS * 16;       // 11264 per buffer
 constexpr int LDS_BYTES = 2 * V_BYTES + 2 * U_BYTES + 2 * P_BYTES;   // 153600 -> one 8-wave workgroup per CU
 
@@ -115,18 +117,19 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
     unsigned p_off[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int s = i * 512 + tid;                  // 16-byte slot of the patch: pixel s>>1, channel half s&1
-        const int px = s >> 1, half = s & 1;
-        const int py = px / PW, pxx = px - py * PW;
+        const int s = i * 512 + tid;                  // 16-byte slot of the patch image: s = (py*2 + half)*PWP + px
+        const int rowh = s / PWP, pxx = s - rowh * PWP;
+        const int py = rowh >> 1, half = rowh & 1;
         const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-        const bool ok = s < PW * PW * 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const bool ok = py < PW && pxx < PW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;      // nn.Upsample(nearest, x2) folded into the gather
         p_off[i] = ok ? (unsigned)((((n * a.Hs + sy) * a.Ws + sx) * a.ldx + half * 4) * 4) : OOB;
     }
     // U slice DMA: this wave fetches positions 2*wave, 2*wave+1 for all 64 couts (2 x 1 KB each)
     unsigned u_off[2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) u_off[p] = (unsigned)((((wave * 2 + p) * a.CoutP + n0) * 8) * 4 + lane * 16);
+    for (int p = 0; p < 2; ++p)      // lane -> (cout row = lane>>1, half = lane&1); rows with bit 3 set fetch the other half
+        u_off[p] = (unsigned)((((wave * 2 + p) * a.CoutP + n0) * 8) * 4 + (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) * 16));
     const unsigned u_chunk = (unsigned)(16 * a.CoutP * 8 * 4);          // bytes per channel chunk of U
 
 #define WINO_ISSUE_P(cc_)                                                                                        \
@@ -147,8 +150,10 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
 
     // transform item: thread -> (tile = tid >> 3, ch = tid & 7)
     const int t_ch = tid & 7, t_tile = tid >> 3;
-    const int t_src = (((2 * (t_tile >> 3)) * PW + 2 * (t_tile & 7)) * 8 + t_ch) * 4;
-    const int t_dst = (t_tile * 8 + t_ch) * 4;
+    const int t_src = ((((2 * (t_tile >> 3)) * 2 + (t_ch >> 2)) * PWP + 2 * (t_tile & 7)) * 4 + (t_ch & 3)) * 4;
+    // V / U rows are 32 bytes = two 16-byte halves (ci 0-3 | ci 4-7); rows with bit 3 set store them swapped, which makes the
+    // ds_read_b128 fragment reads (16-lane groups, 32-byte row pitch) bank-conflict-free
+    const int t_dst = (t_tile * 8 + (t_ch ^ (((t_tile >> 3) & 1) << 2))) * 4;
 
     WINO_ISSUE_P(0);
     WINO_ISSUE_U(0);
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d_[i][j] = lds_f(src_ + (i * PW + j) * 32);
+            for (int j = 0; j < 4; ++j) d_[i][j] = lds_f(src_ + (i * 2 * PWP + j) * 16);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             t_[0][j] = d_[0][j] - d_[2][j];
@@ -190,8 +195,9 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
     const long long t_pro = wall_clock64();
     const long long c_pro = clock64();
 #endif
-    const int fragA = ((lane & 31) * 8 + hi * 4) * 4;                  // + (xi*64 + g*32) * 32
-    const int fragB = ((wh * 32 + (lane & 31)) * 8 + hi * 4) * 4;      // + (xi*64) * 32
+    const int hs = hi ^ ((lane >> 3) & 1);                             // physical half holding this lane's logical half
+    const int fragA = ((lane & 31) * 8 + hs * 4) * 4;                  // + (xi*64 + g*32) * 32
+    const int fragB = ((wh * 32 + (lane & 31)) * 8 + hs * 4) * 4;      // + (xi*64) * 32
     const int xi0 = wi * 4;
     // the 8 MFMAs of one position: k = 0..7 -> c = k >> 1, g = k & 1
 #define WINO_MFMA8(j_, fa_, fb_, k_) acc[j_][(k_) & 1] = mfma32((fa_)[(k_) & 1][(k_) >> 1], (fb_)[(k_) >> 1], acc[j_][(k_) & 1])
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
             }
             if (k < 4) {
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) d_[k][jj] = lds_f(src_ + (k * PW + jj) * 32);
+                for (int jj = 0; jj < 4; ++jj) d_[k][jj] = lds_f(src_ + (k * 2 * PWP + jj) * 16);
             }
             if (k == 4) WINO_ISSUE_U(cc + 1);
             if (k == 5) WINO_ISSUE_P(cc + 2);
