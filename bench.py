@@ -33,10 +33,11 @@ import torch.distributed as dist  # noqa: E402
 import centernet_lightning_amd as cl  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
-# HBM bytes per conv launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_fetch_size.txt,
-# r01_pmc_write_size.txt): mean FETCH_SIZE 209.0 MB x 2 (gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md
-# §HBM) + mean WRITE_SIZE 115.4 MB, averaged over the 45 conv launches of a C1 step.  Other configs: not profiled -> null.
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("simple", 32, 512, 512, "cnl_conv::conv_mfma_kernel"): 533.3e6}
+# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_v4.txt): per kernel, mean
+# FETCH_SIZE x 2 (gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md §HBM) + mean WRITE_SIZE over the launches
+# of a C1 step (Winograd: 149.6 MB x 2 + 129.1 MB).  Other configs: not profiled -> null.
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("simple", 32, 512, 512, "cnl_conv::conv_mfma_kernel"): 245.4e6,
+                                     ("simple", 32, 512, 512, "cnl_wino::winograd_conv_kernel"): 428.2e6}
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 
 
