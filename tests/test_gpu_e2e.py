@@ -126,3 +126,22 @@ def test_channels_last_input_and_weight_reload():
     model.load_state_dict(sd2)
     c = model.get_encoded_outputs(x)
     assert not torch.equal(a["box_2d"], c["box_2d"]) and torch.equal(a["heatmap"], c["heatmap"])
+
+
+def test_direct_and_winograd_paths_agree(monkeypatch):
+    """The same model through the two conv implementations (CNL_WINOGRAD=0: every conv on the direct implicit-GEMM kernel;
+    default: 3x3/stride-1 layers on Winograd F(2x2,3x3)): both within 1e-4 of the CPU oracle and ~1e-5 of each other."""
+    x = recipes.images(11, (2, 3, 128, 128))
+    monkeypatch.setenv("CNL_WINOGRAD", "0")
+    model_d, sd = build("resnet34_fpn.yaml")
+    out_d = model_d.get_encoded_outputs(x.cuda())
+    assert not any("winograd" in L.what for plan in model_d._engine.plans.values() for L in plan.launches)
+    monkeypatch.setenv("CNL_WINOGRAD", "1")
+    model_w, _ = build("resnet34_fpn.yaml")
+    out_w = model_w.get_encoded_outputs(x.cuda())
+    assert sum("winograd" in L.what for plan in model_w._engine.plans.values() for L in plan.launches) >= 30
+    ref = ref_cpu.forward(sd, x, sigmoid=False)
+    for name in ref:
+        torch.testing.assert_close(out_d[name].cpu(), ref[name], rtol=TOL, atol=TOL)
+        torch.testing.assert_close(out_w[name].cpu(), ref[name], rtol=TOL, atol=TOL)
+        torch.testing.assert_close(out_w[name], out_d[name], rtol=2e-5, atol=2e-5)
