@@ -316,6 +316,24 @@ class Engine:
             self.weights_device = dev
             self.plans.clear()
         N, _, H, W = x.shape
+        chunk = self.max_batch(H, W)
+        if N > chunk:
+            # the kernels address each tensor through 32-bit buffer offsets (< 4 GiB per tensor): run contiguous sub-batches
+            # (images are independent; results are byte-identical to one big batch) and concatenate
+            parts = [self._run(x[i:i + chunk], sigmoid) for i in range(0, N, chunk)]
+            return OrderedDict((k, torch.cat([p[k] for p in parts], dim=0)) for k in parts[0])
+        return self._run(x, sigmoid)
+
+    def max_batch(self, H, W):
+        """Largest batch whose biggest activation tensor stays below the 4 GiB buffer-addressing limit of the kernels."""
+        widest = max(64, sum(b[0].cout for b in self.weights.head_blocks.values() if b) if self.weights.fused_first is not None else 0,
+                     max((l.cout for b in self.weights.head_blocks.values() for l in b), default=64))
+        per_image = max((H // 2) * (W // 2) * 64, (H // 4) * (W // 4) * widest) * 4
+        return max(1, (0xF0000000 - (1 << 24)) // per_image)
+
+    def _run(self, x, sigmoid):
+        dev = x.device
+        N, _, H, W = x.shape
         key = (N, H, W, bool(sigmoid))
         plan = self.plans.get(key)
         if plan is None:

@@ -145,3 +145,15 @@ def test_direct_and_winograd_paths_agree(monkeypatch):
         torch.testing.assert_close(out_d[name].cpu(), ref[name], rtol=TOL, atol=TOL)
         torch.testing.assert_close(out_w[name].cpu(), ref[name], rtol=TOL, atol=TOL)
         torch.testing.assert_close(out_w[name], out_d[name], rtol=2e-5, atol=2e-5)
+
+
+def test_large_batch_is_split_below_the_4gib_addressing_limit(monkeypatch):
+    """Engine.max_batch: a batch whose fused head buffer would exceed 4 GiB runs as contiguous sub-batches with identical bytes."""
+    model, _ = build("resnet34_fpn.yaml")
+    x = recipes.images(5, (3, 3, 64, 96)).cuda()
+    full = model.get_encoded_outputs(x)
+    assert model._engine.max_batch(512, 512) >= 64 and model._engine.max_batch(608, 1088) < 64
+    monkeypatch.setattr(type(model._engine), "max_batch", lambda self, H, W: 2)
+    split = model.get_encoded_outputs(x)
+    for k in full:
+        assert torch.equal(full[k], split[k])
