@@ -52,7 +52,6 @@ struct WinoArgs {
     int blocks;
     unsigned x_bytes, u_bytes, y_bytes, r_bytes;
     unsigned flags;
-    long long* trace;                 // CNL_TRACE builds only
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -93,45 +92,51 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sV = smem;                                  // [2][16 xi][64 tiles][8 ci]
     char* sU = smem + 2 * V_BYTES;                    // [2][16 xi][64 co][8 ci]
-    char* sP = smem + 2 * V_BYTES + 2 * U_BYTES;      // [2][18*18 px][8 ci] (+ slack)
+    char* sP = smem + 2 * V_BYTES + 2 * U_BYTES;      // [2][18 py][2 halves][19 px][4 ci] (+ slack)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
     const int wi = wave >> 1, wh = wave & 1;          // transform row and cout group owned by this wave
-#ifdef CNL_TRACE
-    const long long t_start = wall_clock64();
-#endif
-
-    // block -> (image n, tile-block row/col, cout block); cout fastest so the blocks sharing a patch are neighbours
-    unsigned b = cnl::xcd_remap(blockIdx.x, (unsigned)a.blocks);
-    const int nbi = b % a.nb; b /= a.nb;
-    const int bxi = b % a.bx; b /= a.bx;
-    const int byi = b % a.by;
-    const int n = b / a.by;
-    const int y0 = byi * 16, x0 = bxi * 16, n0 = nbi * BN;
     const bool up = a.flags & CNL_UPSAMPLE_IN;
-
-    // ---- per-lane DMA bookkeeping ----
-    unsigned p_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int s = i * 512 + tid;                  // 16-byte slot of the patch image: s = (py*2 + half)*PWP + px
-        const int rowh = s / PWP, pxx = s - rowh * PWP;
-        const int py = rowh >> 1, half = rowh & 1;
-        const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-        const bool ok = py < PW && pxx < PW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;      // nn.Upsample(nearest, x2) folded into the gather
-        p_off[i] = ok ? (unsigned)((((n * a.Hs + sy) * a.Ws + sx) * a.ldx + half * 4) * 4) : OOB;
-    }
-    // U slice DMA: this wave fetches positions 2*wave, 2*wave+1 for all 64 couts (2 x 1 KB each)
-    unsigned u_off[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)      // lane -> (cout row = lane>>1, half = lane&1); rows with bit 3 set fetch the other half
-        u_off[p] = (unsigned)((((wave * 2 + p) * a.CoutP + n0) * 8) * 4 + (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) * 16));
     const unsigned u_chunk = (unsigned)(16 * a.CoutP * 8 * 4);          // bytes per channel chunk of U
 
+    // transform item: thread -> (tile = tid >> 3, ch = tid & 7)
+    const int t_ch = tid & 7, t_tile = tid >> 3;
+    const int t_src = ((((2 * (t_tile >> 3)) * 2 + (t_ch >> 2)) * PWP + 2 * (t_tile & 7)) * 4 + (t_ch & 3)) * 4;
+    // V / U rows are 32 bytes = two 16-byte halves (ci 0-3 | ci 4-7); rows with bit 3 set store them swapped, which makes the
+    // ds_read_b128 fragment reads (16-lane groups, 32-byte row pitch) bank-conflict-free
+    const int t_dst = (t_tile * 8 + (t_ch ^ (((t_tile >> 3) & 1) << 2))) * 4;
+    const int hs = hi ^ ((lane >> 3) & 1);                             // physical half holding this lane's logical half
+    const int fragA = ((lane & 31) * 8 + hs * 4) * 4;                  // + (xi*64 + g*32) * 32
+    const int fragB = ((wh * 32 + (lane & 31)) * 8 + hs * 4) * 4;      // + (xi*64) * 32
+    const int xi0 = wi * 4;
+    const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
+
+    // ---- per-work-item bookkeeping: item -> (image n, tile-block row/col, cout block); cout fastest so that the workgroups
+    // sharing an input patch run side by side; per-lane DMA source offsets of the patch and of the U slice ----
+    int n, y0, x0, n0;
+    unsigned p_off[2], u_off[2];
+#define WINO_SETUP(item_)                                                                                        \
+    do {                                                                                                         \
+        unsigned b_ = cnl::xcd_remap((item_), (unsigned)a.blocks);                                               \
+        const int nbi_ = b_ % a.nb; b_ /= a.nb;                                                                  \
+        const int bxi_ = b_ % a.bx; b_ /= a.bx;                                                                  \
+        const int byi_ = b_ % a.by;                                                                              \
+        n = b_ / a.by; y0 = byi_ * 16; x0 = bxi_ * 16; n0 = nbi_ * BN;                                           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+            const int s_ = i * 512 + tid;              /* 16-byte slot of the patch image: (py*2 + half)*PWP + px */ \
+            const int rowh_ = s_ / PWP, pxx_ = s_ - rowh_ * PWP;                                                 \
+            const int py_ = rowh_ >> 1, half_ = rowh_ & 1;                                                       \
+            const int iy_ = y0 - 1 + py_, ix_ = x0 - 1 + pxx_;                                                   \
+            const bool ok_ = py_ < PW && pxx_ < PW && (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W; \
+            const int sy_ = up ? (iy_ >> 1) : iy_, sx_ = up ? (ix_ >> 1) : ix_;   /* nearest-2x upsample folded in */ \
+            p_off[i] = ok_ ? (unsigned)((((n * a.Hs + sy_) * a.Ws + sx_) * a.ldx + half_ * 4) * 4) : OOB;        \
+        }                                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p)  /* lane -> (cout row lane>>1, half lane&1), swapped for rows with bit 3 */ \
+            u_off[p] = (unsigned)((((wave * 2 + p) * a.CoutP + n0) * 8) * 4 + (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) * 16)); \
+    } while (0)
 #define WINO_ISSUE_P(cc_)                                                                                        \
     do {                                                                                                         \
         char* d_ = sP + ((cc_) & 1) * P_BYTES;                                                                   \
@@ -147,198 +152,191 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
             dma16(a.u, a.u_bytes, d_ + (wave * 2 + p) * 2048 + 1024, u_off[p] + 1024u, (unsigned)(cc_) * u_chunk); \
         }                                                                                                        \
     } while (0)
-
-    // transform item: thread -> (tile = tid >> 3, ch = tid & 7)
-    const int t_ch = tid & 7, t_tile = tid >> 3;
-    const int t_src = ((((2 * (t_tile >> 3)) * 2 + (t_ch >> 2)) * PWP + 2 * (t_tile & 7)) * 4 + (t_ch & 3)) * 4;
-    // V / U rows are 32 bytes = two 16-byte halves (ci 0-3 | ci 4-7); rows with bit 3 set store them swapped, which makes the
-    // ds_read_b128 fragment reads (16-lane groups, 32-byte row pitch) bank-conflict-free
-    const int t_dst = (t_tile * 8 + (t_ch ^ (((t_tile >> 3) & 1) << 2))) * 4;
-
-    WINO_ISSUE_P(0);
-    WINO_ISSUE_U(0);
-
-    f32x16 acc[4][2];        // [position j of row wi][tile group]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) acc[j][g] = mfma_zero();
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    {   // input transform of chunk 0 (not overlapped)
-        const char* src_ = sP + t_src;
-        float d_[4][4], t_[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) d_[i][j] = lds_f(src_ + (i * 2 * PWP + j) * 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t_[0][j] = d_[0][j] - d_[2][j];
-            t_[1][j] = d_[1][j] + d_[2][j];
-            t_[2][j] = d_[2][j] - d_[1][j];
-            t_[3][j] = d_[1][j] - d_[3][j];
-        }
-        char* dst_ = sV + t_dst;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float*>(dst_ + (i * 4 + 0) * (T * 32)) = t_[i][0] - t_[i][2];
-            *reinterpret_cast<float*>(dst_ + (i * 4 + 1) * (T * 32)) = t_[i][1] + t_[i][2];
-            *reinterpret_cast<float*>(dst_ + (i * 4 + 2) * (T * 32)) = t_[i][2] - t_[i][1];
-            *reinterpret_cast<float*>(dst_ + (i * 4 + 3) * (T * 32)) = t_[i][1] - t_[i][3];
-        }
-    }
-    if (a.CC > 1) WINO_ISSUE_P(1);
-
-#ifdef CNL_TRACE
-    const long long t_pro = wall_clock64();
-    const long long c_pro = clock64();
-#endif
-    const int hs = hi ^ ((lane >> 3) & 1);                             // physical half holding this lane's logical half
-    const int fragA = ((lane & 31) * 8 + hs * 4) * 4;                  // + (xi*64 + g*32) * 32
-    const int fragB = ((wh * 32 + (lane & 31)) * 8 + hs * 4) * 4;      // + (xi*64) * 32
-    const int xi0 = wi * 4;
     // the 8 MFMAs of one position: k = 0..7 -> c = k >> 1, g = k & 1
 #define WINO_MFMA8(j_, fa_, fb_, k_) acc[j_][(k_) & 1] = mfma32((fa_)[(k_) & 1][(k_) >> 1], (fb_)[(k_) >> 1], acc[j_][(k_) & 1])
 
-    // steady state: ONE barrier per chunk; MFMAs of chunk cc with the input transform of chunk cc+1 hand-interleaved, one
-    // slice = {1 MFMA, 2 VALU | 1 LDS write}, slices fenced by sched_barrier(0): left to itself hipcc emits the whole
-    // transform after the last MFMA, where both waves of a SIMD reach it together and the matrix pipe idles.
-    int cc = 0;
-    for (; cc + 1 < a.CC; ++cc) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();     // V[cc&1] complete, U[cc&1] + patch cc+1 landed; MFMA phase cc-1 and transform cc done everywhere
-        const char* vB = sV + (cc & 1) * V_BYTES + fragA;
-        const char* uB = sU + (cc & 1) * U_BYTES + fragB;
-        const char* src_ = sP + ((cc + 1) & 1) * P_BYTES + t_src;
-        char* dst_ = sV + ((cc + 1) & 1) * V_BYTES + t_dst;
-        f32x4 fa[2][2], fb[2];      // double-buffered fragments: [buffer][tile group]
-        fa[0][0] = lds_f4(vB + (xi0 * 64) * 32); fa[0][1] = lds_f4(vB + (xi0 * 64 + 32) * 32);
-        fb[0] = lds_f4(uB + (xi0 * 64) * 32);
-        float d_[4][4], t_[4][4], v_[4][4];
-        __builtin_amdgcn_sched_barrier(0);
-        // slice schedule after the barrier: first MFMA as soon as the first fragments arrive; patch reads in slices 0-3,
-        // DMA issue (next U chunk, patch after next) in slices 4-5, adds in 6-21, LDS writes of V in 16-31.
+    // Persistent workgroups (grid = one per CU): the first chunk of the NEXT work item is fetched while the epilogue of the
+    // current one runs, so only the very first item of a launch waits for HBM latency with an idle matrix pipe.
+    unsigned item = blockIdx.x;
+    WINO_SETUP(item);
+    WINO_ISSUE_P(0);
+    WINO_ISSUE_U(0);
+    bool first = true;
+    while (true) {
+        f32x16 acc[4][2];        // [position j of row wi][tile group]
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const int j = k >> 3, kk = k & 7, buf = j & 1;
-            WINO_MFMA8(j, fa[buf], fb[buf], kk);
-            if (kk == 2 && j < 3) {                                 // next position's fragments, 6 MFMAs ahead of use
-                fa[buf ^ 1][0] = lds_f4(vB + ((xi0 + j + 1) * 64) * 32);
-                fa[buf ^ 1][1] = lds_f4(vB + ((xi0 + j + 1) * 64 + 32) * 32);
-                fb[buf ^ 1] = lds_f4(uB + ((xi0 + j + 1) * 64) * 32);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc[j][g] = mfma_zero();
+
+        // chunk 0 landed?  Its DMA is followed in this wave's VMEM queue by the second half of the previous item's epilogue
+        // (16 stores, +16 residual loads): a counted wait lets those stay in flight.
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (a.res) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        first = false;
+        __syncthreads();
+        {   // input transform of chunk 0 (not overlapped with MFMAs)
+            const char* src_ = sP + t_src;
+            float d_[4][4], t_[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d_[i][j] = lds_f(src_ + (i * 2 * PWP + j) * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t_[0][j] = d_[0][j] - d_[2][j];
+                t_[1][j] = d_[1][j] + d_[2][j];
+                t_[2][j] = d_[2][j] - d_[1][j];
+                t_[3][j] = d_[1][j] - d_[3][j];
             }
-            if (k < 4) {
+            char* dst_ = sV + t_dst;
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) d_[k][jj] = lds_f(src_ + (k * 2 * PWP + jj) * 16);
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<float*>(dst_ + (i * 4 + 0) * (T * 32)) = t_[i][0] - t_[i][2];
+                *reinterpret_cast<float*>(dst_ + (i * 4 + 1) * (T * 32)) = t_[i][1] + t_[i][2];
+                *reinterpret_cast<float*>(dst_ + (i * 4 + 2) * (T * 32)) = t_[i][2] - t_[i][1];
+                *reinterpret_cast<float*>(dst_ + (i * 4 + 3) * (T * 32)) = t_[i][1] - t_[i][3];
             }
-            if (k == 4) WINO_ISSUE_U(cc + 1);
-            if (k == 5) WINO_ISSUE_P(cc + 2);
-            if (k >= 6 && k < 14) {                                 // t = B^T d   (two columns' worth per slice)
+        }
+        if (a.CC > 1) WINO_ISSUE_P(1);
+
+        // steady state: ONE barrier per chunk; MFMAs of chunk cc with the input transform of chunk cc+1 hand-interleaved, one
+        // slice = {1 MFMA, 2 VALU | 1 LDS write}, slices fenced by sched_barrier(0): left to itself hipcc emits the whole
+        // transform after the last MFMA, where both waves of a SIMD reach it together and the matrix pipe idles.
+        int cc = 0;
+        for (; cc + 1 < a.CC; ++cc) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();     // V[cc&1] complete, U[cc&1] + patch cc+1 landed; MFMA phase cc-1 and transform cc done everywhere
+            const char* vB = sV + (cc & 1) * V_BYTES + fragA;
+            const char* uB = sU + (cc & 1) * U_BYTES + fragB;
+            const char* src_ = sP + ((cc + 1) & 1) * P_BYTES + t_src;
+            char* dst_ = sV + ((cc + 1) & 1) * V_BYTES + t_dst;
+            f32x4 fa[2][2], fb[2];      // double-buffered fragments: [buffer][tile group]
+            fa[0][0] = lds_f4(vB + (xi0 * 64) * 32); fa[0][1] = lds_f4(vB + (xi0 * 64 + 32) * 32);
+            fb[0] = lds_f4(uB + (xi0 * 64) * 32);
+            float d_[4][4], t_[4][4], v_[4][4];
+            __builtin_amdgcn_sched_barrier(0);
+            // slice schedule after the barrier: first MFMA as soon as the first fragments arrive; patch reads in slices 0-3,
+            // DMA issue (next U chunk, patch after next) in slices 4-5, adds in 6-29, LDS writes of V in 16-31.
 #pragma unroll
-                for (int e = 2 * (k - 6); e < 2 * (k - 6) + 2; ++e) {
-                    const int i = e & 3, jj = e >> 2;
-                    t_[i][jj] = i == 0 ? d_[0][jj] - d_[2][jj] : i == 1 ? d_[1][jj] + d_[2][jj] : i == 2 ? d_[2][jj] - d_[1][jj] : d_[1][jj] - d_[3][jj];
+            for (int k = 0; k < 32; ++k) {
+                const int j = k >> 3, kk = k & 7, buf = j & 1;
+                WINO_MFMA8(j, fa[buf], fb[buf], kk);
+                if (kk == 2 && j < 3) {                                 // next position's fragments, 6 MFMAs ahead of use
+                    fa[buf ^ 1][0] = lds_f4(vB + ((xi0 + j + 1) * 64) * 32);
+                    fa[buf ^ 1][1] = lds_f4(vB + ((xi0 + j + 1) * 64 + 32) * 32);
+                    fb[buf ^ 1] = lds_f4(uB + ((xi0 + j + 1) * 64) * 32);
+                }
+                if (k < 4) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) d_[k][jj] = lds_f(src_ + (k * 2 * PWP + jj) * 16);
+                }
+                if (k == 4) WINO_ISSUE_U(cc + 1);
+                if (k == 5) WINO_ISSUE_P(cc + 2);
+                if (k >= 6 && k < 14) {                                 // t = B^T d   (two values per slice)
+#pragma unroll
+                    for (int e = 2 * (k - 6); e < 2 * (k - 6) + 2; ++e) {
+                        const int i = e & 3, jj = e >> 2;
+                        t_[i][jj] = i == 0 ? d_[0][jj] - d_[2][jj] : i == 1 ? d_[1][jj] + d_[2][jj] : i == 2 ? d_[2][jj] - d_[1][jj] : d_[1][jj] - d_[3][jj];
+                    }
+                }
+                if (k >= 14 && k < 30) {                                // V = t B (one value per slice) ...
+                    const int e = k - 14, i = e >> 2, jj = e & 3;
+                    v_[i][jj] = jj == 0 ? t_[i][0] - t_[i][2] : jj == 1 ? t_[i][1] + t_[i][2] : jj == 2 ? t_[i][2] - t_[i][1] : t_[i][1] - t_[i][3];
+                }
+                if (k >= 16) {                                          // ... written two slices after it was computed
+                    const int e = k - 16;
+                    if (e < 14) *reinterpret_cast<float*>(dst_ + e * (T * 32)) = v_[e >> 2][e & 3];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            *reinterpret_cast<float*>(dst_ + 14 * (T * 32)) = v_[3][2];
+            *reinterpret_cast<float*>(dst_ + 15 * (T * 32)) = v_[3][3];
+        }
+        {   // last chunk: MFMAs only
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const char* vB = sV + (cc & 1) * V_BYTES + fragA;
+            const char* uB = sU + (cc & 1) * U_BYTES + fragB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 fa[1][2], fb[1];
+                fa[0][0] = lds_f4(vB + ((xi0 + j) * 64) * 32); fa[0][1] = lds_f4(vB + ((xi0 + j) * 64 + 32) * 32);
+                fb[0] = lds_f4(uB + ((xi0 + j) * 64) * 32);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) WINO_MFMA8(j, fa[0], fb[0], kk);
+            }
+        }
+
+        // ---- epilogue: Y = A^T M A.  Stage 1 (row of positions, in registers): q_c = sum_j A^T[c][j] M[i][j] ----
+        float* sQ = reinterpret_cast<float*>(smem);            // [4 i][2 c][32 tiles][64 co] = 64 KB per tile group (V buffers)
+        const int co = tid & 63;
+        const int col = n0 + co;
+        const bool col_ok = col < a.Cout;
+        const float bv = col_ok ? a.bias[col] : 0.f;
+        const bool full = (y0 + 16 <= a.H) && (x0 + 16 <= a.W) && (n0 + BN <= a.Cout);
+        const int en = n, ey0 = y0, ex0 = x0;                  // this item's coordinates (the setup below moves on to the next)
+        const unsigned next = item + gridDim.x;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            __syncthreads();                                   // done reading V/U (g = 0) or sQ of the previous pass
+            if (g == 1 && next < (unsigned)a.blocks) {         // U and patch buffers are idle now: fetch the next item's chunk 0
+                WINO_SETUP(next);
+                WINO_ISSUE_P(0);
+                WINO_ISSUE_U(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float m0 = acc[0][g][r], m1 = acc[1][g][r], m2 = acc[2][g][r], m3 = acc[3][g][r];
+                sQ[((wi * 2 + 0) * 32 + tl) * 64 + wh * 32 + (lane & 31)] = m0 + m1 + m2;
+                sQ[((wi * 2 + 1) * 32 + tl) * 64 + wh * 32 + (lane & 31)] = m1 - m2 - m3;
+            }
+            __syncthreads();
+            // Stage 2: thread = (tile, co): Y[a][c] = sum_i A^T[a][i] q[i][c]; 4 items per thread
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int tl = (tid >> 6) + 8 * it;            // tile inside this 32-tile group
+                const int tile = g * 32 + tl;
+                const int oy = ey0 + 2 * (tile >> 3), ox = ex0 + 2 * (tile & 7);
+                const unsigned pix = (unsigned)((en * a.H + oy) * a.W + ox);
+                const unsigned y_voff = (pix * (unsigned)a.ldy + (unsigned)col) * 4u;
+                const unsigned r_voff = (pix * (unsigned)a.ldr + (unsigned)col) * 4u;
+                bool ok[2][2];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) ok[dy][dx] = full || (col_ok && oy + dy < a.H && ox + dx < a.W);
+                float rv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+                if (a.res) {
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx)
+                            rv[dy][dx] = buf_load(a.res, a.r_bytes, ok[dy][dx] ? r_voff : OOB, (unsigned)((dy * a.W + dx) * a.ldr * 4));
+                }
+                float q[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) q[i][c] = sQ[((i * 2 + c) * 32 + tl) * 64 + co];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float ya = q[0][c] + q[1][c] + q[2][c];
+                    const float yb = q[1][c] - q[2][c] - q[3][c];
+                    buf_store(fmaxf(ya + bv + rv[0][c], lo), a.y, a.y_bytes, ok[0][c] ? y_voff : OOB, (unsigned)(c * a.ldy * 4));
+                    buf_store(fmaxf(yb + bv + rv[1][c], lo), a.y, a.y_bytes, ok[1][c] ? y_voff : OOB, (unsigned)((a.W + c) * a.ldy * 4));
                 }
             }
-            if (k >= 14 && k < 30) {                                // V = t B (one value per slice) ...
-                const int e = k - 14, i = e >> 2, jj = e & 3;
-                v_[i][jj] = jj == 0 ? t_[i][0] - t_[i][2] : jj == 1 ? t_[i][1] + t_[i][2] : jj == 2 ? t_[i][2] - t_[i][1] : t_[i][1] - t_[i][3];
-            }
-            if (k >= 16) {                                          // ... written two slices after it was computed
-                const int e = k - 16;
-                if (e < 14) *reinterpret_cast<float*>(dst_ + e * (T * 32)) = v_[e >> 2][e & 3];
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
-        *reinterpret_cast<float*>(dst_ + 14 * (T * 32)) = v_[3][2];
-        *reinterpret_cast<float*>(dst_ + 15 * (T * 32)) = v_[3][3];
-    }
-    {   // last chunk: MFMAs only
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const char* vB = sV + (cc & 1) * V_BYTES + fragA;
-        const char* uB = sU + (cc & 1) * U_BYTES + fragB;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 fa[1][2], fb[1];
-            fa[0][0] = lds_f4(vB + ((xi0 + j) * 64) * 32); fa[0][1] = lds_f4(vB + ((xi0 + j) * 64 + 32) * 32);
-            fb[0] = lds_f4(uB + ((xi0 + j) * 64) * 32);
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) WINO_MFMA8(j, fa[0], fb[0], kk);
-        }
+        if (next >= (unsigned)a.blocks) break;
+        item = next;
     }
 #undef WINO_MFMA8
 #undef WINO_ISSUE_P
 #undef WINO_ISSUE_U
-
-#ifdef CNL_TRACE
-    const long long t_loop = wall_clock64();
-    const long long c_loop = clock64();
-#endif
-    // ---- epilogue: Y = A^T M A.  Stage 1 (row of positions, in registers): q_c = sum_j A^T[c][j] M[i][j] ----
-    const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
-    float* sQ = reinterpret_cast<float*>(smem);            // [4 i][2 c][32 tiles][64 co] = 64 KB per tile group
-    const int co = tid & 63;
-    const int col = n0 + co;
-    const bool col_ok = col < a.Cout;
-    const float bv = col_ok ? a.bias[col] : 0.f;
-    const bool full = (y0 + 16 <= a.H) && (x0 + 16 <= a.W) && (n0 + BN <= a.Cout);
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        __syncthreads();                                   // done reading V/U (g = 0) or sQ of the previous pass
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float m0 = acc[0][g][r], m1 = acc[1][g][r], m2 = acc[2][g][r], m3 = acc[3][g][r];
-            sQ[((wi * 2 + 0) * 32 + tl) * 64 + wh * 32 + (lane & 31)] = m0 + m1 + m2;
-            sQ[((wi * 2 + 1) * 32 + tl) * 64 + wh * 32 + (lane & 31)] = m1 - m2 - m3;
-        }
-        __syncthreads();
-        // Stage 2: thread = (tile, co): Y[a][c] = sum_i A^T[a][i] q[i][c]; 4 items per thread
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int tl = (tid >> 6) + 8 * it;            // tile inside this 32-tile group
-            const int tile = g * 32 + tl;
-            const int oy = y0 + 2 * (tile >> 3), ox = x0 + 2 * (tile & 7);
-            const unsigned pix = (unsigned)((n * a.H + oy) * a.W + ox);
-            const unsigned y_voff = (pix * (unsigned)a.ldy + (unsigned)col) * 4u;
-            const unsigned r_voff = (pix * (unsigned)a.ldr + (unsigned)col) * 4u;
-            bool ok[2][2];
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) ok[dy][dx] = full || (col_ok && oy + dy < a.H && ox + dx < a.W);
-            float rv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-            if (a.res) {
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx)
-                        rv[dy][dx] = buf_load(a.res, a.r_bytes, ok[dy][dx] ? r_voff : OOB, (unsigned)((dy * a.W + dx) * a.ldr * 4));
-            }
-            float q[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) q[i][c] = sQ[((i * 2 + c) * 32 + tl) * 64 + co];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const float ya = q[0][c] + q[1][c] + q[2][c];
-                const float yb = q[1][c] - q[2][c] - q[3][c];
-                buf_store(fmaxf(ya + bv + rv[0][c], lo), a.y, a.y_bytes, ok[0][c] ? y_voff : OOB, (unsigned)(c * a.ldy * 4));
-                buf_store(fmaxf(yb + bv + rv[1][c], lo), a.y, a.y_bytes, ok[1][c] ? y_voff : OOB, (unsigned)((a.W + c) * a.ldy * 4));
-            }
-        }
-    }
-#ifdef CNL_TRACE
-    if (a.trace && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long* t = a.trace + (long)blockIdx.x * 8;
-        t[0] = t_start; t[1] = t_pro; t[2] = t_pro; t[3] = t_loop; t[4] = wall_clock64(); t[5] = c_loop - c_pro;
-    }
-#endif
+#undef WINO_SETUP
 }
 
 // U = G g G^T per (co, ci), packed [Cin/8][16][CoutP][8]; rows co >= Cout are zero.
@@ -422,16 +420,22 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.flags = p->flags;
-    a.trace = nullptr;
-#ifdef CNL_TRACE
-    if (const char* e = getenv("CNL_TRACE_PTR")) a.trace = (long long*)strtoull(e, nullptr, 0);
-#endif
     static bool attr_done = false;
     if (!attr_done) {
         CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     LDS_BYTES));
         attr_done = true;
     }
-    hipLaunchKernelGGL(winograd_conv_kernel, dim3((unsigned)blocks), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+    // persistent workgroups: one per CU (150 KB of LDS each), walking the work items with stride gridDim.x
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        CNL_HIP(hipGetDevice(&dev));
+        CNL_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const unsigned grid = (unsigned)(blocks < n_cu ? blocks : n_cu);
+    hipLaunchKernelGGL(winograd_conv_kernel, dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
     return cnl::check_launch("winograd_conv_kernel");
 }
