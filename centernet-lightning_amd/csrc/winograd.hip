@@ -245,14 +245,13 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
                     const int e = k - 14, i = e >> 2, jj = e & 3;
                     v_[i][jj] = jj == 0 ? t_[i][0] - t_[i][2] : jj == 1 ? t_[i][1] + t_[i][2] : jj == 2 ? t_[i][2] - t_[i][1] : t_[i][1] - t_[i][3];
                 }
-                if (k >= 16) {                                          // ... written two slices after it was computed
-                    const int e = k - 16;
-                    if (e < 14) *reinterpret_cast<float*>(dst_ + e * (T * 32)) = v_[e >> 2][e & 3];
+                if (k >= 17 && (k & 1)) {                               // ... written in pairs (one ds_write2st64_b32) on odd slices
+                    const int e = k - 17;
+                    *reinterpret_cast<float*>(dst_ + e * (T * 32)) = v_[e >> 2][e & 3];
+                    *reinterpret_cast<float*>(dst_ + (e + 1) * (T * 32)) = v_[(e + 1) >> 2][(e + 1) & 3];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            *reinterpret_cast<float*>(dst_ + 14 * (T * 32)) = v_[3][2];
-            *reinterpret_cast<float*>(dst_ + 15 * (T * 32)) = v_[3][3];
         }
         {   // last chunk: MFMAs only
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
