@@ -72,6 +72,13 @@ class PackedWeights:
         L = lambda conv, bn=None, stride=None: _Layer(*map(dev, fold_conv_bn(conv.weight, conv.bias, bn)),
                                                       stride=stride if stride is not None else conv.stride[0])
         self.stem = L(bb.conv1, bb.bn1)
+        # the stem kernel DMAs its weights into LDS verbatim: pack OHWI -> [148][64] once (cnl_stem_pack_weights_f32)
+        lib = _lib.load()
+        with torch.cuda.device(device):
+            self.stem_packed = torch.empty((148 * 64,), device=device, dtype=torch.float32)
+            _lib.check(lib.cnl_stem_pack_weights_f32(self.stem.w.data_ptr(), self.stem_packed.data_ptr(),
+                                                     ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
+                       "cnl_stem_pack_weights_f32")
         self.blocks = []
         for li in range(4):
             for blk in getattr(bb, f"layer{li + 1}"):
@@ -159,6 +166,7 @@ class Plan:
     def _build(self, Wt):
         N, H, W = self.N, self.H, self.W
         self._wt_stem = Wt.stem
+        self._wt_stem_packed = Wt.stem_packed
         if H % 32 or W % 32:
             raise ValueError(f"input H, W must be divisible by 32 (got {H}x{W}); docs/implementation.md:52 of the reference")
         # ---- backbone ----
@@ -270,7 +278,7 @@ class Plan:
         for L in self.launches:
             if L.fn == "stem":
                 sn, sc, sh, sw = x.stride()
-                rc = lib.cnl_stem_conv7x7_f32(x.data_ptr(), sn, sc, sh, sw, self._wt_stem.w.data_ptr(), self._wt_stem.b.data_ptr(),
+                rc = lib.cnl_stem_conv7x7_f32(x.data_ptr(), sn, sc, sh, sw, self._wt_stem_packed.data_ptr(), self._wt_stem.b.data_ptr(),
                                               self.stem_out.data_ptr(), self.N, self.H, self.W, stream)
             elif L.fn == "maxpool":
                 src, dst, n, h, w, c = L.args

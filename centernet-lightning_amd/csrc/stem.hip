@@ -22,23 +22,35 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ST_TH = 16, ST_TW = 32;                 // output tile (4 rows per wave)
-constexpr int ST_WS = 65;                             // LDS row stride of the weight image [k][co]
 constexpr int ST_PR = 2 * ST_TH + 5 + 1;              // patch rows (+1 zero row for the k=147 pad tap)
 constexpr int ST_PC = 2 * ST_TW + 5;                  // patch cols
-constexpr int ST_RS = ST_PC * 3 + 1;                  // patch row stride in floats (208)
+constexpr int ST_RS = 256;                            // patch row stride in floats: 207 used; 1 KB = 4 DMA instructions per row
 constexpr int ST_KP = 148;                            // padded K
-constexpr int ST_LDS_FLOATS = ST_PR * ST_RS + ST_KP * ST_WS;
+constexpr int ST_W_BYTES = ST_KP * 64 * 4;            // 37888 = 37 x 1 KB
+constexpr int ST_LDS_BYTES = ST_PR * ST_RS * 4 + ST_W_BYTES;   // 76800 -> 2 workgroups / CU
+constexpr unsigned ST_OOB = 0xFFFFFFF0u;
 
-__global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restrict__ x, long sn, long sc, long sh, long sw,
-                                                           const float* __restrict__ w, const float* __restrict__ bias,
-                                                           float* __restrict__ y, int N, int H, int W, int Ho, int Wo,
-                                                           int tiles_x, int tiles_y) {
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void dma4(const float* base, unsigned bytes, float* lds_dst, unsigned voffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 4, voffset, 0, 0, 0);
+}
+__device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* lds_dst, unsigned voffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restrict__ x, long sn, int sc, int sh, int sw,
+                                                           unsigned x_img_bytes, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int N, int H,
+                                                           int W, int Ho, int Wo, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* patch = reinterpret_cast<float*>(smem);
-    float* wl = patch + ST_PR * ST_RS;                // [148][65], k-major
+    float* wl = patch + ST_PR * ST_RS;                // [148][64], k-major (pre-packed by cnl_stem_pack_weights_f32)
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5, px = lane & 31;
+    const int lane = tid & 63, hi = lane >> 5, px = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int b = blockIdx.x;
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
@@ -46,33 +58,30 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
     const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
 
-    // weights: global OHWI [64][147] (read coalesced) -> LDS [k][co] with row stride 65; row 147 = 0
-    for (int e = tid; e < 64 * 147; e += 256) {
-        const int co = e / 147, k = e - co * 147;
-        wl[k * ST_WS + co] = w[e];
-    }
-    if (tid < 64) wl[147 * ST_WS + tid] = 0.f;
-    // input patch -> LDS [row][col*3 + c]; channel-minor or plane-major traversal for coalescing
+    // ---- staging by LDS-DMA: no VGPR round trip and almost no VALU (this runs beside the co-resident group's MFMA stream) ----
+    // weights: 37 pieces of 1 KB, lane-linear
+    for (int q = wave; q < ST_W_BYTES / 1024; q += 4)
+        dma16(w, (unsigned)ST_W_BYTES, reinterpret_cast<char*>(wl) + q * 1024, (unsigned)(q * 1024 + lane * 16));
+    // input patch -> LDS [row][col*3 + c]: 4-byte DMA, lane f of a row fetches pixel col = f/3, channel c = f%3 from wherever
+    // the caller's strides put it (NCHW planes or channels_last alike); out-of-image lanes get zeros from the bounds check
     const float* xn = x + (long)n * sn;
-    if (sc == 1) {
-        for (int e = tid; e < ST_PR * ST_PC * 3; e += 256) {
-            const int r = e / (ST_PC * 3), cc = e - r * (ST_PC * 3);
-            const int col = cc / 3, c = cc - col * 3;
-            const int iy = iy0 + r, ix = ix0 + col;
-            float v = 0.f;
-            if (r < ST_PR - 1 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xn[iy * sh + ix * sw + c];
-            patch[r * ST_RS + cc] = v;
-        }
-    } else {
-        for (int e = tid; e < 3 * ST_PR * ST_PC; e += 256) {
-            const int c = e / (ST_PR * ST_PC), rem = e - c * (ST_PR * ST_PC);
-            const int r = rem / ST_PC, col = rem - r * ST_PC;
-            const int iy = iy0 + r, ix = ix0 + col;
-            float v = 0.f;
-            if (r < ST_PR - 1 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xn[c * sc + iy * sh + ix * sw];
-            patch[r * ST_RS + col * 3 + c] = v;
-        }
+    unsigned lane_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int f = q * 64 + lane;
+        const int col = f / 3, c = f - col * 3;
+        const int ix = ix0 + col;
+        lane_off[q] = (f < ST_PC * 3 && (unsigned)ix < (unsigned)W) ? (unsigned)((c * sc + ix * sw) * 4) : ST_OOB;
     }
+    for (int r = wave; r < ST_PR; r += 4) {
+        const int iy = iy0 + r;
+        const bool row_ok = r < ST_PR - 1 && (unsigned)iy < (unsigned)H;      // wave-uniform
+        const unsigned row_off = (unsigned)(iy * sh * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            dma4(xn, x_img_bytes, patch + r * ST_RS + q * 64, (row_ok && lane_off[q] != ST_OOB) ? lane_off[q] + row_off : ST_OOB);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     f32x16 acc[4][2];
@@ -85,11 +94,11 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
 
     // lane's A base: output row (wave*4 + i), column px -> patch row 2*(wave*4+i) + ky, col 2*px + kx
     const float* pa = patch + (wave * 8) * ST_RS + px * 6;       // i adds 2*ST_RS
-    const float* pb = wl + hi * ST_WS + px;                      // k = 2s + hi
+    const float* pb = wl + hi * 64 + px;                         // k = 2s + hi
     int kr = hi, rowoff = 0;                                     // k % 21 and (k / 21) * RS
     for (int s = 0; s < ST_KP / 2; ++s) {
-        const float b0 = pb[s * 2 * ST_WS];
-        const float b1 = pb[s * 2 * ST_WS + 32];
+        const float b0 = pb[s * 128];
+        const float b1 = pb[s * 128 + 32];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float av = pa[rowoff + kr + i * 2 * ST_RS];
@@ -146,25 +155,43 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const f32x4* __restrict__ 
     }
 }
 
+// OHWI [64][7][7][3] (BN folded) -> the kernel's LDS image [148][64] (k = (ky*7+kx)*3+c major, row 147 = 0)
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ w, float* __restrict__ wp) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= ST_KP * 64) return;
+    const int k = e >> 6, co = e & 63;
+    wp[e] = k < 147 ? w[co * 147 + k] : 0.f;
+}
+
 }  // namespace cnl_stem
 using namespace cnl_stem;
+
+extern "C" int cnl_stem_pack_weights_f32(const float* w_ohwi, float* w_packed, void* stream) {
+    CNL_REQUIRE(w_ohwi && w_packed, CNL_E_BAD_ARG, "cnl_stem_pack_weights_f32: null pointer");
+    hipLaunchKernelGGL(stem_pack_kernel, dim3((ST_KP * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_ohwi, w_packed);
+    return cnl::check_launch("stem_pack_kernel");
+}
 
 extern "C" int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
                                     const float* bias, float* y, int32_t N, int32_t H, int32_t W, void* stream) {
     CNL_REQUIRE(x && w && bias && y, CNL_E_BAD_ARG, "cnl_stem_conv7x7_f32: null tensor pointer");
     CNL_REQUIRE(N > 0 && H > 0 && W > 0, CNL_E_BAD_ARG, "cnl_stem_conv7x7_f32: non-positive dimension");
+    CNL_REQUIRE(sc > 0 && sh > 0 && sw > 0 && sn >= 0, CNL_E_UNSUPPORTED, "cnl_stem_conv7x7_f32: non-positive strides");
+    CNL_REQUIRE(((uintptr_t)w & 15) == 0, CNL_E_BAD_ARG, "cnl_stem_conv7x7_f32: packed weights must be 16-byte aligned");
+    const unsigned long long img_bytes = (2ull * sc + (unsigned long long)(H - 1) * sh + (unsigned long long)(W - 1) * sw + 1) * 4ull;
+    CNL_REQUIRE(img_bytes < 0xFFFFFF00ull, CNL_E_UNSUPPORTED, "cnl_stem_conv7x7_f32: one image spans >= 4 GiB");
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     const int tiles_x = (Wo + ST_TW - 1) / ST_TW, tiles_y = (Ho + ST_TH - 1) / ST_TH;
     const long long blocks = (long long)N * tiles_x * tiles_y;
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_stem_conv7x7_f32: grid too large");
     static bool attr_done = false;
-    const int lds = ST_LDS_FLOATS * 4;
+    const int lds = ST_LDS_BYTES;
     if (!attr_done) {
         CNL_HIP(hipFuncSetAttribute((const void*)stem_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, (long)sn, (long)sc,
-                       (long)sh, (long)sw, w, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y);
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, (long)sn, (int)sc,
+                       (int)sh, (int)sw, (unsigned)img_bytes, w, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y);
     return cnl::check_launch("stem_conv_kernel");
 }
 

@@ -90,8 +90,10 @@ int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Ci
  * ResNet stem: Conv2d(3,64,7,stride=2,padding=3,bias=False)+BN+ReLU (torchvision resnet.conv1/bn1/relu).
  * x is read through explicit element strides (sn,sc,sh,sw) so NCHW-contiguous and channels_last
  * callers are both zero-copy (models/meta.py:97-98 precedent); y is NHWC [N, H/2, W/2, 64].
- * w: [64][7][7][3] (OHWI, BN folded), bias: [64].
+ * w: the PACKED weight image [148][64] (k = (ky*7+kx)*3+c major, zero row 147) that cnl_stem_pack_weights_f32 makes
+ * from the OHWI [64][7][7][3] (BN-folded) weights — it is copied into LDS verbatim by LDS-DMA; bias: [64].
  */
+int cnl_stem_pack_weights_f32(const float* w_ohwi, float* w_packed /* 148*64 floats */, void* stream);
 int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
                          const float* w, const float* bias, float* y,
                          int32_t N, int32_t H, int32_t W, void* stream);

@@ -150,11 +150,13 @@ def test_stem_matches_cpu(shape, channels_last):
     if channels_last:
         xd = xd.contiguous(memory_format=torch.channels_last)
     wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = torch.full((148 * 64,), float("nan"), device="cuda")
+    _lib.check(lib.cnl_stem_pack_weights_f32(wd.data_ptr(), wp.data_ptr(), _stream()))
     bd = b.cuda()
     N, _, H, W = shape
     y = torch.full((N, ref.shape[2], ref.shape[3], 64), float("nan"), device="cuda")
     sn, sc, sh, sw = xd.stride()
-    _lib.check(lib.cnl_stem_conv7x7_f32(xd.data_ptr(), sn, sc, sh, sw, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), N, H, W, _stream()))
+    _lib.check(lib.cnl_stem_conv7x7_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), y.data_ptr(), N, H, W, _stream()))
     torch.cuda.synchronize()
     torch.testing.assert_close(y.cpu().permute(0, 3, 1, 2), ref, rtol=RTOL, atol=ATOL)
 
