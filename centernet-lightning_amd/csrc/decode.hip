@@ -266,71 +266,123 @@ __device__ __forceinline__ unsigned score_key(float f) {
 
 constexpr int TK_THREADS = 1024;
 
+// wave-level helpers (64-wide wavefront)
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned scan_gt[TK_THREADS], scan_eq[TK_THREADS];
+    __shared__ unsigned hist[4096];
+    __shared__ unsigned wave_tot[TK_THREADS / 64];
     __shared__ unsigned long long cand[1024];
     __shared__ unsigned sh_prefix, sh_need;
 
     const int n = blockIdx.x;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const float* sc = a.ws_score + (long)n * a.HW;
 
-    // --- radix select: find key T of the k-th largest element ---
+    // --- radix select: key T of the k-th largest element, digits of 12 / 10 / 10 bits from the top.  (A 12-bit first digit
+    // spreads sigmoid scores, which share 1-2 exponents, over 16x more bins than an 8-bit one: far less LDS-atomic contention.) ---
     unsigned prefix = 0, mask = 0, need = (unsigned)a.k;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        if (tid < 256) hist[tid] = 0;
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        const int bits = pass == 0 ? 12 : 10;
+        const int shift = pass == 0 ? 20 : (pass == 1 ? 10 : 0);
+        const int nbins = 1 << bits;
+        const int per = nbins / TK_THREADS;               // bins per thread in the scan: 4 or 1
+        for (int i = tid; i < nbins; i += TK_THREADS) hist[i] = 0;
         __syncthreads();
         for (int i = tid; i < a.HW; i += TK_THREADS) {
             const unsigned key = score_key(sc[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (unsigned)(nbins - 1)], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned rem = need;
-            int d = 255;
-            for (; d > 0; --d) {
-                const unsigned c = hist[d];
-                if (c >= rem) break;
-                rem -= c;
+        // block-wide suffix sums over the bins from the top: thread t owns bins per*t .. per*t+per-1
+        unsigned h[4] = {0u, 0u, 0u, 0u};
+        unsigned own = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < per) { h[j] = hist[per * tid + j]; own += h[j]; }
+        unsigned suf = own;                                // -> sum over lanes >= lane within the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_down(suf, off);
+            if (lane + off < 64) suf += t;
+        }
+        if (lane == 0) wave_tot[wave] = suf;
+        __syncthreads();
+        unsigned higher = 0;                               // elements in bins owned by higher waves
+        for (int w = wave + 1; w < TK_THREADS / 64; ++w) higher += wave_tot[w];
+        const unsigned incl = suf + higher;                // elements in bins >= this thread's lowest bin
+        const unsigned above = incl - own;                 // elements in bins above this thread's bins
+        if (above < need && need <= incl) {                // the k-th largest falls in one of this thread's bins (exactly one thread)
+            unsigned rem = need - above;
+            int d = 0;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                if (j < per) {
+                    if (h[j] >= rem) { d = j; break; }
+                    rem -= h[j];
+                }
             }
-            sh_prefix = prefix | ((unsigned)d << shift);
+            sh_prefix = prefix | ((unsigned)(per * tid + d) << shift);
             sh_need = rem;
         }
         __syncthreads();
         prefix = sh_prefix;
-        need = sh_need;                         // how many elements == T (so far: within this digit) are needed
-        mask |= 255u << shift;
-        __syncthreads();
+        need = sh_need;                         // elements == T (within the digits seen so far) still to take
+        mask |= (unsigned)(nbins - 1) << shift;
     }
     const unsigned T = prefix;                   // exact key of the k-th largest
     // `need` = number of elements with key == T to take (lowest indices first); the rest have key > T.
 
-    // --- ordered compaction: thread t owns the contiguous index range [t*CH, (t+1)*CH) ---
+    // --- ordered compaction: thread t owns the contiguous index range [t*CH, (t+1)*CH); counts packed (gt << 16 | eq) ---
     const int CH = (a.HW + TK_THREADS - 1) / TK_THREADS;
     const int i0 = tid * CH, i1 = min(i0 + CH, a.HW);
-    unsigned cgt = 0, ceq = 0;
+    unsigned cnt = 0;
     for (int i = i0; i < i1; ++i) {
         const unsigned key = score_key(sc[i]);
-        cgt += key > T;
-        ceq += key == T;
+        cnt += key > T ? 0x10000u : 0u;
+        cnt += key == T ? 1u : 0u;
     }
-    scan_gt[tid] = cgt;
-    scan_eq[tid] = ceq;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 counters (both arrays)
-    for (int off = 1; off < TK_THREADS; off <<= 1) {
-        unsigned vg = 0, ve = 0;
-        if (tid >= off) { vg = scan_gt[tid - off]; ve = scan_eq[tid - off]; }
+    // CH <= 2^24 / 1024 elements per thread may overflow 16 bits in general; totals are bounded by HW <= 2^24, so scan the
+    // two counters separately when HW > 65535, packed otherwise (the common case)
+    unsigned pos_gt, pos_eq, total_gt;
+    if (a.HW <= 65535) {
+        const unsigned inc = wave_incl_scan(cnt, lane);
+        if (lane == 63) wave_tot[wave] = inc;
         __syncthreads();
-        scan_gt[tid] += vg;
-        scan_eq[tid] += ve;
+        unsigned base = 0, tot = 0;
+        for (int w = 0; w < TK_THREADS / 64; ++w) {
+            const unsigned t = wave_tot[w];
+            if (w < wave) base += t;
+            tot += t;
+        }
+        const unsigned excl = base + inc - cnt;
+        pos_gt = excl >> 16;
+        pos_eq = excl & 0xFFFFu;
+        total_gt = tot >> 16;
+    } else {
+        const unsigned g = cnt >> 16, e = cnt & 0xFFFFu;
+        const unsigned ig = wave_incl_scan(g, lane), ie = wave_incl_scan(e, lane);
+        __shared__ unsigned wave_tot2[TK_THREADS / 64];
+        if (lane == 63) { wave_tot[wave] = ig; wave_tot2[wave] = ie; }
         __syncthreads();
+        unsigned bg = 0, be = 0, tg = 0;
+        for (int w = 0; w < TK_THREADS / 64; ++w) {
+            if (w < wave) { bg += wave_tot[w]; be += wave_tot2[w]; }
+            tg += wave_tot[w];
+        }
+        pos_gt = bg + ig - g;
+        pos_eq = be + ie - e;
+        total_gt = tg;
     }
-    const unsigned total_gt = scan_gt[TK_THREADS - 1];        // == k - need
-    unsigned pos_gt = scan_gt[tid] - cgt;                      // exclusive
-    unsigned pos_eq = scan_eq[tid] - ceq;
     for (int i = tid; i < a.KP; i += TK_THREADS) cand[i] = 0ull;   // padding sorts last
     __syncthreads();
     for (int i = i0; i < i1; ++i) {
@@ -345,18 +397,45 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     }
     __syncthreads();
 
-    // --- bitonic sort, descending, KP <= 1024 elements ---
-    for (int size = 2; size <= a.KP; size <<= 1) {
-        for (int st = size >> 1; st > 0; st >>= 1) {
-            if (tid < a.KP) {
-                const int j = tid ^ st;
-                if (j > tid) {
-                    const unsigned long long x = cand[tid], y = cand[j];
-                    const bool desc = (tid & size) == 0;
-                    if (desc ? (x < y) : (x > y)) { cand[tid] = y; cand[j] = x; }
+    // --- sort descending by (key, ~index) ---
+    if (a.KP <= 128) {
+        // one wave, two elements per lane (indices lane and lane + 64), exchanges by shuffle: no barriers
+        if (wave == 0) {
+            unsigned long long e0 = lane < a.KP ? cand[lane] : 0ull;
+            unsigned long long e1 = lane + 64 < a.KP ? cand[lane + 64] : 0ull;
+            for (int size = 2; size <= 128; size <<= 1) {
+                for (int st = size >> 1; st > 0; st >>= 1) {
+                    if (st == 64) {
+                        // partner of index lane is lane + 64: same lane; direction of the final merge is descending
+                        if (e0 < e1) { const unsigned long long t = e0; e0 = e1; e1 = t; }
+                    } else {
+                        const unsigned long long p0 = __shfl_xor(e0, st), p1 = __shfl_xor(e1, st);
+                        const bool lower = (lane & st) == 0;                   // this lane holds the lower index of the pair
+                        const bool desc0 = (lane & size) == 0;                 // block direction for index lane
+                        const bool desc1 = ((lane + 64) & size) == 0;          // ... and for index lane + 64
+                        const bool take_max0 = lower == desc0, take_max1 = lower == desc1;
+                        e0 = take_max0 ? (e0 > p0 ? e0 : p0) : (e0 < p0 ? e0 : p0);
+                        e1 = take_max1 ? (e1 > p1 ? e1 : p1) : (e1 < p1 ? e1 : p1);
+                    }
                 }
             }
-            __syncthreads();
+            cand[lane] = e0;
+            cand[lane + 64] = e1;
+        }
+        __syncthreads();
+    } else {
+        for (int size = 2; size <= a.KP; size <<= 1) {
+            for (int st = size >> 1; st > 0; st >>= 1) {
+                if (tid < a.KP) {
+                    const int j = tid ^ st;
+                    if (j > tid) {
+                        const unsigned long long x = cand[tid], y = cand[j];
+                        const bool desc = (tid & size) == 0;
+                        if (desc ? (x < y) : (x > y)) { cand[tid] = y; cand[j] = x; }
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
 
