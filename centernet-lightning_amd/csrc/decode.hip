@@ -550,7 +550,7 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
         a.CG = p->C / vec;
         a.PXB = 256 / a.CG;
         if (a.PXB > p->W) a.PXB = p->W;
-        a.R = 8;
+        a.R = 8;                                          // measured best of {4, 8, 16, 32} rows per strip at C1
         a.tiles_x = (p->W + a.PXB - 1) / a.PXB;
         a.strips = (p->H + a.R - 1) / a.R;
         const long long blocks = (long long)p->N * a.tiles_x * a.strips;
