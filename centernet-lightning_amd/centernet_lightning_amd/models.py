@@ -133,6 +133,34 @@ class CenterNet(nn.Module):
             return TrackingOutput(out["heatmap"], out["box_2d"], out["reid"])
         return DetectionOutput(out["heatmap"], out["box_2d"])
 
+    # ------------------------------------------------------------------ step before the path
+    IMAGENET_MEAN = (0.485, 0.456, 0.406)      # datasets/utils.py:9-10 of the reference
+    IMAGENET_STD = (0.229, 0.224, 0.225)
+
+    def preprocess_uint8(self, images: torch.Tensor, mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
+        """uint8 RGB frames [N,H,W,3] on the GPU -> normalised fp32 batch, logical [N,3,H,W] (channels_last storage, read
+        zero-copy by forward()).  Same arithmetic as albumentations A.Normalize + ToTensorV2 (README.md:79-87)."""
+        import ctypes
+        import numpy as np
+        from . import _lib
+        if not (isinstance(images, torch.Tensor) and images.is_cuda):
+            raise RuntimeError("preprocess_uint8 runs on HIP devices only (no CPU fallback)")
+        if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3:
+            raise ValueError(f"expected uint8 [N,H,W,3], got {images.dtype} {tuple(images.shape)}")
+        images = images.contiguous()
+        N, H, W, _ = images.shape
+        m = np.array(mean, dtype=np.float32) * np.float32(255.0)
+        r = np.reciprocal(np.array(std, dtype=np.float32) * np.float32(255.0), dtype=np.float32)
+        lib = _lib.load()
+        with torch.cuda.device(images.device):
+            out = torch.empty((N, H, W, 3), device=images.device, dtype=torch.float32)
+            _lib.check(lib.cnl_normalize_u8_nhwc_f32(images.data_ptr(), out.data_ptr(), N, H, W,
+                                                     m.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                                     r.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                                     ctypes.c_void_p(torch.cuda.current_stream(images.device).cuda_stream)),
+                       "cnl_normalize_u8_nhwc_f32")
+        return out.permute(0, 3, 1, 2)
+
     # ------------------------------------------------------------------ decode (Gen-A names)
     def gather_detection2d(self, heatmap, box_2d=None, num_detections=100, nms_kernel=3, normalize_bbox=False):
         """-> {"bboxes": [N,k,4] x1y1x2y2, "labels": [N,k] i64, "scores": [N,k]} (README.md:58-64,97-101).

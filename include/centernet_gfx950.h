@@ -87,6 +87,15 @@ size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout);        /* elements
 int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream);
 
 /*
+ * Step before the path: uint8 HWC frames -> normalised fp32 NHWC, replacing albumentations
+ * A.Normalize + ToTensorV2 of the reference's inference pre-processing (README.md:79-87, datasets/utils.py:9-21):
+ * y = (float(x) - mean255[c]) * inv_std255[c], with HOST arrays mean255 = mean*255, inv_std255 = 1/(std*255) (3 floats each).
+ * x: [N,H,W,3] u8, y: [N,H,W,3] f32 (feed cnl_stem_conv7x7_f32 with strides sn=H*W*3, sc=1, sh=W*3, sw=3).
+ */
+int cnl_normalize_u8_nhwc_f32(const uint8_t* x, float* y, int32_t N, int32_t H, int32_t W, const float* mean255,
+                              const float* inv_std255, void* stream);
+
+/*
  * ResNet stem: Conv2d(3,64,7,stride=2,padding=3,bias=False)+BN+ReLU (torchvision resnet.conv1/bn1/relu).
  * x is read through explicit element strides (sn,sc,sh,sw) so NCHW-contiguous and channels_last
  * callers are both zero-copy (models/meta.py:97-98 precedent); y is NHWC [N, H/2, W/2, 64].

@@ -136,3 +136,21 @@ def unpack_detections(rec):
     if rec.shape[-1] > 6:
         out["embeddings"] = rec[..., 6:].copy()
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# pre-processing before the path
+# ----------------------------------------------------------------------------------------------
+def normalize_u8(images_u8, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), max_pixel_value=255.0):
+    """albumentations A.Normalize restated (third-party, absent from the reference tree; called at README.md:83-86,
+    datasets/utils.py:13-15 with the IMAGENET constants of datasets/utils.py:9-10):
+        mean *= max_pixel; std *= max_pixel; denominator = reciprocal(std); img = float32(img); img -= mean; img *= denominator
+    all float32.  images_u8: (N,H,W,3) uint8 -> (N,H,W,3) float32.  "parity unpinned" by the reference's tests (it has none for
+    pre-processing); the published algorithm is restated."""
+    m = np.array(mean, dtype=np.float32) * np.float32(max_pixel_value)
+    s = np.array(std, dtype=np.float32) * np.float32(max_pixel_value)
+    denom = np.reciprocal(s, dtype=np.float32)
+    img = np.asarray(images_u8).astype(np.float32)
+    img = img - m
+    img = img * denom
+    return img.astype(np.float32)

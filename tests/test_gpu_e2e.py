@@ -157,3 +157,22 @@ def test_large_batch_is_split_below_the_4gib_addressing_limit(monkeypatch):
     split = model.get_encoded_outputs(x)
     for k in full:
         assert torch.equal(full[k], split[k])
+
+
+def test_preprocess_uint8_bit_exact_and_feeds_forward():
+    """uint8 HWC -> normalised fp32 (cnl_normalize_u8_nhwc_f32) is bit-exact against the numpy restatement of A.Normalize, and
+    the channels_last result goes through forward() like a contiguous NCHW tensor of the same values."""
+    model, _ = build("resnet34_simple.yaml")
+    g = torch.Generator().manual_seed(9)
+    for shape in [(2, 64, 96, 3), (1, 33, 47, 3)]:
+        u8 = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+        out = model.preprocess_uint8(u8.cuda())
+        ref = decode_ref.normalize_u8(u8.numpy())
+        assert tuple(out.shape) == (shape[0], 3, shape[1], shape[2])
+        assert np.array_equal(out.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    u8 = torch.randint(0, 256, (2, 64, 96, 3), generator=g, dtype=torch.uint8)
+    x = model.preprocess_uint8(u8.cuda())
+    a = model.get_encoded_outputs(x)
+    b = model.get_encoded_outputs(x.contiguous())
+    for k in a:
+        assert torch.equal(a[k], b[k])

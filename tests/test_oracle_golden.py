@@ -125,3 +125,13 @@ def test_decode_oracle_matches_live_reference():
         cs, ci, cl, cb = decode_ref.canonicalize(s.numpy(), i.numpy(), l.numpy(), b.numpy())
         assert np.array_equal(cs, o["scores"]) and np.array_equal(ci, o["indices"]) and np.array_equal(cl, o["labels"])
         assert np.array_equal(cb.view(np.uint32), o["boxes"].view(np.uint32))
+
+
+def test_normalize_u8_known_answers():
+    """albumentations-style normalisation (oracle restatement): hand-checkable values."""
+    img = np.array([[[[0, 0, 0], [255, 255, 255], [124, 116, 104]]]], dtype=np.uint8)
+    out = decode_ref.normalize_u8(img)
+    assert out.dtype == np.float32 and out.shape == (1, 1, 3, 3)
+    np.testing.assert_allclose(out[0, 0, 0], [-0.485 / 0.229, -0.456 / 0.224, -0.406 / 0.225], rtol=1e-6)
+    np.testing.assert_allclose(out[0, 0, 1], [(1 - 0.485) / 0.229, (1 - 0.456) / 0.224, (1 - 0.406) / 0.225], rtol=1e-6)
+    np.testing.assert_allclose(out[0, 0, 2], [(124 / 255 - 0.485) / 0.229, (116 / 255 - 0.456) / 0.224, (104 / 255 - 0.406) / 0.225], rtol=1e-5, atol=1e-6)
