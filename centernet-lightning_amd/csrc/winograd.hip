@@ -36,6 +36,7 @@ namespace cnl_wino {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 struct WinoArgs {
@@ -87,6 +88,18 @@ __device__ __forceinline__ f32x16 mfma_zero() {
 }
 __device__ __forceinline__ float lds_f(const char* p) { return *reinterpret_cast<const float*>(p); }
 __device__ __forceinline__ f32x4 lds_f4(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x2 lds_f2(const char* p) { return *reinterpret_cast<const f32x2*>(p); }
+// packed fp32 add / subtract on a channel pair (the compiler scalarises <2 x float> arithmetic in this kernel)
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,12 +115,20 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
     const bool up = a.flags & CNL_UPSAMPLE_IN;
     const unsigned u_chunk = (unsigned)(16 * a.CoutP * 8 * 4);          // bytes per channel chunk of U
 
-    // transform item: thread -> (tile = tid >> 3, ch = tid & 7)
-    const int t_ch = tid & 7, t_tile = tid >> 3;
-    const int t_src = ((((2 * (t_tile >> 3)) * 2 + (t_ch >> 2)) * PWP + 2 * (t_tile & 7)) * 4 + (t_ch & 3)) * 4;
+    // transform item: thread -> (tile, channel PAIR, half): every add of B^T d B is one v_pk_add_f32 on two channels and every
+    // LDS access 8 bytes wide.  The two halves of the workgroup (waves 0-3 / 4-7, one wave of each SIMD) produce output columns
+    // {0,1} / {2,3} of the 4x4 transform from patch columns {0,1,2} / {1,2,3}: 6 ds_read2_b64 + 20 v_pk_add_f32 +
+    // 4 ds_write2st64_b64 per wave and chunk instead of 8 + 32 + 8 for one thread per (tile, channel).
+    const int lt = tid & 255;
+    const int t_cp = lt & 3, t_tile = lt >> 2;
+    const int t_src = ((((2 * (t_tile >> 3)) * 2 + (t_cp >> 1)) * PWP + 2 * (t_tile & 7)) * 4 + (t_cp & 1) * 2) * 4;
     // V / U rows are 32 bytes = two 16-byte halves (ci 0-3 | ci 4-7); rows with bit 3 set store them swapped, which makes the
     // ds_read_b128 fragment reads (16-lane groups, 32-byte row pitch) bank-conflict-free
-    const int t_dst = (t_tile * 8 + (t_ch ^ (((t_tile >> 3) & 1) << 2))) * 4;
+    const int t_dst = (t_tile * 8 + (((t_cp >> 1) ^ ((t_tile >> 3) & 1)) << 2) + (t_cp & 1) * 2) * 4;
+    // chunk-0 transform (prologue, all threads): thread -> (tile = tid >> 3, ch = tid & 7)
+    const int p_ch = tid & 7, p_tile = tid >> 3;
+    const int p_src = ((((2 * (p_tile >> 3)) * 2 + (p_ch >> 2)) * PWP + 2 * (p_tile & 7)) * 4 + (p_ch & 3)) * 4;
+    const int p_dst = (p_tile * 8 + (p_ch ^ (((p_tile >> 3) & 1) << 2))) * 4;
     const int hs = hi ^ ((lane >> 3) & 1);                             // physical half holding this lane's logical half
     const int fragA = ((lane & 31) * 8 + hs * 4) * 4;                  // + (xi*64 + g*32) * 32
     const int fragB = ((wh * 32 + (lane & 31)) * 8 + hs * 4) * 4;      // + (xi*64) * 32
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
         first = false;
         __syncthreads();
         {   // input transform of chunk 0 (not overlapped with MFMAs)
-            const char* src_ = sP + t_src;
+            const char* src_ = sP + p_src;
             float d_[4][4], t_[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -190,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
                 t_[2][j] = d_[2][j] - d_[1][j];
                 t_[3][j] = d_[1][j] - d_[3][j];
             }
-            char* dst_ = sV + t_dst;
+            char* dst_ = sV + p_dst;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 *reinterpret_cast<float*>(dst_ + (i * 4 + 0) * (T * 32)) = t_[i][0] - t_[i][2];
@@ -204,55 +225,68 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
         // steady state: ONE barrier per chunk; MFMAs of chunk cc with the input transform of chunk cc+1 hand-interleaved, one
         // slice = {1 MFMA, 2 VALU | 1 LDS write}, slices fenced by sched_barrier(0): left to itself hipcc emits the whole
         // transform after the last MFMA, where both waves of a SIMD reach it together and the matrix pipe idles.
+        // one chunk: 32 MFMAs in 32 fenced slices; DO_T_ adds this wave's share of the next chunk's input transform
+#define WINO_CHUNK(H_)                                                                                                       \
+        do {                                                                                                                 \
+            const char* vB = sV + (cc & 1) * V_BYTES + fragA;                                                                \
+            const char* uB = sU + (cc & 1) * U_BYTES + fragB;                                                                \
+            const char* src_ = sP + ((cc + 1) & 1) * P_BYTES + t_src;                                                        \
+            char* dst_ = sV + ((cc + 1) & 1) * V_BYTES + t_dst;                                                              \
+            f32x4 fa[2][2], fb[2];      /* double-buffered fragments: [buffer][tile group] */                                \
+            fa[0][0] = lds_f4(vB + (xi0 * 64) * 32); fa[0][1] = lds_f4(vB + (xi0 * 64 + 32) * 32);                           \
+            fb[0] = lds_f4(uB + (xi0 * 64) * 32);                                                                            \
+            f32x2 d_[4][3], t_[4][3], v_[4][2];                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                               \
+            /* slice schedule: first MFMA as soon as the first fragments arrive; patch reads in slices 0-2, DMA issue (next U   \
+               chunk, patch after next) in slices 4-5, packed adds in 6-19, LDS writes of V (pairs) on even slices 14-20 */   \
+            _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                                 \
+                const int j = k >> 3, kk = k & 7, buf = j & 1;                                                               \
+                WINO_MFMA8(j, fa[buf], fb[buf], kk);                                                                         \
+                if (kk == 2 && j < 3) {                                 /* next position's fragments, 6 MFMAs ahead of use */ \
+                    fa[buf ^ 1][0] = lds_f4(vB + ((xi0 + j + 1) * 64) * 32);                                                 \
+                    fa[buf ^ 1][1] = lds_f4(vB + ((xi0 + j + 1) * 64 + 32) * 32);                                            \
+                    fb[buf ^ 1] = lds_f4(uB + ((xi0 + j + 1) * 64) * 32);                                                    \
+                }                                                                                                            \
+                if (k < 3) {                                            /* patch column H_+k of this half-item */            \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i) d_[i][k] = lds_f2(src_ + (i * 2 * PWP + (H_) + k) * 16);   \
+                }                                                                                                            \
+                if (k == 4) WINO_ISSUE_U(cc + 1);                                                                            \
+                if (k == 5) WINO_ISSUE_P(cc + 2);                                                                            \
+                if (k >= 6 && k < 12) {                                 /* t = B^T d, three columns (two packed adds per slice) */\
+                    _Pragma("unroll") for (int e = 2 * (k - 6); e < 2 * (k - 6) + 2; ++e) {                                  \
+                        const int i = e & 3, c = e >> 2;                                                                     \
+                        t_[i][c] = i == 0 ? pk_sub(d_[0][c], d_[2][c]) : i == 1 ? pk_add(d_[1][c], d_[2][c]) : i == 2 ? pk_sub(d_[2][c], d_[1][c]) : pk_sub(d_[1][c], d_[3][c]);\
+                    }                                                                                                        \
+                }                                                                                                            \
+                if (k >= 12 && k < 20) {                                /* V = t B, output columns 2H_, 2H_+1 ... */         \
+                    const int e = k - 12, i = e >> 1;                                                                        \
+                    if ((H_) == 0) v_[i][e & 1] = (e & 1) == 0 ? pk_sub(t_[i][0], t_[i][2]) : pk_add(t_[i][1], t_[i][2]);    \
+                    else v_[i][e & 1] = (e & 1) == 0 ? pk_sub(t_[i][1], t_[i][0]) : pk_sub(t_[i][0], t_[i][2]);              \
+                }                                                                                                            \
+                if (k >= 14 && k <= 20 && !(k & 1)) {                   /* ... each row written as one ds_write2st64_b64 */  \
+                    const int i = (k - 14) >> 1;                                                                             \
+                    *reinterpret_cast<f32x2*>(dst_ + (4 * i + 2 * (H_)) * (T * 32)) = v_[i][0];                              \
+                    *reinterpret_cast<f32x2*>(dst_ + (4 * i + 2 * (H_) + 1) * (T * 32)) = v_[i][1];                          \
+                }                                                                                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                                           \
+            }                                                                                                                \
+        } while (0)
+
         int cc = 0;
-        for (; cc + 1 < a.CC; ++cc) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();     // V[cc&1] complete, U[cc&1] + patch cc+1 landed; MFMA phase cc-1 and transform cc done everywhere
-            const char* vB = sV + (cc & 1) * V_BYTES + fragA;
-            const char* uB = sU + (cc & 1) * U_BYTES + fragB;
-            const char* src_ = sP + ((cc + 1) & 1) * P_BYTES + t_src;
-            char* dst_ = sV + ((cc + 1) & 1) * V_BYTES + t_dst;
-            f32x4 fa[2][2], fb[2];      // double-buffered fragments: [buffer][tile group]
-            fa[0][0] = lds_f4(vB + (xi0 * 64) * 32); fa[0][1] = lds_f4(vB + (xi0 * 64 + 32) * 32);
-            fb[0] = lds_f4(uB + (xi0 * 64) * 32);
-            float d_[4][4], t_[4][4], v_[4][4];
-            __builtin_amdgcn_sched_barrier(0);
-            // slice schedule after the barrier: first MFMA as soon as the first fragments arrive; patch reads in slices 0-3,
-            // DMA issue (next U chunk, patch after next) in slices 4-5, adds in 6-29, LDS writes of V in 16-31.
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                const int j = k >> 3, kk = k & 7, buf = j & 1;
-                WINO_MFMA8(j, fa[buf], fb[buf], kk);
-                if (kk == 2 && j < 3) {                                 // next position's fragments, 6 MFMAs ahead of use
-                    fa[buf ^ 1][0] = lds_f4(vB + ((xi0 + j + 1) * 64) * 32);
-                    fa[buf ^ 1][1] = lds_f4(vB + ((xi0 + j + 1) * 64 + 32) * 32);
-                    fb[buf ^ 1] = lds_f4(uB + ((xi0 + j + 1) * 64) * 32);
-                }
-                if (k < 4) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) d_[k][jj] = lds_f(src_ + (k * 2 * PWP + jj) * 16);
-                }
-                if (k == 4) WINO_ISSUE_U(cc + 1);
-                if (k == 5) WINO_ISSUE_P(cc + 2);
-                if (k >= 6 && k < 14) {                                 // t = B^T d   (two values per slice)
-#pragma unroll
-                    for (int e = 2 * (k - 6); e < 2 * (k - 6) + 2; ++e) {
-                        const int i = e & 3, jj = e >> 2;
-                        t_[i][jj] = i == 0 ? d_[0][jj] - d_[2][jj] : i == 1 ? d_[1][jj] + d_[2][jj] : i == 2 ? d_[2][jj] - d_[1][jj] : d_[1][jj] - d_[3][jj];
-                    }
-                }
-                if (k >= 14 && k < 30) {                                // V = t B (one value per slice) ...
-                    const int e = k - 14, i = e >> 2, jj = e & 3;
-                    v_[i][jj] = jj == 0 ? t_[i][0] - t_[i][2] : jj == 1 ? t_[i][1] + t_[i][2] : jj == 2 ? t_[i][2] - t_[i][1] : t_[i][1] - t_[i][3];
-                }
-                if (k >= 17 && (k & 1)) {                               // ... written in pairs (one ds_write2st64_b32) on odd slices
-                    const int e = k - 17;
-                    *reinterpret_cast<float*>(dst_ + e * (T * 32)) = v_[e >> 2][e & 3];
-                    *reinterpret_cast<float*>(dst_ + (e + 1) * (T * 32)) = v_[(e + 1) >> 2][(e + 1) & 3];
-                }
-                __builtin_amdgcn_sched_barrier(0);
+        if (wave < 4) {          // H_ is a compile-time constant of the loop body (different instructions per half)
+            for (; cc + 1 < a.CC; ++cc) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();     // V[cc&1] complete, U[cc&1] + patch cc+1 landed; MFMA phase cc-1 and transform cc done everywhere
+                WINO_CHUNK(0);
+            }
+        } else {
+            for (; cc + 1 < a.CC; ++cc) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                WINO_CHUNK(1);
             }
         }
+#undef WINO_CHUNK
         {   // last chunk: MFMAs only
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
