@@ -5,7 +5,7 @@ raises.  (The CPU oracle under oracle/ is test infrastructure and is never impor
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p)
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p)
 
 _LIB_NAME = "libcenternet_gfx950.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
@@ -57,6 +57,10 @@ _SIGNATURES = {
                                                  c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "cnl_pack_detections_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "cnl_unpack_detections_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "cnl_track_costs_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_int32,
+                                           c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cnl_track_apply_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
+                                           c_void_p, c_void_p, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1,0 +1,305 @@
+"""Tracker — host side of the tracking association step.
+
+Mirrors the reference's `Tracker` / `Track` / `match_with_threshold` / `build_tracker`
+(centernet_lightning/models/tracker.py:27-43, 45-201, 217-353): same constructor arguments, `step_batch`, `step_single`,
+`update`, `reset`, same track life cycle, same outputs ({"bboxes": [...], "track_ids": [...]} per frame).
+
+What moved to the GPU (csrc/track.hip): the detection-threshold mask, the cosine (re-ID) and IoU / GIoU cost matrices, and the
+track table itself — per-track embedding and box live in HBM and are updated there.  Per frame only the n x T cost matrices
+come to the host, where the Hungarian assignment runs on scipy exactly as in the reference (tracker.py:28), and the short
+match list goes back.  The reference instead copies every frame's k x (6+E) detections to the host (tracker.py:107).
+
+Not supported (raises): `use_kalman=True` (filterpy, third-party, absent), callable `reid_cost` / `box_cost`.
+There is no CPU fallback: without the HIP library or a GPU, `update` raises.
+"""
+import ctypes
+import warnings
+from enum import Enum, auto
+from typing import List
+
+import numpy as np
+import torch
+from scipy.optimize import linear_sum_assignment
+
+from . import _lib
+from .config import load_config
+
+_BOX_MODES = {None: 0, "iou": 1, "giou": 2}
+
+
+class TrackState(Enum):
+    UNCONFIRMED = auto()
+    ACTIVE = auto()
+    INACTIVE = auto()
+    TO_DELETE = auto()
+
+
+def match_with_threshold(cost_matrix, threshold):
+    """tracker.py:27-43: optimal assignment, keeping only pairs with cost < threshold."""
+    row_ind, col_ind = linear_sum_assignment(cost_matrix)
+    matches, matched_row, matched_col = [], set(), set()
+    for row, col in zip(row_ind, col_ind):
+        if cost_matrix[row, col] < threshold:
+            matches.append((int(row), int(col)))
+            matched_row.add(int(row))
+            matched_col.add(int(col))
+    unmatched_row = [x for x in range(cost_matrix.shape[0]) if x not in matched_row]
+    unmatched_col = [x for x in range(cost_matrix.shape[1]) if x not in matched_col]
+    return matches, unmatched_row, unmatched_col
+
+
+class Track:
+    """Host record of one track (tracker.py:217-347).  bbox / label live here (they are reported every frame); the embedding
+    lives in the tracker's device table and is fetched on access."""
+
+    def __init__(self, tracker, track_id, bbox, label, min_birth_age=2, max_inactive_age=30, smoothing_factor=0.9):
+        self._tracker = tracker
+        self._row = -1
+        self.track_id = track_id
+        self.state = TrackState.UNCONFIRMED
+        self.birth_age = 0
+        self.inactive_age = 0
+        self.bbox = bbox
+        self.label = label
+        self.min_birth_age = min_birth_age
+        self.max_inactive_age = max_inactive_age
+        self.smoothing_factor = smoothing_factor
+
+    @property
+    def active(self):
+        return self.state == TrackState.ACTIVE
+
+    @property
+    def confirmed(self):
+        return self.state != TrackState.UNCONFIRMED
+
+    @property
+    def to_delete(self):
+        return self.state == TrackState.TO_DELETE
+
+    @property
+    def embedding(self):
+        return self._tracker._emb[self._row].cpu().numpy()
+
+    def update_matched(self, bbox):
+        if self.state == TrackState.UNCONFIRMED:
+            self.birth_age += 1
+            if self.birth_age >= self.min_birth_age:
+                self.state = TrackState.ACTIVE
+        elif self.state == TrackState.INACTIVE:
+            self.state = TrackState.ACTIVE
+            self.inactive_age = 0
+        self.bbox = bbox
+
+    def update_unmatched(self):
+        if self.state == TrackState.UNCONFIRMED:
+            self.state = TrackState.TO_DELETE
+        elif self.state == TrackState.ACTIVE:
+            self.state = TrackState.INACTIVE
+            self.inactive_age = 0
+        elif self.state == TrackState.INACTIVE:
+            self.inactive_age += 1
+            if self.inactive_age >= self.max_inactive_age:
+                self.state = TrackState.TO_DELETE
+
+    def __repr__(self):
+        return f"track id: {self.track_id}, bbox: {self.bbox}, label: {self.label}, state: {self.state.name}"
+
+
+class Tracker:
+    """Multiple-object tracking on top of `CenterNet.gather_tracking2d` (tracker.py:45-201)."""
+
+    def __init__(self, model=None, nms_kernel=3, num_detections=300, detection_threshold=0.3, reid_cost="cosine",
+                 reid_threshold=0.2, box_cost="iou", box_threshold=0.5, smoothing_factor=0.5, use_kalman=False,
+                 max_inactive_age=30, min_birth_age=2, device=None):
+        self.model = model
+        if model is None:
+            warnings.warn("A model was not provided. Only `.update()` will work")
+        if use_kalman:
+            raise NotImplementedError("use_kalman=True needs filterpy's KalmanFilter (third-party, not in this image); "
+                                      "the MI355X tracker covers the reference default use_kalman=False")
+        if reid_cost != "cosine":
+            raise ValueError(f"reid_cost={reid_cost!r}: only 'cosine' (the reference default) has a gfx950 kernel")
+        if box_cost not in _BOX_MODES:
+            raise ValueError(f"box_cost={box_cost!r}: expected 'iou', 'giou' or None")
+        self.nms_kernel = nms_kernel
+        self.num_detections = num_detections
+        self.detection_threshold = detection_threshold
+        self.reid_cost = reid_cost
+        self.reid_threshold = reid_threshold
+        self.box_cost = box_cost
+        self.box_threshold = box_threshold
+        self.smoothing_factor = smoothing_factor
+        self.use_kalman = False
+        self.max_inactive_age = max_inactive_age
+        self.min_birth_age = min_birth_age
+        self._device = torch.device(device) if device is not None else None
+        self.reset()
+
+    # ------------------------------------------------------------------ state
+    def reset(self):
+        self.frame = 0
+        self.next_track_id = 0
+        self.tracks: List[Track] = []
+        self._emb = None            # device track table [capacity, E] / [capacity, 4]; rows 0..len(tracks)-1 are live
+        self._box = None
+        self._spare = None          # the other half of the ping-pong pair
+        self.last_costs = None      # (reid [n,T] f64, box [n,T] f32 | None, det_index [n]) of the last update (host numpy)
+        self._pinned = None         # page-locked staging buffer of the per-frame device -> host copy
+
+    @property
+    def device(self):
+        if self._device is None:
+            if self.model is not None:
+                self._device = next(self.model.parameters()).device
+            else:
+                self._device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        if self._device.type != "cuda":
+            raise RuntimeError("the tracker's association kernels need a HIP device ('cuda'); there is no CPU fallback")
+        return self._device
+
+    def _tables(self, rows, E):
+        """Return (new_emb, new_box) with room for `rows` rows, distinct from the live table."""
+        dev = self.device
+        if self._spare is None or self._spare[0].shape[0] < rows or self._spare[0].shape[1] != E:
+            cap = max(64, 1 << (max(rows, 1) - 1).bit_length())
+            self._spare = (torch.empty((cap, E), device=dev, dtype=torch.float32), torch.empty((cap, 4), device=dev, dtype=torch.float32))
+        return self._spare
+
+    # ------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def step_batch(self, images: torch.Tensor, **kwargs):
+        """Run the model on a batch of consecutive frames and update the tracks frame by frame (tracker.py:84-121).
+        Returns {"bboxes": [...], "track_ids": [...]} with one list per frame (active tracks only)."""
+        nms_kernel = kwargs.get("nms_kernel", self.nms_kernel)
+        num_detections = kwargs.get("num_detections", self.num_detections)
+        self.model.eval()
+        images = images.to(self.device)
+        heatmap, box_2d, reid = self.model(images)
+        det = self.model.gather_tracking2d(heatmap, box_2d, reid, nms_kernel=nms_kernel, num_detections=num_detections,
+                                           normalize_bbox=True)
+        # boxes / labels / scores of the batch go to the host in one copy (they are reported per track); embeddings stay in HBM
+        host_boxes = det["bboxes"].cpu().numpy()
+        host_labels = det["labels"].cpu().numpy()
+        host_scores = det["scores"].cpu().numpy()
+        out = {"bboxes": [], "track_ids": []}
+        for i in range(images.shape[0]):
+            self._update_device(det["bboxes"][i], det["scores"][i], det["embeddings"][i], host_boxes[i], host_labels[i], host_scores[i], **kwargs)
+            self.frame += 1
+            out["bboxes"].append([x.bbox for x in self.tracks if x.active])
+            out["track_ids"].append([x.track_id for x in self.tracks if x.active])
+        return out
+
+    @torch.no_grad()
+    def step_single(self, img: torch.Tensor, **kwargs):
+        out = self.step_batch(img.unsqueeze(0), **kwargs)
+        return {k: v[0] for k, v in out.items()}
+
+    def update(self, bboxes, labels, scores, embeddings, **kwargs):
+        """Update current tracks with one frame's detections (tracker.py:123-201).  Accepts numpy arrays (as the reference) or
+        torch tensors; the arrays are moved to the HIP device, where the association costs are computed."""
+        dev = self.device
+        to_dev = lambda a: torch.as_tensor(a).to(device=dev, dtype=torch.float32).contiguous()
+        host = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        self._update_device(to_dev(bboxes), to_dev(scores), to_dev(embeddings), host(bboxes), host(labels), host(scores), **kwargs)
+
+    # ------------------------------------------------------------------ one frame
+    def _update_device(self, d_box, d_score, d_emb, h_box, h_label, h_score, **kwargs):
+        detection_threshold = kwargs.get("detection_threshold", self.detection_threshold)
+        reid_threshold = kwargs.get("reid_threshold", self.reid_threshold)
+        box_threshold = kwargs.get("box_threshold", self.box_threshold)
+        lib = _lib.load()
+        dev = self.device
+        k, E = d_emb.shape
+        if d_box.shape != (k, 4) or d_score.shape != (k,):
+            raise ValueError(f"detections: boxes {tuple(d_box.shape)}, scores {tuple(d_score.shape)}, embeddings {tuple(d_emb.shape)}")
+        d_box, d_score, d_emb = d_box.contiguous(), d_score.contiguous(), d_emb.contiguous()
+        T = len(self.tracks)
+        box_mode = _BOX_MODES[self.box_cost]
+        # The host holds the frame's scores too (they travel with the boxes), so it knows the number of kept detections n and can
+        # size the one buffer that comes back: [n_det i32, det_index i32 k | reid f64 n*T | box f32 n*T]
+        n = int(np.count_nonzero(np.asarray(h_score, dtype=np.float32) >= np.float32(detection_threshold)))
+        off_reid = (4 * (1 + k) + 7) // 8 * 8
+        off_box = off_reid + 8 * n * T
+        nbytes = off_box + 4 * n * T
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            buf = torch.empty((nbytes + 16,), device=dev, dtype=torch.uint8)
+            base = buf.data_ptr()
+            _lib.check(lib.cnl_track_costs_f32(d_emb.data_ptr(), d_box.data_ptr(), d_score.data_ptr(), k, E, float(detection_threshold),
+                                               self._emb.data_ptr() if T else None, self._box.data_ptr() if T else None, T, box_mode,
+                                               base, base + 4, base + off_reid if T else None,
+                                               base + off_box if (T and box_mode) else None, stream), "cnl_track_costs_f32")
+            if self._pinned is None or self._pinned.numel() < nbytes:
+                self._pinned = torch.empty((max(2 * nbytes, 1 << 16),), dtype=torch.uint8).pin_memory()
+            self._pinned[:nbytes].copy_(buf[:nbytes], non_blocking=True)      # the frame's only device -> host copy
+            torch.cuda.current_stream(dev).synchronize()
+            h = self._pinned[:nbytes].numpy()
+        if int(h[:4].view(np.int32)[0]) != n:
+            raise RuntimeError(f"detection count mismatch between host ({n}) and device ({int(h[:4].view(np.int32)[0])}): "
+                               "scores on the host and on the device differ")
+        det_index = h[4:4 + 4 * n].view(np.int32)
+        self.d2h_bytes = nbytes
+        self.last_costs = None
+
+        # ---- assignment on the host: tracker.py:139-176 ----
+        if T == 0:
+            matches, unmatched_dets, unmatched_tracks = [], list(range(n)), []
+        else:
+            reid = h[off_reid:off_reid + 8 * n * T].view(np.float64).reshape(n, T)
+            matches, unmatched_dets, unmatched_tracks = match_with_threshold(reid, reid_threshold)
+            box = None
+            if box_mode:
+                box = h[off_box:off_box + 4 * n * T].view(np.float32).reshape(n, T)
+                # element-wise costs: the remaining-pairs matrix of tracker.py:157-162 is a sub-matrix of the full one
+                sub = box[np.ix_(unmatched_dets, unmatched_tracks)]
+                new_matches, ud, ut = match_with_threshold(sub, box_threshold)
+                matches.extend((unmatched_dets[x], unmatched_tracks[y]) for x, y in new_matches)
+                unmatched_dets, unmatched_tracks = [unmatched_dets[x] for x in ud], [unmatched_tracks[y] for y in ut]
+            self.last_costs = (reid.copy(), None if box is None else box.copy(), det_index.copy())
+
+        # ---- track life cycle (host) + the rows of the new device table ----
+        row_det = {}                                  # old track index -> detection row feeding its update
+        for det_idx, track_idx in matches:
+            # reference quirk kept (tracker.py:171): the match indexes the thresholded arrays but the update reads the
+            # unfiltered ones at the same position; identical when scores are sorted descending (gather_tracking2d output)
+            self.tracks[track_idx].update_matched(h_box[det_idx])
+            row_det[track_idx] = det_idx
+        for track_idx in unmatched_tracks:
+            self.tracks[track_idx].update_unmatched()
+        old_rows = list(range(T))
+        for det_idx in unmatched_dets:
+            src = int(det_index[det_idx])
+            self.tracks.append(Track(self, self.next_track_id, h_box[src], h_label[src], min_birth_age=self.min_birth_age,
+                                     max_inactive_age=self.max_inactive_age, smoothing_factor=self.smoothing_factor))
+            self.next_track_id += 1
+            old_rows.append(-1)
+            row_det[len(self.tracks) - 1] = src
+        keep = [i for i, t in enumerate(self.tracks) if not t.to_delete]
+        self.tracks = [self.tracks[i] for i in keep]
+        T_new = len(self.tracks)
+        if T_new:
+            src = np.empty((2, T_new), np.int32)
+            src[0] = [old_rows[i] for i in keep]
+            src[1] = [row_det.get(i, -1) for i in keep]
+            with torch.cuda.device(dev):
+                d_src = torch.from_numpy(src).to(dev)
+                new_emb, new_box = self._tables(T_new, E)
+                _lib.check(lib.cnl_track_apply_f32(self._emb.data_ptr() if T else None, self._box.data_ptr() if T else None,
+                                                   d_emb.data_ptr(), d_box.data_ptr(), d_src[0].data_ptr(), d_src[1].data_ptr(),
+                                                   T_new, E, float(self.smoothing_factor), new_emb.data_ptr(), new_box.data_ptr(),
+                                                   stream), "cnl_track_apply_f32")
+            self._spare, (self._emb, self._box) = ((self._emb, self._box) if self._emb is not None else None), (new_emb, new_box)
+        for r, t in enumerate(self.tracks):
+            t._row = r
+
+    def track_embeddings(self):
+        """Device view [T, E] of the live track table (row order = self.tracks)."""
+        return self._emb[:len(self.tracks)] if self._emb is not None else None
+
+
+def build_tracker(config, model=None):
+    """tracker.py:349-353."""
+    if isinstance(config, str):
+        config = load_config(config)["tracker"]
+    return Tracker(model=model, **config)

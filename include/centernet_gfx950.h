@@ -160,6 +160,31 @@ int cnl_pack_detections_f32(const float* boxes, const float* scores, const int64
 int cnl_unpack_detections_f32(const float* rec, float* boxes, float* scores, int64_t* labels, float* emb,
                               int32_t N, int32_t k, int32_t E, void* stream);
 
+/*
+ * Step after the path for the tracking task: association costs of one frame against the current
+ * track table, and the track-table update, so that per-frame embeddings never leave HBM — only the n x T cost matrices go to
+ * the host for the Hungarian step (scipy, as in the reference) and the match list comes back.
+ *
+ * cnl_track_costs_f32 replaces models/tracker.py:133-137 (mask = scores >= detection_threshold; boolean-mask compaction),
+ * :150 (scipy cdist "cosine", float64) and :162 (utils/box.py:84-92 box_iou_distance_matrix / box_giou_distance_matrix, float32):
+ *   det_emb [k,E], det_box [k,4] x1y1x2y2, det_score [k] (k <= 1024); trk_emb [T,E], trk_box [T,4] (T may be 0);
+ *   box_cost: 0 = none, 1 = "iou", 2 = "giou";
+ *   n_det [1] <- number of detections with score >= threshold; det_index [k] <- their original indices, ascending (first n_det);
+ *   reid_cost [n_det,T] f64 and box_cost_out [n_det,T] f32 <- row r is detection det_index[r] (dense, row stride T).
+ * cnl_track_apply_f32 replaces Track.__init__ / Track.update_matched (models/tracker.py:228, 305-321, use_kalman=False) and the
+ * list rebuild of :186-196 for the device-resident table: new row r is
+ *   src_trk[r] >= 0, src_det[r] <  0 : old row src_trk[r] unchanged
+ *   src_trk[r] >= 0, src_det[r] >= 0 : emb = (1-s)*old + s*e/|e|, box = det_box[src_det[r]]   (e = det_emb[src_det[r]])
+ *   src_trk[r] <  0, src_det[r] >= 0 : emb = e/|e|,               box = det_box[src_det[r]]   (new track)
+ * src_trk / src_det are device int32 arrays of T_new entries; new_emb/new_box must not alias the old table.
+ */
+int cnl_track_costs_f32(const float* det_emb, const float* det_box, const float* det_score, int32_t k, int32_t E,
+                        float detection_threshold, const float* trk_emb, const float* trk_box, int32_t T, int32_t box_cost,
+                        int32_t* n_det, int32_t* det_index, double* reid_cost, float* box_cost_out, void* stream);
+int cnl_track_apply_f32(const float* trk_emb, const float* trk_box, const float* det_emb, const float* det_box,
+                        const int32_t* src_trk, const int32_t* src_det, int32_t T_new, int32_t E, double smoothing,
+                        float* new_emb, float* new_box, void* stream);
+
 int cnl_version(void);
 /* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
 size_t cnl_last_error(char* buf, size_t n);
