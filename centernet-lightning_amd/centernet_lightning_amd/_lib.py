@@ -14,6 +14,7 @@ CNL_RELU = 1 << 0
 CNL_SIGMOID = 1 << 1
 CNL_UPSAMPLE_IN = 1 << 2
 CNL_UPSAMPLE_OUT_ADD = 1 << 3
+CNL_RELU6 = 1 << 4
 
 CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4
 
@@ -22,6 +23,12 @@ class ConvParams(Structure):
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("y", c_void_p),
                 ("N", c_int32), ("H_in", c_int32), ("W_in", c_int32), ("Cin", c_int32), ("Cout", c_int32),
                 ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
+                ("ldx", c_int32), ("ldy", c_int32), ("ldr", c_int32), ("flags", c_uint32)]
+
+
+class DeconvParams(Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("y", c_void_p),
+                ("N", c_int32), ("H_in", c_int32), ("W_in", c_int32), ("Cin", c_int32), ("Cout", c_int32), ("K", c_int32),
                 ("ldx", c_int32), ("ldy", c_int32), ("ldr", c_int32), ("flags", c_uint32)]
 
 
@@ -44,6 +51,13 @@ _SIGNATURES = {
     "cnl_conv3x3_winograd_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
     "cnl_winograd_weight_floats": (c_size_t, [c_int32, c_int32]),
     "cnl_winograd_transform_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "cnl_deconv2x_nhwc_f32": (ctypes.c_int, [POINTER(DeconvParams), c_void_p]),
+    "cnl_deconv_phase_geometry": (ctypes.c_int, [c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
+    "cnl_deconv_weight_floats": (c_size_t, [c_int32, c_int32, c_int32]),
+    "cnl_upsample2x_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                               c_int32, c_int32, c_void_p]),
+    "cnl_depthwise3x3_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                                 c_int32, c_uint32, c_void_p]),
     "cnl_normalize_u8_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float), c_void_p]),
     "cnl_stem_pack_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     "cnl_stem_conv7x7_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,

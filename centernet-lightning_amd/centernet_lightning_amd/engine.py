@@ -19,7 +19,7 @@ from collections import OrderedDict
 import torch
 
 from . import _lib
-from ._lib import CNL_RELU, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD, ConvParams
+from ._lib import CNL_RELU, CNL_RELU6, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD, ConvParams, DeconvParams
 
 BN_EPS_DEFAULT = 1e-5
 
@@ -63,6 +63,60 @@ class _Layer:
                            "cnl_winograd_transform_weights_f32")
 
 
+class _SepLayer:
+    """make_conv(conv_type="separable") (layers.py:56-69) packed: depthwise weight [3][3][C] (tap-major) + bias with BN folded,
+    and the pointwise half as a 1x1 _Layer."""
+
+    def __init__(self, mod, device):
+        w = mod.dw.weight.detach().to(device=device, dtype=torch.float32)                    # [C,1,3,3]
+        bn = mod.dw_bn
+        scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)).to(device)
+        self.dw_w = (w[:, 0] * scale.view(-1, 1, 1)).permute(1, 2, 0).contiguous()            # [3,3,C]
+        self.dw_b = (bn.bias.detach().float().to(device) - bn.running_mean.detach().float().to(device) * scale).contiguous()
+        self.pw = _Layer(*(t.to(device) for t in fold_conv_bn(mod.pw.weight, None, mod.pw_bn)))
+        self.cin, self.cout = w.shape[0], self.pw.cout
+        self.kh = self.kw = 3
+        self.stride, self.pad = 1, 1
+
+
+class _DeconvLayer:
+    """make_upsample("conv_transpose") (layers.py:86-93) packed for cnl_deconv2x_nhwc_f32: BN folded, the K x K taps split into the
+    four sub-pixel phase blocks [Cout][KHp][KWp][Cin] (layout: include/centernet_gfx950.h).  `gain` >= 0 is folded in as well
+    (weighted fusion: relu(z) * g == relu(g * z))."""
+
+    def __init__(self, mod, device, gain=1.0):
+        lib = _lib.load()
+        w = mod.deconv.weight.detach().to(device=device, dtype=torch.float32)                  # [Cin,Cout,K,K]
+        bn = mod.bn
+        scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)).to(device) * gain
+        self.b = ((bn.bias.detach().float().to(device) * gain) - bn.running_mean.detach().float().to(device) * scale).contiguous()
+        self.cin, self.cout, self.k = w.shape[0], w.shape[1], w.shape[2]
+        p = (self.k + self.k % 2) // 2 - 1
+        ws = w * scale.view(1, -1, 1, 1)
+        blocks = []
+        for dy in range(2):
+            for dx in range(2):
+                ty, py, tx, px = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+                _lib.check(lib.cnl_deconv_phase_geometry(self.k, dy, ctypes.byref(ty), ctypes.byref(py)), "cnl_deconv_phase_geometry")
+                _lib.check(lib.cnl_deconv_phase_geometry(self.k, dx, ctypes.byref(tx), ctypes.byref(px)), "cnl_deconv_phase_geometry")
+                kys = [dy + p + 2 * (py.value - j) for j in range(ty.value)]
+                kxs = [dx + p + 2 * (px.value - j) for j in range(tx.value)]
+                blk = ws[:, :, kys][:, :, :, kxs]                                             # [Cin,Cout,KHp,KWp]
+                blocks.append(blk.permute(1, 2, 3, 0).contiguous().view(-1))                  # OHWI
+        self.w = torch.cat(blocks).contiguous()
+        assert self.w.numel() == lib.cnl_deconv_weight_floats(self.cin, self.cout, self.k)
+
+
+def _scaled(layer, gain):
+    """A copy of a (1x1, no-Winograd) _Layer with weight and bias multiplied by `gain` (weighted fusion folded into a projection)."""
+    return _Layer((layer.w * gain).contiguous(), (layer.b * gain).contiguous(), stride=layer.stride)
+
+
+def _identity_layer(c, device, gain=1.0):
+    eye = (torch.eye(c, device=device, dtype=torch.float32) * gain).view(c, 1, 1, c).contiguous()
+    return _Layer(eye, torch.zeros(c, device=device))
+
+
 class PackedWeights:
     """Device-resident, BN-folded weights of a CenterNet model (rebuilt whenever parameters change)."""
 
@@ -85,20 +139,31 @@ class PackedWeights:
                 d = L(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
                 self.blocks.append((L(blk.conv1, blk.bn1), L(blk.conv2, blk.bn2), d, li))
         self.neck_kind = type(neck).__name__
+        C = lambda m: _SepLayer(m, device) if type(m).__name__ == "SeparableConvBn" else L(m.conv_module, m.bn_module)
+        self.upsample_type = getattr(neck, "upsample_type", "nearest")
         if self.neck_kind == "SimpleNeck":
-            self.neck_layers = [L(m.conv_module, m.bn_module) for m in neck.layers]
+            self.neck_layers = [C(m) for m in neck.layers]
+            self.neck_ups = [_DeconvLayer(u, device) if self.upsample_type == "conv_transpose" else None for u in neck.upsamples]
         else:
             self.top = L(neck.top_conv)
             self.fuse = []
             for f in neck.fuse:
+                ga = gb = 1.0
+                if f.weights is not None:                    # Fuse.forward weighted branch (layers.py:164-167), folded on the host
+                    wts = torch.relu(f.weights.detach().float())
+                    den = float(wts.sum()) + 1e-6
+                    ga, gb = float(wts[0]) / den, float(wts[1]) / den
+                c = f.output_conv.pw.in_channels if type(f.output_conv).__name__ == "SeparableConvBn" else f.output_conv.conv_module.in_channels
                 skip_p = L(f.project[0]) if isinstance(f.project[0], torch.nn.Conv2d) else None
-                if isinstance(f.project[1], torch.nn.Conv2d):
-                    top_p = L(f.project[1])
-                else:       # no projection in the reference: an exact identity 1x1 keeps the fused epilogue path
-                    c = f.output_conv.conv_module.in_channels
-                    eye = torch.eye(c, device=device, dtype=torch.float32).view(c, 1, 1, c).contiguous()
-                    top_p = _Layer(eye, torch.zeros(c, device=device))
-                self.fuse.append((skip_p, top_p, L(f.output_conv.conv_module, f.output_conv.bn_module)))
+                if f.weights is not None:
+                    skip_p = _scaled(skip_p, ga) if skip_p is not None else _identity_layer(c, device, ga)
+                top_p = L(f.project[1]) if isinstance(f.project[1], torch.nn.Conv2d) else None
+                resize = None
+                if self.upsample_type == "conv_transpose":
+                    resize = _DeconvLayer(f.resize, device, gain=gb)        # relu(z) * gb == relu(gb * z), gb >= 0
+                elif f.weights is not None:                                 # nearest / bilinear are linear: fold gb into the projection
+                    top_p = _scaled(top_p, gb) if top_p is not None else _identity_layer(c, device, gb)
+                self.fuse.append((skip_p, top_p, resize, C(f.output_conv), gb if f.weights is not None else None))
         # heads: first blocks fused along Cout when every head has depth >= 1
         self.head_names = list(heads.keys())
         self.head_blocks = OrderedDict()
@@ -114,6 +179,7 @@ class PackedWeights:
 
 
 class _Launch:
+    """One C-ABI call of the plan: `args` is a params struct (passed by reference) or a tuple of scalar / pointer arguments."""
     __slots__ = ("fn", "args", "what", "flops", "keep")
 
     def __init__(self, fn, args, what, flops=0, keep=()):
@@ -163,6 +229,43 @@ class Plan:
         self.launches.append(_Launch(fn, p, what, flops, keep=(x, y, residual, layer)))
         return p, ho.value, wo.value
 
+    def _sep(self, layer, x, xh, xw, ldx, y, ldy, what):
+        """Separable conv (layers.py:56-69): depthwise 3x3 + BN + ReLU6 -> pointwise 1x1 + BN + ReLU6."""
+        t = self._buf(self.N, xh, xw, layer.cin)
+        self.launches.append(_Launch(self.lib.cnl_depthwise3x3_nhwc_f32,
+                                     (x.data_ptr(), layer.dw_w.data_ptr(), layer.dw_b.data_ptr(), t.data_ptr(), self.N, xh, xw,
+                                      layer.cin, ldx, layer.cin, CNL_RELU6), what + ".dw", 0, keep=(x, t, layer)))
+        self._conv(layer.pw, t, xh, xw, layer.cin, y, ldy, CNL_RELU6, what=what + ".pw")
+        return xh, xw
+
+    def _block(self, layer, x, xh, xw, ldx, y, ldy, what, up=0):
+        """make_conv(...) of either type; `up` = CNL_UPSAMPLE_IN folds a pending nearest x2 into a normal conv."""
+        if isinstance(layer, _SepLayer):
+            assert not up
+            return self._sep(layer, x, xh, xw, ldx, y, ldy, what)
+        _, oh, ow = self._conv(layer, x, xh, xw, ldx, y, ldy, CNL_RELU | up, what=what)
+        return oh, ow
+
+    def _upsample(self, x, xh, xw, c, ldx, mode, what, residual=None, ldr=0):
+        """nn.Upsample x2 (0 nearest / 1 bilinear) materialised, + optional Fuse sum.  Returns the new buffer."""
+        y = self._buf(self.N, 2 * xh, 2 * xw, c)
+        self.launches.append(_Launch(self.lib.cnl_upsample2x_nhwc_f32,
+                                     (x.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(), self.N, xh, xw,
+                                      c, ldx, ldr, c, mode), what, 0, keep=(x, y, residual)))
+        return y
+
+    def _deconv(self, layer, x, xh, xw, ldx, what, residual=None, ldr=0):
+        """ConvTranspose2d x2 + BN + ReLU (+ Fuse sum after the activation).  Returns the new buffer."""
+        y = self._buf(self.N, 2 * xh, 2 * xw, layer.cout)
+        p = DeconvParams()
+        p.x, p.w, p.bias, p.y = x.data_ptr(), layer.w.data_ptr(), layer.b.data_ptr(), y.data_ptr()
+        p.residual = residual.data_ptr() if residual is not None else None
+        p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.K = self.N, xh, xw, layer.cin, layer.cout, layer.k
+        p.ldx, p.ldy, p.ldr, p.flags = ldx, layer.cout, ldr, CNL_RELU
+        flops = 2 * self.N * xh * xw * layer.cout * layer.k * layer.k * layer.cin
+        self.launches.append(_Launch(self.lib.cnl_deconv2x_nhwc_f32, p, what, flops, keep=(x, y, residual, layer)))
+        return y
+
     def _build(self, Wt):
         N, H, W = self.N, self.H, self.W
         self._wt_stem = Wt.stem
@@ -195,40 +298,65 @@ class Plan:
         self.features = [(s1, h2, w2, 64)] + [feats[i] for i in range(4)]       # strides 2,4,8,16,32
 
         # ---- neck ----
+        bil = 1 if Wt.upsample_type == "bilinear" else 0
         if Wt.neck_kind == "SimpleNeck":
             x, xh, xw, xc = self.features[-1]
-            up = 0
-            for i, layer in enumerate(Wt.neck_layers):
+            up = 0                                    # CNL_UPSAMPLE_IN when a nearest x2 of `x` is still pending
+            for i, (layer, dec) in enumerate(zip(Wt.neck_layers, Wt.neck_ups)):
+                if up and isinstance(layer, _SepLayer):           # the depthwise kernel has no folded-upsample gather
+                    x, xh, xw, up = self._upsample(x, xh, xw, xc, xc, 0, f"neck.upsample.{i - 1} (nearest)"), 2 * xh, 2 * xw, 0
                 y = self._buf(N, xh * (2 if up else 1), xw * (2 if up else 1), layer.cout)
-                _, oh, ow = self._conv(layer, x, xh, xw, xc, y, layer.cout, CNL_RELU | up, what=f"neck.layers.{i}")
-                x, xh, xw, xc, up = y, oh, ow, layer.cout, CNL_UPSAMPLE_IN
-            neck, nh, nw, nc, neck_up = x, xh, xw, xc, CNL_UPSAMPLE_IN      # final upsample folded into the heads
-            oh_, ow_ = 2 * nh, 2 * nw
+                oh, ow = self._block(layer, x, xh, xw, xc, y, layer.cout, f"neck.layers.{i}", up)
+                x, xh, xw, xc, up = y, oh, ow, layer.cout, 0
+                if dec is not None:
+                    x, xh, xw = self._deconv(dec, x, xh, xw, xc, f"neck.upsamples.{i} (conv_transpose)"), 2 * xh, 2 * xw
+                elif bil:
+                    x, xh, xw = self._upsample(x, xh, xw, xc, xc, 1, f"neck.upsample.{i} (bilinear)"), 2 * xh, 2 * xw
+                else:
+                    up = CNL_UPSAMPLE_IN                          # nearest: folded into the consumer
+            neck, nh, nw, nc, neck_up = x, xh, xw, xc, up          # a pending final nearest upsample is folded into the heads
+            oh_, ow_ = (2 * nh, 2 * nw) if up else (nh, nw)
         else:
             top, th, tw, tc = self.features[-1]
-            top_layer = Wt.top
-            for i, (skip_p, top_p, out_conv) in enumerate(Wt.fuse):
+            top_pending = Wt.top                      # level 0 starts with `top = top_conv(c5)` (not yet materialised)
+            for i, (skip_p, top_p, resize, out_conv, gb) in enumerate(Wt.fuse):
                 skip, sh_, sw_, sc_ = self.features[-2 - i]
                 if skip_p is not None:
                     sp = self._buf(N, sh_, sw_, skip_p.cout)
                     self._conv(skip_p, skip, sh_, sw_, sc_, sp, skip_p.cout, 0, what=f"neck.fuse.{i}.project.0")
                     skip, sc_ = sp, skip_p.cout
-                if i == 0:
-                    # level 0: `top = top_conv(c5)`; Fuse.project[1] of level 0 is Identity when channels match
-                    lay = top_layer
-                    if not _is_identity(top_p):
-                        tt = self._buf(N, th, tw, top_layer.cout)
-                        self._conv(top_layer, top, th, tw, tc, tt, top_layer.cout, 0, what="neck.top_conv")
-                        top, tc, lay = tt, top_layer.cout, top_p
-                else:
+                fuse_c = top_p.cout if top_p is not None else (top_pending.cout if top_pending is not None else tc)
+                if fuse_c != sc_ or sh_ != 2 * th or sw_ != 2 * tw:
+                    raise ValueError(f"FPN level {i}: skip {sc_}ch@{sh_}x{sw_} does not match top {fuse_c}ch@{th}x{tw} x2")
+                if resize is None and not bil:
+                    # nearest: project -> upsample -> sum in the epilogue of ONE 1x1 conv (top_conv itself at level 0 when
+                    # Fuse.project[1] is the identity; an exact identity 1x1 when there is nothing to project)
                     lay = top_p
-                if lay.cout != sc_ or sh_ != 2 * th or sw_ != 2 * tw:
-                    raise ValueError(f"FPN level {i}: skip {sc_}ch@{sh_}x{sw_} does not match top {lay.cout}ch@{th}x{tw} x2")
-                fused = self._buf(N, sh_, sw_, lay.cout)
-                self._conv(lay, top, th, tw, tc, fused, lay.cout, CNL_UPSAMPLE_OUT_ADD, residual=skip, ldr=sc_,
-                           what=f"neck.fuse.{i}.project+up+sum")
+                    if top_pending is not None:
+                        if top_p is None:
+                            lay = top_pending
+                        else:
+                            tt = self._buf(N, th, tw, top_pending.cout)
+                            self._conv(top_pending, top, th, tw, tc, tt, top_pending.cout, 0, what="neck.top_conv")
+                            top, tc = tt, top_pending.cout
+                    if lay is None:
+                        lay = _identity_layer(tc, self.device)
+                    fused = self._buf(N, sh_, sw_, lay.cout)
+                    self._conv(lay, top, th, tw, tc, fused, lay.cout, CNL_UPSAMPLE_OUT_ADD, residual=skip, ldr=sc_,
+                               what=f"neck.fuse.{i}.project+up+sum")
+                else:
+                    for lay, nm in ((top_pending, "neck.top_conv"), (top_p, f"neck.fuse.{i}.project.1")):
+                        if lay is not None:
+                            tt = self._buf(N, th, tw, lay.cout)
+                            self._conv(lay, top, th, tw, tc, tt, lay.cout, 0, what=nm)
+                            top, tc = tt, lay.cout
+                    if resize is not None:
+                        fused = self._deconv(resize, top, th, tw, tc, f"neck.fuse.{i}.resize (conv_transpose)+sum", residual=skip, ldr=sc_)
+                    else:
+                        fused = self._upsample(top, th, tw, tc, tc, 1, f"neck.fuse.{i}.resize (bilinear)+sum", residual=skip, ldr=sc_)
+                top_pending = None
                 y = self._buf(N, sh_, sw_, out_conv.cout)
-                self._conv(out_conv, fused, sh_, sw_, sc_, y, out_conv.cout, CNL_RELU, what=f"neck.fuse.{i}.output_conv")
+                self._block(out_conv, fused, sh_, sw_, sc_, y, out_conv.cout, f"neck.fuse.{i}.output_conv")
                 top, th, tw, tc = y, sh_, sw_, out_conv.cout
             neck, nh, nw, nc, neck_up = top, th, tw, tc, 0
             oh_, ow_ = nh, nw
@@ -283,6 +411,8 @@ class Plan:
             elif L.fn == "maxpool":
                 src, dst, n, h, w, c = L.args
                 rc = lib.cnl_maxpool3x3s2_nhwc_f32(src.data_ptr(), dst.data_ptr(), n, h, w, c, stream)
+            elif isinstance(L.args, tuple):
+                rc = L.fn(*L.args, stream)
             else:
                 rc = L.fn(ctypes.byref(L.args), stream)
             if rc != 0:

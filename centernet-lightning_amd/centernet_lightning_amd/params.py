@@ -39,6 +39,71 @@ class ConvBn(nn.Module):
         return getattr(self, self._names[1])
 
 
+class SeparableConvBn(nn.Module):
+    """make_conv(conv_type="separable") (layers.py:56-69): depthwise 3x3 (groups=C, no bias) + BN + ReLU6, then pointwise 1x1
+    (no bias) + BN + ReLU6; state_dict keys 0, 1, 3, 4 as in the reference's nn.Sequential."""
+
+    def __init__(self, cin, cout, k=3, depth_multiplier=1):
+        super().__init__()
+        if depth_multiplier != 1:
+            raise ValueError("separable conv: depth_multiplier != 1 is not constructible in the reference either "
+                             "(layers.py:60 sizes the BatchNorm with in_channels)")
+        self.k = k
+        self.add_module("0", nn.Conv2d(cin, cin, k, padding=(k - 1) // 2, groups=cin, bias=False))
+        self.add_module("1", nn.BatchNorm2d(cin))
+        self.add_module("3", nn.Conv2d(cin, cout, 1, bias=False))
+        self.add_module("4", nn.BatchNorm2d(cout))
+        nn.init.kaiming_normal_(getattr(self, "0").weight, mode="fan_out", nonlinearity="relu")     # layers.py:68-69
+        nn.init.kaiming_normal_(getattr(self, "3").weight, mode="fan_out", nonlinearity="relu")
+
+    dw = property(lambda self: getattr(self, "0"))
+    dw_bn = property(lambda self: getattr(self, "1"))
+    pw = property(lambda self: getattr(self, "3"))
+    pw_bn = property(lambda self: getattr(self, "4"))
+
+
+class DeconvBn(nn.Module):
+    """make_upsample(upsample_type="conv_transpose") (layers.py:86-96): ConvTranspose2d(C, C, k, stride=2, padding, output_padding,
+    bias=False) + BN + ReLU, keys 0, 1; `deconv_init_bilinear` reproduces _init_bilinear_upsampling (layers.py:103-116) as
+    written — it fills w[c, 0] only."""
+
+    def __init__(self, channels, kernel=3, init_bilinear=True):
+        super().__init__()
+        if kernel not in (2, 3, 4):
+            raise ValueError(f"deconv_kernel={kernel}: the gfx950 transposed-conv path covers kernels 2, 3 and 4")
+        op = kernel % 2
+        self.kernel = kernel
+        self.add_module("0", nn.ConvTranspose2d(channels, channels, kernel, stride=2, padding=(kernel + op) // 2 - 1,
+                                                output_padding=op, bias=False))
+        self.add_module("1", nn.BatchNorm2d(channels))
+        if init_bilinear:
+            import math
+            w = getattr(self, "0").weight.data
+            f = math.ceil(w.size(2) / 2)
+            c = (2 * f - 1 - f % 2) / (f * 2.0)
+            for i in range(w.size(2)):
+                for j in range(w.size(3)):
+                    w[0, 0, i, j] = (1 - math.fabs(i / f - c)) * (1 - math.fabs(j / f - c))
+            for ch in range(1, w.size(0)):
+                w[ch, 0, :, :] = w[0, 0, :, :]
+
+    deconv = property(lambda self: getattr(self, "0"))
+    bn = property(lambda self: getattr(self, "1"))
+
+
+def make_conv_params(cin, cout, conv_type="normal"):
+    """Parameter container of layers.py:40-79 make_conv (kernel 3)."""
+    if conv_type == "normal":
+        return ConvBn(cin, cout, 3, names=("0", "1"))
+    if conv_type == "separable":
+        return SeparableConvBn(cin, cout, 3)
+    raise ValueError(f"conv_type={conv_type!r}: 'normal' and 'separable' have gfx950 kernels; 'deformable' (DCNv2, torchvision "
+                     "DeformConv2d) is outside the MI355X hot-path scope — see DESIGN.md")
+
+
+UPSAMPLE_TYPES = ("nearest", "bilinear", "conv_transpose")
+
+
 class BasicBlock(nn.Module):
     def __init__(self, cin, cout, stride):
         super().__init__()
@@ -80,31 +145,41 @@ class ResNetBackbone(nn.Module):
 
 
 class SimpleNeck(nn.Module):
-    """3 x [conv3x3+BN+ReLU -> x2 nearest upsample] on the last backbone feature (docs/implementation.md:40-48;
-    tests/test_necks.py:23-39)."""
+    """3 x [conv3x3+BN+ReLU -> x2 upsample] on the last backbone feature (docs/implementation.md:40-48;
+    tests/test_necks.py:23-39).  conv = make_conv(conv_type), upsample = make_upsample(upsample_type, deconv_channels=c)
+    (layers.py:40-101; option names of configs/test_config.yaml:8-18)."""
 
-    def __init__(self, backbone_channels, upsample_channels=(256, 128, 64), upsample_type="nearest", conv_type="normal", **ignored):
+    def __init__(self, backbone_channels, upsample_channels=(256, 128, 64), upsample_type="nearest", conv_type="normal",
+                 deconv_kernel=3, deconv_init_bilinear=True, **ignored):
         super().__init__()
-        _check_neck_options(upsample_type, conv_type, False)
+        _check_neck_options(upsample_type, conv_type)
+        self.upsample_type, self.conv_type = upsample_type, conv_type
         self.out_channels = upsample_channels[-1]
         self.upsample_stride = 2 ** len(upsample_channels)
-        layers = []
+        layers, ups = [], []
         cin = backbone_channels[-1]
         for c in upsample_channels:
-            layers.append(ConvBn(cin, c, 3, names=("0", "1")))
+            layers.append(make_conv_params(cin, c, conv_type))
+            ups.append(DeconvBn(c, deconv_kernel, deconv_init_bilinear) if upsample_type == "conv_transpose" else nn.Identity())
             cin = c
         self.layers = nn.Sequential(*layers)
+        self.upsamples = nn.ModuleList(ups)
 
 
 class FuseParams(nn.Module):
-    """Parameters of layers.py:138-177 `Fuse(in_channels=[skip_c, top_c], out, resize="up")`: optional 1x1
-    projections WITH bias where channels differ (:152) and the 3x3 output conv+BN (:158)."""
+    """Parameters of layers.py:138-177 `Fuse(in_channels=[skip_c, top_c], out, resize="up", upsample, conv_type, weighted_fusion)`:
+    optional 1x1 projections WITH bias where channels differ (:152), the resize layer (:154, parameters only for
+    conv_transpose), the fusion weights (:148) and the output conv (:158).  Key names equal the reference module's."""
 
-    def __init__(self, skip_c, top_c, out):
+    def __init__(self, skip_c, top_c, out, upsample="nearest", conv_type="normal", weighted_fusion=False, deconv_kernel=3,
+                 deconv_init_bilinear=True):
         super().__init__()
+        self.upsample_type, self.conv_type = upsample, conv_type
+        self.weights = nn.Parameter(torch.ones(2), requires_grad=True) if weighted_fusion else None
         self.project = nn.ModuleList([nn.Conv2d(skip_c, out, 1) if skip_c != out else nn.Identity(),
                                       nn.Conv2d(top_c, out, 1) if top_c != out else nn.Identity()])
-        self.output_conv = ConvBn(out, out, 3, names=("0", "1"))
+        self.resize = DeconvBn(out, deconv_kernel, deconv_init_bilinear) if upsample == "conv_transpose" else nn.Identity()
+        self.output_conv = make_conv_params(out, out, conv_type)
 
 
 class FPNNeck(nn.Module):
@@ -112,11 +187,12 @@ class FPNNeck(nn.Module):
     docs/implementation.md:49-52; tests/test_necks.py:41-56)."""
 
     def __init__(self, backbone_channels, upsample_channels=(256, 128, 64), upsample_type="nearest", conv_type="normal",
-                 weighted_fusion=False, **ignored):
+                 weighted_fusion=False, deconv_kernel=3, deconv_init_bilinear=True, **ignored):
         super().__init__()
-        _check_neck_options(upsample_type, conv_type, weighted_fusion)
+        _check_neck_options(upsample_type, conv_type)
         if len(upsample_channels) > len(backbone_channels) - 1:
             raise ValueError("FPN neck needs one backbone skip feature per upsample stage")
+        self.upsample_type, self.conv_type, self.weighted_fusion = upsample_type, conv_type, bool(weighted_fusion)
         self.out_channels = upsample_channels[-1]
         self.upsample_stride = 2 ** len(upsample_channels)
         self.top_conv = nn.Conv2d(backbone_channels[-1], upsample_channels[0], 1)
@@ -124,15 +200,16 @@ class FPNNeck(nn.Module):
         top_c = upsample_channels[0]
         for i, c in enumerate(upsample_channels):
             skip_c = backbone_channels[-2 - i]
-            fuse.append(FuseParams(skip_c, top_c, c))
+            fuse.append(FuseParams(skip_c, top_c, c, upsample_type, conv_type, weighted_fusion, deconv_kernel, deconv_init_bilinear))
             top_c = c
         self.fuse = nn.ModuleList(fuse)
 
 
-def _check_neck_options(upsample_type, conv_type, weighted_fusion):
-    if upsample_type != "nearest" or conv_type != "normal" or weighted_fusion:
-        raise ValueError("only upsample_type='nearest', conv_type='normal', weighted_fusion=False are on the MI355X hot path "
-                         f"(got {upsample_type!r}, {conv_type!r}, {weighted_fusion!r}); see DESIGN.md 'out of scope'")
+def _check_neck_options(upsample_type, conv_type):
+    if upsample_type not in UPSAMPLE_TYPES:
+        raise ValueError(f"upsample_type={upsample_type!r}: expected one of {UPSAMPLE_TYPES} (layers.py:84)")
+    if conv_type not in ("normal", "separable"):
+        make_conv_params(64, 64, conv_type)          # raises with the explanation
 
 
 class GenericHead(nn.Module):

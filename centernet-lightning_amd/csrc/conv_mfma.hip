@@ -42,7 +42,8 @@ struct ConvArgs {
     const float* res;
     float* y;
     int N, Hin, Win, Cin, Cout;
-    int KH, KW, stride, pad;
+    int KH, KW, stride, pad, pad_x;      // pad = rows, pad_x = columns (equal for every public conv; differ for deconv phases)
+    int sub_dy, sub_dx;                  // CNL_I_SUBPIXEL: phase of the 2x output grid this launch writes
     int ldx, ldy, ldr;
     int HL, WL;        // logical input size (2x when CNL_UPSAMPLE_IN)
     int Ho, Wo, M;     // conv output size, M = N*Ho*Wo
@@ -54,6 +55,7 @@ struct ConvArgs {
     long long* trace;                    // CNL_TRACE builds only: per-workgroup phase timestamps
 };
 
+constexpr unsigned CNL_I_SUBPIXEL = 1u << 16;   // internal: y[n, 2oy+sub_dy, 2ox+sub_dx, :] = act(conv + bias) (+ residual there)
 constexpr unsigned OOB = 0xFFFFFFF0u;   // voffset that is always >= num_records -> DMA writes zeros / store dropped
 
 template <int WM, int WN, int TM, int TN>
@@ -103,7 +105,7 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, unsigne
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 // `voff` = byte offset of (row 0 of this lane, col); the row's r-dependent part goes in the scalar offset.
 template <bool CHECK, bool RES>
-__device__ __forceinline__ void store_tile(const f32x16& acc, float bv, float lo, bool sigm, const ConvArgs& a, unsigned y_voff,
+__device__ __forceinline__ void store_tile(const f32x16& acc, float bv, float lo, float hi6, bool sigm, const ConvArgs& a, unsigned y_voff,
                                            unsigned r_voff, int m_base, bool col_ok) {
     float v[16];
     if constexpr (RES) {
@@ -121,7 +123,7 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, float bv, float lo
         for (int r = 0; r < 16; ++r) v[r] = acc[r] + bv;
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], lo);
+    for (int r = 0; r < 16; ++r) v[r] = fminf(fmaxf(v[r], lo), hi6);
     if (sigm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         const unsigned oy = fast_div(rem, a.mg_w, a.sh_w);
         const unsigned ox = rem - oy * (unsigned)a.Wo;
         const int iy0 = (int)oy * a.stride - a.pad;
-        const int ix0 = (int)ox * a.stride - a.pad;
+        const int ix0 = (int)ox * a.stride - a.pad_x;
         unsigned mask = 0;
         if constexpr (KS != 0) {
             unsigned xb = 0;
@@ -335,10 +337,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #endif
 
     // ---- epilogue ----
-    const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
+    const float lo = (a.flags & (CNL_RELU | CNL_RELU6)) ? 0.f : -__builtin_inff();
+    const float hi6 = (a.flags & CNL_RELU6) ? 6.f : __builtin_inff();
     const bool sigm = a.flags & CNL_SIGMOID;
     const bool full = (m0 + C::BM <= a.M) && (n0 + C::BN <= a.Cout);
-    if (!(a.flags & CNL_UPSAMPLE_OUT_ADD)) {
+    if (!(a.flags & (CNL_UPSAMPLE_OUT_ADD | CNL_I_SUBPIXEL))) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -350,16 +353,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 const unsigned y_voff = (unsigned)((mb * a.ldy + col) * 4);
                 const unsigned r_voff = (unsigned)((mb * a.ldr + col) * 4);
                 if (full) {
-                    if (a.res) store_tile<false, true>(acc[i][j], bv, lo, sigm, a, y_voff, r_voff, mb, true);
-                    else store_tile<false, false>(acc[i][j], bv, lo, sigm, a, y_voff, r_voff, mb, true);
+                    if (a.res) store_tile<false, true>(acc[i][j], bv, lo, hi6, sigm, a, y_voff, r_voff, mb, true);
+                    else store_tile<false, false>(acc[i][j], bv, lo, hi6, sigm, a, y_voff, r_voff, mb, true);
                 } else {
-                    if (a.res) store_tile<true, true>(acc[i][j], bv, lo, sigm, a, y_voff, r_voff, mb, col_ok);
-                    else store_tile<true, false>(acc[i][j], bv, lo, sigm, a, y_voff, r_voff, mb, col_ok);
+                    if (a.res) store_tile<true, true>(acc[i][j], bv, lo, hi6, sigm, a, y_voff, r_voff, mb, col_ok);
+                    else store_tile<true, false>(acc[i][j], bv, lo, hi6, sigm, a, y_voff, r_voff, mb, col_ok);
                 }
             }
         }
     } else {
-        // FPN Fuse: write the four 2x-upsampled positions, adding the skip tensor there (layers.py:160-174)
+        // scatter epilogues into a 2x-resolution output:
+        //   CNL_UPSAMPLE_OUT_ADD  FPN Fuse: write the four 2x-upsampled positions, adding the skip tensor there (layers.py:160-174)
+        //   CNL_I_SUBPIXEL        one phase of a stride-2 transposed conv: write position (sub_dy, sub_dx) only; the optional
+        //                         residual is added AFTER the activation (Fuse: skip + resize(top), resize = deconv+BN+ReLU)
+        const bool sub = a.flags & CNL_I_SUBPIXEL;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -376,6 +383,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                     const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
                     const unsigned oy = fast_div(rem, a.mg_w, a.sh_w);
                     const unsigned ox = rem - oy * (unsigned)a.Wo;
+                    if (sub) {
+                        const size_t pix = ((size_t)n * (2 * a.Ho) + 2 * oy + a.sub_dy) * (2 * a.Wo) + 2 * ox + a.sub_dx;
+                        float o = fminf(fmaxf(v, lo), hi6);
+                        if (a.res) o += a.res[pix * a.ldr + col];
+                        a.y[pix * a.ldy + col] = o;
+                        continue;
+                    }
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const size_t pix = ((size_t)n * (2 * a.Ho) + 2 * oy + (d >> 1)) * (2 * a.Wo) + 2 * ox + (d & 1);
@@ -436,6 +450,39 @@ static void magic_u31(unsigned d, unsigned* magic, unsigned* shift) {
 }  // namespace cnl_conv
 using namespace cnl_conv;
 
+// Derived fields of ConvArgs (a.Ho / a.Wo already set), the 4 GiB addressing checks, and the tile-shape dispatch.
+// out4x: the launch writes into a tensor of 4x the conv's own output pixels (2x-resolution scatter epilogues).
+static int finish_and_launch(ConvArgs& a, bool out4x, const char* who, hipStream_t s) {
+    CNL_REQUIRE(a.Ho > 0 && a.Wo > 0, CNL_E_BAD_ARG, "%s: empty output", who);
+    const long long M = (long long)a.N * a.Ho * a.Wo;
+    CNL_REQUIRE(M < (1ll << 31) - 512, CNL_E_UNSUPPORTED, "%s: N*Ho*Wo too large", who);
+    a.M = (int)M;
+    a.CC = a.Cin / 32; a.KT = a.KH * a.KW * a.CC; a.K = a.KH * a.KW * a.Cin;
+    const unsigned long long lim = 0xFFFFFF00ull;
+    const unsigned long long xb = (((unsigned long long)a.N * a.Hin * a.Win - 1) * a.ldx + a.Cin) * 4ull;
+    const unsigned long long wb = (unsigned long long)a.Cout * a.K * 4ull;
+    const unsigned long long Mo = out4x ? 4ull * M : (unsigned long long)M;
+    const unsigned long long yb = ((Mo - 1) * a.ldy + a.Cout) * 4ull;
+    const unsigned long long rb = a.res ? ((Mo - 1) * a.ldr + a.Cout) * 4ull : 0ull;
+    CNL_REQUIRE(xb < lim && yb + 512ull * a.ldy * 4 < lim && rb + 512ull * a.ldr * 4 < lim, CNL_E_UNSUPPORTED,
+                "%s: a tensor spans >= 4 GiB (x %llu, y %llu bytes); split the batch", who, xb, yb);
+    CNL_REQUIRE(wb + (unsigned long long)256 * a.K * 4ull < lim, CNL_E_UNSUPPORTED, "%s: weight too large", who);
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
+    a.tiles_n = a.tiles = 0;
+    magic_u31((unsigned)(a.Ho * a.Wo), &a.mg_hw, &a.sh_hw);
+    magic_u31((unsigned)a.Wo, &a.mg_w, &a.sh_w);
+    a.trace = nullptr;
+#ifdef CNL_TRACE
+    if (const char* e = getenv("CNL_TRACE_PTR")) a.trace = (long long*)strtoull(e, nullptr, 0);
+#endif
+    // Tile choice: BN follows Cout; shrink BM when the grid would not fill 256 CUs x 2 workgroups.
+    if (a.Cout <= 32) return launch_cfg<4, 1, 2, 1>(a, s);          // 256 x 32
+    if (a.Cout <= 64) return launch_cfg<4, 1, 2, 2>(a, s);          // 256 x 64
+    const long long tiles128 = ((M + 127) / 128) * ((a.Cout + 127) / 128);
+    if (tiles128 < 512) return launch_cfg<2, 2, 1, 2>(a, s);        //  64 x 128
+    return launch_cfg<2, 2, 2, 2>(a, s);                            // 128 x 128
+}
+
 extern "C" int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out) {
     CNL_REQUIRE(p && H_out && W_out, CNL_E_BAD_ARG, "cnl_conv2d_out_hw: null argument");
     CNL_REQUIRE(p->stride > 0 && p->KH > 0 && p->KW > 0, CNL_E_BAD_ARG, "cnl_conv2d_out_hw: bad kernel/stride");
@@ -467,41 +514,69 @@ extern "C" int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream) {
     ConvArgs a;
     a.x = p->x; a.w = p->w; a.bias = p->bias; a.res = p->residual; a.y = p->y;
     a.N = p->N; a.Hin = p->H_in; a.Win = p->W_in; a.Cin = p->Cin; a.Cout = p->Cout;
-    a.KH = p->KH; a.KW = p->KW; a.stride = p->stride; a.pad = p->pad;
+    a.KH = p->KH; a.KW = p->KW; a.stride = p->stride; a.pad = a.pad_x = p->pad;
+    a.sub_dy = a.sub_dx = 0;
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
     a.flags = p->flags;
     const int up = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
     a.HL = p->H_in * up; a.WL = p->W_in * up;
     a.Ho = (a.HL + 2 * p->pad - p->KH) / p->stride + 1;
     a.Wo = (a.WL + 2 * p->pad - p->KW) / p->stride + 1;
-    CNL_REQUIRE(a.Ho > 0 && a.Wo > 0, CNL_E_BAD_ARG, "cnl_conv2d_nhwc_f32: empty output");
-    const long long M = (long long)p->N * a.Ho * a.Wo;
-    CNL_REQUIRE(M < (1ll << 31) - 512, CNL_E_UNSUPPORTED, "cnl_conv2d_nhwc_f32: N*Ho*Wo too large");
-    a.M = (int)M;
-    a.CC = p->Cin / 32; a.KT = p->KH * p->KW * a.CC; a.K = p->KH * p->KW * p->Cin;
-    const unsigned long long lim = 0xFFFFFF00ull;
-    const unsigned long long xb = (((unsigned long long)p->N * p->H_in * p->W_in - 1) * p->ldx + p->Cin) * 4ull;
-    const unsigned long long wb = (unsigned long long)p->Cout * a.K * 4ull;
-    const unsigned long long Mo = up_out ? 4ull * M : (unsigned long long)M;
-    const unsigned long long yb = ((Mo - 1) * p->ldy + p->Cout) * 4ull;
-    const unsigned long long rb = p->residual ? ((Mo - 1) * p->ldr + p->Cout) * 4ull : 0ull;
-    CNL_REQUIRE(xb < lim && yb + 512ull * p->ldy * 4 < lim && rb + 512ull * p->ldr * 4 < lim, CNL_E_UNSUPPORTED,
-                "cnl_conv2d_nhwc_f32: a tensor spans >= 4 GiB (x %llu, y %llu bytes); split the batch", xb, yb);
-    CNL_REQUIRE(wb + (unsigned long long)256 * a.K * 4ull < lim, CNL_E_UNSUPPORTED, "cnl_conv2d_nhwc_f32: weight too large");
-    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
-    a.tiles_n = a.tiles = 0;
-    magic_u31((unsigned)(a.Ho * a.Wo), &a.mg_hw, &a.sh_hw);
-    magic_u31((unsigned)a.Wo, &a.mg_w, &a.sh_w);
-    a.trace = nullptr;
-#ifdef CNL_TRACE
-    if (const char* e = getenv("CNL_TRACE_PTR")) a.trace = (long long*)strtoull(e, nullptr, 0);
-#endif
+    return finish_and_launch(a, up_out, "cnl_conv2d_nhwc_f32", (hipStream_t)stream);
+}
 
-    hipStream_t s = (hipStream_t)stream;
-    // Tile choice: BN follows Cout; shrink BM when the grid would not fill 256 CUs x 2 workgroups.
-    if (a.Cout <= 32) return launch_cfg<4, 1, 2, 1>(a, s);          // 256 x 32
-    if (a.Cout <= 64) return launch_cfg<4, 1, 2, 2>(a, s);          // 256 x 64
-    const long long tiles128 = ((M + 127) / 128) * ((a.Cout + 127) / 128);
-    if (tiles128 < 512) return launch_cfg<2, 2, 1, 2>(a, s);        //  64 x 128
-    return launch_cfg<2, 2, 2, 2>(a, s);                            // 128 x 128
+/*
+ * Stride-2 transposed convolution as four sub-pixel phases, each an ordinary correlation over the input written to one of the
+ * four positions of the 2x output grid (no zero-stuffing, no col2im): out[2y+dy, 2x+dx] = sum over the taps ky == (dy+p) mod 2,
+ * kx == (dx+p) mod 2 of in[y + (dy+p-ky)/2, x + (dx+p-kx)/2] . w[ky][kx].
+ */
+extern "C" int cnl_deconv_phase_geometry(int32_t K, int32_t d, int32_t* taps, int32_t* pad) {
+    CNL_REQUIRE(K >= 2 && K <= 4 && (d == 0 || d == 1) && taps && pad, CNL_E_BAD_ARG, "cnl_deconv_phase_geometry: K in 2..4, d in 0..1");
+    const int p = (K + K % 2) / 2 - 1;                     // make_upsample: padding = (k + output_padding)//2 - 1 (layers.py:87-88)
+    int n = 0, ky_max = -1;
+    for (int ky = 0; ky < K; ++ky)
+        if (((ky - d - p) & 1) == 0) { ++n; ky_max = ky; }
+    *taps = n;
+    *pad = -((d + p - ky_max) / 2);                        // minus the smallest input offset (exact division: same parity)
+    return CNL_OK;
+}
+
+extern "C" size_t cnl_deconv_weight_floats(int32_t Cin, int32_t Cout, int32_t K) {
+    if (Cin <= 0 || Cout <= 0 || K < 2 || K > 4) return 0;
+    return (size_t)Cin * Cout * K * K;
+}
+
+extern "C" int cnl_deconv2x_nhwc_f32(const cnl_deconv_params* p, void* stream) {
+    CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_deconv2x_nhwc_f32: null params");
+    CNL_REQUIRE(p->x && p->w && p->bias && p->y, CNL_E_BAD_ARG, "cnl_deconv2x_nhwc_f32: null tensor pointer");
+    CNL_REQUIRE(p->N > 0 && p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG,
+                "cnl_deconv2x_nhwc_f32: non-positive dimension");
+    CNL_REQUIRE(p->K >= 2 && p->K <= 4, CNL_E_UNSUPPORTED, "cnl_deconv2x_nhwc_f32: deconv_kernel=%d (supported: 2, 3, 4)", p->K);
+    CNL_REQUIRE(p->Cin % 32 == 0, CNL_E_UNSUPPORTED, "cnl_deconv2x_nhwc_f32: Cin=%d is not a multiple of 32", p->Cin);
+    CNL_REQUIRE(p->ldx >= p->Cin && p->ldy >= p->Cout && p->ldx % 4 == 0, CNL_E_BAD_ARG,
+                "cnl_deconv2x_nhwc_f32: pixel strides ldx=%d ldy=%d too small / misaligned", p->ldx, p->ldy);
+    CNL_REQUIRE(((uintptr_t)p->x & 15) == 0 && ((uintptr_t)p->w & 15) == 0, CNL_E_BAD_ARG,
+                "cnl_deconv2x_nhwc_f32: x and w must be 16-byte aligned");
+    CNL_REQUIRE(!(p->flags & ~(uint32_t)(CNL_RELU | CNL_RELU6)), CNL_E_UNSUPPORTED, "cnl_deconv2x_nhwc_f32: flags other than CNL_RELU / CNL_RELU6");
+    CNL_REQUIRE(!p->residual || p->ldr >= p->Cout, CNL_E_BAD_ARG, "cnl_deconv2x_nhwc_f32: ldr=%d < Cout", p->ldr);
+    const float* w = p->w;
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            int32_t kh, kw, py, px;
+            cnl_deconv_phase_geometry(p->K, dy, &kh, &py);
+            cnl_deconv_phase_geometry(p->K, dx, &kw, &px);
+            ConvArgs a;
+            a.x = p->x; a.w = w; a.bias = p->bias; a.res = p->residual; a.y = p->y;
+            a.N = p->N; a.Hin = p->H_in; a.Win = p->W_in; a.Cin = p->Cin; a.Cout = p->Cout;
+            a.KH = kh; a.KW = kw; a.stride = 1; a.pad = py; a.pad_x = px;
+            a.sub_dy = dy; a.sub_dx = dx;
+            a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
+            a.flags = p->flags | CNL_I_SUBPIXEL;
+            a.HL = p->H_in; a.WL = p->W_in;
+            a.Ho = p->H_in; a.Wo = p->W_in;
+            const int rc = finish_and_launch(a, true, "cnl_deconv2x_nhwc_f32", (hipStream_t)stream);
+            if (rc != CNL_OK) return rc;
+            w += (size_t)p->Cout * kh * kw * p->Cin;       // next phase block of the packed weights
+        }
+    return CNL_OK;
 }

@@ -1,0 +1,119 @@
+// resize.hip — the HBM-bound halves of the remaining neck options:
+//   upsample2x_kernel   nn.Upsample(scale_factor=2, mode="nearest"|"bilinear") (+ the Fuse sum)   models/layers.py:99, 160-174
+//   depthwise3x3_kernel depthwise 3x3 + folded BN + ReLU6 of conv_type="separable"                 models/layers.py:58-62
+// Both stream NHWC float4s: one thread per (output pixel, 4 channels); neighbouring pixels' re-reads hit L2.
+#include "cnl_common.h"
+
+#pragma clang fp contract(off)   // ATen's bilinear kernel rounds every multiply and add
+
+namespace cnl_resize {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                         float* __restrict__ y, int N, int H, int W, int C4, int ldx, int ldr,
+                                                         int ldy, int bilinear) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long total = (long)N * Ho * Wo * C4;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int c = (int)(t % C4) * 4;
+        long pix = t / C4;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        const float* xn = x + (long)n * H * W * ldx + c;
+        f32x4 v;
+        if (!bilinear) {
+            v = *reinterpret_cast<const f32x4*>(xn + ((long)(oy >> 1) * W + (ox >> 1)) * ldx);
+        } else {
+            // align_corners=False, scale 2: src = (dst + 0.5) / 2 - 0.5 clamped at 0; lambda in {0, 0.25, 0.75}
+            const float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+            const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+            const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xn + ((long)y0 * W + x0) * ldx);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(xn + ((long)y0 * W + x1) * ldx);
+            const f32x4 cc = *reinterpret_cast<const f32x4*>(xn + ((long)y1 * W + x0) * ldx);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(xn + ((long)y1 * W + x1) * ldx);
+            v = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * cc + lx1 * d);       // ATen upsample_bilinear2d order
+        }
+        const long opix = ((long)n * Ho + oy) * Wo + ox;
+        if (res) v = *reinterpret_cast<const f32x4*>(res + opix * ldr + c) + v;   // Fuse: in1 + resize(in2)
+        *reinterpret_cast<f32x4*>(y + opix * ldy + c) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int N, int H,
+                                                           int W, int C4, int ldx, int ldy, float lo, float hi) {
+    const long total = (long)N * H * W * C4;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int c = (int)(t % C4) * 4;
+        long pix = t / C4;
+        const int ox = (int)(pix % W);
+        pix /= W;
+        const int oy = (int)(pix % H);
+        const int n = (int)(pix / H);
+        const float* xn = x + (long)n * H * W * ldx + c;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy + ky - 1;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox + kx - 1;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xn + ((long)iy * W + ix) * ldx);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (long)(ky * 3 + kx) * C4 * 4 + c);
+                acc = acc + xv * wv;
+            }
+        }
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+        f32x4 v = acc + bv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fminf(fmaxf(v[i], lo), hi);
+        *reinterpret_cast<f32x4*>(y + (((long)n * H + oy) * W + ox) * ldy + c) = v;
+    }
+}
+
+static unsigned grid_for(long total) {
+    long b = (total + 255) / 256;
+    if (b > 256 * 32) b = 256 * 32;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace cnl_resize
+using namespace cnl_resize;
+
+extern "C" int cnl_upsample2x_nhwc_f32(const float* x, const float* residual, float* y, int32_t N, int32_t H_in, int32_t W_in,
+                                       int32_t C, int32_t ldx, int32_t ldr, int32_t ldy, int32_t mode, void* stream) {
+    CNL_REQUIRE(x && y, CNL_E_BAD_ARG, "cnl_upsample2x_nhwc_f32: null tensor pointer");
+    CNL_REQUIRE(N > 0 && H_in > 0 && W_in > 0 && C > 0, CNL_E_BAD_ARG, "cnl_upsample2x_nhwc_f32: non-positive dimension");
+    CNL_REQUIRE(mode == 0 || mode == 1, CNL_E_UNSUPPORTED, "cnl_upsample2x_nhwc_f32: mode %d (0 = nearest, 1 = bilinear)", mode);
+    CNL_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && (!residual || (ldr % 4 == 0 && ldr >= C)),
+                CNL_E_UNSUPPORTED, "cnl_upsample2x_nhwc_f32: C and the pixel strides must be multiples of 4 (C=%d ldx=%d ldy=%d)", C, ldx, ldy);
+    CNL_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0, CNL_E_BAD_ARG, "cnl_upsample2x_nhwc_f32: 16-byte alignment");
+    const long total = (long)N * 4 * H_in * W_in * (C / 4);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, residual, y, N, H_in, W_in, C / 4,
+                       ldx, ldr, ldy, mode);
+    return cnl::check_launch("upsample2x_kernel");
+}
+
+extern "C" int cnl_depthwise3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int32_t N, int32_t H, int32_t W,
+                                         int32_t C, int32_t ldx, int32_t ldy, uint32_t flags, void* stream) {
+    CNL_REQUIRE(x && w && bias && y, CNL_E_BAD_ARG, "cnl_depthwise3x3_nhwc_f32: null tensor pointer");
+    CNL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, CNL_E_BAD_ARG, "cnl_depthwise3x3_nhwc_f32: non-positive dimension");
+    CNL_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C, CNL_E_UNSUPPORTED,
+                "cnl_depthwise3x3_nhwc_f32: C and the pixel strides must be multiples of 4 (C=%d ldx=%d ldy=%d)", C, ldx, ldy);
+    CNL_REQUIRE(!(flags & ~(uint32_t)(CNL_RELU | CNL_RELU6)), CNL_E_UNSUPPORTED, "cnl_depthwise3x3_nhwc_f32: flags other than CNL_RELU / CNL_RELU6");
+    CNL_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)bias) & 15) == 0, CNL_E_BAD_ARG, "cnl_depthwise3x3_nhwc_f32: 16-byte alignment");
+    const float lo = (flags & (CNL_RELU | CNL_RELU6)) ? 0.f : -__builtin_inff();
+    const float hi = (flags & CNL_RELU6) ? 6.f : __builtin_inff();
+    const long total = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(depthwise3x3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, H, W, C / 4, ldx,
+                       ldy, lo, hi);
+    return cnl::check_launch("depthwise3x3_kernel");
+}

@@ -426,7 +426,7 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 "cnl_conv3x3_winograd_f32: non-positive dimension");
     CNL_REQUIRE(p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1, CNL_E_UNSUPPORTED,
                 "cnl_conv3x3_winograd_f32: only 3x3 / stride 1 / pad 1");
-    CNL_REQUIRE(!(p->flags & (CNL_UPSAMPLE_OUT_ADD | CNL_SIGMOID)), CNL_E_UNSUPPORTED,
+    CNL_REQUIRE(!(p->flags & (CNL_UPSAMPLE_OUT_ADD | CNL_SIGMOID | CNL_RELU6)), CNL_E_UNSUPPORTED,
                 "cnl_conv3x3_winograd_f32: UPSAMPLE_OUT_ADD / SIGMOID are handled by cnl_conv2d_nhwc_f32");
     CNL_REQUIRE(p->Cin % 8 == 0 && p->ldx % 4 == 0 && p->ldx >= p->Cin && p->ldy >= p->Cout, CNL_E_UNSUPPORTED,
                 "cnl_conv3x3_winograd_f32: Cin %% 8 != 0 or bad pixel stride");

@@ -43,9 +43,11 @@ enum {
     CNL_SIGMOID = 1u << 1,       /* y = 1/(1+exp(-y))                  .sigmoid()   (centernet.py:205)    */
     CNL_UPSAMPLE_IN = 1u << 2,   /* read x through nn.Upsample(scale_factor=2, mode="nearest")
                                     (layers.py:99): logical input is (2*H_in, 2*W_in)                   */
-    CNL_UPSAMPLE_OUT_ADD = 1u << 3 /* write y at 2x resolution and add `residual` there:
+    CNL_UPSAMPLE_OUT_ADD = 1u << 3, /* write y at 2x resolution and add `residual` there:
                                     y[n,2oy+dy,2ox+dx,:] = conv(x)[n,oy,ox,:] + bias + residual[...]
                                     = Fuse.forward's project -> resize("up") -> sum (layers.py:160-174) */
+    CNL_RELU6 = 1u << 4          /* y = min(max(y, 0), 6)              nn.ReLU6     (layers.py:62,66; separable conv);
+                                    cnl_conv2d_nhwc_f32 / cnl_deconv2x_nhwc_f32 / cnl_depthwise3x3_nhwc_f32 only      */
 };
 
 /*
@@ -159,6 +161,50 @@ int cnl_pack_detections_f32(const float* boxes, const float* scores, const int64
                             float* rec, int32_t N, int32_t k, int32_t E, void* stream);
 int cnl_unpack_detections_f32(const float* rec, float* boxes, float* scores, int64_t* labels, float* emb,
                               int32_t N, int32_t k, int32_t E, void* stream);
+
+/*
+ * SURVEY.md §8f next #3 — the remaining neck options of make_upsample / make_conv (models/layers.py:40-101).
+ *
+ * cnl_deconv2x_nhwc_f32: upsample_type="conv_transpose" = nn.ConvTranspose2d(C, C', K, stride=2, padding=(K + K%2)/2 - 1,
+ * output_padding=K%2, bias=False) + BatchNorm2d + ReLU (layers.py:86-93; K = deconv_kernel in {2,3,4}; output is exactly
+ * 2H x 2W).  Computed as FOUR sub-pixel phase convolutions on the MFMA implicit-GEMM kernel (no zero-stuffing): phase
+ * (dy,dx) writes y[n, 2i+dy, 2j+dx, :].  y = act(deconv(x) + bias) (+ residual at the same 2x position, added after the
+ * activation: Fuse's "in1 + resize(in2)", layers.py:160-174).
+ * `w` is the PACKED weight: for phase ph = 2*dy + dx a block [Cout][KHp][KWp][Cin] (OHWI), blocks back to back, where with
+ * (taps, pad) = cnl_deconv_phase_geometry(K, d) per axis and p = (K + K%2)/2 - 1:
+ *     w_packed[ph][co][jy][jx][ci] = scale[co] * W[ci][co][dy + p + 2*(pad_y - jy)][dx + p + 2*(pad_x - jx)]
+ * (W = ConvTranspose2d.weight [Cin][Cout][K][K]; scale = folded BN gamma/sqrt(var+eps)); cnl_deconv_weight_floats() = K*K*Cin*Cout.
+ */
+typedef struct cnl_deconv_params {
+    const float* x;         /* input  [N, H_in, W_in, ldx]                         */
+    const float* w;         /* packed phase weights (see above)                    */
+    const float* bias;      /* [Cout]                                              */
+    const float* residual;  /* null, or [N, 2H_in, 2W_in, ldr]                     */
+    float* y;               /* output [N, 2H_in, 2W_in, ldy]                       */
+    int32_t N, H_in, W_in, Cin, Cout, K;
+    int32_t ldx, ldy, ldr;
+    uint32_t flags;         /* CNL_RELU | CNL_RELU6                                */
+} cnl_deconv_params;
+int cnl_deconv2x_nhwc_f32(const cnl_deconv_params* p, void* stream);
+int cnl_deconv_phase_geometry(int32_t K, int32_t d, int32_t* taps, int32_t* pad);
+size_t cnl_deconv_weight_floats(int32_t Cin, int32_t Cout, int32_t K);
+
+/*
+ * nn.Upsample(scale_factor=2, mode="nearest" | "bilinear") (layers.py:99; bilinear = align_corners=False) on NHWC, optionally
+ * adding `residual` at the output resolution (Fuse: in1 + resize(in2)).  mode: 0 = nearest, 1 = bilinear.  C % 4 == 0.
+ * Nearest feeding a "normal" conv never needs this (CNL_UPSAMPLE_IN folds it into the conv); it exists for bilinear and for
+ * the depthwise path.
+ */
+int cnl_upsample2x_nhwc_f32(const float* x, const float* residual, float* y, int32_t N, int32_t H_in, int32_t W_in, int32_t C,
+                            int32_t ldx, int32_t ldr, int32_t ldy, int32_t mode, void* stream);
+
+/*
+ * conv_type="separable", depthwise half (layers.py:58-62): nn.Conv2d(C, C, 3, padding=1, groups=C, bias=False) + BN + ReLU6.
+ * w: [3][3][C] (tap-major, BN scale folded), bias [C]; flags: CNL_RELU | CNL_RELU6.  C % 4 == 0.  The pointwise half is
+ * cnl_conv2d_nhwc_f32 (1x1) with CNL_RELU6.
+ */
+int cnl_depthwise3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int32_t N, int32_t H, int32_t W,
+                              int32_t C, int32_t ldx, int32_t ldy, uint32_t flags, void* stream);
 
 /*
  * Step after the path for the tracking task: association costs of one frame against the current

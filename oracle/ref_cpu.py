@@ -3,7 +3,8 @@
 Plain PyTorch CPU fp32 restatement of the CenterNet forward that the HIP path must match:
   GenericModel.forward            <- centernet_lightning/models/meta.py:41-47
   GenericHead                     <- centernet_lightning/models/meta.py:21-30 (block = conv3x3 no-bias + BN + ReLU)
-  make_conv / make_upsample / Fuse <- centernet_lightning/models/layers.py:72-77, :99, :160-177
+  make_conv / make_upsample / Fuse <- centernet_lightning/models/layers.py:40-101, :138-177 (normal + separable conv; nearest,
+                                     bilinear and conv_transpose upsampling; plain and weighted fusion)
   ResNet-34 backbone              <- public torchvision topology (absent from the reference tree; contract
                                      tests/test_backbones.py:60-70)
   .sigmoid() at the forward boundary <- centernet_lightning/models/centernet.py:205
@@ -68,27 +69,59 @@ def backbone_features(sd, x, stats=None):
     return feats
 
 
-def neck_forward(sd, feats, stats=None):
+def make_conv_forward(x, sd, q, stats=None):
+    """layers.py:40-79 make_conv: `q`.0/.1 = conv3x3+BN+ReLU ("normal"); `q`.0/.1/.3/.4 = depthwise+BN+ReLU6, pointwise+BN+ReLU6
+    ("separable", :56-69)."""
+    if q + ".3.weight" in sd:
+        w = sd[q + ".0.weight"]
+        y = F.conv2d(x, w, None, padding=(w.shape[-1] - 1) // 2, groups=w.shape[0])
+        y = F.relu6(_bn(y, sd, q + ".1", stats))
+        y = F.conv2d(y, sd[q + ".3.weight"], None)
+        return F.relu6(_bn(y, sd, q + ".4", stats))
+    return _conv_bn_relu(x, sd, q + ".0", q + ".1", stats=stats)
+
+
+def make_upsample_forward(x, sd, q, upsample_type, stats=None):
+    """layers.py:81-101 make_upsample: ConvTranspose2d(stride 2)+BN+ReLU when `q`.0.weight exists, else nn.Upsample(x2, mode)."""
+    if q + ".0.weight" in sd:
+        w = sd[q + ".0.weight"]
+        k = w.shape[-1]
+        op = k % 2
+        y = F.conv_transpose2d(x, w, None, stride=2, padding=(k + op) // 2 - 1, output_padding=op)
+        return F.relu(_bn(y, sd, q + ".1", stats))
+    return F.interpolate(x, scale_factor=2, mode=upsample_type)
+
+
+def fuse_forward(sd, q, skip, top, upsample_type="nearest", stats=None, eps=1e-6):
+    """Fuse.forward (layers.py:160-177) with in_channels = [skip, top], resize="up"."""
+    out = [skip, top]
+    for j in range(2):
+        if f"{q}project.{j}.weight" in sd:
+            out[j] = F.conv2d(out[j], sd[f"{q}project.{j}.weight"], sd[f"{q}project.{j}.bias"])
+    out[-1] = make_upsample_forward(out[-1], sd, q + "resize", upsample_type, stats)
+    if q + "weights" in sd:
+        w = F.relu(sd[q + "weights"])
+        o = torch.stack([out[j] * w[j] for j in range(2)], dim=-1)
+        o = torch.sum(o, dim=-1) / (torch.sum(w) + eps)
+    else:
+        o = torch.stack(out, dim=-1).sum(dim=-1)
+    return make_conv_forward(o, sd, q + "output_conv", stats)
+
+
+def neck_forward(sd, feats, stats=None, upsample_type="nearest"):
+    """`upsample_type` distinguishes "nearest" from "bilinear" (neither has parameters); "conv_transpose" is read off the keys."""
     if "neck.top_conv.weight" in sd:                           # FPN
         top = F.conv2d(feats[-1], sd["neck.top_conv.weight"], sd["neck.top_conv.bias"])
         i = 0
         while f"neck.fuse.{i}.output_conv.0.weight" in sd:
-            q = f"neck.fuse.{i}."
-            skip = feats[-2 - i]
-            if q + "project.0.weight" in sd:                   # Fuse.forward (layers.py:160-177)
-                skip = F.conv2d(skip, sd[q + "project.0.weight"], sd[q + "project.0.bias"])
-            if q + "project.1.weight" in sd:
-                top = F.conv2d(top, sd[q + "project.1.weight"], sd[q + "project.1.bias"])
-            top = F.interpolate(top, scale_factor=2, mode="nearest")
-            out = torch.stack([skip, top], dim=-1).sum(dim=-1)
-            top = _conv_bn_relu(out, sd, q + "output_conv.0", q + "output_conv.1", stats=stats)
+            top = fuse_forward(sd, f"neck.fuse.{i}.", feats[-2 - i], top, upsample_type, stats)
             i += 1
         return top
     x = feats[-1]                                              # simple neck: conv -> upsample per stage
     i = 0
     while f"neck.layers.{i}.0.weight" in sd:
-        x = _conv_bn_relu(x, sd, f"neck.layers.{i}.0", f"neck.layers.{i}.1", stats=stats)
-        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        x = make_conv_forward(x, sd, f"neck.layers.{i}", stats)
+        x = make_upsample_forward(x, sd, f"neck.upsamples.{i}", upsample_type, stats)
         i += 1
     return x
 
@@ -112,11 +145,11 @@ def head_forward(sd, name, x, stats=None, prefix="heads."):
 
 
 @torch.no_grad()
-def forward(sd, x, sigmoid=True, stats=None, return_intermediates=False):
+def forward(sd, x, sigmoid=True, stats=None, return_intermediates=False, upsample_type="nearest"):
     """sd: state_dict (CPU fp32 tensors) with the key layout of centernet_lightning_amd.CenterNet;
     x: [N,3,H,W] CPU fp32.  Returns OrderedDict(heatmap, box_2d[, reid]) in NCHW."""
     feats = backbone_features(sd, x, stats)
-    neck = neck_forward(sd, feats, stats)
+    neck = neck_forward(sd, feats, stats, upsample_type)
     out = OrderedDict()
     for name in head_names(sd):
         y = head_forward(sd, name, neck, stats)
@@ -127,7 +160,7 @@ def forward(sd, x, sigmoid=True, stats=None, return_intermediates=False):
 
 
 @torch.no_grad()
-def synth_state_dict(model_state_dict, seed=0, calib_shape=(2, 3, 256, 256), calib_seed=1234):
+def synth_state_dict(model_state_dict, seed=0, calib_shape=(2, 3, 256, 256), calib_seed=1234, upsample_type="nearest"):
     """Synthetic weights per BASELINE.md §5 / SURVEY.md §8(d): convs keep their Kaiming init; BN gamma~U(0.5,1.5),
     beta~N(0,0.1); running stats CALIBRATED by one CPU forward on a seeded batch so activations stay O(1);
     out_conv.weight ~ N(0, 0.01^2); out_conv.bias keeps init_bias.  Returns a new CPU state_dict."""
@@ -146,7 +179,9 @@ def synth_state_dict(model_state_dict, seed=0, calib_shape=(2, 3, 256, 256), cal
             v.copy_(torch.randn(v.shape, generator=g) * (2.0 / fan_out) ** 0.5)       # kaiming_normal_(fan_out, relu)
         elif k.endswith(("top_conv.bias", "project.0.bias", "project.1.bias")):
             v.copy_(torch.randn(v.shape, generator=g) * 0.05)
+        elif k.endswith(".weights") and v.dim() == 1:                  # Fuse fusion weights (layers.py:148)
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
     xg = torch.Generator().manual_seed(calib_seed)
     x = torch.rand(*calib_shape, generator=xg)
-    forward(sd, x, stats=True)
+    forward(sd, x, stats=True, upsample_type=upsample_type)
     return sd

@@ -94,8 +94,8 @@ def test_reference_yaml_files_build(name):
 
 def test_out_of_scope_options_raise():
     base = {"backbone": {"name": "resnet34"}, "neck": {"name": "fpn"}, "output_heads": {"heatmap": {"num_classes": 3}, "box_2d": {}}}
-    for bad in ({"backbone": {"name": "mobilenet_v2"}}, {"neck": {"name": "bifpn"}}, {"neck": {"name": "fpn", "conv_type": "separable"}},
-                {"neck": {"name": "simple", "upsample_type": "conv_transpose"}}):
+    for bad in ({"backbone": {"name": "mobilenet_v2"}}, {"neck": {"name": "bifpn"}}, {"neck": {"name": "fpn", "conv_type": "deformable"}},
+                {"neck": {"name": "simple", "upsample_type": "conv_transpose", "deconv_kernel": 7}}):
         cfg = dict(base, **bad)
         with pytest.raises(ValueError):
             cl.CenterNet(cfg["backbone"], cfg["neck"], cfg["output_heads"], "detection")

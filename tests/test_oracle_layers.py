@@ -1,0 +1,91 @@
+"""CPU: oracle/ref_cpu.py's neck primitives (make_conv / make_upsample / Fuse restatements) against golden vectors produced by
+the reference's own models/layers.py (oracle/make_golden_layers.py), and the product's parameter containers / config surface
+for the same options."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ref_cpu
+import centernet_lightning_amd as cl
+from centernet_lightning_amd import params as P
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "layers_neck_options.npz")
+
+
+@pytest.fixture(scope="module")
+def g():
+    return dict(np.load(GOLDEN))
+
+
+def _sd(g, prefix, new_prefix):
+    return {new_prefix + k[len(prefix):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix)}
+
+
+def test_fuse_restatement_matches_reference(g):
+    for name in g["fuse_cases"]:
+        sd = _sd(g, f"fuse.{name}.sd.", "f.")
+        out = ref_cpu.fuse_forward(sd, "f.", torch.from_numpy(g[f"fuse.{name}.skip"]), torch.from_numpy(g[f"fuse.{name}.top"]),
+                                   upsample_type=str(g[f"fuse.{name}.upsample"]))
+        torch.testing.assert_close(out, torch.from_numpy(g[f"fuse.{name}.out"]), rtol=0, atol=1e-6)
+
+
+def test_deconv_and_separable_restatements_match_reference(g):
+    for k in (2, 3, 4):
+        sd = _sd(g, f"deconv.k{k}.sd.", "u.")
+        out = ref_cpu.make_upsample_forward(torch.from_numpy(g[f"deconv.k{k}.x"]), sd, "u", "conv_transpose")
+        torch.testing.assert_close(out, torch.from_numpy(g[f"deconv.k{k}.out"]), rtol=0, atol=1e-6)
+    out = ref_cpu.make_conv_forward(torch.from_numpy(g["sepconv.x"]), _sd(g, "sepconv.sd.", "c."), "c")
+    torch.testing.assert_close(out, torch.from_numpy(g["sepconv.out"]), rtol=0, atol=1e-6)
+    assert float(out.max()) == 6.0 and float(out.min()) == 0.0            # ReLU6 clips on both sides
+
+
+def test_param_containers_mirror_reference_modules(g):
+    """The product's FuseParams / DeconvBn / SeparableConvBn accept the reference modules' state_dicts key for key."""
+    cases = {"nearest_normal": ([16, 32], 16, "nearest", "normal", False),
+             "nearest_noproj": ([16, 16], 16, "nearest", "normal", False),
+             "bilinear_separable_weighted": ([24, 16], 16, "bilinear", "separable", True),
+             "deconv_normal_weighted": ([16, 32], 16, "conv_transpose", "normal", True),
+             "deconv_separable": ([8, 8], 8, "conv_transpose", "separable", False)}
+    for name, (inc, out, ups, ct, wf) in cases.items():
+        m = P.FuseParams(inc[0], inc[1], out, ups, ct, wf)
+        sd = _sd(g, f"fuse.{name}.sd.", "")
+        assert set(m.state_dict().keys()) == set(sd.keys()), name
+        m.load_state_dict(sd, strict=True)
+    for k in (2, 3, 4):                                                   # _init_bilinear_upsampling (layers.py:103-116) as written
+        torch.manual_seed(100 + k)
+        d = P.DeconvBn(8, k, init_bilinear=True)
+        w_ref = g[f"deconv.k{k}.init_w"]
+        assert d.deconv.weight.shape == w_ref.shape and d.deconv.padding == ((k + k % 2) // 2 - 1,) * 2
+        np.testing.assert_array_equal(d.deconv.weight.detach().numpy()[:, 0], w_ref[:, 0])
+        np.testing.assert_array_equal(d.deconv.weight.detach().numpy(), w_ref)      # same RNG stream for the untouched entries
+    s = P.SeparableConvBn(12, 20)
+    assert set(s.state_dict().keys()) == set(_sd(g, "sepconv.sd.", "").keys())
+
+
+def _cfg(neck):
+    return {"task": "detection", "backbone": {"name": "resnet34", "pretrained": False}, "neck": neck,
+            "output_heads": {"heatmap": {"num_classes": 3, "init_bias": -2.19}, "box_2d": {"init_bias": 10}}}
+
+
+def test_config_surface_neck_options():
+    # configs/test_config.yaml:8-18 of the reference: simple neck with transposed-conv upsampling
+    m = cl.build_centernet(_cfg({"name": "simple", "upsample_channels": [256, 128, 64], "upsample_type": "conv_transpose",
+                                 "conv_type": "normal", "deconv_kernel": 3, "deconv_init_bilinear": True}))
+    assert "neck.upsamples.0.0.weight" in m.state_dict() and m.output_stride == 4
+    m = cl.build_centernet(_cfg({"name": "fpn", "upsample_channels": [256, 128, 64], "upsample_type": "bilinear",
+                                 "conv_type": "separable", "weighted_fusion": True}))
+    sd = m.state_dict()
+    assert "neck.fuse.0.weights" in sd and "neck.fuse.2.output_conv.3.weight" in sd and sd["neck.fuse.1.output_conv.0.weight"].shape == (128, 1, 3, 3)
+    for bad in ({"name": "fpn", "conv_type": "deformable"}, {"name": "simple", "upsample_type": "cubic"},
+                {"name": "simple", "upsample_type": "conv_transpose", "deconv_kernel": 5}, {"name": "bifpn"}):
+        with pytest.raises(ValueError):
+            cl.build_centernet(_cfg(bad))
+    # the CPU oracle runs every option (shape contract of tests/test_necks.py:27-28,44-45: stride 32 -> 4, C = upsample_channels[-1])
+    for neck, ups in (({"name": "simple", "upsample_type": "conv_transpose", "conv_type": "separable"}, "conv_transpose"),
+                      ({"name": "fpn", "upsample_type": "bilinear", "weighted_fusion": True}, "bilinear")):
+        m = cl.build_centernet(_cfg(neck))
+        x = torch.rand(1, 3, 64, 96)
+        out, feats, nk = ref_cpu.forward(m.state_dict(), x, return_intermediates=True, upsample_type=ups)
+        assert tuple(nk.shape) == (1, 64, 16, 24) and tuple(out["heatmap"].shape) == (1, 3, 16, 24)
