@@ -165,10 +165,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local_rank)
+    # CNL_BENCH_BACKEND=gloo is a functional check of the N>1 flow on a box with fewer GPUs than ranks (ranks then share
+    # devices and the collective goes through the host); the measured configuration is always nccl = RCCL, one GPU per rank
+    backend = os.environ.get("CNL_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    else:
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))     # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))     # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     tracking = args.config == "tracking"
     torch.manual_seed(0)
