@@ -77,10 +77,15 @@ def conv_kernel_profile(model, x, reps=3):
     import ctypes
     eng = model._engine
     model(x)                                            # make sure the plan exists
-    plan = eng.plans[(x.shape[0], x.shape[2], x.shape[3], True)]
+    # batches whose activations would exceed the kernels' 4 GiB addressing run as equal sub-batches (Engine.forward): time one
+    # sub-batch and scale
+    n_sub = eng.sub_batch(x.shape[0], x.shape[2], x.shape[3])
+    scale = x.shape[0] / n_sub
+    x = x[:n_sub]
+    plan = eng.plans[(n_sub, x.shape[2], x.shape[3], True)]
     lib = plan.lib
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    convs = [L for L in plan.launches if not isinstance(L.fn, str)]
+    convs = [L for L in plan.launches if L.fn in (lib.cnl_conv2d_nhwc_f32, lib.cnl_conv3x3_winograd_f32)]
     acc = [0.0] * len(convs)
     for _ in range(reps):
         model(x)                                        # refresh inputs of every layer
@@ -96,7 +101,8 @@ def conv_kernel_profile(model, x, reps=3):
         torch.cuda.synchronize()
         for i, (e0, e1) in enumerate(evs):
             acc[i] += e0.elapsed_time(e1)
-    rows = [(L.what, L.flops, acc[i] / reps, "winograd" if L.fn is lib.cnl_conv3x3_winograd_f32 else "direct") for i, L in enumerate(convs)]
+    rows = [(L.what, L.flops * scale, acc[i] / reps * scale, "winograd" if L.fn is lib.cnl_conv3x3_winograd_f32 else "direct")
+            for i, L in enumerate(convs)]
     # algorithmic HBM bytes of a conv launch: input + weights + bias + output (+ residual), each touched once
     nbytes = 0
     for L in convs:
@@ -108,7 +114,7 @@ def conv_kernel_profile(model, x, reps=3):
         out_px = p.N * ho * wo * up_out
         nbytes += 4 * (p.N * p.H_in * p.W_in * p.Cin + p.Cout * p.KH * p.KW * p.Cin + p.Cout + out_px * p.Cout
                        + (out_px * p.Cout if p.residual else 0))
-    return sum(r[2] for r in rows), sum(r[1] for r in rows), len(rows), rows, nbytes
+    return sum(r[2] for r in rows), sum(r[1] for r in rows), len(rows), rows, nbytes * scale
 
 
 def cpu_baseline(model, tracking, k, H, W, budget_s=20.0):

@@ -454,13 +454,19 @@ class Engine:
             self.weights_device = dev
             self.plans.clear()
         N, _, H, W = x.shape
-        chunk = self.max_batch(H, W)
+        chunk = self.sub_batch(N, H, W)
         if N > chunk:
-            # the kernels address each tensor through 32-bit buffer offsets (< 4 GiB per tensor): run contiguous sub-batches
-            # (images are independent; results are byte-identical to one big batch) and concatenate
+            # the kernels address each tensor through 32-bit buffer offsets (< 4 GiB per tensor): run contiguous, equally sized
+            # sub-batches (images are independent; results are byte-identical to one big batch) and concatenate
             parts = [self._run(x[i:i + chunk], sigmoid) for i in range(0, N, chunk)]
             return OrderedDict((k, torch.cat([p[k] for p in parts], dim=0)) for k in parts[0])
         return self._run(x, sigmoid)
+
+    def sub_batch(self, N, H, W):
+        """Images per launch plan: N when it fits the addressing limit, else N split into the fewest equal parts that do."""
+        limit = self.max_batch(H, W)
+        parts = -(-N // limit)
+        return -(-N // parts)
 
     def max_batch(self, H, W):
         """Largest batch whose biggest activation tensor stays below the 4 GiB buffer-addressing limit of the kernels."""
