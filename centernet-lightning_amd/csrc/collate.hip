@@ -71,3 +71,23 @@ extern "C" int cnl_unpack_detections_f32(const float* rec, float* boxes, float* 
                        (long long*)labels, emb, D, E);
     return cnl::check_launch("unpack_kernel");
 }
+
+// torchvision.ops.box_convert(boxes, "xyxy", "xywh") as called at models/centernet.py:207: (x1, y1, x2 - x1, y2 - y1).
+namespace cnl_collate {
+__global__ __launch_bounds__(256) void xyxy_to_xywh_kernel(const float4* __restrict__ in, float4* __restrict__ out, long n) {
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
+        const float4 b = in[t];
+        out[t] = make_float4(b.x, b.y, b.z - b.x, b.w - b.y);
+    }
+}
+}  // namespace cnl_collate
+
+extern "C" int cnl_boxes_xyxy_to_xywh_f32(const float* boxes, float* out, int64_t n, void* stream) {
+    CNL_REQUIRE(boxes && out, CNL_E_BAD_ARG, "cnl_boxes_xyxy_to_xywh_f32: null tensor pointer");
+    CNL_REQUIRE(n >= 0, CNL_E_BAD_ARG, "cnl_boxes_xyxy_to_xywh_f32: negative count");
+    CNL_REQUIRE((((uintptr_t)boxes | (uintptr_t)out) & 15) == 0, CNL_E_BAD_ARG, "cnl_boxes_xyxy_to_xywh_f32: 16-byte alignment");
+    if (n == 0) return CNL_OK;
+    hipLaunchKernelGGL(cnl_collate::xyxy_to_xywh_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(boxes), reinterpret_cast<float4*>(out), (long)n);
+    return cnl::check_launch("xyxy_to_xywh_kernel");
+}

@@ -231,6 +231,12 @@ int cnl_track_apply_f32(const float* trk_emb, const float* trk_box, const float*
                         const int32_t* src_trk, const int32_t* src_det, int32_t T_new, int32_t E, double smoothing,
                         float* new_emb, float* new_box, void* stream);
 
+/*
+ * Wire formats: COCO boxes are xywh — torchvision box_convert(boxes, "xyxy", "xywh") of
+ * CenterNet.validation_step (models/centernet.py:207): out[i] = (x1, y1, x2 - x1, y2 - y1); n boxes of 4 floats, may be in place.
+ */
+int cnl_boxes_xyxy_to_xywh_f32(const float* boxes, float* out, int64_t n, void* stream);
+
 int cnl_version(void);
 /* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
 size_t cnl_last_error(char* buf, size_t n);
