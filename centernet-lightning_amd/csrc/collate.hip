@@ -83,10 +83,10 @@ __global__ __launch_bounds__(256) void xyxy_to_xywh_kernel(const float4* __restr
 }  // namespace cnl_collate
 
 extern "C" int cnl_boxes_xyxy_to_xywh_f32(const float* boxes, float* out, int64_t n, void* stream) {
-    CNL_REQUIRE(boxes && out, CNL_E_BAD_ARG, "cnl_boxes_xyxy_to_xywh_f32: null tensor pointer");
     CNL_REQUIRE(n >= 0, CNL_E_BAD_ARG, "cnl_boxes_xyxy_to_xywh_f32: negative count");
-    CNL_REQUIRE((((uintptr_t)boxes | (uintptr_t)out) & 15) == 0, CNL_E_BAD_ARG, "cnl_boxes_xyxy_to_xywh_f32: 16-byte alignment");
     if (n == 0) return CNL_OK;
+    CNL_REQUIRE(boxes && out, CNL_E_BAD_ARG, "cnl_boxes_xyxy_to_xywh_f32: null tensor pointer");
+    CNL_REQUIRE((((uintptr_t)boxes | (uintptr_t)out) & 15) == 0, CNL_E_BAD_ARG, "cnl_boxes_xyxy_to_xywh_f32: 16-byte alignment");
     hipLaunchKernelGGL(cnl_collate::xyxy_to_xywh_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(boxes), reinterpret_cast<float4*>(out), (long)n);
     return cnl::check_launch("xyxy_to_xywh_kernel");

@@ -53,6 +53,7 @@ struct WinoArgs {
     int blocks;
     unsigned x_bytes, u_bytes, y_bytes, r_bytes;
     unsigned flags;
+    long long* trace;                 // CNL_WTRACE builds only: per-wave barrier-wait / chunk-body cycle sums
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -70,6 +71,12 @@ constexpr int LDS_BYTES = 2 * V_BYTES + 2 * U_BYTES + 2 * P_BYTES;   // 153600 -
 __device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* lds_dst, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 0, 0);
+}
+// same, 1024 bytes further on in BOTH the global source and the LDS destination (the instruction's immediate offset applies to
+// both addresses): saves the VALU add of a second per-lane offset
+__device__ __forceinline__ void dma16_plus1k(const float* base, unsigned bytes, char* lds_dst, unsigned voffset, unsigned soffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 1024, 0);
 }
 __device__ __forceinline__ float buf_load(const float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
@@ -116,9 +123,10 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
     const unsigned u_chunk = (unsigned)(16 * a.CoutP * 8 * 4);          // bytes per channel chunk of U
 
     // transform item: thread -> (tile, channel PAIR, half): every add of B^T d B is one v_pk_add_f32 on two channels and every
-    // LDS access 8 bytes wide.  The two halves of the workgroup (waves 0-3 / 4-7, one wave of each SIMD) produce output columns
-    // {0,1} / {2,3} of the 4x4 transform from patch columns {0,1,2} / {1,2,3}: 6 ds_read2_b64 + 20 v_pk_add_f32 +
-    // 4 ds_write2st64_b64 per wave and chunk instead of 8 + 32 + 8 for one thread per (tile, channel).
+    // LDS access 8 bytes wide.  The two halves of the workgroup (waves 0-3 / 4-7, one wave of each SIMD) produce output ROWS
+    // {0,1} / {2,3} of the 4x4 transform from patch rows {0,1,2} / {1,2,3} — rows of t = B^T d are independent, so the split has no
+    // redundant work: 6 ds_read2_b64 + 16 v_pk_add_f32 + 4 ds_write2st64_b64 per wave and chunk (8 + 32 + 8 for one thread per
+    // (tile, channel)).
     const int lt = tid & 255;
     const int t_cp = lt & 3, t_tile = lt >> 2;
     const int t_src = ((((2 * (t_tile >> 3)) * 2 + (t_cp >> 1)) * PWP + 2 * (t_tile & 7)) * 4 + (t_cp & 1) * 2) * 4;
@@ -161,16 +169,19 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
 #define WINO_ISSUE_P(cc_)                                                                                        \
     do {                                                                                                         \
         char* d_ = sP + ((cc_) & 1) * P_BYTES;                                                                   \
-        const bool live_ = (cc_) < a.CC;                   /* prefetch past the end: all lanes out of bounds -> zeros */ \
-        dma16(a.x, a.x_bytes, d_ + (wave * 64) * 16, (p_off[0] == OOB || !live_) ? OOB : p_off[0] + (unsigned)((cc_) * 32), 0); \
-        if (wave < 3) dma16(a.x, a.x_bytes, d_ + (512 + wave * 64) * 16, (p_off[1] == OOB || !live_) ? OOB : p_off[1] + (unsigned)((cc_) * 32), 0); \
+        /* the channel-chunk offset rides in the SCALAR offset (no VALU): the bounds check looks at the vector offset alone, so   \
+           halo lanes (p_off == OOB) still read zeros; a chunk past the end is simply not fetched (nothing consumes it) */      \
+        if ((cc_) < a.CC) {                                                                                      \
+            dma16(a.x, a.x_bytes, d_ + (wave * 64) * 16, p_off[0], (unsigned)((cc_) * 32));                      \
+            if (wave < 3) dma16(a.x, a.x_bytes, d_ + (512 + wave * 64) * 16, p_off[1], (unsigned)((cc_) * 32));  \
+        }                                                                                                        \
     } while (0)
 #define WINO_ISSUE_U(cc_)                                                                                        \
     do {                                                                                                         \
         char* d_ = sU + ((cc_) & 1) * U_BYTES;                                                                   \
         _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                          \
             dma16(a.u, a.u_bytes, d_ + (wave * 2 + p) * 2048, u_off[p], (unsigned)(cc_) * u_chunk);              \
-            dma16(a.u, a.u_bytes, d_ + (wave * 2 + p) * 2048 + 1024, u_off[p] + 1024u, (unsigned)(cc_) * u_chunk); \
+            dma16_plus1k(a.u, a.u_bytes, d_ + (wave * 2 + p) * 2048, u_off[p], (unsigned)(cc_) * u_chunk);       \
         }                                                                                                        \
     } while (0)
     // the 8 MFMAs of one position: k = 0..7 -> c = k >> 1, g = k & 1
@@ -178,6 +189,17 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
 
     // Persistent workgroups (grid = one per CU): the first chunk of the NEXT work item is fetched while the epilogue of the
     // current one runs, so only the very first item of a launch waits for HBM latency with an idle matrix pipe.
+#ifdef CNL_WTRACE
+    long long tr_wait = 0, tr_body = 0, tr_n = 0, tr_a = 0, tr_b = 0, tr_vm = 0;
+    const long long tr_start = clock64();
+#define WTRACE_PRE()  do { tr_a = clock64(); if (tr_b) { tr_body += tr_a - tr_b; ++tr_n; } } while (0)
+#define WTRACE_POST() do { tr_b = clock64(); tr_wait += tr_b - tr_a; } while (0)
+#define WTRACE_MID()  do { tr_vm += clock64() - tr_a; } while (0)
+#else
+#define WTRACE_MID()  do { } while (0)
+#define WTRACE_PRE()  do { } while (0)
+#define WTRACE_POST() do { } while (0)
+#endif
     unsigned item = blockIdx.x;
     WINO_SETUP(item);
     WINO_ISSUE_P(0);
@@ -226,6 +248,18 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
         // slice = {1 MFMA, 2 VALU | 1 LDS write}, slices fenced by sched_barrier(0): left to itself hipcc emits the whole
         // transform after the last MFMA, where both waves of a SIMD reach it together and the matrix pipe idles.
         // one chunk: 32 MFMAs in 32 fenced slices; DO_T_ adds this wave's share of the next chunk's input transform
+// slice schedule of the input transform inside a chunk (slice = one MFMA): WS_RD patch reads; WS_DMA, +1 DMA issue; t adds WS_TN per
+// slice from WS_T; v adds WS_VN per slice from WS_V; WS_WN write pairs per slice from WS_W.  A VALU instruction right after an MFMA
+// costs the issuing wave ~14 cycles and each further one ~5 (tools/mfma_coexec.hip), so the adds go in few, dense bursts, and early
+// in the chunk, where the other wave of the SIMD is certain to have MFMAs to fill the pipe with.
+#define WS_RD 0      /* 6 ds_read2_b64 of the patch            */
+#define WS_DMA 1     /* DMA issue: U chunk, then patch (slice 2) */
+#define WS_T 4       /* 8 packed adds: t = B^T d                */
+#define WS_TN 8
+#define WS_V 5       /* 8 packed adds: V = t B                  */
+#define WS_VN 8
+#define WS_W 6       /* 2 + 2 ds_write2st64_b64 (slices 6, 7)   */
+#define WS_WN 2
 #define WINO_CHUNK(H_)                                                                                                       \
         do {                                                                                                                 \
             const char* vB = sV + (cc & 1) * V_BYTES + fragA;                                                                \
@@ -235,10 +269,8 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
             f32x4 fa[2][2], fb[2];      /* double-buffered fragments: [buffer][tile group] */                                \
             fa[0][0] = lds_f4(vB + (xi0 * 64) * 32); fa[0][1] = lds_f4(vB + (xi0 * 64 + 32) * 32);                           \
             fb[0] = lds_f4(uB + (xi0 * 64) * 32);                                                                            \
-            f32x2 d_[4][3], t_[4][3], v_[4][2];                                                                              \
+            f32x2 d_[3][4], t_[2][4], v_[2][4];                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                               \
-            /* slice schedule: first MFMA as soon as the first fragments arrive; patch reads in slices 0-2, DMA issue (next U   \
-               chunk, patch after next) in slices 4-5, packed adds in 6-19, LDS writes of V (pairs) on even slices 14-20 */   \
             _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                                 \
                 const int j = k >> 3, kk = k & 7, buf = j & 1;                                                               \
                 WINO_MFMA8(j, fa[buf], fb[buf], kk);                                                                         \
@@ -247,26 +279,31 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
                     fa[buf ^ 1][1] = lds_f4(vB + ((xi0 + j + 1) * 64 + 32) * 32);                                            \
                     fb[buf ^ 1] = lds_f4(uB + ((xi0 + j + 1) * 64) * 32);                                                    \
                 }                                                                                                            \
-                if (k < 3) {                                            /* patch column H_+k of this half-item */            \
-                    _Pragma("unroll") for (int i = 0; i < 4; ++i) d_[i][k] = lds_f2(src_ + (i * 2 * PWP + (H_) + k) * 16);   \
+                if (k == WS_RD) {                                       /* patch rows H_, H_+1, H_+2 of this half-item */    \
+                    _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                            \
+                        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) d_[m][jj] = lds_f2(src_ + (((H_) + m) * 2 * PWP + jj) * 16);\
                 }                                                                                                            \
-                if (k == 4) WINO_ISSUE_U(cc + 1);                                                                            \
-                if (k == 5) WINO_ISSUE_P(cc + 2);                                                                            \
-                if (k >= 6 && k < 12) {                                 /* t = B^T d, three columns (two packed adds per slice) */\
-                    _Pragma("unroll") for (int e = 2 * (k - 6); e < 2 * (k - 6) + 2; ++e) {                                  \
-                        const int i = e & 3, c = e >> 2;                                                                     \
-                        t_[i][c] = i == 0 ? pk_sub(d_[0][c], d_[2][c]) : i == 1 ? pk_add(d_[1][c], d_[2][c]) : i == 2 ? pk_sub(d_[2][c], d_[1][c]) : pk_sub(d_[1][c], d_[3][c]);\
+                if (k == WS_DMA) WINO_ISSUE_U(cc + 1);                                                                       \
+                if (k == WS_DMA + 1) WINO_ISSUE_P(cc + 2);                                                                   \
+                if (k >= WS_T && k < WS_T + 8 / WS_TN) {                /* t = B^T d: output rows 2H_, 2H_+1, four columns */\
+                    _Pragma("unroll") for (int e = WS_TN * (k - WS_T); e < WS_TN * (k - WS_T) + WS_TN; ++e) {                \
+                        const int ii = e >> 2, jj = e & 3;                                                                   \
+                        if ((H_) == 0) t_[ii][jj] = ii == 0 ? pk_sub(d_[0][jj], d_[2][jj]) : pk_add(d_[1][jj], d_[2][jj]);   \
+                        else t_[ii][jj] = ii == 0 ? pk_sub(d_[1][jj], d_[0][jj]) : pk_sub(d_[0][jj], d_[2][jj]);             \
                     }                                                                                                        \
                 }                                                                                                            \
-                if (k >= 12 && k < 20) {                                /* V = t B, output columns 2H_, 2H_+1 ... */         \
-                    const int e = k - 12, i = e >> 1;                                                                        \
-                    if ((H_) == 0) v_[i][e & 1] = (e & 1) == 0 ? pk_sub(t_[i][0], t_[i][2]) : pk_add(t_[i][1], t_[i][2]);    \
-                    else v_[i][e & 1] = (e & 1) == 0 ? pk_sub(t_[i][1], t_[i][0]) : pk_sub(t_[i][0], t_[i][2]);              \
+                if (k >= WS_V && k < WS_V + 8 / WS_VN) {                /* V = t B ... */                                    \
+                    _Pragma("unroll") for (int e = WS_VN * (k - WS_V); e < WS_VN * (k - WS_V) + WS_VN; ++e) {                \
+                        const int ii = e >> 2, jj = e & 3;                                                                   \
+                        v_[ii][jj] = jj == 0 ? pk_sub(t_[ii][0], t_[ii][2]) : jj == 1 ? pk_add(t_[ii][1], t_[ii][2]) : jj == 2 ? pk_sub(t_[ii][2], t_[ii][1]) : pk_sub(t_[ii][1], t_[ii][3]);\
+                    }                                                                                                        \
                 }                                                                                                            \
-                if (k >= 14 && k <= 20 && !(k & 1)) {                   /* ... each row written as one ds_write2st64_b64 */  \
-                    const int i = (k - 14) >> 1;                                                                             \
-                    *reinterpret_cast<f32x2*>(dst_ + (4 * i + 2 * (H_)) * (T * 32)) = v_[i][0];                              \
-                    *reinterpret_cast<f32x2*>(dst_ + (4 * i + 2 * (H_) + 1) * (T * 32)) = v_[i][1];                          \
+                if (k >= WS_W && k < WS_W + 4 / WS_WN) {                /* ... written as ds_write2st64_b64 pairs */         \
+                    _Pragma("unroll") for (int e = WS_WN * (k - WS_W); e < WS_WN * (k - WS_W) + WS_WN; ++e) {                \
+                        const int ii = e >> 1, jj = (e & 1) * 2;                                                             \
+                        *reinterpret_cast<f32x2*>(dst_ + (4 * (2 * (H_) + ii) + jj) * (T * 32)) = v_[ii][jj];                \
+                        *reinterpret_cast<f32x2*>(dst_ + (4 * (2 * (H_) + ii) + jj + 1) * (T * 32)) = v_[ii][jj + 1];        \
+                    }                                                                                                        \
                 }                                                                                                            \
                 __builtin_amdgcn_sched_barrier(0);                                                                           \
             }                                                                                                                \
@@ -275,14 +312,20 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
         int cc = 0;
         if (wave < 4) {          // H_ is a compile-time constant of the loop body (different instructions per half)
             for (; cc + 1 < a.CC; ++cc) {
+                WTRACE_PRE();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                WTRACE_MID();
                 __syncthreads();     // V[cc&1] complete, U[cc&1] + patch cc+1 landed; MFMA phase cc-1 and transform cc done everywhere
+                WTRACE_POST();
                 WINO_CHUNK(0);
             }
         } else {
             for (; cc + 1 < a.CC; ++cc) {
+                WTRACE_PRE();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                WTRACE_MID();
                 __syncthreads();
+                WTRACE_POST();
                 WINO_CHUNK(1);
             }
         }
@@ -363,9 +406,19 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
                 }
             }
         }
+#ifdef CNL_WTRACE
+        tr_b = 0;                      // the body of the last loop chunk runs into the last chunk + epilogue: not counted
+#endif
         if (next >= (unsigned)a.blocks) break;
         item = next;
     }
+#ifdef CNL_WTRACE
+    if (a.trace && lane == 0) {
+        long long* t = a.trace + ((long)blockIdx.x * 8 + wave) * 4;
+        t[0] = tr_wait; t[1] = tr_body; t[2] = tr_n; t[3] = clock64() - tr_start;
+        a.trace[256 * 8 * 4 + (long)blockIdx.x * 8 + wave] = tr_vm;
+    }
+#endif
 #undef WINO_MFMA8
 #undef WINO_ISSUE_P
 #undef WINO_ISSUE_U
@@ -442,6 +495,10 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
     a.nb = a.CoutP / BN; a.bx = (a.W + 15) / 16; a.by = (a.H + 15) / 16;
     const long long blocks = (long long)p->N * a.by * a.bx * a.nb;
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: grid too large");
+    a.trace = nullptr;
+#ifdef CNL_WTRACE
+    if (const char* e = getenv("CNL_TRACE_PTR")) a.trace = (long long*)strtoull(e, nullptr, 0);
+#endif
     a.blocks = (int)blocks;
     const unsigned long long xb = (((unsigned long long)p->N * p->H_in * p->W_in - 1) * p->ldx + p->Cin) * 4ull;
     const unsigned long long ub = (unsigned long long)cnl_winograd_weight_floats(p->Cin, p->Cout) * 4ull;
