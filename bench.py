@@ -36,8 +36,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_v4.txt): per kernel, mean
 # FETCH_SIZE x 2 (gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md §HBM) + mean WRITE_SIZE over the launches
 # of a C1 step (Winograd: 149.6 MB x 2 + 129.1 MB).  Other configs: not profiled -> null.
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("simple", 32, 512, 512, "cnl_conv::conv_mfma_kernel"): 245.4e6,
-                                     ("simple", 32, 512, 512, "cnl_wino::winograd_conv_kernel"): 428.2e6}
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("simple", 32, 512, 512, "cnl_conv::conv_mfma_kernel"): 238.7e6,
+                                     ("simple", 32, 512, 512, "cnl_wino::winograd_conv_kernel"): 450.2e6}
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 
 
@@ -249,7 +249,7 @@ def main():
                     "kernel_ms_per_step": round(ms_d, 3), "algorithmic_gflop_per_step": round(fl_d / 1e9, 2),
                     "avg_launch_us": round(ms_d * 1e3 / max(n_d, 1), 2)}
         roof["traffic"] = MEASURED_TRAFFIC_BYTES_PER_LAUNCH.get((args.config, B, H, W, roof["kernel"].split(" ")[0]))
-        roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, see profiles/)"
+        roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic_final2.txt)"
         roof["algorithmic_bytes_per_launch"] = round(conv_bytes / n_launch)
         roof["sustained_clock_note"] = "chip sustains ~2.1 GHz under this load (DVFS; profiles/r01_mfma_peak_onbox.txt), i.e. ~140 TFLOP/s ceiling"
         roof["other_kernels"] = {"cnl_conv::conv_mfma_kernel": {"launches_per_step": n_d, "kernel_ms_per_step": round(ms_d, 3),
