@@ -147,6 +147,43 @@ def test_direct_and_winograd_paths_agree(monkeypatch):
         torch.testing.assert_close(out_w[name], out_d[name], rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("cfg,shape,k", [("resnet34_simple.yaml", (32, 3, 512, 512), 100),          # BASELINE C1
+                                         ("resnet34_fpn.yaml", (64, 3, 512, 512), 100),             # C2 / one rank of C3
+                                         ("tracking_resnet34_fpn.yaml", (32, 3, 608, 1088), 300)])  # one rank of C4
+def test_full_size_properties(cfg, shape, k):
+    """BASELINE.json's full per-GPU sizes, through size-independent properties (the CPU oracle needs minutes here):
+    image i of the batch == the same image alone (bit-equal: kernels are batch-invariant, sub-batching included);
+    the oracle agrees on a 2-image slice; decode output is sorted, in range, and consistent with the maps it was cut from."""
+    model, sd = build(cfg)
+    x = recipes.images(99, shape).cuda()
+    out = model(x)
+    N, _, H, W = shape
+    h, w = H // 4, W // 4
+    assert tuple(out[0].shape) == (N, model.num_classes, h, w) and tuple(out[1].shape) == (N, 4, h, w)
+    for i in (0, N // 2 + 1, N - 1):
+        single = model(x[i:i + 1])
+        for a, b in zip(out, single):
+            assert torch.equal(a[i:i + 1], b), i
+    ref = ref_cpu.forward(sd, x[:2].cpu(), sigmoid=True)
+    for name, o in zip(ref, out):
+        torch.testing.assert_close(o[:2].cpu(), ref[name], rtol=TOL, atol=TOL)
+    dets = (model.gather_tracking2d if model.task == "tracking" else model.gather_detection2d)(out, num_detections=k)
+    s, l, b = dets["scores"], dets["labels"], dets["bboxes"]
+    assert tuple(s.shape) == (N, k) and bool((s[:, :-1] >= s[:, 1:]).all())                       # sorted descending
+    assert int(l.min()) >= 0 and int(l.max()) < model.num_classes and bool((b[..., 2:] >= b[..., :2]).all())
+    full = cl.decode.decode(out[0], out[1], out[2] if model.task == "tracking" else None, k, 3, stride=model.output_stride)
+    idx = full["indices"]
+    assert int(idx.min()) >= 0 and int(idx.max()) < h * w
+    assert all(len(torch.unique(idx[n])) == k for n in range(0, N, 7))                             # k distinct peaks per image
+    heat_flat = out[0].flatten(2)                                                                  # score == heat[label, index]
+    picked = heat_flat.gather(2, idx.unsqueeze(1).expand(-1, heat_flat.shape[1], -1)).gather(1, l.unsqueeze(1)).squeeze(1)
+    assert torch.equal(picked, s)
+    again = cl.decode.gather_boxes(out[1], idx, stride=model.output_stride)                        # boxes re-gathered at the indices
+    assert torch.equal(again, b)
+    if model.task == "tracking":
+        assert torch.equal(cl.decode.gather_embeddings(out[2], idx), dets["embeddings"])
+
+
 def test_large_batch_is_split_below_the_4gib_addressing_limit(monkeypatch):
     """Engine.max_batch: a batch whose fused head buffer would exceed 4 GiB runs as contiguous sub-batches with identical bytes."""
     model, _ = build("resnet34_fpn.yaml")
