@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -41,24 +42,28 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, long long* clk) 
     for (int i = 0; i < 8; ++i) s += v[i].x + v[i].y;
     for (int i = 0; i < 4; ++i) s += l[i].x;
     out[blockIdx.x * 512 + threadIdx.x] = s;
-    if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 8 + (threadIdx.x >> 6)] = c1 - c0;
+    if ((threadIdx.x & 63) == 0) { clk[blockIdx.x * 16 + (threadIdx.x >> 6)] = c0; clk[blockIdx.x * 16 + 8 + (threadIdx.x >> 6)] = c1; }
 }
 
 template <int NV, int NL>
 void run(int threads) {
     const int blocks = 256, iters = 2000;
     float* out; long long* clk;
-    hipMalloc(&out, blocks * 512 * 4); hipMalloc(&clk, blocks * 64);
+    hipMalloc(&out, blocks * 512 * 4); hipMalloc(&clk, blocks * 128);
     k<NV, NL><<<blocks, threads>>>(out, 50, clk);
     hipDeviceSynchronize();
     k<NV, NL><<<blocks, threads>>>(out, iters, clk);
     hipDeviceSynchronize();
-    std::vector<long long> h(blocks * 8);
-    hipMemcpy(h.data(), clk, blocks * 64, hipMemcpyDeviceToHost);
+    std::vector<long long> h(blocks * 16);
+    hipMemcpy(h.data(), clk, blocks * 128, hipMemcpyDeviceToHost);
     const int waves = threads / 64;
-    double cyc = 0;
-    for (int b = 0; b < blocks; ++b) for (int w = 0; w < waves; ++w) cyc += (double)h[b * 8 + w];
-    cyc /= blocks * waves;
+    double cyc = 0;          // per workgroup: first wave's start to last wave's end (the two waves of a SIMD need not start together)
+    for (int b = 0; b < blocks; ++b) {
+        long long lo = h[b * 16], hi = h[b * 16 + 8];
+        for (int w = 1; w < waves; ++w) { lo = std::min(lo, h[b * 16 + w]); hi = std::max(hi, h[b * 16 + 8 + w]); }
+        cyc += (double)(hi - lo);
+    }
+    cyc /= blocks;
     const double mfma_per_simd = (double)iters * 16 * (waves / 4);
     printf("NV=%d NL=%d waves/SIMD=%d : %.1f cycles per MFMA per SIMD\n", NV, NL, waves / 4, cyc / mfma_per_simd);
     hipFree(out); hipFree(clk);
