@@ -126,10 +126,10 @@ class PackedWeights:
         L = lambda conv, bn=None, stride=None: _Layer(*map(dev, fold_conv_bn(conv.weight, conv.bias, bn)),
                                                       stride=stride if stride is not None else conv.stride[0])
         self.stem = L(bb.conv1, bb.bn1)
-        # the stem kernel DMAs its weights into LDS verbatim: pack OHWI -> [148][64] once (cnl_stem_pack_weights_f32)
+        # the stem kernel DMAs its weights into LDS verbatim: pack OHWI -> [154][64] once (cnl_stem_pack_weights_f32)
         lib = _lib.load()
         with torch.cuda.device(device):
-            self.stem_packed = torch.empty((148 * 64,), device=device, dtype=torch.float32)
+            self.stem_packed = torch.empty((lib.cnl_stem_packed_weight_floats(),), device=device, dtype=torch.float32)
             _lib.check(lib.cnl_stem_pack_weights_f32(self.stem.w.data_ptr(), self.stem_packed.data_ptr(),
                                                      ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
                        "cnl_stem_pack_weights_f32")

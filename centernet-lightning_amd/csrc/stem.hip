@@ -4,17 +4,21 @@
 // Replaces torchvision resnet.conv1/bn1/relu/maxpool reached through backbone.forward_features
 // (reference models/meta.py:42; contract tests/test_backbones.py:60-70: stride-2 feature with 64 ch).
 //
-// conv: implicit GEMM with K = 7*7*3 = 147 (padded to 148 with a zero weight row).  Cin = 3 makes a
-// global-memory im2col hopeless (12-byte pixels), so the im2col happens on the LDS side: a workgroup
-// stages the (2*8+5) x (2*32+5) x 3 input patch of its 8x32 output tile and the whole 148x64 weight
-// matrix in LDS; each MFMA A operand is a per-lane ds_read_b32 at  row(ky) * RS + 6*px + (k % 21)
-// (kx and c are contiguous in the patch row, so k % 21 is a plain offset).  Each wave computes four
-// output rows (4 x 32 pixels) x 64 channels = eight 32x32 accumulators with v_mfma_f32_32x32x2_f32.
+// conv: implicit GEMM with K = 7*7*3 = 147, ordered k = ky*22 + t (t = kx*3 + c < 21, t = 21 a zero weight row): 154.
+// Cin = 3 makes a global-memory im2col hopeless (12-byte pixels), so the im2col happens on the LDS side: a workgroup
+// stages the (2*16+5) x (2*32+5) x 3 input patch of its 16x32 output tile and the whole 154x64 weight
+// matrix in LDS; each MFMA A operand is a per-lane ds_read_b32 at  row(ky) * RS + 6*px + t
+// (kx and c are contiguous in the patch row, so t is a plain offset).  The even row length makes the K step of lane half
+// hi (k = 2s + hi) fall in ONE patch row for both halves, so with the 77 steps fully unrolled every LDS address is
+// "lane base + immediate": no VALU instruction in the MFMA loop (on gfx950 VALU work does not overlap the matrix pipe,
+// tools/mfma_coexec.hip; the previous per-lane k%21 / k/21 bookkeeping cost 2 VALU per MFMA, a quarter of the loop).
+// Each wave computes four output rows (4 x 32 pixels) x 64 channels = eight 32x32 accumulators with v_mfma_f32_32x32x2_f32.
 // The weight matrix is copied global -> LDS with coalesced reads (thread e reads w[e]) into a [k][65]
 // image (row stride 65 keeps both the transposing write and the fragment reads bank-conflict-free); the first
 // version read it with a 147-float stride per lane and spent 3/4 of its time there.
 // The input is read through explicit element strides, so NCHW and channels_last callers are zero-copy.
 #include "cnl_common.h"
+#include <cstdlib>
 
 namespace cnl_stem {
 
@@ -22,12 +26,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ST_TH = 16, ST_TW = 32;                 // output tile (4 rows per wave)
-constexpr int ST_PR = 2 * ST_TH + 5 + 1;              // patch rows (+1 zero row for the k=147 pad tap)
+constexpr int ST_PR = 2 * ST_TH + 5;                  // patch rows
 constexpr int ST_PC = 2 * ST_TW + 5;                  // patch cols
 constexpr int ST_RS = 256;                            // patch row stride in floats: 207 used; 1 KB = 4 DMA instructions per row
-constexpr int ST_KP = 148;                            // padded K
-constexpr int ST_W_BYTES = ST_KP * 64 * 4;            // 37888 = 37 x 1 KB
-constexpr int ST_LDS_BYTES = ST_PR * ST_RS * 4 + ST_W_BYTES;   // 76800 -> 2 workgroups / CU
+constexpr int ST_KROW = 22;                           // K entries per kernel row: 7 taps x 3 channels + 1 zero pad
+constexpr int ST_KP = 7 * ST_KROW;                    // 154
+constexpr int ST_W_BYTES = ST_KP * 64 * 4;            // 39424 = 38.5 x 1 KB (the 39th DMA piece's upper lanes are out of bounds: zeros)
+constexpr int ST_LDS_BYTES = ST_PR * ST_RS * 4 + 39 * 1024;    // 77824 -> 2 workgroups / CU
 constexpr unsigned ST_OOB = 0xFFFFFFF0u;
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -59,8 +64,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
 
     // ---- staging by LDS-DMA: no VGPR round trip and almost no VALU (this runs beside the co-resident group's MFMA stream) ----
-    // weights: 37 pieces of 1 KB, lane-linear
-    for (int q = wave; q < ST_W_BYTES / 1024; q += 4)
+    // weights: 39 pieces of 1 KB, lane-linear
+    for (int q = wave; q < (ST_W_BYTES + 1023) / 1024; q += 4)
         dma16(w, (unsigned)ST_W_BYTES, reinterpret_cast<char*>(wl) + q * 1024, (unsigned)(q * 1024 + lane * 16));
     // input patch -> LDS [row][col*3 + c]: 4-byte DMA, lane f of a row fetches pixel col = f/3, channel c = f%3 from wherever
     // the caller's strides put it (NCHW planes or channels_last alike); out-of-image lanes get zeros from the bounds check
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
     }
     for (int r = wave; r < ST_PR; r += 4) {
         const int iy = iy0 + r;
-        const bool row_ok = r < ST_PR - 1 && (unsigned)iy < (unsigned)H;      // wave-uniform
+        const bool row_ok = (unsigned)iy < (unsigned)H;                       // wave-uniform
         const unsigned row_off = (unsigned)(iy * sh * 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -92,21 +97,26 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // lane's A base: output row (wave*4 + i), column px -> patch row 2*(wave*4+i) + ky, col 2*px + kx
-    const float* pa = patch + (wave * 8) * ST_RS + px * 6;       // i adds 2*ST_RS
-    const float* pb = wl + hi * 64 + px;                         // k = 2s + hi
-    int kr = hi, rowoff = 0;                                     // k % 21 and (k / 21) * RS
-    for (int s = 0; s < ST_KP / 2; ++s) {
-        const float b0 = pb[s * 128];
-        const float b1 = pb[s * 128 + 32];
+    // lane's A base: output row (wave*4 + i), column px -> patch row 2*(wave*4+i) + ky, col 2*px + kx; K step s covers
+    // k = 2s + hi = ky*22 + t with ky = s / 11 and t = 2*(s % 11) + hi: the lane half only shifts the base by one float
+    const float* pa = patch + (wave * 8) * ST_RS + px * 6 + hi;  // + (2*i + ky) * ST_RS + 2 * (s % 11)
+    const float* pb = wl + hi * 64 + px;                         // + s * 128 (+ 32 for the second cout group)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float av = pa[rowoff + kr + i * 2 * ST_RS];
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[i][1], 0, 0, 0);
+    for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+        for (int u = 0; u < ST_KROW / 2; ++u) {
+            const int s = ky * (ST_KROW / 2) + u;
+            const float b0 = pb[s * 128];
+            const float b1 = pb[s * 128 + 32];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float av = pa[(2 * i + ky) * ST_RS + 2 * u];
+                if (u == ST_KROW / 2 - 1) av = hi ? 0.f : av;     // t = 21 is the pad entry: its patch slot holds a neighbouring pixel
+                                                                  // (zero weight, but 0 x inf would not be 0)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[i][1], 0, 0, 0);
+            }
         }
-        kr += 2;
-        if (kr >= 21) { kr -= 21; rowoff += ST_RS; }
     }
 
     // epilogue: bias + ReLU, NHWC store (col = lane&31 -> channel, rows -> pixels of the row)
@@ -155,16 +165,19 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const f32x4* __restrict__ 
     }
 }
 
-// OHWI [64][7][7][3] (BN folded) -> the kernel's LDS image [148][64] (k = (ky*7+kx)*3+c major, row 147 = 0)
+// OHWI [64][7][7][3] (BN folded) -> the kernel's LDS image [154][64]: row k = ky*22 + t holds tap (ky, kx = t/3, c = t%3), t = 21 zeros
 __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ w, float* __restrict__ wp) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= ST_KP * 64) return;
     const int k = e >> 6, co = e & 63;
-    wp[e] = k < 147 ? w[co * 147 + k] : 0.f;
+    const int ky = k / ST_KROW, t = k - ky * ST_KROW;
+    wp[e] = t < 21 ? w[co * 147 + ky * 21 + t] : 0.f;
 }
 
 }  // namespace cnl_stem
 using namespace cnl_stem;
+
+extern "C" size_t cnl_stem_packed_weight_floats(void) { return (size_t)ST_KP * 64; }
 
 extern "C" int cnl_stem_pack_weights_f32(const float* w_ohwi, float* w_packed, void* stream) {
     CNL_REQUIRE(w_ohwi && w_packed, CNL_E_BAD_ARG, "cnl_stem_pack_weights_f32: null pointer");

@@ -101,10 +101,12 @@ int cnl_normalize_u8_nhwc_f32(const uint8_t* x, float* y, int32_t N, int32_t H, 
  * ResNet stem: Conv2d(3,64,7,stride=2,padding=3,bias=False)+BN+ReLU (torchvision resnet.conv1/bn1/relu).
  * x is read through explicit element strides (sn,sc,sh,sw) so NCHW-contiguous and channels_last
  * callers are both zero-copy (models/meta.py:97-98 precedent); y is NHWC [N, H/2, W/2, 64].
- * w: the PACKED weight image [148][64] (k = (ky*7+kx)*3+c major, zero row 147) that cnl_stem_pack_weights_f32 makes
- * from the OHWI [64][7][7][3] (BN-folded) weights — it is copied into LDS verbatim by LDS-DMA; bias: [64].
+ * w: the PACKED weight image [154][64] (row k = ky*22 + kx*3 + c; the 22nd row of every ky is zero) that
+ * cnl_stem_pack_weights_f32 makes from the OHWI [64][7][7][3] (BN-folded) weights — it is copied into LDS verbatim by LDS-DMA;
+ * cnl_stem_packed_weight_floats() = 154*64 sizes it; bias: [64].
  */
-int cnl_stem_pack_weights_f32(const float* w_ohwi, float* w_packed /* 148*64 floats */, void* stream);
+size_t cnl_stem_packed_weight_floats(void);
+int cnl_stem_pack_weights_f32(const float* w_ohwi, float* w_packed, void* stream);
 int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
                          const float* w, const float* bias, float* y,
                          int32_t N, int32_t H, int32_t W, void* stream);

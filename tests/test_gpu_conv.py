@@ -150,7 +150,7 @@ def test_stem_matches_cpu(shape, channels_last):
     if channels_last:
         xd = xd.contiguous(memory_format=torch.channels_last)
     wd = w.permute(0, 2, 3, 1).contiguous().cuda()
-    wp = torch.full((148 * 64,), float("nan"), device="cuda")
+    wp = torch.full((lib.cnl_stem_packed_weight_floats(),), float("nan"), device="cuda")
     _lib.check(lib.cnl_stem_pack_weights_f32(wd.data_ptr(), wp.data_ptr(), _stream()))
     bd = b.cuda()
     N, _, H, W = shape
