@@ -367,33 +367,48 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         //   CNL_I_SUBPIXEL        one phase of a stride-2 transposed conv: write position (sub_dy, sub_dx) only; the optional
         //                         residual is added AFTER the activation (Fuse: skip + resize(top), resize = deconv+BN+ReLU)
         const bool sub = a.flags & CNL_I_SUBPIXEL;
+        float bvj[TN];
+        bool colj[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-            const bool col_ok = col < a.Cout;
-            const float bv = col_ok ? a.bias[col] : 0.f;
+            colj[j] = col < a.Cout;
+            bvj[j] = colj[j] ? a.bias[col] : 0.f;
+        }
+        const unsigned col0 = (unsigned)(n0 + wn * TN * 32 + (lane & 31));
+        const unsigned Wo2 = 2u * (unsigned)a.Wo;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mb = m0 + (wm * TM + i) * 32 + 4 * hi;
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (!(col_ok && m < a.M)) continue;
-                    const float v = acc[i][j][r] + bv;
-                    const unsigned n = fast_div((unsigned)m, a.mg_hw, a.sh_hw);
-                    const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
-                    const unsigned oy = fast_div(rem, a.mg_w, a.sh_w);
-                    const unsigned ox = rem - oy * (unsigned)a.Wo;
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + (wm * TM + i) * 32 + 4 * hi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // one (n, oy, ox) decomposition per accumulator row; the four 2x positions and the TN column groups only add
+                // wave-uniform offsets, which ride in the buffer instructions' scalar offset
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const bool row_ok = m < a.M;
+                const unsigned n = fast_div((unsigned)m, a.mg_hw, a.sh_hw);
+                const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
+                const unsigned oy = fast_div(rem, a.mg_w, a.sh_w);
+                const unsigned ox = rem - oy * (unsigned)a.Wo;
+                const unsigned pix = (n * 2u * (unsigned)a.Ho + 2u * oy) * Wo2 + 2u * ox;      // < 2^30: checked on the host (4 GiB rule)
+                const unsigned y_v = (pix * (unsigned)a.ldy + col0) * 4u, r_v = (pix * (unsigned)a.ldr + col0) * 4u;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bool ok = row_ok && colj[j];
+                    const float v = acc[i][j][r] + bvj[j];
                     if (sub) {
-                        const size_t pix = ((size_t)n * (2 * a.Ho) + 2 * oy + a.sub_dy) * (2 * a.Wo) + 2 * ox + a.sub_dx;
+                        const unsigned dp = (unsigned)a.sub_dy * Wo2 + (unsigned)a.sub_dx;
                         float o = fminf(fmaxf(v, lo), hi6);
-                        if (a.res) o += a.res[pix * a.ldr + col];
-                        a.y[pix * a.ldy + col] = o;
-                        continue;
-                    }
+                        if (a.res) o += buf_load(a.res, a.r_bytes, ok ? r_v : OOB, (dp * (unsigned)a.ldr + j * 32u) * 4u);
+                        buf_store(o, a.y, a.y_bytes, ok ? y_v : OOB, (dp * (unsigned)a.ldy + j * 32u) * 4u);
+                    } else {
+                        float rv[4];
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const size_t pix = ((size_t)n * (2 * a.Ho) + 2 * oy + (d >> 1)) * (2 * a.Wo) + 2 * ox + (d & 1);
-                        a.y[pix * a.ldy + col] = fmaxf(v + a.res[pix * a.ldr + col], lo);
+                        for (int d = 0; d < 4; ++d)
+                            rv[d] = buf_load(a.res, a.r_bytes, ok ? r_v : OOB, (((d >> 1) * Wo2 + (d & 1)) * (unsigned)a.ldr + j * 32u) * 4u);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d)
+                            buf_store(fmaxf(v + rv[d], lo), a.y, a.y_bytes, ok ? y_v : OOB, (((d >> 1) * Wo2 + (d & 1)) * (unsigned)a.ldy + j * 32u) * 4u);
                     }
                 }
             }
