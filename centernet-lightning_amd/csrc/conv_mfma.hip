@@ -493,6 +493,7 @@ static int finish_and_launch(ConvArgs& a, bool out4x, const char* who, hipStream
     // Tile choice: BN follows Cout; shrink BM when the grid would not fill 256 CUs x 2 workgroups.
     if (a.Cout <= 32) return launch_cfg<4, 1, 2, 1>(a, s);          // 256 x 32
     if (a.Cout <= 64) return launch_cfg<4, 1, 2, 2>(a, s);          // 256 x 64
+    if (a.Cout <= 96) return launch_cfg<4, 1, 1, 3>(a, s);          // 128 x 96 (the 80-class heatmap out_conv: 17 % instead of 37 % idle columns)
     const long long tiles128 = ((M + 127) / 128) * ((a.Cout + 127) / 128);
     if (tiles128 < 512) return launch_cfg<2, 2, 1, 2>(a, s);        //  64 x 128
     return launch_cfg<2, 2, 2, 2>(a, s);                            // 128 x 128
