@@ -423,11 +423,6 @@ class Plan:
         return sum(L.flops for L in self.launches)
 
 
-def _is_identity(layer):
-    return layer.kh == 1 and layer.cin == layer.cout and bool(torch.equal(
-        layer.w.view(layer.cout, layer.cin), torch.eye(layer.cout, device=layer.w.device)))
-
-
 class Engine:
     """Per-model cache of packed weights and per-shape plans."""
 

@@ -18,13 +18,17 @@
 //   MFMA      wave w owns transform row i = w>>1 (positions 4i..4i+3) for cout group h = w&1 and both 32-tile groups:
 //             per position two A fragments + one B fragment, each ONE ds_read_b128 (lanes 0-31 take ci 0-3, lanes
 //             32-63 ci 4-7: four K=2 steps per read), 8 MFMAs; 32 MFMAs per wave per chunk;
-//   transform of chunk cc+1 (thread = (tile, channel): 16 LDS reads, 32 adds, 16 LDS writes) is hand-interleaved with
-//             those MFMAs, one slice = {1 MFMA, 2 adds | 1 write}, fenced by sched_barrier(0).
-// Measured and rejected (round 1): a wave-specialised variant (8 matrix waves + 4 producer waves doing all DMA and the
-// transform, 3 waves/SIMD) was correct but 5 % slower (2707 vs 2568 us on the 256->256 @128^2 x32 layer), with or without
-// s_setprio for the producers.  Ablation of this kernel on that layer: 2536 us full; -146 us without the transform's LDS
-// traffic, -51 without the DMA, -36 without the barrier, ~0 without the fragment reads; 2182 us with all four removed,
-// against 2057 us of pure MFMA time at the 2.04 GHz the chip sustains in this loop.
+//   transform of chunk cc+1: thread = (tile, channel PAIR, output-row half) — packed fp32 adds (v_pk_add_f32), 8-byte LDS
+//             accesses; the two waves of a SIMD take output rows {0,1} / {2,3} of B^T d B (no redundant work): 6 ds_read2_b64,
+//             16 packed adds, 4 ds_write2st64_b64 per wave and chunk, placed in fenced slices among those MFMAs — the adds in two
+//             dense bursts early in the chunk, because on gfx950 VALU work does not overlap the matrix pipe of its SIMD and an
+//             MFMA -> VALU switch costs ~13 cycles (tools/mfma_coexec.hip, profiles/r01_mfma_coexec.txt).
+// Persistent workgroups (one per CU) walk the work items; the next item's first chunk is fetched during the epilogue.
+// Measured and rejected (round 1, details in DESIGN.md 3.1): a wave-specialised variant (8 matrix + 4 producer waves, 5 % slower);
+// a software-pipelined chunk loop with the barrier in mid-chunk; s_setprio schedules that equalise the two waves of a SIMD (no
+// change); two independent 4-wave workgroups per CU with wave-private V / U (correct, 2.5 % slower: LDS-DMA traffic doubles).
+// Where the time goes (tools/wino_trace.py, PMC in profiles/): matrix pipes ~84 % busy; the older wave of each SIMD wins issue
+// arbitration and idles ~40 % of a chunk at the barrier while the younger one finishes alone.
 // Epilogue: owning a whole transform row lets each wave apply the first half of A^T M A in registers (4 -> 2 matrices);
 // the halves meet through LDS ([i][c][tile][co], two passes) where thread = (tile, co) finishes Y, adds bias
 // (+ residual) (+ ReLU) and stores the 2x2 outputs NHWC with buffer stores (uniform part of the address in the SGPR
