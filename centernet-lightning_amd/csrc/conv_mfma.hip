@@ -207,19 +207,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         b_off[j] = (unsigned)(((n0 + r) * a.K + q) * 4);   // rows >= Cout land beyond w_bytes -> zeros
     }
 
-    // LDS-DMA of K chunk (tap_, ky_, kx_, c0_) into `stage_`.  (A macro, not a lambda: see the note above.)
-#define CNL_ISSUE(stage_, tap_, ky_, kx_, c0_, kbase_)                                                            \
+    // Per-lane DMA source offsets of the CURRENT tap (a_voff): recomputed only when the tap changes, i.e. once per CC chunks; the
+    // channel offset of a chunk inside the tap is wave-uniform and rides in the scalar offset, so a chunk's DMA issue needs no
+    // VALU at all (VALU work does not overlap the matrix pipe on gfx950: tools/mfma_coexec.hip).  The tap part must stay in the
+    // VECTOR offset: a_base is "negative" (wrapped) for border pixels and the bounds check looks at the vector offset alone.
+    unsigned a_voff[C::A_INSTR];
+#define CNL_TAP(tap_, ky_, kx_)                                                                                   \
     do {                                                                                                          \
-        char* sA_ = smem + (stage_) * C::STAGE_BYTES;                                                             \
-        char* sB_ = sA_ + C::BM * 128;                                                                            \
         const unsigned bit_ = 1u << (tap_);                                                                       \
-        const unsigned delta_ = UP_IN ? (unsigned)((c0_) * 4) : (unsigned)((((ky_) * a.Win + (kx_)) * a.ldx + (c0_)) * 4); \
+        const unsigned delta_ = UP_IN ? 0u : (unsigned)((((ky_) * a.Win + (kx_)) * a.ldx) * 4);                   \
         _Pragma("unroll") for (int j = 0; j < C::A_INSTR; ++j) {                                                  \
             unsigned off_ = a_base[j] + delta_;                                                                   \
             if constexpr (UP_IN)                                                                                  \
                 off_ += (unsigned)(((((a_iy0[j] + (ky_)) >> 1) * a.Win + ((a_ix0[j] + (kx_)) >> 1)) * a.ldx) * 4); \
-            dma16(a.x, a.x_bytes, sA_ + (j * C::NW + wave) * 1024, (a_mask[j] & bit_) ? off_ : OOB, 0);           \
+            a_voff[j] = (a_mask[j] & bit_) ? off_ : OOB;                                                          \
         }                                                                                                         \
+    } while (0)
+    // LDS-DMA of K chunk (channels c0_.. of the current tap) into `stage_`.  (A macro, not a lambda: see the note above.)
+#define CNL_ISSUE(stage_, c0_, kbase_)                                                                            \
+    do {                                                                                                          \
+        char* sA_ = smem + (stage_) * C::STAGE_BYTES;                                                             \
+        char* sB_ = sA_ + C::BM * 128;                                                                            \
+        _Pragma("unroll") for (int j = 0; j < C::A_INSTR; ++j)                                                    \
+            dma16(a.x, a.x_bytes, sA_ + (j * C::NW + wave) * 1024, a_voff[j], (unsigned)((c0_) * 4));             \
         _Pragma("unroll") for (int j = 0; j < C::B_INSTR; ++j)                                                    \
             dma16(a.w, a.w_bytes, sB_ + (j * C::NW + wave) * 1024, b_off[j], (unsigned)((kbase_) * 4));           \
     } while (0)
@@ -231,13 +241,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             cc = 0;                                     \
             ++tap;                                      \
             if (++kx == KW) { kx = 0; ++ky; }           \
+            CNL_TAP(tap, ky, kx);                       \
         }                                               \
     } while (0)
 #ifdef CNL_TRACE
     const long long t_pro = wall_clock64();
     const long long c_pro = clock64();
 #endif
-    CNL_ISSUE(0, 0, 0, 0, 0, 0);             // first chunk in flight before anything else
+    CNL_TAP(0, 0, 0);
+    CNL_ISSUE(0, 0, 0);                      // first chunk in flight before anything else
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             __syncthreads();                                                                                      \
             if (ISSUE_) {                                                                                         \
                 CNL_ADVANCE();                                                                                    \
-                CNL_ISSUE((kt_) & 1, tap, ky, kx, cc * 32, ((kt_) + 2) * 32);                                     \
+                CNL_ISSUE((kt_) & 1, cc * 32, ((kt_) + 2) * 32);                                                  \
             }                                                                                                     \
             CNL_READ(0, sN, 0);                                                                                   \
         }                                                                                                         \
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     __syncthreads();                                    // ... and everyone's
     if (a.KT > 1) {
         CNL_ADVANCE();
-        CNL_ISSUE(1, tap, ky, kx, cc * 32, 32);
+        CNL_ISSUE(1, cc * 32, 32);
     }
     CNL_READ(0, smem, 0);
     int kt = 0;
@@ -328,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #undef CNL_CHUNK
 #undef CNL_SCHED_RM
 #undef CNL_ADVANCE
+#undef CNL_TAP
 #undef CNL_ISSUE
 #undef CNL_READ
 #undef CNL_MFMA
