@@ -79,6 +79,28 @@ class _SepLayer:
         self.stride, self.pad = 1, 1
 
 
+class _DeformLayer:
+    """make_conv(conv_type="deformable") packed: ONE k x k conv producing offsets (+ mask logits) and the [Cout][k*k*Cin] GEMM
+    weight (OHWI, BN folded) that multiplies the sampled columns (cnl_deform_sample_nhwc_f32 -> 1x1 cnl_conv2d_nhwc_f32)."""
+
+    def __init__(self, mod, device):
+        blk = mod.block
+        ws, bs = [blk.offset_conv.weight], [blk.offset_conv.bias]
+        self.has_mask = blk.mask_conv is not None
+        if self.has_mask:
+            ws.append(blk.mask_conv[0].weight)
+            bs.append(blk.mask_conv[0].bias)
+        w = torch.cat([t.detach().float() for t in ws], dim=0)
+        b = torch.cat([t.detach().float() for t in bs], dim=0)
+        self.om = _Layer(*(t.to(device) for t in fold_conv_bn(w, b, None)))          # offsets | mask logits, no activation
+        gw, gb = fold_conv_bn(blk.deform_conv.weight, None, mod.bn)                   # OHWI [Cout, k, k, Cin]
+        cout, k, _, cin = gw.shape
+        self.gemm = _Layer(gw.reshape(cout, 1, 1, k * k * cin).contiguous().to(device), gb.to(device))
+        self.cin, self.cout, self.k = cin, cout, k
+        self.kh = self.kw = k
+        self.stride, self.pad = 1, (k - 1) // 2
+
+
 class _DeconvLayer:
     """make_upsample("conv_transpose") (layers.py:86-93) packed for cnl_deconv2x_nhwc_f32: BN folded, the K x K taps split into the
     four sub-pixel phase blocks [Cout][KHp][KWp][Cin] (layout: include/centernet_gfx950.h).  `gain` >= 0 is folded in as well
@@ -139,7 +161,13 @@ class PackedWeights:
                 d = L(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
                 self.blocks.append((L(blk.conv1, blk.bn1), L(blk.conv2, blk.bn2), d, li))
         self.neck_kind = type(neck).__name__
-        C = lambda m: _SepLayer(m, device) if type(m).__name__ == "SeparableConvBn" else L(m.conv_module, m.bn_module)
+        def C(m):
+            kind = type(m).__name__
+            if kind == "SeparableConvBn":
+                return _SepLayer(m, device)
+            if kind == "DeformableConvBn":
+                return _DeformLayer(m, device)
+            return L(m.conv_module, m.bn_module)
         self.upsample_type = getattr(neck, "upsample_type", "nearest")
         if self.neck_kind == "SimpleNeck":
             self.neck_layers = [C(m) for m in neck.layers]
@@ -153,7 +181,9 @@ class PackedWeights:
                     wts = torch.relu(f.weights.detach().float())
                     den = float(wts.sum()) + 1e-6
                     ga, gb = float(wts[0]) / den, float(wts[1]) / den
-                c = f.output_conv.pw.in_channels if type(f.output_conv).__name__ == "SeparableConvBn" else f.output_conv.conv_module.in_channels
+                oc = f.output_conv
+                c = {"SeparableConvBn": lambda: oc.pw.in_channels, "DeformableConvBn": lambda: oc.block.deform_conv.in_channels}.get(
+                    type(oc).__name__, lambda: oc.conv_module.in_channels)()
                 skip_p = L(f.project[0]) if isinstance(f.project[0], torch.nn.Conv2d) else None
                 if f.weights is not None:
                     skip_p = _scaled(skip_p, ga) if skip_p is not None else _identity_layer(c, device, ga)
@@ -238,8 +268,24 @@ class Plan:
         self._conv(layer.pw, t, xh, xw, layer.cin, y, ldy, CNL_RELU6, what=what + ".pw")
         return xh, xw
 
+    def _deform(self, layer, x, xh, xw, ldx, y, ldy, what):
+        """Deformable conv (layers.py:9-38, 47-54): offsets / mask conv -> deformable sampling into columns -> 1x1 GEMM + BN + ReLU."""
+        no = layer.om.cout
+        om = self._buf(self.N, xh, xw, no)
+        self._conv(layer.om, x, xh, xw, ldx, om, no, 0, what=what + ".offset+mask_conv")
+        kk = layer.k * layer.k
+        col = self._buf(self.N, xh, xw, kk * layer.cin)
+        self.launches.append(_Launch(self.lib.cnl_deform_sample_nhwc_f32,
+                                     (x.data_ptr(), om.data_ptr(), col.data_ptr(), self.N, xh, xw, layer.cin, ldx, no, layer.k,
+                                      int(layer.has_mask)), what + ".sample", 0, keep=(x, om, col)))
+        self._conv(layer.gemm, col, xh, xw, kk * layer.cin, y, ldy, CNL_RELU, what=what + ".deform_conv (GEMM)")
+        return xh, xw
+
     def _block(self, layer, x, xh, xw, ldx, y, ldy, what, up=0):
-        """make_conv(...) of either type; `up` = CNL_UPSAMPLE_IN folds a pending nearest x2 into a normal conv."""
+        """make_conv(...) of any type; `up` = CNL_UPSAMPLE_IN folds a pending nearest x2 into a normal conv."""
+        if isinstance(layer, _DeformLayer):
+            assert not up
+            return self._deform(layer, x, xh, xw, ldx, y, ldy, what)
         if isinstance(layer, _SepLayer):
             assert not up
             return self._sep(layer, x, xh, xw, ldx, y, ldy, what)
@@ -303,7 +349,7 @@ class Plan:
             x, xh, xw, xc = self.features[-1]
             up = 0                                    # CNL_UPSAMPLE_IN when a nearest x2 of `x` is still pending
             for i, (layer, dec) in enumerate(zip(Wt.neck_layers, Wt.neck_ups)):
-                if up and isinstance(layer, _SepLayer):           # the depthwise kernel has no folded-upsample gather
+                if up and isinstance(layer, (_SepLayer, _DeformLayer)):   # only the normal conv kernels fold the upsample gather
                     x, xh, xw, up = self._upsample(x, xh, xw, xc, xc, 0, f"neck.upsample.{i - 1} (nearest)"), 2 * xh, 2 * xw, 0
                 y = self._buf(N, xh * (2 if up else 1), xw * (2 if up else 1), layer.cout)
                 oh, ow = self._block(layer, x, xh, xw, xc, y, layer.cout, f"neck.layers.{i}", up)

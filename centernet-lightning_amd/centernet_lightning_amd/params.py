@@ -62,6 +62,40 @@ class SeparableConvBn(nn.Module):
     pw_bn = property(lambda self: getattr(self, "4"))
 
 
+class _DeformableBlock(nn.Module):
+    """Parameters of layers.py:9-38 DeformableConv2dBlock: offset_conv (zero-initialised), mask_conv.0 (+ Sigmoid, version 2 only),
+    deform_conv.weight [out, in, k, k] (torchvision DeformConv2d, bias=False)."""
+
+    def __init__(self, cin, cout, k=3, version=2, mask_init_bias=0.0):
+        super().__init__()
+        pad = (k - 1) // 2
+        self.offset_conv = nn.Conv2d(cin, 2 * k * k, k, padding=pad)
+        self.mask_conv = nn.Sequential(nn.Conv2d(cin, k * k, k, padding=pad), nn.Sigmoid()) if version == 2 else None
+        self.deform_conv = nn.Conv2d(cin, cout, k, padding=pad, bias=False)      # same parameter shape / default init as DeformConv2d
+        nn.init.constant_(self.offset_conv.weight, 0)
+        nn.init.constant_(self.offset_conv.bias, 0)
+        if self.mask_conv is not None:
+            nn.init.constant_(self.mask_conv[0].weight, 0)
+            nn.init.constant_(self.mask_conv[0].bias, mask_init_bias)
+
+
+class DeformableConvBn(nn.Module):
+    """make_conv(conv_type="deformable") (layers.py:47-54): DeformableConv2dBlock + BN + ReLU, state_dict keys 0.*, 1.*."""
+
+    def __init__(self, cin, cout, k=3, version=2, mask_activation=None, mask_init_bias=0.0):
+        super().__init__()
+        if mask_activation not in (None, "Sigmoid"):
+            raise ValueError(f"mask_activation={mask_activation!r}: the gfx950 deformable path applies the reference default (Sigmoid)")
+        if version not in (1, 2):
+            raise ValueError(f"deformable conv version {version}: expected 1 or 2")
+        self.k, self.version = k, version
+        self.add_module("0", _DeformableBlock(cin, cout, k, version, mask_init_bias))
+        self.add_module("1", nn.BatchNorm2d(cout))
+
+    block = property(lambda self: getattr(self, "0"))
+    bn = property(lambda self: getattr(self, "1"))
+
+
 class DeconvBn(nn.Module):
     """make_upsample(upsample_type="conv_transpose") (layers.py:86-96): ConvTranspose2d(C, C, k, stride=2, padding, output_padding,
     bias=False) + BN + ReLU, keys 0, 1; `deconv_init_bilinear` reproduces _init_bilinear_upsampling (layers.py:103-116) as
@@ -91,14 +125,16 @@ class DeconvBn(nn.Module):
     bn = property(lambda self: getattr(self, "1"))
 
 
-def make_conv_params(cin, cout, conv_type="normal"):
+def make_conv_params(cin, cout, conv_type="normal", **kw):
     """Parameter container of layers.py:40-79 make_conv (kernel 3)."""
     if conv_type == "normal":
         return ConvBn(cin, cout, 3, names=("0", "1"))
     if conv_type == "separable":
         return SeparableConvBn(cin, cout, 3)
-    raise ValueError(f"conv_type={conv_type!r}: 'normal' and 'separable' have gfx950 kernels; 'deformable' (DCNv2, torchvision "
-                     "DeformConv2d) is outside the MI355X hot-path scope — see DESIGN.md")
+    if conv_type == "deformable":
+        return DeformableConvBn(cin, cout, 3, version=kw.get("version", 2), mask_activation=kw.get("mask_activation"),
+                                mask_init_bias=kw.get("mask_init_bias", 0.0))
+    raise ValueError(f"conv_type={conv_type!r}: expected 'normal', 'separable' or 'deformable' (layers.py:43)")
 
 
 UPSAMPLE_TYPES = ("nearest", "bilinear", "conv_transpose")
@@ -150,7 +186,7 @@ class SimpleNeck(nn.Module):
     (layers.py:40-101; option names of configs/test_config.yaml:8-18)."""
 
     def __init__(self, backbone_channels, upsample_channels=(256, 128, 64), upsample_type="nearest", conv_type="normal",
-                 deconv_kernel=3, deconv_init_bilinear=True, **ignored):
+                 deconv_kernel=3, deconv_init_bilinear=True, **conv_kw):
         super().__init__()
         _check_neck_options(upsample_type, conv_type)
         self.upsample_type, self.conv_type = upsample_type, conv_type
@@ -159,7 +195,7 @@ class SimpleNeck(nn.Module):
         layers, ups = [], []
         cin = backbone_channels[-1]
         for c in upsample_channels:
-            layers.append(make_conv_params(cin, c, conv_type))
+            layers.append(make_conv_params(cin, c, conv_type, **conv_kw))
             ups.append(DeconvBn(c, deconv_kernel, deconv_init_bilinear) if upsample_type == "conv_transpose" else nn.Identity())
             cin = c
         self.layers = nn.Sequential(*layers)
@@ -172,14 +208,14 @@ class FuseParams(nn.Module):
     conv_transpose), the fusion weights (:148) and the output conv (:158).  Key names equal the reference module's."""
 
     def __init__(self, skip_c, top_c, out, upsample="nearest", conv_type="normal", weighted_fusion=False, deconv_kernel=3,
-                 deconv_init_bilinear=True):
+                 deconv_init_bilinear=True, **conv_kw):
         super().__init__()
         self.upsample_type, self.conv_type = upsample, conv_type
         self.weights = nn.Parameter(torch.ones(2), requires_grad=True) if weighted_fusion else None
         self.project = nn.ModuleList([nn.Conv2d(skip_c, out, 1) if skip_c != out else nn.Identity(),
                                       nn.Conv2d(top_c, out, 1) if top_c != out else nn.Identity()])
         self.resize = DeconvBn(out, deconv_kernel, deconv_init_bilinear) if upsample == "conv_transpose" else nn.Identity()
-        self.output_conv = make_conv_params(out, out, conv_type)
+        self.output_conv = make_conv_params(out, out, conv_type, **conv_kw)
 
 
 class FPNNeck(nn.Module):
@@ -187,7 +223,7 @@ class FPNNeck(nn.Module):
     docs/implementation.md:49-52; tests/test_necks.py:41-56)."""
 
     def __init__(self, backbone_channels, upsample_channels=(256, 128, 64), upsample_type="nearest", conv_type="normal",
-                 weighted_fusion=False, deconv_kernel=3, deconv_init_bilinear=True, **ignored):
+                 weighted_fusion=False, deconv_kernel=3, deconv_init_bilinear=True, **conv_kw):
         super().__init__()
         _check_neck_options(upsample_type, conv_type)
         if len(upsample_channels) > len(backbone_channels) - 1:
@@ -200,7 +236,8 @@ class FPNNeck(nn.Module):
         top_c = upsample_channels[0]
         for i, c in enumerate(upsample_channels):
             skip_c = backbone_channels[-2 - i]
-            fuse.append(FuseParams(skip_c, top_c, c, upsample_type, conv_type, weighted_fusion, deconv_kernel, deconv_init_bilinear))
+            fuse.append(FuseParams(skip_c, top_c, c, upsample_type, conv_type, weighted_fusion, deconv_kernel, deconv_init_bilinear,
+                                   **conv_kw))
             top_c = c
         self.fuse = nn.ModuleList(fuse)
 
@@ -208,7 +245,7 @@ class FPNNeck(nn.Module):
 def _check_neck_options(upsample_type, conv_type):
     if upsample_type not in UPSAMPLE_TYPES:
         raise ValueError(f"upsample_type={upsample_type!r}: expected one of {UPSAMPLE_TYPES} (layers.py:84)")
-    if conv_type not in ("normal", "separable"):
+    if conv_type not in ("normal", "separable", "deformable"):
         make_conv_params(64, 64, conv_type)          # raises with the explanation
 
 

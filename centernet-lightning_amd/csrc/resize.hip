@@ -117,3 +117,59 @@ extern "C" int cnl_depthwise3x3_nhwc_f32(const float* x, const float* w, const f
                        ldy, lo, hi);
     return cnl::check_launch("depthwise3x3_kernel");
 }
+
+// ---- deformable convolution, sampling half (DCNv1 / v2: models/layers.py:9-38 DeformableConv2dBlock over torchvision DeformConv2d) ----
+// col[n, y, x, k, :] = m_k . bilinear(x[n], y - p + ky + dy_k, x - p + kx + dx_k)   for the K*K taps k = ky*K + kx, all C channels,
+// with torchvision's sampling rule (zero outside (-1, H) x (-1, W); corners outside the image contribute zero); the multiply
+// with the [Cout, K*K*C] weight is then an ordinary 1x1 convolution on the matrix cores over this col tensor.
+// om[n, y, x, 0 .. 2KK) = offsets (dy, dx interleaved per tap), om[.., 2KK .. 3KK) = mask LOGITS (sigmoid applied here) when has_mask.
+namespace cnl_resize {
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void deform_sample_kernel(const float* __restrict__ x, const float* __restrict__ om,
+                                                            float* __restrict__ col, int N, int H, int W, int C4, int ldx, int ldo,
+                                                            int K, int has_mask) {
+    const int KK = K * K, pad = (K - 1) / 2;
+    const long total = (long)N * H * W * KK * C4;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int c = (int)(t % C4) * 4;
+        long q = t / C4;
+        const int k = (int)(q % KK);
+        const long pix = q / KK;
+        const int ox = (int)(pix % W);
+        const int oy = (int)((pix / W) % H);
+        const int n = (int)(pix / ((long)W * H));
+        const float* o = om + pix * ldo;
+        const float py = (float)(oy - pad + k / K) + o[2 * k];
+        const float px = (float)(ox - pad + k % K) + o[2 * k + 1];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (py > -1.f && py < (float)H && px > -1.f && px < (float)W) {
+            const float hl = floorf(py), wl = floorf(px);
+            const int h0 = (int)hl, w0 = (int)wl, h1 = h0 + 1, w1 = w0 + 1;
+            const float lh = py - hl, lw = px - wl, hh = 1.f - lh, hw = 1.f - lw;
+            const float* xn = x + (long)n * H * W * ldx + c;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v1 = (h0 >= 0 && w0 >= 0) ? *reinterpret_cast<const f32x4*>(xn + ((long)h0 * W + w0) * ldx) : z;
+            const f32x4 v2 = (h0 >= 0 && w1 <= W - 1) ? *reinterpret_cast<const f32x4*>(xn + ((long)h0 * W + w1) * ldx) : z;
+            const f32x4 v3 = (h1 <= H - 1 && w0 >= 0) ? *reinterpret_cast<const f32x4*>(xn + ((long)h1 * W + w0) * ldx) : z;
+            const f32x4 v4 = (h1 <= H - 1 && w1 <= W - 1) ? *reinterpret_cast<const f32x4*>(xn + ((long)h1 * W + w1) * ldx) : z;
+            v = (hh * hw) * v1 + (hh * lw) * v2 + (lh * hw) * v3 + (lh * lw) * v4;
+        }
+        if (has_mask) v = v * (1.0f / (1.0f + expf(-o[2 * KK + k])));
+        *reinterpret_cast<f32x4*>(col + (pix * KK + k) * (long)(C4 * 4) + c) = v;
+    }
+}
+}  // namespace cnl_resize
+
+extern "C" int cnl_deform_sample_nhwc_f32(const float* x, const float* om, float* col, int32_t N, int32_t H, int32_t W, int32_t C,
+                                          int32_t ldx, int32_t ldo, int32_t K, int32_t has_mask, void* stream) {
+    CNL_REQUIRE(x && om && col, CNL_E_BAD_ARG, "cnl_deform_sample_nhwc_f32: null tensor pointer");
+    CNL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, CNL_E_BAD_ARG, "cnl_deform_sample_nhwc_f32: non-positive dimension");
+    CNL_REQUIRE(K == 1 || K == 3 || K == 5, CNL_E_UNSUPPORTED, "cnl_deform_sample_nhwc_f32: kernel size %d (1, 3 or 5)", K);
+    CNL_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldx >= C && ldo >= (has_mask ? 3 : 2) * K * K, CNL_E_UNSUPPORTED,
+                "cnl_deform_sample_nhwc_f32: C %% 4 != 0 or pixel strides too small (C=%d ldx=%d ldo=%d)", C, ldx, ldo);
+    CNL_REQUIRE((((uintptr_t)x | (uintptr_t)col) & 15) == 0, CNL_E_BAD_ARG, "cnl_deform_sample_nhwc_f32: 16-byte alignment");
+    const long total = (long)N * H * W * K * K * (C / 4);
+    hipLaunchKernelGGL(cnl_resize::deform_sample_kernel, dim3(cnl_resize::grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, om, col,
+                       N, H, W, C / 4, ldx, ldo, K, has_mask);
+    return cnl::check_launch("deform_sample_kernel");
+}

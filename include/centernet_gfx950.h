@@ -209,6 +209,18 @@ int cnl_depthwise3x3_nhwc_f32(const float* x, const float* w, const float* bias,
                               int32_t C, int32_t ldx, int32_t ldy, uint32_t flags, void* stream);
 
 /*
+ * conv_type="deformable" (layers.py:9-38, 47-54): DeformableConv2dBlock = offset_conv (+ sigmoid mask_conv for version 2) feeding
+ * torchvision DeformConv2d(K x K, stride 1, padding (K-1)/2, bias=False), then BN + ReLU.  Here: offsets and mask logits come from
+ * ONE ordinary K x K conv (cnl_conv2d_nhwc_f32, Cout = 2KK [+ KK], weights concatenated); this entry point does the deformable
+ * sampling   col[n,y,x,k,:] = sigmoid(mask_k) . bilinear(x[n], y - p + ky + dy_k, x - p + kx + dx_k)   (torchvision's rule: zero
+ * outside (-1,H) x (-1,W), corners outside the image contribute zero; offsets (dy, dx) interleaved per tap k = ky*K + kx);
+ * the product with the [Cout][K*K*C] weight (OHWI order, BN folded) is a 1x1 cnl_conv2d_nhwc_f32 over col (pixel stride K*K*C).
+ * om: [N,H,W,ldo] with channels [0, 2KK) offsets, [2KK, 3KK) mask logits (has_mask != 0).  C % 4 == 0.
+ */
+int cnl_deform_sample_nhwc_f32(const float* x, const float* om, float* col, int32_t N, int32_t H, int32_t W, int32_t C,
+                               int32_t ldx, int32_t ldo, int32_t K, int32_t has_mask, void* stream);
+
+/*
  * Step after the path for the tracking task: association costs of one frame against the current
  * track table, and the track-table update, so that per-frame embeddings never leave HBM — only the n x T cost matrices go to
  * the host for the Hungarian step (scipy, as in the reference) and the match list comes back.

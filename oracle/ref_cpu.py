@@ -69,9 +69,62 @@ def backbone_features(sd, x, stats=None):
     return feats
 
 
+def _bilinear_zero(x, py, px):
+    """torchvision deform_conv2d's bilinear_interpolate (torchvision/csrc/ops/cpu/deform_conv2d_kernel.cpp): 0 when the point is
+    outside (-1, H) x (-1, W); corners outside the image contribute 0.  x [N,C,H,W]; py, px [N,Ho,Wo] -> [N,C,Ho,Wo]."""
+    N, C, H, W = x.shape
+    inside = (py > -1) & (py < H) & (px > -1) & (px < W)
+    h_low, w_low = torch.floor(py), torch.floor(px)
+    lh, lw = py - h_low, px - w_low
+    hh, hw = 1 - lh, 1 - lw
+    h_low, w_low = h_low.long(), w_low.long()
+    h_high, w_high = h_low + 1, w_low + 1
+    flat = x.reshape(N, C, H * W)
+
+    def corner(hy, wx, ok):
+        idx = (hy.clamp(0, H - 1) * W + wx.clamp(0, W - 1)).reshape(N, 1, -1).expand(N, C, -1)
+        v = flat.gather(2, idx).reshape(N, C, *py.shape[1:])
+        return v * (ok & inside).unsqueeze(1).to(x.dtype)
+
+    v1 = corner(h_low, w_low, (h_low >= 0) & (w_low >= 0))
+    v2 = corner(h_low, w_high, (h_low >= 0) & (w_high <= W - 1))
+    v3 = corner(h_high, w_low, (h_high <= H - 1) & (w_low >= 0))
+    v4 = corner(h_high, w_high, (h_high <= H - 1) & (w_high <= W - 1))
+    w1, w2, w3, w4 = (hh * hw).unsqueeze(1), (hh * lw).unsqueeze(1), (lh * hw).unsqueeze(1), (lh * lw).unsqueeze(1)
+    return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4
+
+
+def deform_conv2d(x, offset, weight, mask=None, padding=1):
+    """torchvision.ops.deform_conv2d restated (stride 1, dilation 1, one offset group) — third-party, absent from the image
+    ("parity unpinned"): out(p) = sum_k w_k . x(p + p_k + dp_k) . m_k, offsets stored (dy, dx) interleaved per tap."""
+    N, C, H, W = x.shape
+    O, _, kh, kw = weight.shape
+    ys = torch.arange(H, dtype=x.dtype).view(1, H, 1)
+    xs = torch.arange(W, dtype=x.dtype).view(1, 1, W)
+    out = torch.zeros(N, O, H, W, dtype=x.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            k = i * kw + j
+            py = ys - padding + i + offset[:, 2 * k]
+            px = xs - padding + j + offset[:, 2 * k + 1]
+            val = _bilinear_zero(x, py, px)
+            if mask is not None:
+                val = val * mask[:, k].unsqueeze(1)
+            out += torch.einsum("oc,nchw->nohw", weight[:, :, i, j], val)
+    return out
+
+
 def make_conv_forward(x, sd, q, stats=None):
     """layers.py:40-79 make_conv: `q`.0/.1 = conv3x3+BN+ReLU ("normal"); `q`.0/.1/.3/.4 = depthwise+BN+ReLU6, pointwise+BN+ReLU6
     ("separable", :56-69)."""
+    if q + ".0.deform_conv.weight" in sd:                    # DeformableConv2dBlock (layers.py:9-38) + BN + ReLU (:47-54)
+        w = sd[q + ".0.deform_conv.weight"]
+        pad = (w.shape[-1] - 1) // 2
+        offset = F.conv2d(x, sd[q + ".0.offset_conv.weight"], sd[q + ".0.offset_conv.bias"], padding=pad)
+        mask = None
+        if q + ".0.mask_conv.0.weight" in sd:               # version 2: modulated, sigmoid mask
+            mask = torch.sigmoid(F.conv2d(x, sd[q + ".0.mask_conv.0.weight"], sd[q + ".0.mask_conv.0.bias"], padding=pad))
+        return F.relu(_bn(deform_conv2d(x, offset, w, mask, pad), sd, q + ".1", stats))
     if q + ".3.weight" in sd:
         w = sd[q + ".0.weight"]
         y = F.conv2d(x, w, None, padding=(w.shape[-1] - 1) // 2, groups=w.shape[0])
@@ -113,13 +166,13 @@ def neck_forward(sd, feats, stats=None, upsample_type="nearest"):
     if "neck.top_conv.weight" in sd:                           # FPN
         top = F.conv2d(feats[-1], sd["neck.top_conv.weight"], sd["neck.top_conv.bias"])
         i = 0
-        while f"neck.fuse.{i}.output_conv.0.weight" in sd:
+        while f"neck.fuse.{i}.output_conv.1.weight" in sd:
             top = fuse_forward(sd, f"neck.fuse.{i}.", feats[-2 - i], top, upsample_type, stats)
             i += 1
         return top
     x = feats[-1]                                              # simple neck: conv -> upsample per stage
     i = 0
-    while f"neck.layers.{i}.0.weight" in sd:
+    while f"neck.layers.{i}.1.weight" in sd:
         x = make_conv_forward(x, sd, f"neck.layers.{i}", stats)
         x = make_upsample_forward(x, sd, f"neck.upsamples.{i}", upsample_type, stats)
         i += 1
@@ -177,6 +230,10 @@ def synth_state_dict(model_state_dict, seed=0, calib_shape=(2, 3, 256, 256), cal
         elif k.endswith("weight") and v.dim() == 4:
             fan_out = v.shape[0] * v.shape[2] * v.shape[3]
             v.copy_(torch.randn(v.shape, generator=g) * (2.0 / fan_out) ** 0.5)       # kaiming_normal_(fan_out, relu)
+            if k.endswith("offset_conv.weight"):
+                # the reference zero-initialises the offset conv (layers.py:27); Kaiming-sized weights on O(10) activations would
+                # throw the sampling points tens of pixels away and make the layer chaotically sensitive to 1e-6 input noise
+                v.mul_(0.02)
         elif k.endswith(("top_conv.bias", "project.0.bias", "project.1.bias")):
             v.copy_(torch.randn(v.shape, generator=g) * 0.05)
         elif k.endswith(".weights") and v.dim() == 1:                  # Fuse fusion weights (layers.py:148)

@@ -143,6 +143,36 @@ def test_conv_relu6_flag():
     assert lib.cnl_conv3x3_winograd_f32(ctypes.byref(p), None) == _lib.CNL_E_UNSUPPORTED
 
 
+@pytest.mark.parametrize("shape,K,has_mask", [((2, 32, 9, 11), 3, True), ((1, 64, 16, 16), 3, False), ((1, 8, 5, 7), 1, True)])
+def test_deform_sample_matches_torchvision_rule(shape, K, has_mask):
+    """cnl_deform_sample_nhwc_f32 against the oracle's restatement of torchvision's deformable sampling (offsets up to +-2.5 px:
+    taps leave the image on every side)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(K + shape[1])
+    N, C, H, W = shape
+    KK = K * K
+    x = torch.randn(*shape, generator=g)
+    off = (torch.rand(N, 2 * KK, H, W, generator=g) - 0.5) * 5
+    off[:, :, 0, 0] = 0.0                                        # exact-integer positions too
+    off[:, 0, 1, 1] = -1.0
+    mlog = torch.randn(N, KK, H, W, generator=g)
+    pad = (K - 1) // 2
+    ys = torch.arange(H, dtype=torch.float32).view(1, H, 1)
+    xs = torch.arange(W, dtype=torch.float32).view(1, 1, W)
+    cols = []
+    for k in range(KK):
+        v = ref_cpu._bilinear_zero(x, ys - pad + k // K + off[:, 2 * k], xs - pad + k % K + off[:, 2 * k + 1])
+        cols.append(v * torch.sigmoid(mlog[:, k]).unsqueeze(1) if has_mask else v)
+    ref = torch.stack(cols, dim=1)                               # [N, KK, C, H, W]
+    om = torch.cat([off, mlog], dim=1) if has_mask else off
+    omd, xd = nhwc(om), nhwc(x)
+    col = torch.full((N, H, W, KK * C), float("nan"), device="cuda")
+    _lib.check(lib.cnl_deform_sample_nhwc_f32(xd.data_ptr(), omd.data_ptr(), col.data_ptr(), N, H, W, C, C, om.shape[1], K, int(has_mask), None))
+    got = col.cpu().view(N, H, W, KK, C).permute(0, 3, 4, 1, 2)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+    assert lib.cnl_deform_sample_nhwc_f32(xd.data_ptr(), omd.data_ptr(), col.data_ptr(), N, H, W, C, C, om.shape[1], 4, 1, None) == _lib.CNL_E_UNSUPPORTED
+
+
 NECKS = {
     "simple_deconv": {"name": "simple", "upsample_type": "conv_transpose", "deconv_kernel": 3},        # configs/test_config.yaml
     "simple_deconv4_separable": {"name": "simple", "upsample_type": "conv_transpose", "deconv_kernel": 4, "conv_type": "separable"},
@@ -153,6 +183,9 @@ NECKS = {
     "fpn_deconv_weighted": {"name": "fpn", "upsample_type": "conv_transpose", "weighted_fusion": True},
     "fpn_deconv2_separable": {"name": "fpn", "upsample_type": "conv_transpose", "deconv_kernel": 2, "conv_type": "separable"},
     "fpn_bilinear": {"name": "fpn", "upsample_type": "bilinear"},
+    "fpn_deformable": {"name": "fpn", "upsample_type": "nearest", "conv_type": "deformable"},                       # DCNv2 (mask)
+    "simple_deformable_v1_bilinear": {"name": "simple", "upsample_type": "bilinear", "conv_type": "deformable", "version": 1},
+    "simple_deformable_nearest": {"name": "simple", "upsample_type": "nearest", "conv_type": "deformable"},
 }
 
 
@@ -183,3 +216,5 @@ def test_model_with_neck_option_matches_cpu_oracle(name):
         assert sum("bilinear" in w for w in what) == 3
     if neck.get("conv_type") == "separable":
         assert sum(w.endswith(".dw") for w in what) == 3
+    if neck.get("conv_type") == "deformable":
+        assert sum(w.endswith(".sample") for w in what) == 3 and sum("deform_conv (GEMM)" in w for w in what) == 3

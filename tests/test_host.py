@@ -94,7 +94,7 @@ def test_reference_yaml_files_build(name):
 
 def test_out_of_scope_options_raise():
     base = {"backbone": {"name": "resnet34"}, "neck": {"name": "fpn"}, "output_heads": {"heatmap": {"num_classes": 3}, "box_2d": {}}}
-    for bad in ({"backbone": {"name": "mobilenet_v2"}}, {"neck": {"name": "bifpn"}}, {"neck": {"name": "fpn", "conv_type": "deformable"}},
+    for bad in ({"backbone": {"name": "mobilenet_v2"}}, {"neck": {"name": "bifpn"}}, {"neck": {"name": "fpn", "conv_type": "dilated"}},
                 {"neck": {"name": "simple", "upsample_type": "conv_transpose", "deconv_kernel": 7}}):
         cfg = dict(base, **bad)
         with pytest.raises(ValueError):

@@ -78,7 +78,8 @@ def test_config_surface_neck_options():
                                  "conv_type": "separable", "weighted_fusion": True}))
     sd = m.state_dict()
     assert "neck.fuse.0.weights" in sd and "neck.fuse.2.output_conv.3.weight" in sd and sd["neck.fuse.1.output_conv.0.weight"].shape == (128, 1, 3, 3)
-    for bad in ({"name": "fpn", "conv_type": "deformable"}, {"name": "simple", "upsample_type": "cubic"},
+    for bad in ({"name": "fpn", "conv_type": "dilated"}, {"name": "simple", "upsample_type": "cubic"},
+                {"name": "fpn", "conv_type": "deformable", "mask_activation": "Hardsigmoid"}, {"name": "fpn", "conv_type": "deformable", "version": 3},
                 {"name": "simple", "upsample_type": "conv_transpose", "deconv_kernel": 5}, {"name": "bifpn"}):
         with pytest.raises(ValueError):
             cl.build_centernet(_cfg(bad))
@@ -89,3 +90,32 @@ def test_config_surface_neck_options():
         x = torch.rand(1, 3, 64, 96)
         out, feats, nk = ref_cpu.forward(m.state_dict(), x, return_intermediates=True, upsample_type=ups)
         assert tuple(nk.shape) == (1, 64, 16, 24) and tuple(out["heatmap"].shape) == (1, 3, 16, 24)
+
+
+def test_deformable_conv_params_and_oracle():
+    """conv_type="deformable" (layers.py:9-38, 47-54): key names / initialisation of the reference module, and the oracle's
+    restatement of torchvision's deform_conv2d (absent from the image: "parity unpinned") on cases with a known answer."""
+    m = P.DeformableConvBn(16, 24)
+    keys = set(m.state_dict().keys())
+    assert {"0.offset_conv.weight", "0.offset_conv.bias", "0.mask_conv.0.weight", "0.mask_conv.0.bias", "0.deform_conv.weight",
+            "1.weight", "1.bias", "1.running_mean", "1.running_var"} <= keys
+    assert m.block.offset_conv.weight.shape == (18, 16, 3, 3) and m.block.mask_conv[0].weight.shape == (9, 16, 3, 3)
+    assert m.block.deform_conv.weight.shape == (24, 16, 3, 3) and "0.deform_conv.bias" not in keys
+    assert float(m.block.offset_conv.weight.abs().sum()) == 0 and float(m.block.mask_conv[0].bias.abs().sum()) == 0     # layers.py:27-31
+    assert "0.mask_conv.0.weight" not in P.DeformableConvBn(8, 8, version=1).state_dict()
+    g = torch.Generator().manual_seed(0)
+    x, w = torch.randn(2, 5, 7, 9, generator=g), torch.randn(4, 5, 3, 3, generator=g)
+    F = torch.nn.functional
+    # zero offsets, unit mask == the plain convolution; at initialisation (sigmoid(0) = 0.5 mask) it is half of it
+    torch.testing.assert_close(ref_cpu.deform_conv2d(x, torch.zeros(2, 18, 7, 9), w, torch.ones(2, 9, 7, 9)), F.conv2d(x, w, padding=1), rtol=0, atol=2e-5)
+    # dy = +1 on every tap == correlation with rows y .. y+2 (zeros beyond the image)
+    off = torch.zeros(2, 18, 7, 9); off[:, 0::2] = 1.0
+    torch.testing.assert_close(ref_cpu.deform_conv2d(x, off, w), F.conv2d(F.pad(x, (1, 1, 0, 2)), w), rtol=0, atol=2e-5)
+    # dx = +0.5 == the mean of horizontal neighbours (zero padding)
+    off = torch.zeros(2, 18, 7, 9); off[:, 1::2] = 0.5
+    xp = F.pad(x, (1, 2, 1, 1))
+    torch.testing.assert_close(ref_cpu.deform_conv2d(x, off, w), F.conv2d(0.5 * (xp[..., :-1] + xp[..., 1:]), w), rtol=0, atol=2e-5)
+    # a tap thrown far outside the image contributes nothing
+    off = torch.zeros(2, 18, 7, 9); off[:, 8] = 100.0            # tap k = 4 (the centre): dy = +100
+    w_c = w.clone(); w_c[:, :, 1, 1] = 0
+    torch.testing.assert_close(ref_cpu.deform_conv2d(x, off, w), F.conv2d(x, w_c, padding=1), rtol=0, atol=2e-5)
