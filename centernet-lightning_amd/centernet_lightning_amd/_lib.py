@@ -17,6 +17,7 @@ CNL_UPSAMPLE_OUT_ADD = 1 << 3
 CNL_RELU6 = 1 << 4
 
 CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4
+ABI_VERSION = 2          # CNL_ABI_VERSION of include/centernet_gfx950.h
 
 
 class ConvParams(Structure):
@@ -115,6 +116,9 @@ def load():
             raise HipLibraryError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    if lib.cnl_version() != ABI_VERSION:
+        raise HipLibraryError(f"{path} has ABI version {lib.cnl_version()}, this binding expects {ABI_VERSION}: rebuild it "
+                              "(__graft_entry__.build())")
     _lib = lib
     return lib
 

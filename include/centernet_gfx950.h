@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 1
+#define CNL_ABI_VERSION 2   /* 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
