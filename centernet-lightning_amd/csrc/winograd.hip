@@ -11,13 +11,15 @@
 // which is 16 independent GEMMs, one per transform position xi = 4i+j:  M_xi[tile][co] = sum_ci V_xi[tile][ci] U_xi[co][ci].
 //
 // Workgroup = 8 waves = 8x8 tiles (16x16 output pixels of one image) x 64 output channels x all 16 positions; one
-// workgroup per CU (150 KB of LDS: V, U and the input patch are all double-buffered), two waves per SIMD.
+// workgroup per CU (86 KB of LDS: V and the input patch, both double-buffered), two waves per SIMD.
 // Per chunk of 8 input channels, ONE barrier:
-//   LDS-DMA   the 18x18x8 input patch of chunk cc+2 (zero halo from the buffer bounds check; optional nearest-2x source)
-//             and the U slice of chunk cc+1 ([xi][64 co][8 ci], pre-transformed and pre-packed once per weight load);
+//   LDS-DMA   the 18x18x8 input patch of chunk cc+2 (zero halo from the buffer bounds check; optional nearest-2x source);
 //   MFMA      wave w owns transform row i = w>>1 (positions 4i..4i+3) for cout group h = w&1 and both 32-tile groups:
-//             per position two A fragments + one B fragment, each ONE ds_read_b128 (lanes 0-31 take ci 0-3, lanes
-//             32-63 ci 4-7: four K=2 steps per read), 8 MFMAs; 32 MFMAs per wave per chunk;
+//             per position two A fragments (ONE ds_read_b128 each: lanes 0-31 take ci 0-3, lanes 32-63 ci 4-7, four K=2 steps
+//             per read) + one B fragment, 8 MFMAs; 32 MFMAs per wave per chunk.  The B (weight) fragments go global -> registers
+//             directly (U = [ci/8][xi][co][8], pre-transformed once per weight load): every U element is used by exactly one
+//             wave, so staging it in LDS (as this kernel first did) bought no reuse — dropping it removed 29 % of the LDS
+//             traffic and half of the LDS footprint at unchanged speed: LDS bandwidth is not what limits this loop;
 //   transform of chunk cc+1: thread = (tile, channel PAIR, output-row half) — packed fp32 adds (v_pk_add_f32), 8-byte LDS
 //             accesses; the two waves of a SIMD take output rows {0,1} / {2,3} of B^T d B (no redundant work): 6 ds_read2_b64,
 //             16 packed adds, 4 ds_write2st64_b64 per wave and chunk, placed in fenced slices among those MFMAs — the adds in two
@@ -65,12 +67,11 @@ constexpr int T = 64;                       // tiles per workgroup (8 x 8 -> 16 
 constexpr int BN = 64;                      // output channels per workgroup
 constexpr int PW = 18;                      // patch width / height in pixels
 constexpr int V_BYTES = 16 * T * 32;        // 32768 per buffer
-constexpr int U_BYTES = 16 * BN * 32;       // 32768 per buffer
 constexpr int PWP = 19;                     // padded patch row (pixels) of the LDS image [py][half][PWP][4 floats]: the 76-float
                                             // half-row stride makes the transform's 4x4 gathers bank-conflict-free
 constexpr int P_SLOTS = 704;                // 684 used; 512 (all waves) + 192 (waves 0-2)
 constexpr int P_BYTES = P_SLOTS * 16;       // 11264 per buffer
-constexpr int LDS_BYTES = 2 * V_BYTES + 2 * U_BYTES + 2 * P_BYTES;   // 153600 -> one 8-wave workgroup per CU
+constexpr int LDS_BYTES = 2 * V_BYTES + 2 * P_BYTES;                 // 88064: V and the patch; U never touches LDS (see the kernel)
 
 __device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* lds_dst, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
@@ -81,6 +82,11 @@ __device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* l
 __device__ __forceinline__ void dma16_plus1k(const float* base, unsigned bytes, char* lds_dst, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 1024, 0);
+}
+__device__ __forceinline__ f32x4 buf_load16(const float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
 }
 __device__ __forceinline__ float buf_load(const float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
@@ -106,6 +112,12 @@ __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// b * s + a with s = +-1 (exact: one rounding, the same result as the add / subtract it stands for)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 b, f32x2 s, f32x2 a) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(s), "v"(a));
+    return r;
+}
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
     f32x2 r;
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
@@ -115,8 +127,7 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
 __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sV = smem;                                  // [2][16 xi][64 tiles][8 ci]
-    char* sU = smem + 2 * V_BYTES;                    // [2][16 xi][64 co][8 ci]
-    char* sP = smem + 2 * V_BYTES + 2 * U_BYTES;      // [2][18 py][2 halves][19 px][4 ci] (+ slack)
+    char* sP = smem + 2 * V_BYTES;                    // [2][18 py][2 halves][19 px][4 ci] (+ slack)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -125,6 +136,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
     const int wi = wave >> 1, wh = wave & 1;          // transform row and cout group owned by this wave
     const bool up = a.flags & CNL_UPSAMPLE_IN;
     const unsigned u_chunk = (unsigned)(16 * a.CoutP * 8 * 4);          // bytes per channel chunk of U
+    const unsigned u_pos = (unsigned)(a.CoutP * 8 * 4);                 // bytes per transform position inside a chunk
 
     // transform item: thread -> (tile, channel PAIR, half): every add of B^T d B is one v_pk_add_f32 on two channels and every
     // LDS access 8 bytes wide.  The two halves of the workgroup (waves 0-3 / 4-7, one wave of each SIMD) produce output ROWS
@@ -132,25 +144,31 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
     // redundant work: 6 ds_read2_b64 + 16 v_pk_add_f32 + 4 ds_write2st64_b64 per wave and chunk (8 + 32 + 8 for one thread per
     // (tile, channel)).
     const int lt = tid & 255;
+    const int th = tid >> 8;                                           // transform half of this wave (waves 0-3: 0, 4-7: 1)
     const int t_cp = lt & 3, t_tile = lt >> 2;
     const int t_src = ((((2 * (t_tile >> 3)) * 2 + (t_cp >> 1)) * PWP + 2 * (t_tile & 7)) * 4 + (t_cp & 1) * 2) * 4;
+    // rows (r0, r1, r2) of the patch read by this half, chosen so that ONE instruction sequence serves both:
+    //   t0 = r0 - r2,  t1 = sg * r1 + r2   with  half 0: (d0, d1, d2), sg = +1   ->  d0 - d2, d1 + d2   (output rows 0, 1)
+    //                                            half 1: (d2, d3, d1), sg = -1   ->  d2 - d1, d1 - d3   (output rows 2, 3)
+    const int t_r0 = t_src + (th ? 2 : 0) * 2 * PWP * 16, t_r1 = t_src + (th ? 3 : 1) * 2 * PWP * 16, t_r2 = t_src + (th ? 1 : 2) * 2 * PWP * 16;
+    const float sgf = th ? -1.f : 1.f;
+    const f32x2 sg = {sgf, sgf};
     // V / U rows are 32 bytes = two 16-byte halves (ci 0-3 | ci 4-7); rows with bit 3 set store them swapped, which makes the
     // ds_read_b128 fragment reads (16-lane groups, 32-byte row pitch) bank-conflict-free
-    const int t_dst = (t_tile * 8 + (((t_cp >> 1) ^ ((t_tile >> 3) & 1)) << 2) + (t_cp & 1) * 2) * 4;
+    const int t_dst = (t_tile * 8 + (((t_cp >> 1) ^ ((t_tile >> 3) & 1)) << 2) + (t_cp & 1) * 2) * 4 + th * 8 * (T * 32);
     // chunk-0 transform (prologue, all threads): thread -> (tile = tid >> 3, ch = tid & 7)
     const int p_ch = tid & 7, p_tile = tid >> 3;
     const int p_src = ((((2 * (p_tile >> 3)) * 2 + (p_ch >> 2)) * PWP + 2 * (p_tile & 7)) * 4 + (p_ch & 3)) * 4;
     const int p_dst = (p_tile * 8 + (p_ch ^ (((p_tile >> 3) & 1) << 2))) * 4;
     const int hs = hi ^ ((lane >> 3) & 1);                             // physical half holding this lane's logical half
     const int fragA = ((lane & 31) * 8 + hs * 4) * 4;                  // + (xi*64 + g*32) * 32
-    const int fragB = ((wh * 32 + (lane & 31)) * 8 + hs * 4) * 4;      // + (xi*64) * 32
     const int xi0 = wi * 4;
     const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
 
     // ---- per-work-item bookkeeping: item -> (image n, tile-block row/col, cout block); cout fastest so that the workgroups
     // sharing an input patch run side by side; per-lane DMA source offsets of the patch and of the U slice ----
     int n, y0, x0, n0;
-    unsigned p_off[2], u_off[2];
+    unsigned p_off[2], u_off;
 #define WINO_SETUP(item_)                                                                                        \
     do {                                                                                                         \
         unsigned b_ = cnl::xcd_remap((item_), (unsigned)a.blocks);                                               \
@@ -167,8 +185,8 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
             const int sy_ = up ? (iy_ >> 1) : iy_, sx_ = up ? (ix_ >> 1) : ix_;   /* nearest-2x upsample folded in */ \
             p_off[i] = ok_ ? (unsigned)((((n * a.Hs + sy_) * a.Ws + sx_) * a.ldx + half_ * 4) * 4) : OOB;        \
         }                                                                                                        \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p)  /* lane -> (cout row lane>>1, half lane&1), swapped for rows with bit 3 */ \
-            u_off[p] = (unsigned)((((wave * 2 + p) * a.CoutP + n0) * 8) * 4 + (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) * 16)); \
+        /* this lane's B fragment of position xi: cout row n0 + wh*32 + (lane & 31), channel half hi */          \
+        u_off = (unsigned)((((xi0 * a.CoutP + n0 + wh * 32 + (lane & 31)) * 8) + hi * 4) * 4);                   \
     } while (0)
 #define WINO_ISSUE_P(cc_)                                                                                        \
     do {                                                                                                         \
@@ -180,16 +198,20 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
             if (wave < 3) dma16(a.x, a.x_bytes, d_ + (512 + wave * 64) * 16, p_off[1], (unsigned)((cc_) * 32));  \
         }                                                                                                        \
     } while (0)
-#define WINO_ISSUE_U(cc_)                                                                                        \
+    // B (weight) fragments never touch LDS: every U element is used by exactly one wave (positions x cout half partition U), so
+    // each wave loads its own fragments global -> registers, 16 bytes per lane and position, one chunk ahead: the slot of position
+    // j is refilled for chunk cc+1 right after position j's last MFMA of chunk cc.  No LDS write + read, no barrier dependency;
+    // the compiler orders uses after the loads with counted vmcnt waits of its own (VMEM returns in issue order) — which is why the
+    // chunk loop below has ONE body for both transform halves: with two loop bodies the register allocator reused fragment
+    // registers of one for other data in the other, and the inserted waits drained vmcnt to 0 in every chunk.
+#define WINO_LOAD_U(cc_, j_)                                                                                     \
     do {                                                                                                         \
-        char* d_ = sU + ((cc_) & 1) * U_BYTES;                                                                   \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                          \
-            dma16(a.u, a.u_bytes, d_ + (wave * 2 + p) * 2048, u_off[p], (unsigned)(cc_) * u_chunk);              \
-            dma16_plus1k(a.u, a.u_bytes, d_ + (wave * 2 + p) * 2048, u_off[p], (unsigned)(cc_) * u_chunk);       \
-        }                                                                                                        \
+        if ((cc_) < a.CC) fbU[j_] = buf_load16(a.u, a.u_bytes, u_off, (unsigned)(cc_) * u_chunk + (unsigned)(j_) * u_pos); \
     } while (0)
     // the 8 MFMAs of one position: k = 0..7 -> c = k >> 1, g = k & 1
-#define WINO_MFMA8(j_, fa_, fb_, k_) acc[j_][(k_) & 1] = mfma32((fa_)[(k_) & 1][(k_) >> 1], (fb_)[(k_) >> 1], acc[j_][(k_) & 1])
+#define WINO_MFMA8(j_, fa_, k_) acc[j_][(k_) & 1] = mfma32((fa_)[(k_) & 1][(k_) >> 1], fbU[j_][(k_) >> 1], acc[j_][(k_) & 1])
+    // workgroup barrier WITHOUT the vmcnt(0) that __syncthreads() adds while VMEM -> LDS transfers are in flight
+#define WINO_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
     // Persistent workgroups (grid = one per CU): the first chunk of the NEXT work item is fetched while the epilogue of the
     // current one runs, so only the very first item of a launch waits for HBM latency with an idle matrix pipe.
@@ -205,9 +227,12 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
 #define WTRACE_POST() do { } while (0)
 #endif
     unsigned item = blockIdx.x;
+    f32x4 fbU[4];            // B fragments of this wave's four positions (current chunk; refilled in a rolling fashion)
     WINO_SETUP(item);
     WINO_ISSUE_P(0);
-    WINO_ISSUE_U(0);
+    WINO_ISSUE_P(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) WINO_LOAD_U(0, j);
     bool first = true;
     while (true) {
         f32x16 acc[4][2];        // [position j of row wi][tile group]
@@ -216,13 +241,13 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
 #pragma unroll
             for (int g = 0; g < 2; ++g) acc[j][g] = mfma_zero();
 
-        // chunk 0 landed?  Its DMA is followed in this wave's VMEM queue by the second half of the previous item's epilogue
-        // (16 stores, +16 residual loads): a counted wait lets those stay in flight.
+        // patches 0 / 1 and the B fragments of chunk 0 landed?  They are followed in this wave's VMEM queue by the second half of the
+        // previous item's epilogue (16 stores, +16 residual loads): a counted wait lets those stay in flight.
         if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (a.res) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         first = false;
-        __syncthreads();
+        WINO_BARRIER();
         {   // input transform of chunk 0 (not overlapped with MFMAs)
             const char* src_ = sP + p_src;
             float d_[4][4], t_[4][4];
@@ -246,7 +271,6 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
                 *reinterpret_cast<float*>(dst_ + (i * 4 + 3) * (T * 32)) = t_[i][1] - t_[i][3];
             }
         }
-        if (a.CC > 1) WINO_ISSUE_P(1);
 
         // steady state: ONE barrier per chunk; MFMAs of chunk cc with the input transform of chunk cc+1 hand-interleaved, one
         // slice = {1 MFMA, 2 VALU | 1 LDS write}, slices fenced by sched_barrier(0): left to itself hipcc emits the whole
@@ -257,95 +281,83 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
 // costs the issuing wave ~14 cycles and each further one ~5 (tools/mfma_coexec.hip), so the adds go in few, dense bursts, and early
 // in the chunk, where the other wave of the SIMD is certain to have MFMAs to fill the pipe with.
 #define WS_RD 0      /* 6 ds_read2_b64 of the patch            */
-#define WS_DMA 1     /* DMA issue: U chunk, then patch (slice 2) */
+#define WS_DMA 2     /* patch DMA issue                          */
 #define WS_T 4       /* 8 packed adds: t = B^T d                */
-#define WS_TN 8
 #define WS_V 5       /* 8 packed adds: V = t B                  */
-#define WS_VN 8
 #define WS_W 6       /* 2 + 2 ds_write2st64_b64 (slices 6, 7)   */
-#define WS_WN 2
-#define WINO_CHUNK(H_)                                                                                                       \
+#define WINO_CHUNK()                                                                                                         \
         do {                                                                                                                 \
             const char* vB = sV + (cc & 1) * V_BYTES + fragA;                                                                \
-            const char* uB = sU + (cc & 1) * U_BYTES + fragB;                                                                \
-            const char* src_ = sP + ((cc + 1) & 1) * P_BYTES + t_src;                                                        \
+            const char* pB = sP + ((cc + 1) & 1) * P_BYTES;                                                                  \
             char* dst_ = sV + ((cc + 1) & 1) * V_BYTES + t_dst;                                                              \
-            f32x4 fa[2][2], fb[2];      /* double-buffered fragments: [buffer][tile group] */                                \
+            f32x4 fa[2][2];             /* double-buffered A fragments: [buffer][tile group] */                              \
             fa[0][0] = lds_f4(vB + (xi0 * 64) * 32); fa[0][1] = lds_f4(vB + (xi0 * 64 + 32) * 32);                           \
-            fb[0] = lds_f4(uB + (xi0 * 64) * 32);                                                                            \
             f32x2 d_[3][4], t_[2][4], v_[2][4];                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                               \
             _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                                 \
                 const int j = k >> 3, kk = k & 7, buf = j & 1;                                                               \
-                WINO_MFMA8(j, fa[buf], fb[buf], kk);                                                                         \
-                if (kk == 2 && j < 3) {                                 /* next position's fragments, 6 MFMAs ahead of use */ \
+                WINO_MFMA8(j, fa[buf], kk);                                                                                  \
+                if (kk == 7) WINO_LOAD_U(cc + 1, j);                    /* position j is done: refill its slot for the next chunk */ \
+                if (kk == 2 && j < 3) {                                 /* next position's A fragments, 6 MFMAs ahead of use */ \
                     fa[buf ^ 1][0] = lds_f4(vB + ((xi0 + j + 1) * 64) * 32);                                                 \
                     fa[buf ^ 1][1] = lds_f4(vB + ((xi0 + j + 1) * 64 + 32) * 32);                                            \
-                    fb[buf ^ 1] = lds_f4(uB + ((xi0 + j + 1) * 64) * 32);                                                    \
                 }                                                                                                            \
-                if (k == WS_RD) {                                       /* patch rows H_, H_+1, H_+2 of this half-item */    \
-                    _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                            \
-                        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) d_[m][jj] = lds_f2(src_ + (((H_) + m) * 2 * PWP + jj) * 16);\
-                }                                                                                                            \
-                if (k == WS_DMA) WINO_ISSUE_U(cc + 1);                                                                       \
-                if (k == WS_DMA + 1) WINO_ISSUE_P(cc + 2);                                                                   \
-                if (k >= WS_T && k < WS_T + 8 / WS_TN) {                /* t = B^T d: output rows 2H_, 2H_+1, four columns */\
-                    _Pragma("unroll") for (int e = WS_TN * (k - WS_T); e < WS_TN * (k - WS_T) + WS_TN; ++e) {                \
-                        const int ii = e >> 2, jj = e & 3;                                                                   \
-                        if ((H_) == 0) t_[ii][jj] = ii == 0 ? pk_sub(d_[0][jj], d_[2][jj]) : pk_add(d_[1][jj], d_[2][jj]);   \
-                        else t_[ii][jj] = ii == 0 ? pk_sub(d_[1][jj], d_[0][jj]) : pk_sub(d_[0][jj], d_[2][jj]);             \
+                if (k == WS_RD) {                                       /* three patch rows of this half-item */             \
+                    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                       \
+                        d_[0][jj] = lds_f2(pB + t_r0 + jj * 16);                                                             \
+                        d_[1][jj] = lds_f2(pB + t_r1 + jj * 16);                                                             \
+                        d_[2][jj] = lds_f2(pB + t_r2 + jj * 16);                                                             \
                     }                                                                                                        \
                 }                                                                                                            \
-                if (k >= WS_V && k < WS_V + 8 / WS_VN) {                /* V = t B ... */                                    \
-                    _Pragma("unroll") for (int e = WS_VN * (k - WS_V); e < WS_VN * (k - WS_V) + WS_VN; ++e) {                \
-                        const int ii = e >> 2, jj = e & 3;                                                                   \
-                        v_[ii][jj] = jj == 0 ? pk_sub(t_[ii][0], t_[ii][2]) : jj == 1 ? pk_add(t_[ii][1], t_[ii][2]) : jj == 2 ? pk_sub(t_[ii][2], t_[ii][1]) : pk_sub(t_[ii][1], t_[ii][3]);\
+                if (k == WS_DMA) WINO_ISSUE_P(cc + 2);                                                                       \
+                if (k == WS_T) {                                        /* t = B^T d: two output rows, four columns */       \
+                    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                       \
+                        t_[0][jj] = pk_sub(d_[0][jj], d_[2][jj]);                                                            \
+                        t_[1][jj] = pk_fma(d_[1][jj], sg, d_[2][jj]);                                                        \
                     }                                                                                                        \
                 }                                                                                                            \
-                if (k >= WS_W && k < WS_W + 4 / WS_WN) {                /* ... written as ds_write2st64_b64 pairs */         \
-                    _Pragma("unroll") for (int e = WS_WN * (k - WS_W); e < WS_WN * (k - WS_W) + WS_WN; ++e) {                \
-                        const int ii = e >> 1, jj = (e & 1) * 2;                                                             \
-                        *reinterpret_cast<f32x2*>(dst_ + (4 * (2 * (H_) + ii) + jj) * (T * 32)) = v_[ii][jj];                \
-                        *reinterpret_cast<f32x2*>(dst_ + (4 * (2 * (H_) + ii) + jj + 1) * (T * 32)) = v_[ii][jj + 1];        \
+                if (k == WS_V) {                                        /* V = t B ... */                                    \
+                    _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) {                                                       \
+                        v_[ii][0] = pk_sub(t_[ii][0], t_[ii][2]);                                                            \
+                        v_[ii][1] = pk_add(t_[ii][1], t_[ii][2]);                                                            \
+                        v_[ii][2] = pk_sub(t_[ii][2], t_[ii][1]);                                                            \
+                        v_[ii][3] = pk_sub(t_[ii][1], t_[ii][3]);                                                            \
                     }                                                                                                        \
+                }                                                                                                            \
+                if (k >= WS_W && k < WS_W + 2) {                        /* ... written as ds_write2st64_b64 pairs */         \
+                    const int ii = k - WS_W;                                                                                 \
+                    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                         \
+                        *reinterpret_cast<f32x2*>(dst_ + (4 * ii + jj) * (T * 32)) = v_[ii][jj];                             \
                 }                                                                                                            \
                 __builtin_amdgcn_sched_barrier(0);                                                                           \
             }                                                                                                                \
         } while (0)
 
+        // chunk top: this wave's share of patch cc+1 landed (4 newer loads: the B fragments) + barrier: V[cc&1] complete, patch cc+1
+        // complete, MFMA phase cc-1 and transform cc done everywhere.  Chunk 0 has nothing to wait for (item-start wait above).
+#define WINO_TOP()                                                                  \
+        do {                                                                        \
+            WTRACE_PRE();                                                           \
+            if (cc > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            \
+            WTRACE_MID();                                                           \
+            WINO_BARRIER();                                                         \
+            WTRACE_POST();                                                          \
+        } while (0)
         int cc = 0;
-        if (wave < 4) {          // H_ is a compile-time constant of the loop body (different instructions per half)
-            for (; cc + 1 < a.CC; ++cc) {
-                WTRACE_PRE();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                WTRACE_MID();
-                __syncthreads();     // V[cc&1] complete, U[cc&1] + patch cc+1 landed; MFMA phase cc-1 and transform cc done everywhere
-                WTRACE_POST();
-                WINO_CHUNK(0);
-            }
-        } else {
-            for (; cc + 1 < a.CC; ++cc) {
-                WTRACE_PRE();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                WTRACE_MID();
-                __syncthreads();
-                WTRACE_POST();
-                WINO_CHUNK(1);
-            }
+        for (; cc + 1 < a.CC; ++cc) {
+            WINO_TOP();
+            WINO_CHUNK();
         }
 #undef WINO_CHUNK
-        {   // last chunk: MFMAs only
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+        {   // last chunk: MFMAs only; its B fragments were requested during the previous chunk
+            WINO_BARRIER();
             const char* vB = sV + (cc & 1) * V_BYTES + fragA;
-            const char* uB = sU + (cc & 1) * U_BYTES + fragB;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 fa[1][2], fb[1];
+                f32x4 fa[1][2];
                 fa[0][0] = lds_f4(vB + ((xi0 + j) * 64) * 32); fa[0][1] = lds_f4(vB + ((xi0 + j) * 64 + 32) * 32);
-                fb[0] = lds_f4(uB + ((xi0 + j) * 64) * 32);
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) WINO_MFMA8(j, fa[0], fb[0], kk);
+                for (int kk = 0; kk < 8; ++kk) WINO_MFMA8(j, fa[0], kk);
             }
         }
 
@@ -360,11 +372,13 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
         const unsigned next = item + gridDim.x;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            __syncthreads();                                   // done reading V/U (g = 0) or sQ of the previous pass
-            if (g == 1 && next < (unsigned)a.blocks) {         // U and patch buffers are idle now: fetch the next item's chunk 0
+            WINO_BARRIER();                                    // done reading V (g = 0) or sQ of the previous pass
+            if (g == 1 && next < (unsigned)a.blocks) {         // fetch the next item's first two patches and first B fragments
                 WINO_SETUP(next);
                 WINO_ISSUE_P(0);
-                WINO_ISSUE_U(0);
+                WINO_ISSUE_P(1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) WINO_LOAD_U(0, j);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
                 sQ[((wi * 2 + 0) * 32 + tl) * 64 + wh * 32 + (lane & 31)] = m0 + m1 + m2;
                 sQ[((wi * 2 + 1) * 32 + tl) * 64 + wh * 32 + (lane & 31)] = m1 - m2 - m3;
             }
-            __syncthreads();
+            WINO_BARRIER();
             // Stage 2: thread = (tile, co): Y[a][c] = sum_i A^T[a][i] q[i][c]; 4 items per thread
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -425,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void winograd_conv_kernel(const WinoArgs a)
 #endif
 #undef WINO_MFMA8
 #undef WINO_ISSUE_P
-#undef WINO_ISSUE_U
+#undef WINO_LOAD_U
 #undef WINO_SETUP
 }
 
