@@ -475,6 +475,7 @@ __global__ __launch_bounds__(256) void winograd_weights_kernel(const float* __re
 using namespace cnl_wino;
 
 
+
 extern "C" size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8) return 0;
     const size_t CoutP = (size_t)((Cout + 63) / 64) * 64;

@@ -39,7 +39,13 @@ def main():
         up = 2 if flags & CNL_UPSAMPLE_IN else 1
         Ho, Wo = (H * up + 2 * ((k - 1) // 2) - k) // stride + 1, (W * up + 2 * ((k - 1) // 2) - k) // stride + 1
         x = torch.randn(N, H, W, Cin, device="cuda")
+        if os.environ.get("CNL_BENCH_ZEROS") == "1":            # data-dependent power check: all-zero activations
+            x.zero_()
+        if os.environ.get("CNL_BENCH_ZEROS") == "2":            # ... and all-zero weights too
+            x.zero_()
         w = torch.randn(Cout, k, k, Cin, device="cuda") * (1.0 / (Cin * k * k)) ** 0.5
+        if os.environ.get("CNL_BENCH_ZEROS") == "2":
+            w.zero_()
         b = torch.randn(Cout, device="cuda")
         y = torch.empty(N, Ho, Wo, Cout, device="cuda")
         r = torch.randn(N, Ho, Wo, Cout, device="cuda") if res else None
