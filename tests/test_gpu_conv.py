@@ -246,3 +246,44 @@ def test_winograd_exact_on_small_integers():
     w = torch.randint(-2, 3, (48, 16, 3, 3), generator=g).float() * 4
     b = torch.randint(-5, 6, (48,), generator=g).float()
     assert torch.equal(run_winograd(x, w, b, 0), ref_conv(x, w, b, 1, 0))
+
+
+def _fresh_lib(variant):
+    """A private handle of the library with CNL_WINO=<variant> read at its first Winograd call (the choice is cached per process
+    image, so each forced variant needs its own dlopen of a private copy)."""
+    import os
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp()
+    path = os.path.join(d, f"libcenternet_gfx950_v{variant}.so")
+    shutil.copy(_lib.lib_path(), path)
+    os.environ["CNL_WINO"] = str(variant)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _lib._SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def test_winograd_decompositions_are_bit_identical(monkeypatch):
+    """winograd.hip (16x16-pixel blocks) and winograd2.hip (8x16) do the same arithmetic in the same order: forced onto the same
+    inputs they must agree bit for bit — which is what makes the shape-based choice between them invisible (batch invariance,
+    shard == full batch)."""
+    import os
+    libs = {v: _fresh_lib(v) for v in (1, 2)}
+    os.environ.pop("CNL_WINO", None)
+    g = torch.Generator().manual_seed(5)
+    for (N, Cin, H, W, Cout, flags, use_res) in [(2, 64, 19, 34, 96, CNL_RELU, True), (1, 256, 38, 68, 256, CNL_RELU, False),
+                                                 (1, 16, 7, 5, 20, 0, False), (2, 32, 12, 20, 64, CNL_RELU | CNL_UPSAMPLE_IN, False)]:
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * (1.0 / (Cin * 9)) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        up = 2 if flags & CNL_UPSAMPLE_IN else 1
+        res = torch.randn(N, Cout, H * up, W * up, generator=g) if use_res else None
+        outs = []
+        for v in (1, 2):
+            monkeypatch.setattr(_lib, "_lib", libs[v])
+            outs.append(run_winograd(x, w, b, flags, res))
+        monkeypatch.undo()
+        assert torch.equal(outs[0], outs[1]), (N, Cin, H, W, Cout)
+        torch.testing.assert_close(outs[0], ref_conv(x, w, b, 1, flags, res), rtol=RTOL, atol=ATOL)
