@@ -11,7 +11,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
               (`--config fpn --batch 64` = C2/C3, `--config tracking --batch 32 --height 608 --width 1088` = C4).
   value     = total images / max-over-ranks wall time of the K timed steps (weak scaling: batch per GPU fixed).
   roofline  = the dominant kernel by time, measured with HIP events on the launch stream around every launch of one step:
-              `cnl_wino::winograd_conv_kernel` (3x3/s1 layers, Winograd F(2x2,3x3) on fp32 MFMA).  `achieved` counts the
+              `cnl_wino2::winograd2_kernel` (3x3/s1 layers, Winograd F(2x2,3x3) on fp32 MFMA).  `achieved` counts the
               matrix-core flops the kernel EXECUTES (direct-conv flops x 16/36), so `frac` is an honest hardware fraction;
               `effective_tflops` is the same time against the direct-conv (algorithmic) flops.  The direct implicit-GEMM
               kernel (`cnl_conv::conv_mfma_kernel`, remaining layers) is reported next to it.
@@ -33,11 +33,11 @@ import torch.distributed as dist  # noqa: E402
 import centernet_lightning_amd as cl  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
-# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_v4.txt): per kernel, mean
+# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_final3.txt): per kernel, mean
 # FETCH_SIZE x 2 (gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md §HBM) + mean WRITE_SIZE over the launches
-# of a C1 step (Winograd: 149.6 MB x 2 + 129.1 MB).  Other configs: not profiled -> null.
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("simple", 32, 512, 512, "cnl_conv::conv_mfma_kernel"): 238.7e6,
-                                     ("simple", 32, 512, 512, "cnl_wino::winograd_conv_kernel"): 450.2e6}
+# of a C1 step (Winograd: 188.6 MB x 2 + 127.9 MB).  Other configs: not profiled -> null.
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("simple", 32, 512, 512, "cnl_conv::conv_mfma_kernel"): 237.0e6,
+                                     ("simple", 32, 512, 512, "cnl_wino2::winograd2_kernel"): 505.1e6}
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 
 
@@ -235,7 +235,7 @@ def main():
         direct_tf = fl_d / (ms_d * 1e-3) / 1e12 if ms_d else 0.0
         if ms_w >= ms_d:          # dominant kernel: Winograd
             exec_tf = fl_w * (16.0 / 36.0) / (ms_w * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "cnl_wino::winograd_conv_kernel (F(2x2,3x3), fp32 v_mfma_f32_32x32x2_f32)",
+            roof = {"bound": "mfma", "kernel": "cnl_wino2::winograd2_kernel (F(2x2,3x3), fp32 v_mfma_f32_32x32x2_f32)",
                     "achieved": round(exec_tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(exec_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                     "achieved_counts": "executed matrix-core flops = direct-conv flops x 16/36",
@@ -249,7 +249,7 @@ def main():
                     "kernel_ms_per_step": round(ms_d, 3), "algorithmic_gflop_per_step": round(fl_d / 1e9, 2),
                     "avg_launch_us": round(ms_d * 1e3 / max(n_d, 1), 2)}
         roof["traffic"] = MEASURED_TRAFFIC_BYTES_PER_LAUNCH.get((args.config, B, H, W, roof["kernel"].split(" ")[0]))
-        roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic_final2.txt)"
+        roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic_final3.txt)"
         roof["algorithmic_bytes_per_launch"] = round(conv_bytes / n_launch)
         roof["sustained_clock_note"] = "chip sustains ~2.1 GHz under this load (DVFS; profiles/r01_mfma_peak_onbox.txt), i.e. ~140 TFLOP/s ceiling"
         roof["other_kernels"] = {"cnl_conv::conv_mfma_kernel": {"launches_per_step": n_d, "kernel_ms_per_step": round(ms_d, 3),

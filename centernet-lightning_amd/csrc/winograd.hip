@@ -532,13 +532,13 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.flags = p->flags;
-    // Two work decompositions of the same arithmetic (bit-identical results): this file's 16x16-pixel blocks (one 8-wave workgroup
-    // per CU) and winograd2.hip's 8x16-pixel blocks (two 4-wave workgroups per CU).  They run equally fast per padded pixel, so the
-    // choice is the one that pads the map less — a function of the layer shape only, never of the batch size (batch invariance).
-    static const int forced = getenv("CNL_WINO") ? atoi(getenv("CNL_WINO")) : 0;       // 1 / 2: force a variant (tests, A/B)
-    const long long pad16 = (long long)((a.H + 15) / 16 * 16) * ((a.W + 15) / 16 * 16);
-    const long long pad8 = (long long)((a.H + 7) / 8 * 8) * ((a.W + 15) / 16 * 16);
-    if (forced == 2 || (forced == 0 && pad8 < pad16)) return cnl_wino2_launch(p, cnl_winograd_weight_floats(p->Cin, p->Cout), stream);
+    // Two work decompositions of the same arithmetic (bit-identical results): winograd2.hip's 8x16-pixel blocks (two independent
+    // 4-wave workgroups per CU) and this file's 16x16-pixel blocks (one 8-wave workgroup per CU).  Measured per layer
+    // (profiles/r01_winograd_variants.txt) the 8x16 form is never slower — equal on the 128x128 head maps, 3-4 % faster on the
+    // backbone maps, 1.75x on 16x16 maps where 16x16 blocks leave CUs idle — so it is the default for every shape; the choice
+    // never depends on the batch size (batch invariance).  CNL_WINO=1 selects the 16x16 form (bit-identity test, A/B runs).
+    static const int forced = getenv("CNL_WINO") ? atoi(getenv("CNL_WINO")) : 0;
+    if (forced != 1) return cnl_wino2_launch(p, cnl_winograd_weight_floats(p->Cin, p->Cout), stream);
     static bool attr_done = false;
     if (!attr_done) {
         CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -21,6 +21,8 @@ SHAPES = {
     "layer2": (32, 64, 64, 128, 128, 3, 1, CNL_RELU, True),
     "layer3": (32, 32, 32, 256, 256, 3, 1, CNL_RELU, True),
     "layer4": (32, 16, 16, 512, 512, 3, 1, CNL_RELU, True),
+    "big256px": (8, 256, 256, 64, 64, 3, 1, CNL_RELU, False),
+    "neck0": (32, 16, 16, 512, 256, 3, 1, CNL_RELU, False),
     "out80": (32, 128, 128, 256, 80, 1, 1, CNL_SIGMOID, False),
     "out4": (32, 128, 128, 256, 4, 1, 1, 0, False),
 }
