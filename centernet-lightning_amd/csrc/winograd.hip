@@ -475,13 +475,20 @@ __global__ __launch_bounds__(256) void winograd_weights_kernel(const float* __re
 using namespace cnl_wino;
 
 int cnl_wino2_launch(const cnl_conv_params* p, size_t u_floats, void* stream);     // winograd2.hip
+size_t cnl_wino3_weight_bytes(int Cin, int Cout);                                  // winograd3.hip
+int cnl_wino3_transform_weights(const float* w_ohwi, void* u3, int Cin, int Cout, void* stream);
+int cnl_wino3_launch(const cnl_conv_params* p, const void* u3, void* stream);
 
+// floats of the fp32 U = [ci/8][xi][CoutP][8]; the bf16-split copy for winograd3.hip (layers with Cin % 16 == 0) follows it
+static size_t wino_f32_floats(int Cin, int Cout) {
+    const size_t CoutP = (size_t)((Cout + 63) / 64) * 64;
+    return (size_t)(Cin / 8) * 16 * CoutP * 8;
+}
 
 
 extern "C" size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8) return 0;
-    const size_t CoutP = (size_t)((Cout + 63) / 64) * 64;
-    return (size_t)(Cin / 8) * 16 * CoutP * 8;
+    return wino_f32_floats(Cin, Cout) + cnl_wino3_weight_bytes(Cin, Cout) / 4;
 }
 
 extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream) {
@@ -491,7 +498,9 @@ extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u,
     const long total = (long)CoutP * Cin;
     hipLaunchKernelGGL(winograd_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_ohwi, u, Cin,
                        Cout, CoutP);
-    return cnl::check_launch("winograd_weights_kernel");
+    const int rc = cnl::check_launch("winograd_weights_kernel");
+    if (rc != CNL_OK || Cin % 16) return rc;
+    return cnl_wino3_transform_weights(w_ohwi, u + wino_f32_floats(Cin, Cout), Cin, Cout, stream);
 }
 
 extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) {
@@ -523,7 +532,7 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
 #endif
     a.blocks = (int)blocks;
     const unsigned long long xb = (((unsigned long long)p->N * p->H_in * p->W_in - 1) * p->ldx + p->Cin) * 4ull;
-    const unsigned long long ub = (unsigned long long)cnl_winograd_weight_floats(p->Cin, p->Cout) * 4ull;
+    const unsigned long long ub = (unsigned long long)wino_f32_floats(p->Cin, p->Cout) * 4ull;
     const unsigned long long Mo = (unsigned long long)p->N * a.H * a.W;
     const unsigned long long yb = ((Mo - 1) * p->ldy + p->Cout) * 4ull;
     const unsigned long long rb = p->residual ? ((Mo - 1) * p->ldr + p->Cout) * 4ull : 0ull;
@@ -538,7 +547,8 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
     // backbone maps, 1.75x on 16x16 maps where 16x16 blocks leave CUs idle — so it is the default for every shape; the choice
     // never depends on the batch size (batch invariance).  CNL_WINO=1 selects the 16x16 form (bit-identity test, A/B runs).
     static const int forced = getenv("CNL_WINO") ? atoi(getenv("CNL_WINO")) : 0;
-    if (forced != 1) return cnl_wino2_launch(p, cnl_winograd_weight_floats(p->Cin, p->Cout), stream);
+    if (forced == 3 && p->Cin % 16 == 0) return cnl_wino3_launch(p, p->w + wino_f32_floats(p->Cin, p->Cout), stream);
+    if (forced != 1) return cnl_wino2_launch(p, wino_f32_floats(p->Cin, p->Cout), stream);
     static bool attr_done = false;
     if (!attr_done) {
         CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
