@@ -10,11 +10,15 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
   workload  = BASELINE.json configs[1] (C1): ResNet34 + simple upsample neck, batch 32 per GPU, 512x512, 80 classes
               (`--config fpn --batch 64` = C2/C3, `--config tracking --batch 32 --height 608 --width 1088` = C4).
   value     = total images / max-over-ranks wall time of the K timed steps (weak scaling: batch per GPU fixed).
-  roofline  = the dominant kernel by time, measured with HIP events on the launch stream around every launch of one step:
-              `cnl_wino2::winograd2_kernel` (3x3/s1 layers, Winograd F(2x2,3x3) on fp32 MFMA).  `achieved` counts the
-              matrix-core flops the kernel EXECUTES (direct-conv flops x 16/36), so `frac` is an honest hardware fraction;
-              `effective_tflops` is the same time against the direct-conv (algorithmic) flops.  The direct implicit-GEMM
-              kernel (`cnl_conv::conv_mfma_kernel`, remaining layers) is reported next to it.
+  roofline  = the dominant kernel by time, measured with HIP events on the launch stream around every launch of one step.  The
+              3x3/s1 layers run Winograd F(2x2,3x3) on one of two multiplier arrays, chosen per layer SHAPE (include/centernet_gfx950.h):
+              `cnl_wino3::winograd3_kernel` (Cin >= 256: fp32 operands split EXACTLY into three bf16 pieces, six bf16 MFMAs per
+              product, fp32 accumulation — fp32-grade accuracy on the 16x faster bf16 matrix core; peak = 2.5 PFLOP/s dense bf16) or
+              `cnl_wino2::winograd2_kernel` (fp32 MFMA, peak 157.3).  `achieved` counts the matrix-core flops the kernel EXECUTES
+              (direct-conv flops x 16/36, x 6 for the split), so `frac` is an honest hardware fraction; `effective_tflops` is the same
+              time against the direct-conv (algorithmic) flops.  The other conv kernels are reported under `other_kernels`.
+  dtype     = "f32": inputs, weights, accumulation and outputs are fp32 and every product is formed to fp32 accuracy (the dropped
+              split terms are <= 2^-24 relative); `cpu_baseline.sample` carries the max |GPU - CPU oracle| of this very run.
   cpu_baseline = the CPU oracle (oracle/ref_cpu.py + oracle/decode_ref.py: the plain PyTorch restatement of the
               reference path — kind "port") timed on this box's host cores on a bounded sample; rank 0, N=1 only.
 """
@@ -33,11 +37,13 @@ import torch.distributed as dist  # noqa: E402
 import centernet_lightning_amd as cl  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
-# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_final3.txt): per kernel, mean
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16), 16x the fp32 MFMA rate
+# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_final4.txt): per kernel, mean
 # FETCH_SIZE x 2 (gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md §HBM) + mean WRITE_SIZE over the launches
-# of a C1 step (Winograd: 188.6 MB x 2 + 127.9 MB).  Other configs: not profiled -> null.
+# of a C1 step (bf16-split Winograd: 300.0 MB x 2 + 131.4 MB = 731.5 MB).  Other configs: not profiled -> null.
 MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("simple", 32, 512, 512, "cnl_conv::conv_mfma_kernel"): 237.0e6,
-                                     ("simple", 32, 512, 512, "cnl_wino2::winograd2_kernel"): 505.1e6}
+                                     ("simple", 32, 512, 512, "cnl_wino2::winograd2_kernel"): 312.8e6,
+                                     ("simple", 32, 512, 512, "cnl_wino3::winograd3_kernel"): 731.5e6}
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 
 
@@ -101,10 +107,14 @@ def conv_kernel_profile(model, x, reps=3):
         torch.cuda.synchronize()
         for i, (e0, e1) in enumerate(evs):
             acc[i] += e0.elapsed_time(e1)
-    rows = [(L.what, L.flops * scale, acc[i] / reps * scale, "winograd" if L.fn is lib.cnl_conv3x3_winograd_f32 else "direct")
-            for i, L in enumerate(convs)]
+    def kind(L):
+        if L.fn is not lib.cnl_conv3x3_winograd_f32:
+            return "direct"
+        return "winograd_bf16x3" if lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)) == 3 else "winograd_f32"
+    rows = [(L.what, L.flops * scale, acc[i] / reps * scale, kind(L)) for i, L in enumerate(convs)]
     # algorithmic HBM bytes of a conv launch: input + weights + bias + output (+ residual), each touched once
     nbytes = 0
+    bytes_by_kind = {}
     for L in convs:
         p = L.args
         up_in = 2 if p.flags & 4 else 1
@@ -112,9 +122,11 @@ def conv_kernel_profile(model, x, reps=3):
         wo = (p.W_in * up_in + 2 * p.pad - p.KW) // p.stride + 1
         up_out = 4 if p.flags & 8 else 1
         out_px = p.N * ho * wo * up_out
-        nbytes += 4 * (p.N * p.H_in * p.W_in * p.Cin + p.Cout * p.KH * p.KW * p.Cin + p.Cout + out_px * p.Cout
-                       + (out_px * p.Cout if p.residual else 0))
-    return sum(r[2] for r in rows), sum(r[1] for r in rows), len(rows), rows, nbytes * scale
+        b_ = 4 * (p.N * p.H_in * p.W_in * p.Cin + p.Cout * p.KH * p.KW * p.Cin + p.Cout + out_px * p.Cout
+                  + (out_px * p.Cout if p.residual else 0))
+        nbytes += b_
+        bytes_by_kind[kind(L)] = bytes_by_kind.get(kind(L), 0) + b_ * scale
+    return sum(r[2] for r in rows), sum(r[1] for r in rows), len(rows), rows, bytes_by_kind
 
 
 def cpu_baseline(model, tracking, k, H, W, budget_s=20.0):
@@ -230,18 +242,32 @@ def main():
             ms = sum(r[2] for r in sel)
             fl = sum(r[1] for r in sel)
             return len(sel), ms, fl
-        n_w, ms_w, fl_w = agg("winograd")
+        n_w, ms_w, fl_w = agg("winograd_f32")
+        n_b, ms_b, fl_b = agg("winograd_bf16x3")
         n_d, ms_d, fl_d = agg("direct")
         direct_tf = fl_d / (ms_d * 1e-3) / 1e12 if ms_d else 0.0
-        if ms_w >= ms_d:          # dominant kernel: Winograd
-            exec_tf = fl_w * (16.0 / 36.0) / (ms_w * 1e-3) / 1e12
+        f32_exec_tf = fl_w * (16.0 / 36.0) / (ms_w * 1e-3) / 1e12 if ms_w else 0.0
+        if ms_b >= ms_w and ms_b >= ms_d:      # dominant kernel: Winograd on the bf16 matrix cores (exact 3-way split, 6 MFMAs per product)
+            exec_tf = fl_b * (16.0 / 36.0) * 6.0 / (ms_b * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "cnl_wino3::winograd3_kernel (F(2x2,3x3); fp32 operands split exactly into 3 bf16 pieces, "
+                                               "6 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)",
+                    "achieved": round(exec_tf, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(exec_tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                    "achieved_counts": "executed bf16 matrix-core flops = direct-conv flops x 16/36 (Winograd) x 6 (split terms)",
+                    "effective_tflops": round(fl_b / (ms_b * 1e-3) / 1e12, 2),
+                    "launches_per_step": n_b, "kernel_ms_per_step": round(ms_b, 3),
+                    "algorithmic_gflop_per_step": round(fl_b / 1e9, 2), "avg_launch_us": round(ms_b * 1e3 / n_b, 2),
+                    "sustained_clock_note": "the chip sustains ~1.6-1.65 GHz under this kernel (power-limited DVFS; tools/wino3_trace.py): "
+                                            "bf16 ceiling at that clock ~1.7 PFLOP/s"}
+        elif ms_w >= ms_d:          # dominant kernel: Winograd on the fp32 matrix cores
             roof = {"bound": "mfma", "kernel": "cnl_wino2::winograd2_kernel (F(2x2,3x3), fp32 v_mfma_f32_32x32x2_f32)",
-                    "achieved": round(exec_tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(exec_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "achieved": round(f32_exec_tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(f32_exec_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                     "achieved_counts": "executed matrix-core flops = direct-conv flops x 16/36",
                     "effective_tflops": round(fl_w / (ms_w * 1e-3) / 1e12, 2),
                     "launches_per_step": n_w, "kernel_ms_per_step": round(ms_w, 3),
-                    "algorithmic_gflop_per_step": round(fl_w / 1e9, 2), "avg_launch_us": round(ms_w * 1e3 / n_w, 2)}
+                    "algorithmic_gflop_per_step": round(fl_w / 1e9, 2), "avg_launch_us": round(ms_w * 1e3 / n_w, 2),
+                    "sustained_clock_note": "chip sustains ~2.1 GHz under this load (DVFS; profiles/r01_mfma_peak_onbox.txt), i.e. ~140 TFLOP/s ceiling"}
         else:
             roof = {"bound": "mfma", "kernel": "cnl_conv::conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
                     "achieved": round(direct_tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -249,10 +275,14 @@ def main():
                     "kernel_ms_per_step": round(ms_d, 3), "algorithmic_gflop_per_step": round(fl_d / 1e9, 2),
                     "avg_launch_us": round(ms_d * 1e3 / max(n_d, 1), 2)}
         roof["traffic"] = MEASURED_TRAFFIC_BYTES_PER_LAUNCH.get((args.config, B, H, W, roof["kernel"].split(" ")[0]))
-        roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic_final3.txt)"
-        roof["algorithmic_bytes_per_launch"] = round(conv_bytes / n_launch)
-        roof["sustained_clock_note"] = "chip sustains ~2.1 GHz under this load (DVFS; profiles/r01_mfma_peak_onbox.txt), i.e. ~140 TFLOP/s ceiling"
-        roof["other_kernels"] = {"cnl_conv::conv_mfma_kernel": {"launches_per_step": n_d, "kernel_ms_per_step": round(ms_d, 3),
+        roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic_final4.txt)"
+        dom = "winograd_bf16x3" if "wino3" in roof["kernel"] else ("winograd_f32" if "wino2" in roof["kernel"] else "direct")
+        roof["algorithmic_bytes_per_launch"] = round(conv_bytes.get(dom, 0) / max(roof["launches_per_step"], 1))
+        roof["other_kernels"] = {"cnl_wino2::winograd2_kernel (fp32 MFMA)": {"launches_per_step": n_w, "kernel_ms_per_step": round(ms_w, 3),
+                                                                             "achieved_tflops_executed": round(f32_exec_tf, 2),
+                                                                             "frac_of_fp32_mfma_peak": round(f32_exec_tf / FP32_MFMA_PEAK_TFLOPS, 4)},
+                                 "cnl_wino3::winograd3_kernel (bf16 MFMA, exact split)": {"launches_per_step": n_b, "kernel_ms_per_step": round(ms_b, 3)},
+                                 "cnl_conv::conv_mfma_kernel": {"launches_per_step": n_d, "kernel_ms_per_step": round(ms_d, 3),
                                                                 "achieved_tflops": round(direct_tf, 2)}}
         ms_per_step = elapsed / args.steps * 1e3
         result = {
@@ -262,7 +292,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded rand images; random-init weights of the named architecture)",
+            "dtype": "f32",
+            "dtype_note": "fp32 in / fp32 accumulate / fp32 out; 3x3 layers with Cin >= 256 form each fp32 product on the bf16 matrix cores from the "
+                          "exact 3-way bf16 split of both operands (6 cross terms, error <= the fp32 MFMA's: tools/bf16x3_probe.hip, "
+                          "tests/test_gpu_conv.py::test_winograd_bf16x3_error_not_above_fp32_mfma)",
+            "data": "synthetic (seeded rand images; random-init weights of the named architecture)",
             "config": {"workload": f"BASELINE C{'1' if args.config == 'simple' else ('4' if tracking else '2/3')}: ResNet34 + {args.config} neck, "
                                    f"{B} img/GPU x {H}x{W}, heads {'2+4+reid64' if tracking else '80+4'} (w256), k={args.k}, nms 3",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of detections" if world > 1 else "")},

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "cnl_conv2d_nhwc_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
     "cnl_conv2d_out_hw": (ctypes.c_int, [POINTER(ConvParams), POINTER(c_int32), POINTER(c_int32)]),
     "cnl_conv3x3_winograd_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
+    "cnl_conv3x3_winograd_kernel": (ctypes.c_int, [POINTER(ConvParams)]),
     "cnl_winograd_weight_floats": (c_size_t, [c_int32, c_int32]),
     "cnl_winograd_transform_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "cnl_deconv2x_nhwc_f32": (ctypes.c_int, [POINTER(DeconvParams), c_void_p]),

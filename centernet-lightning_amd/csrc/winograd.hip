@@ -503,6 +503,17 @@ extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u,
     return cnl_wino3_transform_weights(w_ohwi, u + wino_f32_floats(Cin, Cout), Cin, Cout, stream);
 }
 
+extern "C" int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p) {
+    CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: null params");
+    CNL_REQUIRE(p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: non-positive dimension");
+    static const int forced = getenv("CNL_WINO") ? atoi(getenv("CNL_WINO")) : 0;
+    const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
+    const int H = p->H_in * upf, W = p->W_in * upf, CoutP = (p->Cout + 63) / 64 * 64;
+    const int items_per_image = ((H + 15) / 16) * ((W + 15) / 16) * (CoutP / 64);
+    const bool bf16x3 = p->Cin % 16 == 0 && (forced == 3 || (forced == 0 && p->Cin >= 256 && items_per_image >= 8));
+    return bf16x3 ? CNL_WINO_BF16X3 : CNL_WINO_F32;
+}
+
 extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) {
     CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: null params");
     CNL_REQUIRE(p->x && p->w && p->bias && p->y, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: null tensor pointer");
@@ -541,13 +552,16 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.flags = p->flags;
-    // Two work decompositions of the same arithmetic (bit-identical results): winograd2.hip's 8x16-pixel blocks (two independent
-    // 4-wave workgroups per CU) and this file's 16x16-pixel blocks (one 8-wave workgroup per CU).  Measured per layer
-    // (profiles/r01_winograd_variants.txt) the 8x16 form is never slower — equal on the 128x128 head maps, 3-4 % faster on the
-    // backbone maps, 1.75x on 16x16 maps where 16x16 blocks leave CUs idle — so it is the default for every shape; the choice
-    // never depends on the batch size (batch invariance).  CNL_WINO=1 selects the 16x16 form (bit-identity test, A/B runs).
+    // Three kernels behind this entry point.  winograd3.hip forms the fp32 products on the bf16 matrix cores (exact three-way
+    // bf16 split, six cross terms, fp32 accumulation: error at or below that of the fp32 MFMA, see its header) in 16x16-pixel x
+    // 64-cout work items with a sizeable fixed cost per item; measured per layer (profiles/r01_winograd_variants.txt) it wins
+    // where the channel loop is long and an image supplies enough items: Cin >= 256 and >= 8 items per image (head blocks 256 ->
+    // 256 on 128x128: -16 %, layer3 -16 %, layer4 -22 %); it loses on Cin = 64 layers (+14 %) and on 16x16 maps with few cout
+    // blocks.  Everything else takes winograd2.hip (fp32 MFMA, 8x16-pixel blocks, two 4-wave workgroups per CU), which is never
+    // slower than this file's 16x16-pixel form (bit-identical to it; CNL_WINO=1 selects it for the bit-identity test).  The
+    // choice is a function of the layer shape alone, never of the batch size (batch invariance).  CNL_WINO=1|2|3 forces a kernel.
     static const int forced = getenv("CNL_WINO") ? atoi(getenv("CNL_WINO")) : 0;
-    if (forced == 3 && p->Cin % 16 == 0) return cnl_wino3_launch(p, p->w + wino_f32_floats(p->Cin, p->Cout), stream);
+    if (cnl_conv3x3_winograd_kernel(p) == CNL_WINO_BF16X3) return cnl_wino3_launch(p, p->w + wino_f32_floats(p->Cin, p->Cout), stream);
     if (forced != 1) return cnl_wino2_launch(p, wino_f32_floats(p->Cin, p->Cout), stream);
     static bool attr_done = false;
     if (!attr_done) {

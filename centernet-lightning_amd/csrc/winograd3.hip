@@ -46,8 +46,8 @@
 #ifndef W3_EXP_NOOPS
 #define W3_EXP_NOOPS 0
 #endif
-#ifndef W3_PRO_PIPE
-#define W3_PRO_PIPE 1
+#ifndef W3_HOLD_T
+#define W3_HOLD_T 1
 #endif
 #ifndef W3_EPI_HOIST
 #define W3_EPI_HOIST 1
@@ -128,17 +128,31 @@ __device__ __forceinline__ u32x4 lds_u4(const char* p) { return *reinterpret_cas
 struct Xf {
     f32x4 da[2][3], db[2][3];       // [register set][column]: rows ra / rb of the patch (read one pass-item ahead)
     f32x4 t[3], v[2];
+    f32x4 th[4][2];                 // t of patch columns 1, 2 of each item, kept from pass 0 for pass 1 (W3_HOLD_T)
     float h[4], r[4], l[4];
     unsigned pk[2][3][2];           // [position of the pair][piece][channel pair]
 };
-__device__ __forceinline__ void xop(Xf& s, const int set, const int P, const int op, const float sg) {
+__device__ __forceinline__ void xop(Xf& s, const int set, const int P, const int op, const float sg, const int it = 0) {
     if (op < 12) {
         const int c = op >> 2, e = op & 3;
+#if W3_HOLD_T
+        // pass 0 computes t of columns 0, 1, 2 and keeps 1, 2; pass 1 computes only column 3 (read into slot 2 of the set)
+        if (P == 0) {
+            const float t_ = __builtin_fmaf(s.db[set][c][e], sg, s.da[set][c][e]);
+            if (c == 0) s.t[0][e] = t_; else s.th[it][c - 1][e] = t_;
+        } else if (c == 2) s.t[2][e] = __builtin_fmaf(s.db[set][2][e], sg, s.da[set][2][e]);
+#else
         s.t[c][e] = __builtin_fmaf(s.db[set][c][e], sg, s.da[set][c][e]);
+#endif
     } else if (op < 20) {
         const int vi = (op - 12) >> 2, e = op & 3;
+#if W3_HOLD_T
+        if (P == 0) s.v[vi][e] = vi == 0 ? s.t[0][e] - s.th[it][1][e] : s.th[it][0][e] + s.th[it][1][e];
+        else s.v[vi][e] = vi == 0 ? s.th[it][1][e] - s.th[it][0][e] : s.th[it][0][e] - s.t[2][e];
+#else
         if (P == 0) s.v[vi][e] = vi == 0 ? s.t[0][e] - s.t[2][e] : s.t[1][e] + s.t[2][e];
         else s.v[vi][e] = vi == 0 ? s.t[1][e] - s.t[0][e] : s.t[0][e] - s.t[2][e];
+#endif
     } else if (op < 64) {
         // per v[vi] 22 operations, ordered so that consecutive ones are independent (a dependent VALU instruction issues ~4 cycles
         // later than an independent one): the four elements advance through the split side by side
@@ -248,6 +262,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // patch reads of pass-item (P_, it_) into register set set_; pa_ / pb_ = patch buffer + src_a / src_b
 #define W3_X_READ1(set_, pa_, pb_, P_, it_, c_, row_)                                                            \
     do {                                                                                                         \
+        if (W3_HOLD_T && (P_) == 1 && (c_) != 2) break;                                                          \
         if ((row_) == 0) xf.da[set_][c_] = lds_f4((pa_) + (it_) * IT_STRIDE + ((P_) + (c_)) * 16);               \
         else xf.db[set_][c_] = lds_f4((pb_) + (it_) * IT_STRIDE + ((P_) + (c_)) * 16);                           \
     } while (0)
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (JOBS_) {                                                                                         \
                 if (k < 6 && !W3_EXP_NOXR) W3_X_READ1(1, pa, pb, P_, (it0_) + 1, k >> 1, k & 1);                 \
                 if (ks < 11) {                                                                                   \
-                    if (!W3_EXP_NOOPS) { _Pragma("unroll") for (int o_ = 0; o_ < 6; ++o_) xop(xf, pi, P_, ks * 6 + o_, sg); } \
+                    if (!W3_EXP_NOOPS) { _Pragma("unroll") for (int o_ = 0; o_ < 6; ++o_) xop(xf, pi, P_, ks * 6 + o_, sg, (it0_) + pi); } \
                 } else if (!W3_EXP_NOXW) {                                                                       \
                     if (pi == 0) { W3_X_WRITE(P_, it0_); } else { W3_X_WRITE(P_, (it0_) + 1); }                  \
                 }                                                                                                \
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } while (0)
 
 #ifdef CNL_W3TRACE
-    long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = clock64(), tr_m = 0;
+    long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_t = clock64(), tr_m = 0;
     const long long tr_start = tr_t;
 #define W3T(i_) do { const long long c_ = clock64(); tr[i_] += c_ - tr_t; tr_t = c_; } while (0)
 #define W3T_MID0() do { tr_m = clock64(); } while (0)
@@ -345,7 +360,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         first = false;
         W3_BARRIER();                                         // ... and everybody's
         W3T(1);
-#if W3_PRO_PIPE
         {   // input transform of chunk 0, all four positions (not overlapped with MFMAs): eight pass-items, each read one ahead
             const char* pa = sP + src_a;
             const char* pb = sP + src_b;
@@ -355,26 +369,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const int it = g >> 1, P = g & 1, set = g & 1;
                 if (g < 7) { W3_X_READ(set ^ 1, pa, pb, (g + 1) & 1, (g + 1) >> 1); }
 #pragma unroll
-                for (int o = 0; o < 64; ++o) xop(xf, set, P, o, sg);
+                for (int o = 0; o < 64; ++o) xop(xf, set, P, o, sg, it);
                 W3_X_WRITE(P, it);
             }
         }
-#else
-        {   // input transform of chunk 0, all four positions (not overlapped with MFMAs)
-            const char* pa = sP + src_a;
-            const char* pb = sP + src_b;
-#pragma unroll 1
-            for (int it = 0; it < 4; ++it) {
-#pragma unroll
-                for (int P = 0; P < 2; ++P) {
-                    W3_X_READ(0, pa, pb, P, it);
-#pragma unroll
-                    for (int o = 0; o < 64; ++o) xop(xf, 0, P, o, sg);
-                    W3_X_WRITE(P, it);
-                }
-            }
-        }
-#endif
         W3T(2);
         W3_READ_A(0, 0, 0);
         W3_READ_A(0, 0, 1);
@@ -449,7 +447,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
             }
+            W3T(8);
             W3_BARRIER();                                      // everyone is done reading V / the patches (tg = 0) or sQ
+            W3T(9);
             if (tg == 1 && more) {                             // patch buffers and fragment registers are idle
                 W3_SETUP(next);
                 W3_ISSUE_P(0);
@@ -468,6 +468,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     sQ[(((wave * 2 + 1) * 2 + g) * 32 + tl) * 32 + (lane & 31)] = m1 - m2 - m3;
                 }
             W3_BARRIER();
+            W3T(10);
             // Stage 2: thread = (tile, co): Y[a][c] = sum_i A^T[a][i] q[i][c]; 4 tiles x 2 cout groups per thread and pass
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -496,8 +497,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
         }
-        W3T(4);
+        W3T(11);
 #ifdef CNL_W3TRACE
+        tr[4] = tr[8] + tr[9] + tr[10] + tr[11];
         tr[6] += 1;
 #endif
         if (!more) break;
@@ -505,9 +507,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 #ifdef CNL_W3TRACE
     if (a.trace && lane == 0) {
-        long long* t_ = a.trace + ((long)blockIdx.x * 4 + wave) * 8;
+        long long* t_ = a.trace + ((long)blockIdx.x * 4 + wave) * 12;
         tr[7] = clock64() - tr_start;
-        for (int i = 0; i < 8; ++i) t_[i] = tr[i];
+        for (int i = 0; i < 12; ++i) t_[i] = tr[i];
     }
 #endif
 #undef W3_SLOT

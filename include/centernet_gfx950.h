@@ -83,8 +83,16 @@ int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);
  * Winograd F(2x2,3x3): 2.25x fewer matrix-core multiplies, same result up to fp32 rounding (see csrc/winograd.hip).
  * `p->w` must point to the PRE-TRANSFORMED weights produced by cnl_winograd_transform_weights_f32 from the OHWI
  * (BN-folded) weights; flags: CNL_RELU only (upsample / sigmoid variants stay on cnl_conv2d_nhwc_f32). Cin % 8 == 0.
+ *
+ * Two multiplier arrays serve this entry point, chosen from the layer SHAPE alone (never the batch size): the fp32 matrix core
+ * (csrc/winograd2.hip), or — where the channel loop is long (Cin >= 256, Cin % 16 == 0) — the bf16 matrix core fed with the exact
+ * three-way bf16 split of both fp32 operands (six cross terms, fp32 accumulation: csrc/winograd3.hip; error at or below the
+ * fp32 matrix core's, 16x its rate).  cnl_conv3x3_winograd_kernel reports which one a layer takes: CNL_WINO_F32 / CNL_WINO_BF16X3.
  */
+#define CNL_WINO_F32 2
+#define CNL_WINO_BF16X3 3
 int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream);
+int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p);            /* CNL_WINO_* for this layer shape, < 0: error code */
 size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout);        /* elements of the transformed weight buffer */
 int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream);
 

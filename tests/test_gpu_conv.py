@@ -210,6 +210,8 @@ WINO_CASES = [
     (1, 8, 6, 10, 40, False, False),           # tiny, Cout tail (40 -> padded 64), partial 16x16 block
     (2, 24, 19, 34, 96, True, False),          # odd height (608x1088 /32 grid), ragged blocks
     (1, 128, 40, 24, 128, False, True),
+    (1, 256, 19, 34, 96, True, True),          # bf16-split kernel (Cin >= 256): ragged 16x16 blocks, Cout tail (96 -> 128)
+    (2, 256, 48, 16, 64, False, False),        # bf16-split kernel, one cout block, no ReLU
 ]
 
 
@@ -228,7 +230,7 @@ def test_winograd_matches_cpu(case):
         torch.testing.assert_close(out, run_conv(x, w, b, 1, flags, res), rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 8, 8, 128), (1, 128, 16, 24, 64), (1, 32, 5, 9, 32)])
+@pytest.mark.parametrize("shape", [(2, 64, 8, 8, 128), (1, 128, 16, 24, 64), (1, 32, 5, 9, 32), (1, 256, 9, 12, 128)])
 def test_winograd_upsample_in(shape):
     """conv3x3 on a nearest-2x upsampled input (simple neck stages and the heads behind it), upsample folded into the gather."""
     N, Cin, H, W, Cout = shape
@@ -245,6 +247,19 @@ def test_winograd_exact_on_small_integers():
     x = torch.randint(-3, 4, (2, 16, 12, 20), generator=g).float()
     w = torch.randint(-2, 3, (48, 16, 3, 3), generator=g).float() * 4
     b = torch.randint(-5, 6, (48,), generator=g).float()
+    assert torch.equal(run_winograd(x, w, b, 0), ref_conv(x, w, b, 1, 0))
+
+
+def test_winograd_bf16_split_exact_on_small_integers():
+    """The same exactness check on a layer that takes the bf16-split kernel (Cin = 256): small integers are exact in the first
+    bf16 piece, so every product and every partial sum is exact there too."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-3, 4, (1, 256, 32, 32), generator=g).float()
+    w = torch.randint(-2, 3, (128, 256, 3, 3), generator=g).float() * 4
+    b = torch.randint(-5, 6, (128,), generator=g).float()
+    p = ConvParams()
+    p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.flags = 1, 32, 32, 256, 128, 3, 3, 1, 1, 0
+    assert _lib.load().cnl_conv3x3_winograd_kernel(ctypes.byref(p)) == 3
     assert torch.equal(run_winograd(x, w, b, 0), ref_conv(x, w, b, 1, 0))
 
 
@@ -287,3 +302,28 @@ def test_winograd_decompositions_are_bit_identical(monkeypatch):
         monkeypatch.undo()
         assert torch.equal(outs[0], outs[1]), (N, Cin, H, W, Cout)
         torch.testing.assert_close(outs[0], ref_conv(x, w, b, 1, flags, res), rtol=RTOL, atol=ATOL)
+
+
+def test_winograd_bf16x3_error_not_above_fp32_mfma(monkeypatch):
+    """winograd3.hip forms each fp32 product from the exact three-way bf16 split of both operands (six cross terms; the dropped
+    ones are <= 2^-24 relative) and accumulates in fp32: its error against float64 must be no larger than that of the fp32
+    matrix-core kernel on the same layer (K = 2304) — also with inputs spanning six decades, where a 2-piece split would fail."""
+    import os
+    libs = {v: _fresh_lib(v) for v in (2, 3)}
+    os.environ.pop("CNL_WINO", None)
+    g = torch.Generator().manual_seed(11)
+    for scale_spread in (False, True):
+        x = torch.randn(1, 256, 32, 32, generator=g).clamp_min(0)
+        if scale_spread:
+            x = x * torch.pow(10.0, torch.randint(-3, 4, (1, 256, 1, 1), generator=g).float())
+        w = torch.randn(256, 256, 3, 3, generator=g) * (2.0 / (256 * 9)) ** 0.5
+        b = torch.zeros(256)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+        err = {}
+        for v in (2, 3):
+            monkeypatch.setattr(_lib, "_lib", libs[v])
+            err[v] = (run_winograd(x, w, b, 0).double() - ref).abs().max().item()
+        monkeypatch.undo()
+        scale = ref.abs().max().item()
+        assert err[3] <= 1.25 * err[2] + 1e-7 * scale, (scale_spread, err, scale)
+        assert err[2] < 2e-5 * max(scale, 1.0) and err[3] < 2e-5 * max(scale, 1.0), (scale_spread, err, scale)

@@ -29,7 +29,7 @@ p = ConvParams()
 p.x, p.w, p.bias, p.y = x.data_ptr(), u.data_ptr(), b.data_ptr(), y.data_ptr()
 p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad = N, H, W, Cin, Cout, 3, 3, 1, 1
 p.ldx, p.ldy, p.flags = Cin, Cout, 1
-trace = torch.zeros(256 * 4 * 8, dtype=torch.int64, device="cuda")
+trace = torch.zeros(256 * 4 * 12, dtype=torch.int64, device="cuda")
 for _ in range(2):
     assert lib.cnl_conv3x3_winograd_f32(ctypes.byref(p), stream) == 0
 torch.cuda.synchronize()
@@ -39,7 +39,7 @@ e0.record()
 assert lib.cnl_conv3x3_winograd_f32(ctypes.byref(p), stream) == 0
 e1.record()
 torch.cuda.synchronize()
-t = trace.cpu().numpy().reshape(256, 4, 8).astype(np.float64)
+t = trace.cpu().numpy().reshape(256, 4, 12).astype(np.float64)
 t = t[t[:, 0, 7] > 0]
 items = t[..., 6]
 cc = Cin // 16
@@ -48,6 +48,8 @@ print(f"{name}: {e0.elapsed_time(e1) * 1e3:.1f} us, {len(t)} workgroups, items/w
 for i, nm in enumerate(names):
     per_item = (t[..., i] / items).mean()
     print(f"  {nm:45s} {per_item:10.0f} cycles/item   per wave: {np.round((t[..., i] / items).mean(axis=0)).astype(int)}")
+for i, nm in ((8, "epilogue: addresses + residual loads"), (9, "epilogue: barrier before stage 1"), (10, "epilogue: stage-1 writes + barrier"), (11, "epilogue: stage 2 (reads, stores)")):
+    print(f"  {nm:45s} {(t[..., i] / items).mean():10.0f} cycles/item")
 loop = (t[..., 3] / items).mean()
 print(f"  chunk loop per chunk: {loop / cc:.0f} cycles (96 MFMAs: ideal 3072) -> {loop / cc / 96:.1f} cycles per MFMA; mid wait per chunk {(t[..., 5] / items).mean() / cc:.0f}")
 print(f"  total per item {(t[..., 7] / items).mean():.0f} cycles; clock {t[..., 7].mean() / (e0.elapsed_time(e1) * 1e-3) / 1e9:.2f} GHz (cycles / wall)")
