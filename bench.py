@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer conv table to stderr")
+    ap.add_argument("--no-fp32-mfma-leg", action="store_true",
+                    help="skip the extra short run with every Winograd layer on the fp32 matrix core (CNL_WINO=2), reported beside `value`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -308,6 +310,21 @@ def main():
         if args.layers:
             for what, fl, ms, _kind in rows:
                 print(f"{what:44s} {fl / 1e9:10.2f} GFLOP {ms * 1e3:10.1f} us {fl / (ms * 1e-3) / 1e12 if ms else 0:8.1f} TF", file=sys.stderr)
+        if world == 1 and not args.no_fp32_mfma_leg and not os.environ.get("CNL_WINO"):
+            # the same job with every 3x3 layer on the fp32 matrix core (the kernel choice is read once per process: child process)
+            import subprocess
+            env = dict(os.environ, CNL_WINO="2")
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(max(args.steps // 2, 3)), "--warmup", str(min(args.warmup, 3)),
+                   "--config", args.config, "--batch", str(B), "--height", str(H), "--width", str(W), "--k", str(args.k),
+                   "--no-cpu-baseline", "--no-fp32-mfma-leg"]
+            try:
+                out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
+                alt = json.loads(out)
+                result["fp32_mfma_only"] = {"value": alt["value"], "unit": alt["unit"], "ms_per_step": alt["ms_per_step"], "steps": alt["steps"],
+                                            "roofline_frac_of_fp32_mfma_peak": alt["roofline"]["frac"],
+                                            "note": "CNL_WINO=2: all Winograd layers on v_mfma_f32_32x32x2_f32 (no bf16 split anywhere)"}
+            except Exception as e:      # reported, never fatal: `value` above is the measurement
+                result["fp32_mfma_only"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(model, tracking, args.k, H, W)
         print(json.dumps(result), flush=True)
