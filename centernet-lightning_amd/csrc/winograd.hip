@@ -478,6 +478,7 @@ int cnl_wino2_launch(const cnl_conv_params* p, size_t u_floats, void* stream);  
 size_t cnl_wino3_weight_bytes(int Cin, int Cout);                                  // winograd3.hip
 int cnl_wino3_transform_weights(const float* w_ohwi, void* u3, int Cin, int Cout, void* stream);
 int cnl_wino3_launch(const cnl_conv_params* p, const void* u3, void* stream);
+int cnl_wino4_launch(const cnl_conv_params* p, const void* u3, void* stream);        // winograd4.hip
 
 // floats of the fp32 U = [ci/8][xi][CoutP][8]; the bf16-split copy for winograd3.hip (layers with Cin % 16 == 0) follows it
 static size_t wino_f32_floats(int Cin, int Cout) {
@@ -510,7 +511,7 @@ extern "C" int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p) {
     const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
     const int H = p->H_in * upf, W = p->W_in * upf, CoutP = (p->Cout + 63) / 64 * 64;
     const int items_per_image = ((H + 15) / 16) * ((W + 15) / 16) * (CoutP / 64);
-    const bool bf16x3 = p->Cin % 16 == 0 && (forced == 3 || (forced == 0 && p->Cin >= 256 && items_per_image >= 8));
+    const bool bf16x3 = p->Cin % 16 == 0 && (forced == 3 || forced == 4 || (forced == 0 && p->Cin >= 256 && items_per_image >= 8));
     return bf16x3 ? CNL_WINO_BF16X3 : CNL_WINO_F32;
 }
 
@@ -559,8 +560,10 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
     // 256 on 128x128: -16 %, layer3 -16 %, layer4 -22 %); it loses on Cin = 64 layers (+14 %) and on 16x16 maps with few cout
     // blocks.  Everything else takes winograd2.hip (fp32 MFMA, 8x16-pixel blocks, two 4-wave workgroups per CU), which is never
     // slower than this file's 16x16-pixel form (bit-identical to it; CNL_WINO=1 selects it for the bit-identity test).  The
-    // choice is a function of the layer shape alone, never of the batch size (batch invariance).  CNL_WINO=1|2|3 forces a kernel.
+    // choice is a function of the layer shape alone, never of the batch size (batch invariance).  CNL_WINO=1|2|3 forces a kernel; CNL_WINO=4 runs the
+    // bf16-split layers on winograd4.hip (two waves per SIMD: the same time at a lower clock — the kernel is power-bound; kept for A/B).
     static const int forced = getenv("CNL_WINO") ? atoi(getenv("CNL_WINO")) : 0;
+    if (forced == 4 && p->Cin % 16 == 0) return cnl_wino4_launch(p, p->w + wino_f32_floats(p->Cin, p->Cout), stream);
     if (cnl_conv3x3_winograd_kernel(p) == CNL_WINO_BF16X3) return cnl_wino3_launch(p, p->w + wino_f32_floats(p->Cin, p->Cout), stream);
     if (forced != 1) return cnl_wino2_launch(p, wino_f32_floats(p->Cin, p->Cout), stream);
     static bool attr_done = false;
