@@ -297,7 +297,7 @@ def main():
             "dtype": "f32",
             "dtype_note": "fp32 in / fp32 accumulate / fp32 out; 3x3 layers with Cin >= 256 form each fp32 product on the bf16 matrix cores from the "
                           "exact 3-way bf16 split of both operands (6 cross terms, error <= the fp32 MFMA's: tools/bf16x3_probe.hip, "
-                          "tests/test_gpu_conv.py::test_winograd_bf16x3_error_not_above_fp32_mfma)",
+                          "tests/test_gpu_conv.py::test_winograd_split_kernels_error_not_above_fp32_mfma)",
             "data": "synthetic (seeded rand images; random-init weights of the named architecture)",
             "config": {"workload": f"BASELINE C{'1' if args.config == 'simple' else ('4' if tracking else '2/3')}: ResNet34 + {args.config} neck, "
                                    f"{B} img/GPU x {H}x{W}, heads {'2+4+reid64' if tracking else '80+4'} (w256), k={args.k}, nms 3",

@@ -479,6 +479,10 @@ size_t cnl_wino3_weight_bytes(int Cin, int Cout);                               
 int cnl_wino3_transform_weights(const float* w_ohwi, void* u3, int Cin, int Cout, void* stream);
 int cnl_wino3_launch(const cnl_conv_params* p, const void* u3, void* stream);
 int cnl_wino4_launch(const cnl_conv_params* p, const void* u3, void* stream);        // winograd4.hip
+size_t cnl_wino5_weight_bytes(int Cin, int Cout);                                  // winograd5.hip
+size_t cnl_wino5_scalar_floats();
+int cnl_wino5_transform_weights(const float* w_ohwi, const float* u_f32, size_t u_f32_floats, void* u5, float* scal, int Cin, int Cout, void* stream);
+int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream);
 
 // floats of the fp32 U = [ci/8][xi][CoutP][8]; the bf16-split copy for winograd3.hip (layers with Cin % 16 == 0) follows it
 static size_t wino_f32_floats(int Cin, int Cout) {
@@ -489,7 +493,8 @@ static size_t wino_f32_floats(int Cin, int Cout) {
 
 extern "C" size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8) return 0;
-    return wino_f32_floats(Cin, Cout) + cnl_wino3_weight_bytes(Cin, Cout) / 4;
+    return wino_f32_floats(Cin, Cout) + cnl_wino3_weight_bytes(Cin, Cout) / 4 + cnl_wino5_weight_bytes(Cin, Cout) / 4 +
+           (Cin % 16 ? 0 : cnl_wino5_scalar_floats());
 }
 
 extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream) {
@@ -501,18 +506,33 @@ extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u,
                        Cout, CoutP);
     const int rc = cnl::check_launch("winograd_weights_kernel");
     if (rc != CNL_OK || Cin % 16) return rc;
-    return cnl_wino3_transform_weights(w_ohwi, u + wino_f32_floats(Cin, Cout), Cin, Cout, stream);
+    const int rc3 = cnl_wino3_transform_weights(w_ohwi, u + wino_f32_floats(Cin, Cout), Cin, Cout, stream);
+    if (rc3 != CNL_OK) return rc3;
+    float* u5 = u + wino_f32_floats(Cin, Cout) + cnl_wino3_weight_bytes(Cin, Cout) / 4;
+    return cnl_wino5_transform_weights(w_ohwi, u, wino_f32_floats(Cin, Cout), u5, u5 + cnl_wino5_weight_bytes(Cin, Cout) / 4, Cin, Cout, stream);
+}
+
+// which kernel a layer shape takes: 2 = fp32 MFMA (winograd2.hip), 3 = bf16 three-way split (winograd3.hip), 5 = fp16 two-way split
+// (winograd5.hip); CNL_WINO=1..5 forces one (4 = winograd4.hip, the two-waves-per-SIMD form of 3)
+static int wino_choice(const cnl_conv_params* p) {
+    static const int forced = getenv("CNL_WINO") ? atoi(getenv("CNL_WINO")) : 0;
+    static const int min_cin5 = getenv("CNL_W5_MINCIN") ? atoi(getenv("CNL_W5_MINCIN")) : 128;
+    static const int min_cout5 = getenv("CNL_W5_MINCOUT") ? atoi(getenv("CNL_W5_MINCOUT")) : 512;
+    const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
+    const int H = p->H_in * upf, W = p->W_in * upf, CoutP = (p->Cout + 63) / 64 * 64;
+    const int items_per_image = ((H + 15) / 16) * ((W + 15) / 16) * (CoutP / 64);
+    if (forced == 1 || forced == 2) return forced;
+    if (p->Cin % 16) return 2;
+    if (forced >= 3 && forced <= 5) return forced;
+    if (items_per_image >= 8 && (p->Cin >= min_cin5 || p->Cout >= min_cout5)) return 5;
+    return 2;
 }
 
 extern "C" int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p) {
     CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: null params");
     CNL_REQUIRE(p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: non-positive dimension");
-    static const int forced = getenv("CNL_WINO") ? atoi(getenv("CNL_WINO")) : 0;
-    const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
-    const int H = p->H_in * upf, W = p->W_in * upf, CoutP = (p->Cout + 63) / 64 * 64;
-    const int items_per_image = ((H + 15) / 16) * ((W + 15) / 16) * (CoutP / 64);
-    const bool bf16x3 = p->Cin % 16 == 0 && (forced == 3 || forced == 4 || (forced == 0 && p->Cin >= 256 && items_per_image >= 8));
-    return bf16x3 ? CNL_WINO_BF16X3 : CNL_WINO_F32;
+    const int c = wino_choice(p);
+    return c == 5 ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
 }
 
 extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) {
@@ -562,10 +582,15 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
     // slower than this file's 16x16-pixel form (bit-identical to it; CNL_WINO=1 selects it for the bit-identity test).  The
     // choice is a function of the layer shape alone, never of the batch size (batch invariance).  CNL_WINO=1|2|3 forces a kernel; CNL_WINO=4 runs the
     // bf16-split layers on winograd4.hip (two waves per SIMD: the same time at a lower clock — the kernel is power-bound; kept for A/B).
-    static const int forced = getenv("CNL_WINO") ? atoi(getenv("CNL_WINO")) : 0;
-    if (forced == 4 && p->Cin % 16 == 0) return cnl_wino4_launch(p, p->w + wino_f32_floats(p->Cin, p->Cout), stream);
-    if (cnl_conv3x3_winograd_kernel(p) == CNL_WINO_BF16X3) return cnl_wino3_launch(p, p->w + wino_f32_floats(p->Cin, p->Cout), stream);
-    if (forced != 1) return cnl_wino2_launch(p, wino_f32_floats(p->Cin, p->Cout), stream);
+    const int choice = wino_choice(p);
+    const float* u3 = p->w + wino_f32_floats(p->Cin, p->Cout);
+    if (choice == 5) {
+        float* u5 = const_cast<float*>(u3) + cnl_wino3_weight_bytes(p->Cin, p->Cout) / 4;
+        return cnl_wino5_launch(p, u5, u5 + cnl_wino5_weight_bytes(p->Cin, p->Cout) / 4, stream);
+    }
+    if (choice == 4) return cnl_wino4_launch(p, u3, stream);
+    if (choice == 3) return cnl_wino3_launch(p, u3, stream);
+    if (choice == 2) return cnl_wino2_launch(p, wino_f32_floats(p->Cin, p->Cout), stream);
     static bool attr_done = false;
     if (!attr_done) {
         CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -91,6 +91,7 @@ int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);
  */
 #define CNL_WINO_F32 2
 #define CNL_WINO_BF16X3 3
+#define CNL_WINO_F16X2 5
 int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream);
 int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p);            /* CNL_WINO_* for this layer shape, < 0: error code */
 size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout);        /* elements of the transformed weight buffer */

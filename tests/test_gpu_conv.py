@@ -250,16 +250,16 @@ def test_winograd_exact_on_small_integers():
     assert torch.equal(run_winograd(x, w, b, 0), ref_conv(x, w, b, 1, 0))
 
 
-def test_winograd_bf16_split_exact_on_small_integers():
-    """The same exactness check on a layer that takes the bf16-split kernel (Cin = 256): small integers are exact in the first
-    bf16 piece, so every product and every partial sum is exact there too."""
+def test_winograd_split_kernels_exact_on_small_integers():
+    """The same exactness check on a layer that takes a split-operand kernel (Cin = 256): small integers are exact in the first
+    piece (and stay so under the power-of-two scaling of the fp16 kernel), so every product and partial sum is exact there too."""
     g = torch.Generator().manual_seed(3)
     x = torch.randint(-3, 4, (1, 256, 32, 32), generator=g).float()
     w = torch.randint(-2, 3, (128, 256, 3, 3), generator=g).float() * 4
     b = torch.randint(-5, 6, (128,), generator=g).float()
     p = ConvParams()
     p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.flags = 1, 32, 32, 256, 128, 3, 3, 1, 1, 0
-    assert _lib.load().cnl_conv3x3_winograd_kernel(ctypes.byref(p)) == 3
+    assert _lib.load().cnl_conv3x3_winograd_kernel(ctypes.byref(p)) in (3, 5)      # a split-operand kernel (bf16 x 3 or fp16 x 2)
     assert torch.equal(run_winograd(x, w, b, 0), ref_conv(x, w, b, 1, 0))
 
 
@@ -304,26 +304,35 @@ def test_winograd_decompositions_are_bit_identical(monkeypatch):
         torch.testing.assert_close(outs[0], ref_conv(x, w, b, 1, flags, res), rtol=RTOL, atol=ATOL)
 
 
-def test_winograd_bf16x3_error_not_above_fp32_mfma(monkeypatch):
-    """winograd3.hip forms each fp32 product from the exact three-way bf16 split of both operands (six cross terms; the dropped
-    ones are <= 2^-24 relative) and accumulates in fp32: its error against float64 must be no larger than that of the fp32
-    matrix-core kernel on the same layer (K = 2304) — also with inputs spanning six decades, where a 2-piece split would fail."""
+def test_winograd_split_kernels_error_not_above_fp32_mfma(monkeypatch):
+    """winograd3.hip (exact three-way bf16 split, six cross terms) and winograd5.hip (scaled two-way fp16 split, three cross terms)
+    form fp32 products on the 16x faster matrix cores and accumulate in fp32: their error against float64 must be no larger than
+    that of the fp32 matrix-core kernel on the same layer (K = 2304) — also with channels spanning six decades of magnitude and
+    with a tensor whose values are all tiny or all huge (the fp16 kernel's scale follows the tensor's maximum)."""
     import os
-    libs = {v: _fresh_lib(v) for v in (2, 3)}
+    libs = {v: _fresh_lib(v) for v in (2, 3, 5)}
     os.environ.pop("CNL_WINO", None)
     g = torch.Generator().manual_seed(11)
-    for scale_spread in (False, True):
+    for case in ("plain", "spread", "tiny", "huge"):
         x = torch.randn(1, 256, 32, 32, generator=g).clamp_min(0)
-        if scale_spread:
+        if case == "spread":
             x = x * torch.pow(10.0, torch.randint(-3, 4, (1, 256, 1, 1), generator=g).float())
+        elif case == "tiny":
+            x = x * 1e-12
+        elif case == "huge":
+            x = x * 1e12
         w = torch.randn(256, 256, 3, 3, generator=g) * (2.0 / (256 * 9)) ** 0.5
         b = torch.zeros(256)
         ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
         err = {}
-        for v in (2, 3):
+        for v in (2, 3, 5):
             monkeypatch.setattr(_lib, "_lib", libs[v])
-            err[v] = (run_winograd(x, w, b, 0).double() - ref).abs().max().item()
+            out = run_winograd(x, w, b, 0)
+            assert torch.isfinite(out).all(), (case, v)
+            err[v] = (out.double() - ref).abs().max().item()
         monkeypatch.undo()
         scale = ref.abs().max().item()
-        assert err[3] <= 1.25 * err[2] + 1e-7 * scale, (scale_spread, err, scale)
-        assert err[2] < 2e-5 * max(scale, 1.0) and err[3] < 2e-5 * max(scale, 1.0), (scale_spread, err, scale)
+        for v in (3, 5):
+            assert err[v] <= 1.25 * err[2] + 1e-7 * scale, (case, v, err, scale)
+            assert err[v] < 2e-5 * scale, (case, v, err, scale)
+        assert err[2] < 2e-5 * scale, (case, err, scale)

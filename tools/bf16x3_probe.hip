@@ -15,6 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsigned& l) {
     const unsigned b = __float_as_uint(v);
@@ -56,6 +57,46 @@ __global__ __launch_bounds__(64) void acc_kernel(const float* A, const float* B,
         }
     }
     for (int r = 0; r < 16; ++r) C[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + row] = c[r];
+}
+
+// fp16 two-way split with power-of-two scales: x * S = hi + lo (hi = RN16(x S), lo = RN16(x S - hi)); terms hi lo', lo hi', hi hi'
+__global__ __launch_bounds__(64) void acc16_kernel(const float* A, const float* B, int K, float* C, float sa, float sb, int terms) {
+    const int lane = threadIdx.x, row = lane & 31, half = lane >> 5;
+    f32x16 c = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        f16x8 ah, al, bh, bl;
+        for (int e = 0; e < 8; ++e) {
+            const float x = A[row * K + k0 + half * 8 + e] * sa, y = B[(k0 + half * 8 + e) * 32 + row] * sb;
+            ah[e] = (_Float16)x; al[e] = (_Float16)(x - (float)ah[e]);
+            bh[e] = (_Float16)y; bl[e] = (_Float16)(y - (float)bh[e]);
+        }
+        if (terms == 4) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+    }
+    const float inv = 1.f / (sa * sb);
+    for (int r = 0; r < 16; ++r) C[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + row] = c[r] * inv;
+}
+
+// time of a pure fp16 MFMA loop whose A operand holds normal numbers (mode 0), subnormals (1) or zeros (2)
+__global__ __launch_bounds__(256) void denorm_kernel(float* out, int iters, int mode, long long* clk) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const unsigned short bits = mode == 0 ? 0x3C00 : mode == 1 ? (unsigned short)(0x0001 + (threadIdx.x & 0xFF)) : 0;
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    u16x8 au; for (int e = 0; e < 8; ++e) au[e] = bits;
+    const f16x8 a = __builtin_bit_cast(f16x8, au);
+    f16x8 b; for (int e = 0; e < 8; ++e) b[e] = (_Float16)(1.0f + 0.001f * e);
+    const long long c0 = clock64();
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[u & 3], 0, 0, 0);
+    const long long c1 = clock64();
+    float s = 0;
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) clk[blockIdx.x] = c1 - c0;
 }
 
 // KIND 0: 32-bit VALU mix (v_and_b32, v_sub_f32, v_perm_b32), KIND 1: v_pk_add_f32, KIND 2: v_cvt_pk_bf16_f32
@@ -153,6 +194,41 @@ int main() {
             double mx = 0, rms = 0, sc = 0;
             for (int i = 0; i < 1024; ++i) { const double e = C[i] - ref[i]; mx = std::max(mx, std::fabs(e)); rms += e * e; sc = std::max(sc, std::fabs(ref[i])); }
             printf("(A) K=%d  %-22s max |err| %.3e   rms %.3e   (max |C| %.2f)\n", K, names[mode], mx, std::sqrt(rms / 1024), sc);
+        }
+    }
+    {   // (A') fp16 two-way split
+        const int K = 2304;
+        std::mt19937 rng(1);
+        std::normal_distribution<float> nd(0.f, 1.f);
+        std::vector<float> A(32 * K), B(K * 32);
+        for (auto& x : A) { const float a = nd(rng), b = nd(rng), c = nd(rng), d = nd(rng); x = std::max(a, 0.f) - std::max(b, 0.f) - std::max(c, 0.f) + std::max(d, 0.f); }
+        for (auto& x : B) x = nd(rng) * 0.03f;
+        std::vector<double> ref(32 * 32, 0.0);
+        for (int m = 0; m < 32; ++m) for (int n = 0; n < 32; ++n) { double s = 0; for (int k = 0; k < K; ++k) s += (double)A[m * K + k] * B[k * 32 + n]; ref[m * 32 + n] = s; }
+        float *dA, *dB, *dC;
+        hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dC, 32 * 32 * 4);
+        hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+        const float scales[4][2] = {{1.f, 1.f}, {64.f, 256.f}, {1024.f, 4096.f}, {1.f / 1024, 1.f}};
+        for (int si = 0; si < 4; ++si)
+            for (int terms = 3; terms <= 4; ++terms) {
+                acc16_kernel<<<1, 64>>>(dA, dB, K, dC, scales[si][0], scales[si][1], terms);
+                std::vector<float> C(32 * 32);
+                hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost);
+                double mx = 0, rms = 0;
+                for (int i = 0; i < 1024; ++i) { const double e = C[i] - ref[i]; mx = std::max(mx, std::fabs(e)); rms += e * e; }
+                printf("(A') K=%d fp16 split, %d terms, scales %g x %g : max |err| %.3e   rms %.3e\n", K, terms, scales[si][0], scales[si][1], mx, std::sqrt(rms / 1024));
+            }
+        float* out; long long* clk;
+        hipMalloc(&out, 256 * 256 * 4); hipMalloc(&clk, 256 * 8);
+        for (int mode = 0; mode < 3; ++mode) {
+            denorm_kernel<<<256, 256>>>(out, 200, mode, clk);
+            hipDeviceSynchronize();
+            denorm_kernel<<<256, 256>>>(out, 2000, mode, clk);
+            hipDeviceSynchronize();
+            std::vector<long long> h(256);
+            hipMemcpy(h.data(), clk, 256 * 8, hipMemcpyDeviceToHost);
+            double c = 0; for (auto v : h) c += v; c /= 256;
+            printf("(A') fp16 MFMA with %s A operand: %.1f cycles per MFMA\n", mode == 0 ? "normal" : mode == 1 ? "SUBNORMAL" : "zero", c / (2000.0 * 16));
         }
     }
     // (B)
