@@ -12,10 +12,10 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
   value     = total images / max-over-ranks wall time of the K timed steps (weak scaling: batch per GPU fixed).
   roofline  = the dominant kernel by time, measured with HIP events on the launch stream around every launch of one step.  The
               3x3/s1 layers run Winograd F(2x2,3x3) on one of two multiplier arrays, chosen per layer SHAPE (include/centernet_gfx950.h):
-              `cnl_wino3::winograd3_kernel` (Cin >= 256: fp32 operands split EXACTLY into three bf16 pieces, six bf16 MFMAs per
-              product, fp32 accumulation — fp32-grade accuracy on the 16x faster bf16 matrix core; peak = 2.5 PFLOP/s dense bf16) or
-              `cnl_wino2::winograd2_kernel` (fp32 MFMA, peak 157.3).  `achieved` counts the matrix-core flops the kernel EXECUTES
-              (direct-conv flops x 16/36, x 6 for the split), so `frac` is an honest hardware fraction; `effective_tflops` is the same
+              `cnl_wino5::winograd5_kernel` (Cin >= 128 or Cout >= 512: fp32 operands scaled by a per-tensor power of two and split
+              into two fp16 pieces, three fp16 MFMAs per product, fp32 accumulation — fp32-grade accuracy on the 16x faster fp16
+              matrix core; peak = 2.5 PFLOP/s dense fp16) or `cnl_wino2::winograd2_kernel` (fp32 MFMA, peak 157.3).  `achieved` counts the matrix-core flops the kernel EXECUTES
+              (direct-conv flops x 16/36, x 3 for the split), so `frac` is an honest hardware fraction; `effective_tflops` is the same
               time against the direct-conv (algorithmic) flops.  The other conv kernels are reported under `other_kernels`.
   dtype     = "f32": inputs, weights, accumulation and outputs are fp32 and every product is formed to fp32 accuracy (the dropped
               split terms are <= 2^-24 relative); `cpu_baseline.sample` carries the max |GPU - CPU oracle| of this very run.
@@ -38,12 +38,14 @@ import centernet_lightning_amd as cl  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16), 16x the fp32 MFMA rate
+F16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense fp16 = bf16 rate
 # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_final4.txt): per kernel, mean
 # FETCH_SIZE x 2 (gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md §HBM) + mean WRITE_SIZE over the launches
 # of a C1 step (bf16-split Winograd: 300.0 MB x 2 + 131.4 MB = 731.5 MB).  Other configs: not profiled -> null.
 MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("simple", 32, 512, 512, "cnl_conv::conv_mfma_kernel"): 237.0e6,
                                      ("simple", 32, 512, 512, "cnl_wino2::winograd2_kernel"): 312.8e6,
-                                     ("simple", 32, 512, 512, "cnl_wino3::winograd3_kernel"): 731.5e6}
+                                     ("simple", 32, 512, 512, "cnl_wino3::winograd3_kernel"): 731.5e6,
+                                     ("simple", 32, 512, 512, "cnl_wino5::winograd5_kernel"): None}
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 
 
@@ -110,7 +112,7 @@ def conv_kernel_profile(model, x, reps=3):
     def kind(L):
         if L.fn is not lib.cnl_conv3x3_winograd_f32:
             return "direct"
-        return "winograd_bf16x3" if lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)) == 3 else "winograd_f32"
+        return {3: "winograd_bf16x3", 5: "winograd_f16x2"}.get(lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)), "winograd_f32")
     rows = [(L.what, L.flops * scale, acc[i] / reps * scale, kind(L)) for i, L in enumerate(convs)]
     # algorithmic HBM bytes of a conv launch: input + weights + bias + output (+ residual), each touched once
     nbytes = 0
@@ -246,10 +248,24 @@ def main():
             return len(sel), ms, fl
         n_w, ms_w, fl_w = agg("winograd_f32")
         n_b, ms_b, fl_b = agg("winograd_bf16x3")
+        n_h, ms_h, fl_h = agg("winograd_f16x2")
         n_d, ms_d, fl_d = agg("direct")
         direct_tf = fl_d / (ms_d * 1e-3) / 1e12 if ms_d else 0.0
         f32_exec_tf = fl_w * (16.0 / 36.0) / (ms_w * 1e-3) / 1e12 if ms_w else 0.0
-        if ms_b >= ms_w and ms_b >= ms_d:      # dominant kernel: Winograd on the bf16 matrix cores (exact 3-way split, 6 MFMAs per product)
+        if ms_h >= ms_b and ms_h >= ms_w and ms_h >= ms_d:
+            # dominant: Winograd on the fp16 matrix cores (scaled two-way split, 3 MFMAs per product); HIP events around the entry
+            # point include the absmax pass over the input that fixes the scale
+            exec_tf = fl_h * (16.0 / 36.0) * 3.0 / (ms_h * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "cnl_wino5::winograd5_kernel (F(2x2,3x3); fp32 operands scaled by a power of two and split into 2 fp16 "
+                                               "pieces, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; + absmax_kernel pass)",
+                    "achieved": round(exec_tf, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(exec_tf / F16_MFMA_PEAK_TFLOPS, 4),
+                    "achieved_counts": "executed fp16 matrix-core flops = direct-conv flops x 16/36 (Winograd) x 3 (split terms)",
+                    "effective_tflops": round(fl_h / (ms_h * 1e-3) / 1e12, 2),
+                    "launches_per_step": n_h, "kernel_ms_per_step": round(ms_h, 3),
+                    "algorithmic_gflop_per_step": round(fl_h / 1e9, 2), "avg_launch_us": round(ms_h * 1e3 / n_h, 2),
+                    "sustained_clock_note": "power-limited DVFS: the split-operand kernels hold 1.8-2.0 GHz of 2.4 (tools/clk_probe.sh)"}
+        elif ms_b >= ms_w and ms_b >= ms_d:      # dominant kernel: Winograd on the bf16 matrix cores (exact 3-way split, 6 MFMAs per product)
             exec_tf = fl_b * (16.0 / 36.0) * 6.0 / (ms_b * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "cnl_wino3::winograd3_kernel (F(2x2,3x3); fp32 operands split exactly into 3 bf16 pieces, "
                                                "6 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)",
@@ -278,12 +294,13 @@ def main():
                     "avg_launch_us": round(ms_d * 1e3 / max(n_d, 1), 2)}
         roof["traffic"] = MEASURED_TRAFFIC_BYTES_PER_LAUNCH.get((args.config, B, H, W, roof["kernel"].split(" ")[0]))
         roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic_final4.txt)"
-        dom = "winograd_bf16x3" if "wino3" in roof["kernel"] else ("winograd_f32" if "wino2" in roof["kernel"] else "direct")
+        dom = "winograd_f16x2" if "wino5" in roof["kernel"] else "winograd_bf16x3" if "wino3" in roof["kernel"] else ("winograd_f32" if "wino2" in roof["kernel"] else "direct")
         roof["algorithmic_bytes_per_launch"] = round(conv_bytes.get(dom, 0) / max(roof["launches_per_step"], 1))
         roof["other_kernels"] = {"cnl_wino2::winograd2_kernel (fp32 MFMA)": {"launches_per_step": n_w, "kernel_ms_per_step": round(ms_w, 3),
                                                                              "achieved_tflops_executed": round(f32_exec_tf, 2),
                                                                              "frac_of_fp32_mfma_peak": round(f32_exec_tf / FP32_MFMA_PEAK_TFLOPS, 4)},
-                                 "cnl_wino3::winograd3_kernel (bf16 MFMA, exact split)": {"launches_per_step": n_b, "kernel_ms_per_step": round(ms_b, 3)},
+                                 "cnl_wino3::winograd3_kernel (bf16 MFMA, exact 3-way split)": {"launches_per_step": n_b, "kernel_ms_per_step": round(ms_b, 3)},
+                                 "cnl_wino5::winograd5_kernel (fp16 MFMA, scaled 2-way split)": {"launches_per_step": n_h, "kernel_ms_per_step": round(ms_h, 3)},
                                  "cnl_conv::conv_mfma_kernel": {"launches_per_step": n_d, "kernel_ms_per_step": round(ms_d, 3),
                                                                 "achieved_tflops": round(direct_tf, 2)}}
         ms_per_step = elapsed / args.steps * 1e3
@@ -295,8 +312,8 @@ def main():
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",
-            "dtype_note": "fp32 in / fp32 accumulate / fp32 out; 3x3 layers with Cin >= 256 form each fp32 product on the bf16 matrix cores from the "
-                          "exact 3-way bf16 split of both operands (6 cross terms, error <= the fp32 MFMA's: tools/bf16x3_probe.hip, "
+            "dtype_note": "fp32 in / fp32 accumulate / fp32 out; the long-channel 3x3 layers form each fp32 product on the fp16 matrix cores from "
+                          "a two-way fp16 split of both (power-of-two scaled) operands (3 cross terms, error <= the fp32 MFMA's: tools/bf16x3_probe.hip, "
                           "tests/test_gpu_conv.py::test_winograd_split_kernels_error_not_above_fp32_mfma)",
             "data": "synthetic (seeded rand images; random-init weights of the named architecture)",
             "config": {"workload": f"BASELINE C{'1' if args.config == 'simple' else ('4' if tracking else '2/3')}: ResNet34 + {args.config} neck, "

@@ -17,14 +17,15 @@ CNL_UPSAMPLE_OUT_ADD = 1 << 3
 CNL_RELU6 = 1 << 4
 
 CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4
-ABI_VERSION = 2          # CNL_ABI_VERSION of include/centernet_gfx950.h
+ABI_VERSION = 3          # CNL_ABI_VERSION of include/centernet_gfx950.h
 
 
 class ConvParams(Structure):
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("y", c_void_p),
                 ("N", c_int32), ("H_in", c_int32), ("W_in", c_int32), ("Cin", c_int32), ("Cout", c_int32),
                 ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
-                ("ldx", c_int32), ("ldy", c_int32), ("ldr", c_int32), ("flags", c_uint32)]
+                ("ldx", c_int32), ("ldy", c_int32), ("ldr", c_int32), ("flags", c_uint32),
+                ("x_absmax", c_void_p), ("y_absmax", c_void_p)]
 
 
 class DeconvParams(Structure):

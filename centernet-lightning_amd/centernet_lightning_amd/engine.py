@@ -228,6 +228,38 @@ class Plan:
         self.out_params = {}              # name -> ConvParams writing that output (y patched per call)
         self.stem_args = None
         self._build(weights)
+        self._wire_absmax()
+
+    def _wire_absmax(self):
+        """Hand the maximum magnitude of a tensor from the launch that produces it to the fp16-split Winograd launches that
+        consume it (cnl_conv_params.x_absmax / y_absmax): those then skip their own pass over the input.  Only where it is
+        provably the whole story: the consumer's input buffer has exactly one writer in the plan, that writer is a Winograd
+        launch on the fp32-MFMA or fp16-split kernel (the ones that report max |y|) and it writes every channel of the buffer."""
+        lib, wino = self.lib, self.lib.cnl_conv3x3_winograd_f32
+        writers, unsafe = {}, set()
+        for L in self.launches:
+            if isinstance(L.args, ConvParams):
+                writers.setdefault(id(L.keep[1]), []).append(L)
+            else:                       # other launches: anything they hold may be written by them
+                unsafe.update(id(t) for t in L.keep if isinstance(t, torch.Tensor))
+        slot_of, pairs = {}, []
+        for L in self.launches:
+            if not isinstance(L.args, ConvParams) or L.fn is not wino or lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)) != 5:
+                continue
+            x = L.keep[0]
+            ws = writers.get(id(x), [])
+            if id(x) in unsafe or len(ws) != 1 or ws[0] is L:
+                continue
+            P = ws[0]
+            if P.fn is not wino or lib.cnl_conv3x3_winograd_kernel(ctypes.byref(P.args)) not in (2, 5):
+                continue
+            if P.args.y != x.data_ptr() or P.args.Cout != P.args.ldy:
+                continue
+            pairs.append((P, L, slot_of.setdefault(id(P), len(slot_of))))
+        self.absmax = torch.zeros(max(len(slot_of), 1), device=self.device, dtype=torch.float32) if pairs else None
+        for P, L, i in pairs:
+            P.args.y_absmax = self.absmax.data_ptr() + 4 * i
+            L.args.x_absmax = self.absmax.data_ptr() + 4 * i
 
     # -- helpers --
     def _buf(self, n, h, w, c):
@@ -449,6 +481,8 @@ class Plan:
             t = torch.empty((self.N, oh, ow, c), device=self.device, dtype=torch.float32)
             p.y = t.data_ptr()
             outs[name] = t
+        if self.absmax is not None:
+            self.absmax.zero_()                                # the producers fold max |y| into these with atomic max
         for L in self.launches:
             if L.fn == "stem":
                 sn, sc, sh, sw = x.stride()

@@ -30,7 +30,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 struct Args {
     const float* x;
     const void* u3;                   // pre-split, pre-scaled weights (fp16 pieces)
-    const float* scal;                // [0] max |x| of this launch's input (absmax_kernel), [1] scale of the weights
+    const float* xmax;                // max |x| of this launch's input (absmax_kernel, or handed over by the producer)
+    const float* su;                  // scale of the weights
+    unsigned* ymax;                   // optional: max |y| of this launch's output, for the consumer (atomic max on the bits)
     const float* bias;
     const float* res;
     float* y;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // together with the scale of the weights
     float S = 1.f;
     {
-        const float mx4 = 4.f * a.scal[0];
+        const float mx4 = 4.f * a.xmax[0];
         if (mx4 > 0.f && mx4 < __builtin_inff()) {
             int e_;
             (void)__builtin_frexpf(mx4, &e_);                 // 2^(e-1) <= mx4 < 2^e
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             S = __builtin_ldexpf(1.f, e_ < -100 ? -100 : (e_ > 100 ? 100 : e_));
         }
     }
-    const float inv = 1.f / (S * a.scal[1]);
+    const float inv = 1.f / (S * a.su[0]);
+    float omax = 0.f;          // running max |y| of this lane's stores
 
     int n, y0, x0, n0;
     unsigned p_off[6], u_voff;
@@ -450,14 +453,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int c = 0; c < 2; ++c) {
                         const float ya = (q[0][c] + q[1][c] + q[2][c]) * inv;
                         const float yb = (q[1][c] - q[2][c] - q[3][c]) * inv;
-                        buf_store(fmaxf(ya + bv[g] + rv[g][it][0][c], lo), a.y, a.y_bytes, ok[g][it][0][c] ? y_voff[g][it] : OOB, (unsigned)(c * a.ldy * 4));
-                        buf_store(fmaxf(yb + bv[g] + rv[g][it][1][c], lo), a.y, a.y_bytes, ok[g][it][1][c] ? y_voff[g][it] : OOB, (unsigned)((a.W + c) * a.ldy * 4));
+                        const float oa = fmaxf(ya + bv[g] + rv[g][it][0][c], lo), ob = fmaxf(yb + bv[g] + rv[g][it][1][c], lo);
+                        omax = fmaxf(omax, fmaxf(ok[g][it][0][c] ? fabsf(oa) : 0.f, ok[g][it][1][c] ? fabsf(ob) : 0.f));
+                        buf_store(oa, a.y, a.y_bytes, ok[g][it][0][c] ? y_voff[g][it] : OOB, (unsigned)(c * a.ldy * 4));
+                        buf_store(ob, a.y, a.y_bytes, ok[g][it][1][c] ? y_voff[g][it] : OOB, (unsigned)((a.W + c) * a.ldy * 4));
                     }
                 }
             }
         }
         if (!more) break;
         item = next;
+    }
+    if (a.ymax) {              // one atomic per wave and launch
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
+        if (lane == 0 && omax > 0.f) atomicMax(a.ymax, __float_as_uint(omax));
     }
 #undef W5_SLOT
 #undef W5_MFMA
@@ -564,7 +574,8 @@ int cnl_wino5_transform_weights(const float* w_ohwi, const float* u_f32, size_t 
 int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream) {
     using namespace cnl_wino5;
     Args a;
-    a.x = p->x; a.u3 = u5; a.scal = scal; a.bias = p->bias; a.res = p->residual; a.y = p->y;
+    a.x = p->x; a.u3 = u5; a.xmax = p->x_absmax ? p->x_absmax : scal; a.su = scal + 1; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
+    a.bias = p->bias; a.res = p->residual; a.y = p->y;
     const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
     a.N = p->N; a.Hs = p->H_in; a.Ws = p->W_in; a.H = p->H_in * upf; a.W = p->W_in * upf; a.Cin = p->Cin; a.Cout = p->Cout;
     a.CoutP = (p->Cout + 63) / 64 * 64;
@@ -597,13 +608,16 @@ int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void
         CNL_HIP(hipGetDeviceProperties(&prop, dev));
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    // the scale of the activations: max |x| of this launch's input, one pass over it (stream-ordered before the convolution)
+    // the scale of the activations: max |x| of this launch's input — handed over by the producer (x_absmax), else one pass over it
+    // (stream-ordered before the convolution)
+    if (!p->x_absmax) {
     CNL_HIP(hipMemsetAsync(scal, 0, sizeof(float), (hipStream_t)stream));
     const long long vec4 = (long long)p->N * p->H_in * p->W_in * (p->Cin / 4);
     const long long want = (vec4 + 256 * 16 - 1) / (256 * 16);                  // >= 16 float4 per thread
     const unsigned mgrid = (unsigned)(want < 1 ? 1 : (want > 8ll * n_cu ? 8ll * n_cu : want));
     hipLaunchKernelGGL(absmax_kernel, dim3(mgrid), dim3(256), 0, (hipStream_t)stream, p->x, (long)p->N * p->H_in * p->W_in,
                        p->Cin, p->ldx, reinterpret_cast<unsigned*>(scal));
+    }
     const unsigned grid = (unsigned)(blocks < (long long)n_cu ? blocks : (long long)n_cu);
     hipLaunchKernelGGL(winograd5_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return cnl::check_launch("winograd5_kernel");

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 2   /* 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 3   /* 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -71,6 +71,13 @@ typedef struct cnl_conv_params {
     int32_t KH, KW, stride, pad;
     int32_t ldx, ldy, ldr;  /* pixel strides in elements                                             */
     uint32_t flags;         /* CNL_RELU | CNL_SIGMOID | CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD        */
+    /* Optional hand-over of a tensor's maximum magnitude between launches (cnl_conv3x3_winograd_f32 only; NULL = unused).  The
+     * fp16-split Winograd kernel scales its input by a power of two derived from max |x|: with x_absmax it reads that maximum from
+     * device memory instead of making its own pass over x; a producer given y_absmax folds max |y| of everything it stores into
+     * that float (atomic max on the bit pattern: zero it on the stream before the producer runs).  A maximum over a superset of
+     * the consumer's channels is a valid, slightly conservative bound.                                                        */
+    const float* x_absmax;
+    float* y_absmax;
 } cnl_conv_params;
 
 int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream);
