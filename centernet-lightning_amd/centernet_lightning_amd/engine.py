@@ -234,7 +234,7 @@ class Plan:
         """Hand the maximum magnitude of a tensor from the launch that produces it to the fp16-split Winograd launches that
         consume it (cnl_conv_params.x_absmax / y_absmax): those then skip their own pass over the input.  Only where it is
         provably the whole story: the consumer's input buffer has exactly one writer in the plan, that writer is a Winograd
-        launch on the fp32-MFMA or fp16-split kernel (the ones that report max |y|) and it writes every channel of the buffer."""
+        launch on the fp16-split kernel (the one that reports max |y|) and it writes every channel of the buffer."""
         lib, wino = self.lib, self.lib.cnl_conv3x3_winograd_f32
         writers, unsafe = {}, set()
         for L in self.launches:
@@ -251,7 +251,7 @@ class Plan:
             if id(x) in unsafe or len(ws) != 1 or ws[0] is L:
                 continue
             P = ws[0]
-            if P.fn is not wino or lib.cnl_conv3x3_winograd_kernel(ctypes.byref(P.args)) not in (2, 5):
+            if P.fn is not wino or lib.cnl_conv3x3_winograd_kernel(ctypes.byref(P.args)) != 5:
                 continue
             if P.args.y != x.data_ptr() or P.args.Cout != P.args.ldy:
                 continue

@@ -39,7 +39,6 @@ struct Args {
     int blocks;
     unsigned x_bytes, u_bytes, y_bytes, r_bytes;
     unsigned flags;
-    unsigned* ymax;                   // optional: max |y| of this launch's output (cnl_conv_params.y_absmax)
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -133,7 +132,6 @@ __global__ __launch_bounds__(256, 2) void winograd2_kernel(const Args a) {
     const int hs = hi ^ ((lane >> 3) & 1);                              // physical half holding this lane's logical half
     const int fragA = ((xi0 * T + (lane & 31)) * 8 + hs * 4) * 4;       // + j * T * 32
     const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
-    float omax = 0.f;          // running max |y| of this lane's stores (only reported when a.ymax is set)
 
     int n, y0, x0, n0;
     unsigned p_off[2], u_voff;
@@ -360,20 +358,13 @@ __global__ __launch_bounds__(256, 2) void winograd2_kernel(const Args a) {
                 for (int c = 0; c < 2; ++c) {
                     const float ya = q[0][c] + q[1][c] + q[2][c];
                     const float yb = q[1][c] - q[2][c] - q[3][c];
-                    const float oa = fmaxf(ya + bv + rv[0][c], lo), ob = fmaxf(yb + bv + rv[1][c], lo);
-                    omax = fmaxf(omax, fmaxf(ok[0][c] ? fabsf(oa) : 0.f, ok[1][c] ? fabsf(ob) : 0.f));
-                    buf_store(oa, a.y, a.y_bytes, ok[0][c] ? y_voff : OOB, (unsigned)(c * a.ldy * 4));
-                    buf_store(ob, a.y, a.y_bytes, ok[1][c] ? y_voff : OOB, (unsigned)((a.W + c) * a.ldy * 4));
+                    buf_store(fmaxf(ya + bv + rv[0][c], lo), a.y, a.y_bytes, ok[0][c] ? y_voff : OOB, (unsigned)(c * a.ldy * 4));
+                    buf_store(fmaxf(yb + bv + rv[1][c], lo), a.y, a.y_bytes, ok[1][c] ? y_voff : OOB, (unsigned)((a.W + c) * a.ldy * 4));
                 }
             }
         }
         if (!more) break;
         item = next;
-    }
-    if (a.ymax) {              // one atomic per wave and launch
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
-        if (lane == 0 && omax > 0.f) atomicMax(a.ymax, __float_as_uint(omax));
     }
 #undef W2_MFMA8
 #undef W2_ISSUE_P
@@ -407,7 +398,6 @@ int cnl_wino2_launch(const cnl_conv_params* p, size_t u_floats, void* stream) {
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.flags = p->flags;
-    a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
     static bool attr_done = false;
     if (!attr_done) {
         CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
