@@ -573,15 +573,15 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.flags = p->flags;
-    // Three kernels behind this entry point.  winograd3.hip forms the fp32 products on the bf16 matrix cores (exact three-way
-    // bf16 split, six cross terms, fp32 accumulation: error at or below that of the fp32 MFMA, see its header) in 16x16-pixel x
-    // 64-cout work items with a sizeable fixed cost per item; measured per layer (profiles/r01_winograd_variants.txt) it wins
-    // where the channel loop is long and an image supplies enough items: Cin >= 256 and >= 8 items per image (head blocks 256 ->
-    // 256 on 128x128: -16 %, layer3 -16 %, layer4 -22 %); it loses on Cin = 64 layers (+14 %) and on 16x16 maps with few cout
-    // blocks.  Everything else takes winograd2.hip (fp32 MFMA, 8x16-pixel blocks, two 4-wave workgroups per CU), which is never
-    // slower than this file's 16x16-pixel form (bit-identical to it; CNL_WINO=1 selects it for the bit-identity test).  The
-    // choice is a function of the layer shape alone, never of the batch size (batch invariance).  CNL_WINO=1|2|3 forces a kernel; CNL_WINO=4 runs the
-    // bf16-split layers on winograd4.hip (two waves per SIMD: the same time at a lower clock — the kernel is power-bound; kept for A/B).
+    // Kernels behind this entry point (wino_choice; a function of the layer SHAPE alone, never of the batch size — batch
+    // invariance; measured per layer in profiles/r01_winograd_variants.txt):
+    //   5  winograd5.hip  fp32 products formed on the fp16 matrix cores (scaled two-way fp16 split, three cross terms, fp32
+    //                     accumulation: error at or below the fp32 MFMA's) — the default where the channel loop is long enough to
+    //                     pay for its 16x16-pixel x 64-cout work items: Cin >= 128 or Cout >= 512, >= 8 items per image;
+    //   2  winograd2.hip  fp32 MFMA, 8x16-pixel blocks, two 4-wave workgroups per CU — everything else (and everything under
+    //                     CNL_WINO=2); never slower than this file's 16x16-pixel form (1, bit-identical to it, kept for that test);
+    //   3  winograd3.hip  exact three-way bf16 split, six cross terms (the range-preserving form of 5; CNL_WINO=3);
+    //   4  winograd4.hip  3 with two waves per SIMD (same time at a lower clock: power-bound; CNL_WINO=4, A/B only).
     const int choice = wino_choice(p);
     const float* u3 = p->w + wino_f32_floats(p->Cin, p->Cout);
     if (choice == 5) {

@@ -92,10 +92,12 @@ int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);
  * `p->w` must point to the PRE-TRANSFORMED weights produced by cnl_winograd_transform_weights_f32 from the OHWI
  * (BN-folded) weights; flags: CNL_RELU only (upsample / sigmoid variants stay on cnl_conv2d_nhwc_f32). Cin % 8 == 0.
  *
- * Two multiplier arrays serve this entry point, chosen from the layer SHAPE alone (never the batch size): the fp32 matrix core
- * (csrc/winograd2.hip), or — where the channel loop is long (Cin >= 256, Cin % 16 == 0) — the bf16 matrix core fed with the exact
- * three-way bf16 split of both fp32 operands (six cross terms, fp32 accumulation: csrc/winograd3.hip; error at or below the
- * fp32 matrix core's, 16x its rate).  cnl_conv3x3_winograd_kernel reports which one a layer takes: CNL_WINO_F32 / CNL_WINO_BF16X3.
+ * Several multiplier arrays serve this entry point, chosen from the layer SHAPE alone (never the batch size): the fp32 matrix
+ * core (csrc/winograd2.hip), or — where the channel loop is long (Cin >= 128 or Cout >= 512, Cin % 16 == 0) — the fp16 matrix core
+ * fed with a two-way fp16 split of both fp32 operands under a per-tensor power-of-two scale (three cross terms, fp32
+ * accumulation: csrc/winograd5.hip; measured error at or below the fp32 matrix core's, half-precision rate = 16x).  The exact,
+ * range-preserving three-way bf16 split (csrc/winograd3.hip) is selectable with CNL_WINO=3; CNL_WINO=2 pins the fp32 matrix
+ * core.  cnl_conv3x3_winograd_kernel reports which one a layer takes: CNL_WINO_F32 / CNL_WINO_BF16X3 / CNL_WINO_F16X2.
  */
 #define CNL_WINO_F32 2
 #define CNL_WINO_BF16X3 3
