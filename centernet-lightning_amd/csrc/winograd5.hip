@@ -47,6 +47,7 @@ struct Args {
     int blocks;
     unsigned x_bytes, u_bytes, y_bytes, r_bytes;
     unsigned flags;
+    int order;                        // work-item order (see W5_SETUP)
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -197,10 +198,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W5_SETUP(item_)                                                                                          \
     do {                                                                                                         \
         unsigned b_ = cnl::xcd_remap((item_), (unsigned)a.blocks);                                               \
-        const int nbi_ = b_ % a.nb; b_ /= a.nb;                                                                  \
-        const int bxi_ = b_ % a.bx; b_ /= a.bx;                                                                  \
-        const int byi_ = b_ % a.by;                                                                              \
-        n = b_ / a.by; y0 = byi_ * 16; x0 = bxi_ * 16; n0 = nbi_ * BN;                                           \
+        int nbi_, bxi_, byi_;                                                                                    \
+        if (a.order == 0) {          /* cout block fastest: the workgroups sharing an input patch run side by side */ \
+            nbi_ = b_ % a.nb; b_ /= a.nb; bxi_ = b_ % a.bx; b_ /= a.bx; byi_ = b_ % a.by; n = b_ / a.by;         \
+        } else if (a.order == 1) {   /* cout block slowest inside an image: the CUs of an XCD share one slice of U */ \
+            bxi_ = b_ % a.bx; b_ /= a.bx; byi_ = b_ % a.by; b_ /= a.by; nbi_ = b_ % a.nb; n = b_ / a.nb;         \
+        } else {                     /* pairs of cout blocks fastest, then the tile, then the pair index */       \
+            const int np_ = (a.nb + 1) / 2;                                                                      \
+            const int lo_ = b_ % 2; b_ /= 2; bxi_ = b_ % a.bx; b_ /= a.bx; byi_ = b_ % a.by; b_ /= a.by;         \
+            const int pr_ = b_ % np_; n = b_ / np_; nbi_ = pr_ * 2 + lo_;                                        \
+        }                                                                                                        \
+        y0 = byi_ * 16; x0 = bxi_ * 16; n0 = nbi_ * BN;                                                          \
         _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                          \
             const int s_ = i * 256 + tid;              /* 16-byte slot of the patch image: (py*4 + quad)*PWP + px */ \
             const int rowq_ = s_ / PWP, pxx_ = s_ - rowq_ * PWP;                                                 \
@@ -598,6 +606,8 @@ int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.flags = p->flags;
+    static const int order_env = getenv("CNL_W5_ORDER") ? atoi(getenv("CNL_W5_ORDER")) : 2;   // measured: 2 best (profiles/r01_winograd_variants.txt)
+    a.order = (order_env == 2 && (a.nb & 1)) ? 0 : order_env;
     static bool attr_done = false;
     if (!attr_done) {
         CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
