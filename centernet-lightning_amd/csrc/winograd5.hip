@@ -177,20 +177,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int dstv = wave * VW_BYTES + (t_tyl * 8 + t_tx) * 32 + (((t_q >> 1) ^ t_tyl) << 4) + (t_q & 1) * 8;   // + it*512 + (j*NP+k)*VPIECE
     const int fragA = wave * VW_BYTES + (lane & 31) * 32 + ((hi ^ ((lane >> 3) & 1)) << 4);                    // + (j*NP+k)*VPIECE + tg*1024
     const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
-    // power-of-two scale of V: |V| <= 4 max |x| (sums of four inputs), 4 max |x| S in [2^13, 2^14) — exact, undone in the epilogue
-    // together with the scale of the weights
-    float S = 1.f;
-    {
-        const float mx4 = 4.f * a.xmax[0];
-        if (mx4 > 0.f && mx4 < __builtin_inff()) {
-            int e_;
-            (void)__builtin_frexpf(mx4, &e_);                 // 2^(e-1) <= mx4 < 2^e
-            e_ = 14 - e_;
-            S = __builtin_ldexpf(1.f, e_ < -100 ? -100 : (e_ > 100 ? 100 : e_));
-        }
-    }
-    const float inv = 1.f / (S * a.su[0]);
-    float omax = 0.f;          // running max |y| of this lane's stores
+    // power-of-two scale of V, PER IMAGE (an image's result never depends on its batch neighbours — batch invariance, shard == full
+    // batch): |V| <= 4 max |x| (sums of four inputs), 4 max |x| S in [2^13, 2^14) — exact, undone in the epilogue together with the
+    // scale of the weights.  S / inv_n belong to the item set up last (W5_SETUP), `inv` to the one in the epilogue.
+    const float Su = a.su[0];
+    float S = 1.f, inv_n = 1.f / Su;
+    float omax = 0.f;          // running max |y| of this lane's stores of the current item
 
     int n, y0, x0, n0;
     unsigned p_off[6], u_voff;
@@ -220,6 +212,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }                                                                                                        \
         /* this lane's B fragments: cout row n0 + (lane & 31) (+ 32 for the second group), channel half hi */    \
         u_voff = (unsigned)((n0 + (lane & 31)) * 32 + hi * 16);                                                  \
+        {                                                                                                        \
+            const float mx4_ = 4.f * a.xmax[n];                                                                  \
+            S = 1.f;                                                                                             \
+            if (mx4_ > 0.f && mx4_ < __builtin_inff()) {                                                         \
+                int e_;                                                                                          \
+                (void)__builtin_frexpf(mx4_, &e_);            /* 2^(e-1) <= mx4 < 2^e */                         \
+                e_ = 14 - e_;                                                                                    \
+                S = __builtin_ldexpf(1.f, e_ < -100 ? -100 : (e_ > 100 ? 100 : e_));                             \
+            }                                                                                                    \
+            inv_n = 1.f / (S * Su);                                                                              \
+        }                                                                                                        \
         /* bias of this thread's two epilogue columns: requested now, used after the chunk loop */               \
         _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                                       \
             const int col_ = n0 + g_ * 32 + (tid & 31);                                                          \
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int en = n, ey0 = y0, ex0 = x0, en0 = n0;        // this item's coordinates (the setup below moves on to the next)
         const bool full = (y0 + 16 <= a.H) && (x0 + 16 <= a.W) && (n0 + BN <= a.Cout);
         const float bv[2] = {bias_n[0], bias_n[1]};
+        const float inv = inv_n;
         const unsigned next = item + gridDim.x;
         const bool more = next < (unsigned)a.blocks;
 #pragma unroll
@@ -472,13 +476,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
         }
+        if (a.ymax) {          // max |y| of this item into its image's slot: one atomic per wave and item (no return value awaited)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
+            if (lane == 0 && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
+            omax = 0.f;
+        }
         if (!more) break;
         item = next;
-    }
-    if (a.ymax) {              // one atomic per wave and launch
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
-        if (lane == 0 && omax > 0.f) atomicMax(a.ymax, __float_as_uint(omax));
     }
 #undef W5_SLOT
 #undef W5_MFMA
@@ -489,9 +494,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 // max |x| over [pixels][C] floats with pixel stride ld (C % 4 == 0, 16-byte aligned): non-negative floats order like their bit
 // patterns, so the reduction is an unsigned atomicMax; *out must be zeroed first.  NaNs are ignored (they would poison the scale).
+// blockIdx.y = image (pixels per image, one result per image): the scale of an image must not depend on its batch neighbours.
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long pixels, int C, int ld, unsigned* __restrict__ out) {
     const int c4 = C >> 2;
     const long total = pixels * c4;
+    x += (long)blockIdx.y * pixels * ld;
+    out += blockIdx.y;
     float m = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long px = i / c4;
@@ -565,14 +573,14 @@ size_t cnl_wino5_weight_bytes(int Cin, int Cout) {
     const size_t CoutP = (size_t)((Cout + 63) / 64) * 64;
     return (size_t)(Cin / 16) * 16 * cnl_wino5::NP * CoutP * 32;
 }
-size_t cnl_wino5_scalar_floats() { return 16; }        // [0] max |x| of the current launch, [1] S_u, [2] max |U|
+size_t cnl_wino5_scalar_floats() { return 16 + 4096; }  // [1] S_u, [2] max |U|, [16 + n] max |x| of image n of the current launch (own pass)
 
 // u_f32 = the fp32 U of the layer (already computed), u5 = destination of the pieces, scal = the layer's scalars
 int cnl_wino5_transform_weights(const float* w_ohwi, const float* u_f32, size_t u_f32_floats, void* u5, float* scal, int Cin, int Cout,
                                 void* stream) {
     using namespace cnl_wino5;
     const int CoutP = (Cout + 63) / 64 * 64;
-    CNL_HIP(hipMemsetAsync(scal, 0, cnl_wino5_scalar_floats() * sizeof(float), (hipStream_t)stream));
+    CNL_HIP(hipMemsetAsync(scal, 0, 16 * sizeof(float), (hipStream_t)stream));
     hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, u_f32, (long)(u_f32_floats / 4), 4, 4,
                        reinterpret_cast<unsigned*>(scal + 2));
     const long total = (long)CoutP * Cin;
@@ -585,7 +593,8 @@ int cnl_wino5_transform_weights(const float* w_ohwi, const float* u_f32, size_t 
 int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream) {
     using namespace cnl_wino5;
     Args a;
-    a.x = p->x; a.u3 = u5; a.xmax = p->x_absmax ? p->x_absmax : scal; a.su = scal + 1; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
+    CNL_REQUIRE(p->x_absmax || p->N <= 4096, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: more than 4096 images per launch need x_absmax");
+    a.x = p->x; a.u3 = u5; a.xmax = p->x_absmax ? p->x_absmax : scal + 16; a.su = scal + 1; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
     a.bias = p->bias; a.res = p->residual; a.y = p->y;
     const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
     a.N = p->N; a.Hs = p->H_in; a.Ws = p->W_in; a.H = p->H_in * upf; a.W = p->W_in * upf; a.Cin = p->Cin; a.Cout = p->Cout;
@@ -624,12 +633,12 @@ int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void
     // the scale of the activations: max |x| of this launch's input — handed over by the producer (x_absmax), else one pass over it
     // (stream-ordered before the convolution)
     if (!p->x_absmax) {
-    CNL_HIP(hipMemsetAsync(scal, 0, sizeof(float), (hipStream_t)stream));
-    const long long vec4 = (long long)p->N * p->H_in * p->W_in * (p->Cin / 4);
+    CNL_HIP(hipMemsetAsync(scal + 16, 0, sizeof(float) * (size_t)p->N, (hipStream_t)stream));
+    const long long vec4 = (long long)p->H_in * p->W_in * (p->Cin / 4);         // per image
     const long long want = (vec4 + 256 * 16 - 1) / (256 * 16);                  // >= 16 float4 per thread
-    const unsigned mgrid = (unsigned)(want < 1 ? 1 : (want > 8ll * n_cu ? 8ll * n_cu : want));
-    hipLaunchKernelGGL(absmax_kernel, dim3(mgrid), dim3(256), 0, (hipStream_t)stream, p->x, (long)p->N * p->H_in * p->W_in,
-                       p->Cin, p->ldx, reinterpret_cast<unsigned*>(scal));
+    const unsigned mgrid = (unsigned)(want < 1 ? 1 : (want > 64 ? 64 : want));
+    hipLaunchKernelGGL(absmax_kernel, dim3(mgrid, (unsigned)p->N), dim3(256), 0, (hipStream_t)stream, p->x, (long)p->H_in * p->W_in,
+                       p->Cin, p->ldx, reinterpret_cast<unsigned*>(scal + 16));
     }
     const unsigned grid = (unsigned)(blocks < (long long)n_cu ? blocks : (long long)n_cu);
     hipLaunchKernelGGL(winograd5_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);

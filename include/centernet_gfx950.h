@@ -71,12 +71,13 @@ typedef struct cnl_conv_params {
     int32_t KH, KW, stride, pad;
     int32_t ldx, ldy, ldr;  /* pixel strides in elements                                             */
     uint32_t flags;         /* CNL_RELU | CNL_SIGMOID | CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD        */
-    /* Optional hand-over of a tensor's maximum magnitude between launches (cnl_conv3x3_winograd_f32 only; NULL = unused).  The
-     * fp16-split Winograd kernel scales its input by a power of two derived from max |x|: with x_absmax it reads that maximum
-     * from device memory instead of making its own pass over x.  A producer given y_absmax folds max |y| of everything it stores
-     * into that float (atomic max on the bit pattern: zero it on the stream before the producer runs); the fp16-split kernel
-     * honours it, the other kernels ignore it.  A maximum over a superset of the consumer's channels is a valid, slightly
-     * conservative bound.                                                                                                     */
+    /* Optional hand-over of the per-image maximum magnitude of a tensor between launches (cnl_conv3x3_winograd_f32 only; NULL =
+     * unused).  Both point to N floats, one per image.  The fp16-split Winograd kernel scales each image's input by a power of two
+     * derived from max |x| of THAT image (an image's result never depends on its batch neighbours): with x_absmax it reads the
+     * maxima from device memory instead of making its own pass over x.  A producer given y_absmax folds max |y| of everything it
+     * stores for image n into y_absmax[n] (atomic max on the bit pattern: zero the array on the stream before the producer
+     * runs); the fp16-split kernel honours it, the other kernels ignore it.  A maximum over a superset of the consumer's
+     * channels is a valid, slightly conservative bound.                                                                        */
     const float* x_absmax;
     float* y_absmax;
 } cnl_conv_params;

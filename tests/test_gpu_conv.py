@@ -264,6 +264,20 @@ def test_winograd_split_kernels_exact_on_small_integers():
     assert torch.equal(run_winograd(x, w, b, 0), ref_conv(x, w, b, 1, 0))
 
 
+def test_winograd_is_batch_invariant_across_magnitudes():
+    """An image's output must not depend on its batch neighbours (shard == full batch) — also on the fp16-split
+    kernel, whose power-of-two input scale therefore is taken per image: images of very different magnitude in one launch give
+    bit for bit what each gives alone."""
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(3, 256, 32, 32, generator=g).clamp_min(0) * torch.tensor([1.0, 1e-3, 300.0]).view(3, 1, 1, 1)
+    w = torch.randn(128, 256, 3, 3, generator=g) * (2.0 / (256 * 9)) ** 0.5
+    b = torch.randn(128, generator=g)
+    full = run_winograd(x, w, b, CNL_RELU)
+    for i in range(3):
+        assert torch.equal(full[i:i + 1], run_winograd(x[i:i + 1], w, b, CNL_RELU)), i
+    torch.testing.assert_close(full, ref_conv(x, w, b, 1, CNL_RELU), rtol=RTOL, atol=ATOL * 300)
+
+
 def _fresh_lib(variant):
     """A private handle of the library with CNL_WINO=<variant> read at its first Winograd call (the choice is cached per process
     image, so each forced variant needs its own dlopen of a private copy)."""

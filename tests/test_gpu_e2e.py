@@ -115,6 +115,18 @@ def test_batch_shard_equals_full_batch():
         assert torch.equal(full[key], torch.cat([p[key] for p in parts], dim=0)), key
 
 
+def test_batch_shard_equals_full_batch_with_unequal_images():
+    """The same with images of very different magnitude in one batch and maps large enough for the fp16-split kernel (whose
+    input scale is per image for exactly this reason)."""
+    model, _ = build("resnet34_simple.yaml")
+    x = (recipes.images(9, (4, 3, 256, 256)) * torch.tensor([1.0, 0.02, 30.0, 1.0]).view(4, 1, 1, 1)).cuda()
+    full = model.get_encoded_outputs(x)
+    for r in range(4):
+        part = model.get_encoded_outputs(x[r:r + 1])
+        for key in full:
+            assert torch.equal(full[key][r:r + 1], part[key]), (key, r)
+
+
 def test_channels_last_input_and_weight_reload():
     model, sd = build("resnet34_simple.yaml")
     x = recipes.images(3, (1, 3, 128, 128)).cuda()
@@ -145,6 +157,29 @@ def test_direct_and_winograd_paths_agree(monkeypatch):
         torch.testing.assert_close(out_d[name].cpu(), ref[name], rtol=TOL, atol=TOL)
         torch.testing.assert_close(out_w[name].cpu(), ref[name], rtol=TOL, atol=TOL)
         torch.testing.assert_close(out_w[name], out_d[name], rtol=2e-5, atol=2e-5)
+
+
+def test_absmax_handover_matches_own_pass(monkeypatch):
+    """The fp16-split Winograd launches scale their input by a power of two taken from the tensor's maximum magnitude.  The engine
+    hands that maximum over from the producing launch (cnl_conv_params.x_absmax / y_absmax); without the hand-over each launch
+    makes its own pass over its input.  Both give the same network outputs up to fp32 rounding (the handed-over maximum may cover
+    a superset of the consumer's channels, i.e. a scale that differs by a power of two), and the slots really are filled."""
+    x = recipes.images(13, (2, 3, 256, 256)).cuda()
+    model_h, sd = build("resnet34_fpn.yaml")
+    out_h = model_h.get_encoded_outputs(x)
+    plan = next(iter(model_h._engine.plans.values()))
+    wired = [L for L in plan.launches if getattr(L.args, "x_absmax", None)]
+    if not wired:
+        pytest.skip("no fp16-split launch in this configuration (CNL_WINO pins another kernel)")
+    assert plan.absmax is not None and len(wired) >= 10 and bool((plan.absmax > 0).all())
+    monkeypatch.setenv("CNL_ABSMAX_HANDOVER", "0")
+    model_o, _ = build("resnet34_fpn.yaml")
+    out_o = model_o.get_encoded_outputs(x)
+    assert next(iter(model_o._engine.plans.values())).absmax is None
+    ref = ref_cpu.forward(sd, x.cpu(), sigmoid=False)
+    for name in ref:
+        torch.testing.assert_close(out_h[name], out_o[name], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(out_h[name].cpu(), ref[name], rtol=TOL, atol=TOL)
 
 
 @pytest.mark.parametrize("cfg,shape,k", [("resnet34_simple.yaml", (32, 3, 512, 512), 100),          # BASELINE C1
