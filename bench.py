@@ -41,11 +41,11 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 (v_mfma_f32_32x32x16_
 F16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense fp16 = bf16 rate
 # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_final5.txt): per kernel, mean
 # FETCH_SIZE x 2 (gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md §HBM) + mean WRITE_SIZE over the launches
-# of a C1 step (fp16-split Winograd: 203.7 MB x 2 + 146.4 MB = 553.8 MB).  Other configs: not profiled -> null.
+# of a C1 step (fp16-split Winograd: 186.2 MB x 2 + 146.6 MB = 518.9 MB).  Other configs: not profiled -> null.
 MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("simple", 32, 512, 512, "cnl_conv::conv_mfma_kernel"): 237.0e6,
-                                     ("simple", 32, 512, 512, "cnl_wino2::winograd2_kernel"): 328.5e6,
+                                     ("simple", 32, 512, 512, "cnl_wino2::winograd2_kernel"): 328.9e6,
                                      ("simple", 32, 512, 512, "cnl_wino3::winograd3_kernel"): 731.5e6,
-                                     ("simple", 32, 512, 512, "cnl_wino5::winograd5_kernel"): 553.8e6}
+                                     ("simple", 32, 512, 512, "cnl_wino5::winograd5_kernel"): 518.9e6}
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 
 
