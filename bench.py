@@ -160,9 +160,21 @@ def cpu_baseline(model, tracking, k, H, W, budget_s=20.0):
     with torch.no_grad():
         out = model(x.cuda())
     err = float((out[0].cpu() - o["heatmap"]).abs().max())
-    return {"value": round(n * iters / spent, 3), "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": round(n * iters / spent, 3), "unit": "images/s", "cores": cores, "kind": "port", "max_abs_err_heatmap": err,
             "sample": f"{iters} timed passes of oracle/ref_cpu.forward + decode_ref on {n}x3x{H}x{W} (same weights), "
                       f"torch {torch.__version__} CPU fp32, {cores} threads; max |heatmap_gpu - heatmap_cpu| = {err:.2e}"}
+
+
+def oracle_check(model, H, W):
+    """max |heatmap_gpu - heatmap_cpu| on a 2-image sample: one pass of the CPU oracle, no timing (the checker, not the product)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_cpu
+    sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
+    x = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(1234))
+    o = ref_cpu.forward(sd, x, sigmoid=True)
+    with torch.no_grad():
+        out = model(x.cuda())
+    return float((out[0].cpu() - o["heatmap"]).abs().max())
 
 
 def main():
@@ -177,6 +189,7 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer conv table to stderr")
+    ap.add_argument("--oracle-check", action="store_true", help="add max |heatmap - CPU oracle| of this configuration (one oracle pass)")
     ap.add_argument("--no-fp32-mfma-leg", action="store_true",
                     help="skip the extra short run with every Winograd layer on the fp32 matrix core (CNL_WINO=2), reported beside `value`")
     args = ap.parse_args()
@@ -333,17 +346,23 @@ def main():
             env = dict(os.environ, CNL_WINO="2")
             cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(max(args.steps // 2, 3)), "--warmup", str(min(args.warmup, 3)),
                    "--config", args.config, "--batch", str(B), "--height", str(H), "--width", str(W), "--k", str(args.k),
-                   "--no-cpu-baseline", "--no-fp32-mfma-leg"]
+                   "--no-cpu-baseline", "--no-fp32-mfma-leg", "--oracle-check"]
             try:
                 out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
                 alt = json.loads(out)
                 result["fp32_mfma_only"] = {"value": alt["value"], "unit": alt["unit"], "ms_per_step": alt["ms_per_step"], "steps": alt["steps"],
                                             "roofline_frac_of_fp32_mfma_peak": alt["roofline"]["frac"],
+                                            "max_abs_err_heatmap_vs_cpu_oracle": alt.get("oracle_check", {}).get("max_abs_err_heatmap"),
                                             "note": "CNL_WINO=2: all Winograd layers on v_mfma_f32_32x32x2_f32 (no bf16 split anywhere)"}
             except Exception as e:      # reported, never fatal: `value` above is the measurement
                 result["fp32_mfma_only"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(model, tracking, args.k, H, W)
+            result["accuracy"] = {"max_abs_err_heatmap_vs_cpu_oracle": result["cpu_baseline"]["max_abs_err_heatmap"],
+                                  "same_with_every_layer_on_the_fp32_mfma": result.get("fp32_mfma_only", {}).get("max_abs_err_heatmap_vs_cpu_oracle"),
+                                  "tolerance": 1e-4, "sample": "2 images of the bench shape, same weights"}
+        elif world == 1 and args.oracle_check:
+            result["oracle_check"] = {"max_abs_err_heatmap": oracle_check(model, H, W)}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
