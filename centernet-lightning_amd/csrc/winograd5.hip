@@ -84,9 +84,12 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 // the split of a channel pair (v0, v1), scaled by the power of two S:  hi = RN16(v S) packed, r = v S - hi exactly
-__device__ __forceinline__ unsigned split_hi(float v0, float v1, float S) {
+__device__ __forceinline__ unsigned split_hi_lo(float v0, float S) {            // RN16(v0 S) in the low half
     unsigned pk;
     asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(pk) : "v"(v0), "v"(S));
+    return pk;
+}
+__device__ __forceinline__ unsigned split_hi_hi(unsigned pk, float v1, float S) {   // ... and RN16(v1 S) in the high half
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(pk) : "v"(v1), "v"(S));
     return pk;
 }
@@ -109,18 +112,18 @@ __device__ __forceinline__ f32x4 lds_f4(const char* p) { return *reinterpret_cas
 __device__ __forceinline__ u32x4 lds_u4(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
 
 // Registers of one wave's input-transform pipeline.  A "pass-item" = (item: tile, 4 channels) x (pass P: position pair {2P, 2P+1}
-// of the wave's row).  Its VALU operations are indexed 0..43 so that the main loop can place them per MFMA slice:
+// of the wave's row).  Its VALU operations are indexed 0..39 so that the main loop can place them per MFMA slice:
 //   0..11   t[c] = da[c] + sg * db[c]      the wave's row of B^T d; pass 0: columns 0, 1, 2 (1, 2 are kept), pass 1: column 3 only
 //   12..19  v[0], v[1]                     the two positions of the pair: (t0 - t2, t1 + t2) or (t2 - t1, t1 - t3)
-//   20..43  per v (12 slots): hi pairs (mixlo + mixhi: one unit in two slots) x 2, residuals x 4, lo pairs (pkrtz) x 2
+//   20..39  both v together: 4 x mixlo, 4 x mixhi (packed hi pairs), 8 residuals, 4 x pkrtz (packed lo pairs)
 struct Xf {
     f32x4 da[2][3], db[2][3];       // [register set][column]: rows ra / rb of the patch (read one pass-item ahead)
     f32x4 t[3], v[2];
     f32x4 th[4][2];                 // t of patch columns 1, 2 of each item, kept from pass 0 for pass 1
-    float r[4];
+    float r[2][4];
     unsigned pk[2][NP][2];          // [position of the pair][piece][channel pair]
 };
-constexpr int XOPS = 44;
+constexpr int XOPS = 40;
 __device__ __forceinline__ void xop(Xf& s, const int set, const int P, const int op, const float sg, const float S, const int it) {
     if (op < 12) {
         const int c = op >> 2, e = op & 3;
@@ -133,15 +136,18 @@ __device__ __forceinline__ void xop(Xf& s, const int set, const int P, const int
         if (P == 0) s.v[vi][e] = vi == 0 ? s.t[0][e] - s.th[it][1][e] : s.th[it][0][e] + s.th[it][1][e];
         else s.v[vi][e] = vi == 0 ? s.th[it][1][e] - s.th[it][0][e] : s.th[it][0][e] - s.t[2][e];
     } else if (op < XOPS) {
-        const int q = op - 20, vi = q / 12, w = q % 12;
-        if (w == 0) s.pk[vi][0][0] = split_hi(s.v[vi][0], s.v[vi][1], S);
-        else if (w == 2) s.pk[vi][0][1] = split_hi(s.v[vi][2], s.v[vi][3], S);
-        else if (w == 4) s.r[0] = split_res_lo(s.v[vi][0], S, s.pk[vi][0][0]);
-        else if (w == 5) s.r[1] = split_res_hi(s.v[vi][1], S, s.pk[vi][0][0]);
-        else if (w == 6) s.r[2] = split_res_lo(s.v[vi][2], S, s.pk[vi][0][1]);
-        else if (w == 7) s.r[3] = split_res_hi(s.v[vi][3], S, s.pk[vi][0][1]);
-        else if (w == 8) s.pk[vi][1][0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(s.r[0], s.r[1]));
-        else if (w == 9) s.pk[vi][1][1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(s.r[2], s.r[3]));
+        // the two positions and their channel pairs advance side by side: dependent mixed-precision operations (partial register
+        // writes, half-register reads) stay >= 3 instructions apart, which saves the hazard nops
+        const int w = op - 20;
+        if (w < 4) s.pk[w >> 1][0][w & 1] = split_hi_lo(s.v[w >> 1][2 * (w & 1)], S);
+        else if (w < 8) s.pk[(w - 4) >> 1][0][w & 1] = split_hi_hi(s.pk[(w - 4) >> 1][0][w & 1], s.v[(w - 4) >> 1][2 * (w & 1) + 1], S);
+        else if (w < 16) {
+            const int vi = (w - 8) >> 2, e = w & 3;
+            s.r[vi][e] = (e & 1) ? split_res_hi(s.v[vi][e], S, s.pk[vi][0][e >> 1]) : split_res_lo(s.v[vi][e], S, s.pk[vi][0][e >> 1]);
+        } else {
+            const int vi = (w - 16) >> 1, pp = w & 1;
+            s.pk[vi][1][pp] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(s.r[vi][2 * pp], s.r[vi][2 * pp + 1]));
+        }
     }
 }
 
