@@ -18,6 +18,12 @@
 
 #pragma clang fp contract(off)
 
+#ifndef W5_NT_X
+#define W5_NT_X 0     /* cache policy (aux) of the patch DMA loads: 2 = nt */
+#endif
+#ifndef W5_NT_Y
+#define W5_NT_Y 2     /* cache policy (aux) of the output stores: nt — a layer's output is far larger than the L2 and would only evict the input patches and weights that ARE re-read (fused first head blocks -9 %) */
+#endif
 #ifndef W5_EXP
 #define W5_EXP 0     /* timing experiments (wrong results): 1 no B loads, 2 no A reads, 3 no patch reads, 4 no barrier in the loop */
 #endif
@@ -66,7 +72,7 @@ constexpr int LDS_BYTES = V_BYTES + 2 * P_BYTES;                 // 110592: one 
 
 __device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* lds_dst, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 0, W5_NT_X);
 }
 __device__ __forceinline__ u32x4 buf_load16(const void* base, unsigned bytes, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
@@ -78,7 +84,7 @@ __device__ __forceinline__ float buf_load(const float* base, unsigned bytes, uns
 }
 __device__ __forceinline__ void buf_store(float v, float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voffset, soffset, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voffset, soffset, W5_NT_Y);
 }
 __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
