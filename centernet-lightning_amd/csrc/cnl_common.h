@@ -6,6 +6,13 @@
 #include <cstring>
 #include "centernet_gfx950.h"
 
+// cache policy (aux) of the conv kernels' output stores: 2 = nt.  A layer's output is far larger than the L2 (4 MB per XCD) and is
+// next touched by the following launch; written with the default policy it only evicts the input patches and weights that the
+// running kernel re-reads.
+#ifndef CNL_NT_STORES
+#define CNL_NT_STORES 2
+#endif
+
 namespace cnl {
 
 // Thread-local last-error text, exported through cnl_last_error().
