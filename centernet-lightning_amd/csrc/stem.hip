@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
                 const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (oy < Ho && ox < Wo) {
                     const float v = fmaxf(acc[i][j][r] + bv, 0.f);
-                    y[(((size_t)n * Ho + oy) * Wo + ox) * 64 + co] = v;
+                    __builtin_nontemporal_store(v, &y[(((size_t)n * Ho + oy) * Wo + ox) * 64 + co]);     // CNL_NT_STORES: 537 MB that only the max-pool reads
                 }
             }
         }
