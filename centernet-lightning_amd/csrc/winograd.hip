@@ -483,6 +483,7 @@ size_t cnl_wino5_weight_bytes(int Cin, int Cout);                               
 size_t cnl_wino5_scalar_floats();
 int cnl_wino5_transform_weights(const float* w_ohwi, const float* u_f32, size_t u_f32_floats, void* u5, float* scal, int Cin, int Cout, void* stream);
 int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream);
+int cnl_wino6_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream);        // winograd6.hip
 
 // floats of the fp32 U = [ci/8][xi][CoutP][8]; the bf16-split copy for winograd3.hip (layers with Cin % 16 == 0) follows it
 static size_t wino_f32_floats(int Cin, int Cout) {
@@ -513,7 +514,8 @@ extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u,
 }
 
 // which kernel a layer shape takes: 2 = fp32 MFMA (winograd2.hip), 3 = bf16 three-way split (winograd3.hip), 5 = fp16 two-way split
-// (winograd5.hip); CNL_WINO=1..5 forces one (4 = winograd4.hip, the two-waves-per-SIMD form of 3)
+// (winograd5.hip, or winograd6.hip = the same on 128-cout work items); CNL_WINO=1..6 forces one (4 = winograd4.hip, the
+// two-waves-per-SIMD form of 3)
 static int wino_choice(const cnl_conv_params* p) {
     static const int forced = getenv("CNL_WINO") ? atoi(getenv("CNL_WINO")) : 0;
     static const int min_cin5 = getenv("CNL_W5_MINCIN") ? atoi(getenv("CNL_W5_MINCIN")) : 128;
@@ -523,8 +525,9 @@ static int wino_choice(const cnl_conv_params* p) {
     const int items_per_image = ((H + 15) / 16) * ((W + 15) / 16) * (CoutP / 64);
     if (forced == 1 || forced == 2) return forced;
     if (p->Cin % 16) return 2;
-    if (forced >= 3 && forced <= 5) return forced;
-    if (items_per_image >= 8 && (p->Cin >= min_cin5 || p->Cout >= min_cout5)) return 5;
+    if (forced >= 3 && forced <= 6) return forced;
+    if (items_per_image >= 8 && (p->Cin >= min_cin5 || p->Cout >= min_cout5))
+        return (p->Cin < min_cin5 && p->Cout % 128 == 0) ? 6 : 5;    // short channel loop, many couts: the 128-cout work items of winograd6.hip
     return 2;
 }
 
@@ -532,7 +535,7 @@ extern "C" int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p) {
     CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: null params");
     CNL_REQUIRE(p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: non-positive dimension");
     const int c = wino_choice(p);
-    return c == 5 ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
+    return (c == 5 || c == 6) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
 }
 
 extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) {
@@ -580,13 +583,16 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
     //                     pay for its 16x16-pixel x 64-cout work items: Cin >= 128 or Cout >= 512, >= 8 items per image;
     //   2  winograd2.hip  fp32 MFMA, 8x16-pixel blocks, two 4-wave workgroups per CU — everything else (and everything under
     //                     CNL_WINO=2); never slower than this file's 16x16-pixel form (1, bit-identical to it, kept for that test);
+    //   6  winograd6.hip  5 on 8x16-pixel x 128-cout work items (half the transform work per output, twice the weight stream):
+    //                     -7 % where the channel loop is short and the couts are many (the fused first head blocks, 64 -> 512),
+    //                     +2 % on the 256 -> 256 blocks — used for Cin < 128 with Cout % 128 == 0 only;
     //   3  winograd3.hip  exact three-way bf16 split, six cross terms (the range-preserving form of 5; CNL_WINO=3);
     //   4  winograd4.hip  3 with two waves per SIMD (same time at a lower clock: power-bound; CNL_WINO=4, A/B only).
     const int choice = wino_choice(p);
     const float* u3 = p->w + wino_f32_floats(p->Cin, p->Cout);
-    if (choice == 5) {
+    if (choice == 5 || choice == 6) {
         float* u5 = const_cast<float*>(u3) + cnl_wino3_weight_bytes(p->Cin, p->Cout) / 4;
-        return cnl_wino5_launch(p, u5, u5 + cnl_wino5_weight_bytes(p->Cin, p->Cout) / 4, stream);
+        return (choice == 6 ? cnl_wino6_launch : cnl_wino5_launch)(p, u5, u5 + cnl_wino5_weight_bytes(p->Cin, p->Cout) / 4, stream);
     }
     if (choice == 4) return cnl_wino4_launch(p, u3, stream);
     if (choice == 3) return cnl_wino3_launch(p, u3, stream);
