@@ -526,8 +526,12 @@ static int wino_choice(const cnl_conv_params* p) {
     if (forced == 1 || forced == 2) return forced;
     if (p->Cin % 16) return 2;
     if (forced >= 3 && forced <= 6) return forced;
-    if (items_per_image >= 8 && (p->Cin >= min_cin5 || p->Cout >= min_cout5))
-        return (p->Cin < min_cin5 && p->Cout % 128 == 0) ? 6 : 5;    // short channel loop, many couts: the 128-cout work items of winograd6.hip
+    if (items_per_image >= 8 && (p->Cin >= min_cin5 || p->Cout >= min_cout5)) {
+        // the 8x16-pixel x 128-cout work items of winograd6.hip: where the channel loop is short and the couts many, and on maps
+        // that 16-row blocks pad more than 8-row blocks (19x34, 38x68, 152x272 of 608x1088 frames: -1 .. -4 %)
+        const long long pad16 = (long long)((H + 15) / 16 * 16) * ((W + 15) / 16 * 16), pad8 = (long long)((H + 7) / 8 * 8) * ((W + 15) / 16 * 16);
+        return (p->Cout % 128 == 0 && (p->Cin < min_cin5 || pad8 < pad16)) ? 6 : 5;
+    }
     return 2;
 }
 

@@ -23,6 +23,10 @@ SHAPES = {
     "layer4": (32, 16, 16, 512, 512, 3, 1, CNL_RELU, True),
     "big256px": (8, 256, 256, 64, 64, 3, 1, CNL_RELU, False),
     "neck0": (32, 16, 16, 512, 256, 3, 1, CNL_RELU, False),
+    "c4l4": (16, 19, 34, 512, 512, 3, 1, CNL_RELU, False),
+    "c4l3": (16, 38, 68, 256, 256, 3, 1, CNL_RELU, False),
+    "c4l2": (16, 76, 136, 128, 128, 3, 1, CNL_RELU, False),
+    "c4head": (16, 152, 272, 256, 256, 3, 1, CNL_RELU, False),
     "out80": (32, 128, 128, 256, 80, 1, 1, CNL_SIGMOID, False),
     "out4": (32, 128, 128, 256, 4, 1, 1, 0, False),
 }
