@@ -270,7 +270,7 @@ def main():
             # point include the absmax pass over the input that fixes the scale
             exec_tf = fl_h * (16.0 / 36.0) * 3.0 / (ms_h * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "cnl_wino5::winograd5_kernel (F(2x2,3x3); fp32 operands scaled by a power of two and split into 2 fp16 "
-                                               "pieces, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; incl. cnl_wino6::winograd6_kernel, its 128-cout form, and the few absmax_kernel passes)",
+                                               "pieces, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; incl. cnl_wino6::winograd6_kernel and cnl_wino7::winograd7_kernel, its 128-cout and two-waves-per-SIMD forms, and the few absmax_kernel passes)",
                     "achieved": round(exec_tf, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(exec_tf / F16_MFMA_PEAK_TFLOPS, 4),
                     "achieved_counts": "executed fp16 matrix-core flops = direct-conv flops x 16/36 (Winograd) x 3 (split terms)",

@@ -484,6 +484,7 @@ size_t cnl_wino5_scalar_floats();
 int cnl_wino5_transform_weights(const float* w_ohwi, const float* u_f32, size_t u_f32_floats, void* u5, float* scal, int Cin, int Cout, void* stream);
 int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream);
 int cnl_wino6_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream);        // winograd6.hip
+int cnl_wino7_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream);        // winograd7.hip
 
 // floats of the fp32 U = [ci/8][xi][CoutP][8]; the bf16-split copy for winograd3.hip (layers with Cin % 16 == 0) follows it
 static size_t wino_f32_floats(int Cin, int Cout) {
@@ -514,19 +515,23 @@ extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u,
 }
 
 // which kernel a layer shape takes: 2 = fp32 MFMA (winograd2.hip), 3 = bf16 three-way split (winograd3.hip), 5 = fp16 two-way split
-// (winograd5.hip, or winograd6.hip = the same on 128-cout work items); CNL_WINO=1..6 forces one (4 = winograd4.hip, the
-// two-waves-per-SIMD form of 3)
+// (winograd5.hip, winograd6.hip = the same on 128-cout work items, or winograd7.hip = the same with two waves per SIMD);
+// CNL_WINO=1..7 forces one (4 = winograd4.hip, the two-waves-per-SIMD form of 3)
 static int wino_choice(const cnl_conv_params* p) {
     static const int forced = getenv("CNL_WINO") ? atoi(getenv("CNL_WINO")) : 0;
     static const int min_cin5 = getenv("CNL_W5_MINCIN") ? atoi(getenv("CNL_W5_MINCIN")) : 128;
     static const int min_cout5 = getenv("CNL_W5_MINCOUT") ? atoi(getenv("CNL_W5_MINCOUT")) : 512;
+    static const int max_cin7 = getenv("CNL_W7_MAXCIN") ? atoi(getenv("CNL_W7_MAXCIN")) : 128;
     const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
     const int H = p->H_in * upf, W = p->W_in * upf, CoutP = (p->Cout + 63) / 64 * 64;
     const int items_per_image = ((H + 15) / 16) * ((W + 15) / 16) * (CoutP / 64);
     if (forced == 1 || forced == 2) return forced;
     if (p->Cin % 16) return 2;
-    if (forced >= 3 && forced <= 6) return forced;
+    if (forced >= 3 && forced <= 7) return forced;
     if (items_per_image >= 8 && (p->Cin >= min_cin5 || p->Cout >= min_cout5)) {
+        // short channel loops (<= 8 chunks of 16): the item prologue / epilogue weigh most, and a second wave per SIMD hides them
+        // (winograd7.hip: -3 .. -4 % against both other forms at Cin = 64 and 128; +1.5 % at Cin = 256, +5 % at 512)
+        if (p->Cin <= max_cin7) return 7;
         // the 8x16-pixel x 128-cout work items of winograd6.hip: where the channel loop is short and the couts many, and on maps
         // that 16-row blocks pad more than 8-row blocks (19x34, 38x68, 152x272 of 608x1088 frames: -1 .. -4 %)
         const long long pad16 = (long long)((H + 15) / 16 * 16) * ((W + 15) / 16 * 16), pad8 = (long long)((H + 7) / 8 * 8) * ((W + 15) / 16 * 16);
@@ -539,7 +544,7 @@ extern "C" int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p) {
     CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: null params");
     CNL_REQUIRE(p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: non-positive dimension");
     const int c = wino_choice(p);
-    return (c == 5 || c == 6) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
+    return (c == 5 || c == 6 || c == 7) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
 }
 
 extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) {
@@ -594,9 +599,9 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
     //   4  winograd4.hip  3 with two waves per SIMD (same time at a lower clock: power-bound; CNL_WINO=4, A/B only).
     const int choice = wino_choice(p);
     const float* u3 = p->w + wino_f32_floats(p->Cin, p->Cout);
-    if (choice == 5 || choice == 6) {
+    if (choice == 5 || choice == 6 || choice == 7) {
         float* u5 = const_cast<float*>(u3) + cnl_wino3_weight_bytes(p->Cin, p->Cout) / 4;
-        return (choice == 6 ? cnl_wino6_launch : cnl_wino5_launch)(p, u5, u5 + cnl_wino5_weight_bytes(p->Cin, p->Cout) / 4, stream);
+        return (choice == 7 ? cnl_wino7_launch : choice == 6 ? cnl_wino6_launch : cnl_wino5_launch)(p, u5, u5 + cnl_wino5_weight_bytes(p->Cin, p->Cout) / 4, stream);
     }
     if (choice == 4) return cnl_wino4_launch(p, u3, stream);
     if (choice == 3) return cnl_wino3_launch(p, u3, stream);

@@ -320,12 +320,12 @@ def test_winograd_decompositions_are_bit_identical(monkeypatch):
 
 
 def test_winograd_split_kernels_error_not_above_fp32_mfma(monkeypatch):
-    """winograd3.hip (exact three-way bf16 split, six cross terms) and winograd5.hip (scaled two-way fp16 split, three cross terms)
-    form fp32 products on the 16x faster matrix cores and accumulate in fp32: their error against float64 must be no larger than
+    """winograd3.hip (exact three-way bf16 split, six cross terms) and winograd5.hip (scaled two-way fp16 split, three cross terms;
+    winograd6.hip and winograd7.hip are its 128-cout and two-waves-per-SIMD forms) form fp32 products on the 16x faster matrix cores and accumulate in fp32: their error against float64 must be no larger than
     that of the fp32 matrix-core kernel on the same layer (K = 2304) — also with channels spanning six decades of magnitude and
     with a tensor whose values are all tiny or all huge (the fp16 kernel's scale follows the tensor's maximum)."""
     import os
-    libs = {v: _fresh_lib(v) for v in (2, 3, 5)}
+    libs = {v: _fresh_lib(v) for v in (2, 3, 5, 6, 7)}
     os.environ.pop("CNL_WINO", None)
     g = torch.Generator().manual_seed(11)
     for case in ("plain", "spread", "tiny", "huge"):
@@ -340,14 +340,14 @@ def test_winograd_split_kernels_error_not_above_fp32_mfma(monkeypatch):
         b = torch.zeros(256)
         ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
         err = {}
-        for v in (2, 3, 5):
+        for v in (2, 3, 5, 6, 7):
             monkeypatch.setattr(_lib, "_lib", libs[v])
             out = run_winograd(x, w, b, 0)
             assert torch.isfinite(out).all(), (case, v)
             err[v] = (out.double() - ref).abs().max().item()
         monkeypatch.undo()
         scale = ref.abs().max().item()
-        for v in (3, 5):
+        for v in (3, 5, 6, 7):
             assert err[v] <= 1.25 * err[2] + 1e-7 * scale, (case, v, err, scale)
             assert err[v] < 2e-5 * scale, (case, v, err, scale)
         assert err[2] < 2e-5 * scale, (case, err, scale)

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for v in 2 3 4; do
+for v in 2 3 5 6; do
   rm -rf gpurun_out/clk$v
   CNL_WINO=$v timeout 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d gpurun_out/clk$v -o r -- python tools/conv_bench.py head256 --winograd > /dev/null 2>&1
   python - <<PY
