@@ -111,7 +111,7 @@ def conv_kernel_profile(model, x, reps=3):
             acc[i] += e0.elapsed_time(e1)
     def kind(L):
         if L.fn is not lib.cnl_conv3x3_winograd_f32:
-            return "direct"
+            return "direct_f16x2" if lib.cnl_conv2d_kernel(ctypes.byref(L.args)) == 5 else "direct"
         return {3: "winograd_bf16x3", 5: "winograd_f16x2"}.get(lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)), "winograd_f32")
     rows = [(L.what, L.flops * scale, acc[i] / reps * scale, kind(L)) for i, L in enumerate(convs)]
     # algorithmic HBM bytes of a conv launch: input + weights + bias + output (+ residual), each touched once
@@ -191,7 +191,7 @@ def main():
     ap.add_argument("--layers", action="store_true", help="also print the per-layer conv table to stderr")
     ap.add_argument("--oracle-check", action="store_true", help="add max |heatmap - CPU oracle| of this configuration (one oracle pass)")
     ap.add_argument("--no-fp32-mfma-leg", action="store_true",
-                    help="skip the extra short run with every Winograd layer on the fp32 matrix core (CNL_WINO=2), reported beside `value`")
+                    help="skip the extra short run with every conv on the fp32 matrix core (CNL_WINO=2 CNL_CONV_F16X2=0), reported beside `value`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -263,6 +263,7 @@ def main():
         n_b, ms_b, fl_b = agg("winograd_bf16x3")
         n_h, ms_h, fl_h = agg("winograd_f16x2")
         n_d, ms_d, fl_d = agg("direct")
+        n_d5, ms_d5, fl_d5 = agg("direct_f16x2")
         direct_tf = fl_d / (ms_d * 1e-3) / 1e12 if ms_d else 0.0
         f32_exec_tf = fl_w * (16.0 / 36.0) / (ms_w * 1e-3) / 1e12 if ms_w else 0.0
         if ms_h >= ms_b and ms_h >= ms_w and ms_h >= ms_d:
@@ -315,7 +316,10 @@ def main():
                                  "cnl_wino3::winograd3_kernel (bf16 MFMA, exact 3-way split)": {"launches_per_step": n_b, "kernel_ms_per_step": round(ms_b, 3)},
                                  "cnl_wino5::winograd5_kernel (fp16 MFMA, scaled 2-way split)": {"launches_per_step": n_h, "kernel_ms_per_step": round(ms_h, 3)},
                                  "cnl_conv::conv_mfma_kernel": {"launches_per_step": n_d, "kernel_ms_per_step": round(ms_d, 3),
-                                                                "achieved_tflops": round(direct_tf, 2)}}
+                                                                "achieved_tflops": round(direct_tf, 2)},
+                                 "cnl_conv::conv_f16x2_kernel (direct conv, fp16 MFMA, scaled 2-way split)": {
+                                     "launches_per_step": n_d5, "kernel_ms_per_step": round(ms_d5, 3),
+                                     "effective_tflops": round(fl_d5 / (ms_d5 * 1e-3) / 1e12, 2) if ms_d5 else 0.0}}
         ms_per_step = elapsed / args.steps * 1e3
         result = {
             "metric": "images/sec @512x512 ResNet34 CenterNet forward + gather_detection2d",
@@ -343,7 +347,7 @@ def main():
         if world == 1 and not args.no_fp32_mfma_leg and not os.environ.get("CNL_WINO"):
             # the same job with every 3x3 layer on the fp32 matrix core (the kernel choice is read once per process: child process)
             import subprocess
-            env = dict(os.environ, CNL_WINO="2")
+            env = dict(os.environ, CNL_WINO="2", CNL_CONV_F16X2="0")
             cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(max(args.steps // 2, 3)), "--warmup", str(min(args.warmup, 3)),
                    "--config", args.config, "--batch", str(B), "--height", str(H), "--width", str(W), "--k", str(args.k),
                    "--no-cpu-baseline", "--no-fp32-mfma-leg", "--oracle-check"]
@@ -353,7 +357,7 @@ def main():
                 result["fp32_mfma_only"] = {"value": alt["value"], "unit": alt["unit"], "ms_per_step": alt["ms_per_step"], "steps": alt["steps"],
                                             "roofline_frac_of_fp32_mfma_peak": alt["roofline"]["frac"],
                                             "max_abs_err_heatmap_vs_cpu_oracle": alt.get("oracle_check", {}).get("max_abs_err_heatmap"),
-                                            "note": "CNL_WINO=2: all Winograd layers on v_mfma_f32_32x32x2_f32 (no bf16 split anywhere)"}
+                                            "note": "CNL_WINO=2 CNL_CONV_F16X2=0: every conv on v_mfma_f32_32x32x2_f32 (no split operands anywhere)"}
             except Exception as e:      # reported, never fatal: `value` above is the measurement
                 result["fp32_mfma_only"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

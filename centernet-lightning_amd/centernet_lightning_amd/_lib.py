@@ -17,7 +17,7 @@ CNL_UPSAMPLE_OUT_ADD = 1 << 3
 CNL_RELU6 = 1 << 4
 
 CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4
-ABI_VERSION = 3          # CNL_ABI_VERSION of include/centernet_gfx950.h
+ABI_VERSION = 4          # CNL_ABI_VERSION of include/centernet_gfx950.h
 
 
 class ConvParams(Structure):
@@ -25,7 +25,7 @@ class ConvParams(Structure):
                 ("N", c_int32), ("H_in", c_int32), ("W_in", c_int32), ("Cin", c_int32), ("Cout", c_int32),
                 ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
                 ("ldx", c_int32), ("ldy", c_int32), ("ldr", c_int32), ("flags", c_uint32),
-                ("x_absmax", c_void_p), ("y_absmax", c_void_p)]
+                ("x_absmax", c_void_p), ("y_absmax", c_void_p), ("w_absmax", c_void_p)]
 
 
 class DeconvParams(Structure):
@@ -52,6 +52,8 @@ _SIGNATURES = {
     "cnl_conv2d_out_hw": (ctypes.c_int, [POINTER(ConvParams), POINTER(c_int32), POINTER(c_int32)]),
     "cnl_conv3x3_winograd_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
     "cnl_conv3x3_winograd_kernel": (ctypes.c_int, [POINTER(ConvParams)]),
+    "cnl_conv2d_kernel": (ctypes.c_int, [POINTER(ConvParams)]),
+    "cnl_absmax_per_image_f32": (ctypes.c_int, [c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_void_p, c_void_p]),
     "cnl_winograd_weight_floats": (c_size_t, [c_int32, c_int32]),
     "cnl_winograd_transform_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "cnl_deconv2x_nhwc_f32": (ctypes.c_int, [POINTER(DeconvParams), c_void_p]),

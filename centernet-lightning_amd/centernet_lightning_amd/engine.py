@@ -52,6 +52,7 @@ class _Layer:
         self.cout, self.kh, self.kw, self.cin = w_ohwi.shape
         self.stride = stride
         self.pad = (self.kh - 1) // 2
+        self.wmax = w_ohwi.abs().max().reshape(1).contiguous()      # cnl_conv_params.w_absmax (fp16-split direct kernel)
         self.u = None
         if self.kh == 3 and self.kw == 3 and stride == 1 and self.cin % 8 == 0 and w_ohwi.is_cuda and winograd_enabled():
             lib = _lib.load()
@@ -231,39 +232,63 @@ class Plan:
         self._wire_absmax()
 
     def _wire_absmax(self):
-        """Hand the maximum magnitude of a tensor from the launch that produces it to the fp16-split Winograd launches that
-        consume it (cnl_conv_params.x_absmax / y_absmax): those then skip their own pass over the input.  Only where it is
-        provably the whole story: the consumer's input buffer has exactly one writer in the plan, that writer is a Winograd
-        launch on the fp16-split kernel (the one that reports max |y|) and it writes every channel of the buffer."""
-        lib, wino = self.lib, self.lib.cnl_conv3x3_winograd_f32
+        """Hand the per-image maximum magnitude of a tensor from the launch that produces it to the fp16-split launches that
+        consume it (cnl_conv_params.x_absmax / y_absmax): the Winograd ones then skip their own pass over the input, and the
+        direct convs (which never make one) take the fp16-split kernel instead of the fp32 one.  Only where it is provably the
+        whole story: the consumer's input buffer has exactly one writer in the plan, that writer runs an fp16-split kernel (the
+        ones that report max |y|) and it writes every channel of the buffer.  A 3x3 direct conv without such a producer (the
+        stride-2 conv after layer1) gets an explicit cnl_absmax_per_image_f32 pass: cheaper than what the split kernel saves."""
+        lib, wino, direct = self.lib, self.lib.cnl_conv3x3_winograd_f32, self.lib.cnl_conv2d_nhwc_f32
         self.absmax = None
-        if os.environ.get("CNL_ABSMAX_HANDOVER", "1") == "0":      # debugging: every fp16-split launch makes its own pass
-            return
+        if os.environ.get("CNL_ABSMAX_HANDOVER", "1") == "0":      # debugging: every fp16-split Winograd launch makes its own pass,
+            return                                                 # every direct conv stays on the fp32 matrix cores
         writers, unsafe = {}, set()
+        fresh_y = {id(p) for p, _ in self.out_params.values()}      # output convs: y is a fresh tensor per call (keep[1] is a placeholder)
         for L in self.launches:
             if isinstance(L.args, ConvParams):
-                writers.setdefault(id(L.keep[1]), []).append(L)
+                if id(L.args) not in fresh_y:
+                    writers.setdefault(id(L.keep[1]), []).append(L)
             else:                       # other launches: anything they hold may be written by them
                 unsafe.update(id(t) for t in L.keep if isinstance(t, torch.Tensor))
-        slot_of, pairs = {}, []
-        for L in self.launches:
-            if not isinstance(L.args, ConvParams) or L.fn is not wino or lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)) != 5:
+
+        def would_split(L):             # a direct conv that takes the fp16-split kernel once it has both hints
+            if L.fn is not direct or not L.args.w_absmax:
+                return False
+            saved, L.args.x_absmax = L.args.x_absmax, L.args.w_absmax      # any non-null pointer: the choice looks at presence only
+            k = lib.cnl_conv2d_kernel(ctypes.byref(L.args))
+            L.args.x_absmax = saved
+            return k == 5
+
+        slot_of, pairs, passes, reports = {}, [], [], set()       # reports: launches that run an fp16-split kernel
+        for L in self.launches:         # plan order: a direct conv only reports max |y| if it got its own hint
+            if not isinstance(L.args, ConvParams):
+                continue
+            is_wino5 = L.fn is wino and lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)) == 5
+            if not is_wino5 and not would_split(L):
                 continue
             x = L.keep[0]
             ws = writers.get(id(x), [])
-            if id(x) in unsafe or len(ws) != 1 or ws[0] is L:
-                continue
-            P = ws[0]
-            if P.fn is not wino or lib.cnl_conv3x3_winograd_kernel(ctypes.byref(P.args)) != 5:
-                continue
-            if P.args.y != x.data_ptr() or P.args.Cout != P.args.ldy:
-                continue
-            pairs.append((P, L, slot_of.setdefault(id(P), len(slot_of))))
+            P = ws[0] if len(ws) == 1 else None
+            if (P is not None and P is not L and id(x) not in unsafe and id(P) in reports and P.args.y == x.data_ptr()
+                    and P.args.Cout == P.args.ldy):
+                pairs.append((P, L, slot_of.setdefault(id(P), len(slot_of))))
+                reports.add(id(L))
+            elif is_wino5:
+                reports.add(id(L))      # makes its own pass over the input
+            elif L.args.KH == 3:
+                passes.append((L, slot_of.setdefault(id(L), len(slot_of))))
+                reports.add(id(L))
         # one float per (tensor, image): an image's scale must not depend on its batch neighbours
-        self.absmax = torch.zeros((max(len(slot_of), 1), self.N), device=self.device, dtype=torch.float32) if pairs else None
+        self.absmax = torch.zeros((max(len(slot_of), 1), self.N), device=self.device, dtype=torch.float32) if slot_of else None
         for P, L, i in pairs:
             P.args.y_absmax = self.absmax.data_ptr() + 4 * i * self.N
             L.args.x_absmax = self.absmax.data_ptr() + 4 * i * self.N
+        for L, i in passes:
+            a = L.args
+            L.args.x_absmax = self.absmax.data_ptr() + 4 * i * self.N
+            self.launches.insert(self.launches.index(L), _Launch(
+                lib.cnl_absmax_per_image_f32, (a.x, self.N, a.H_in * a.W_in, a.Cin, a.ldx, L.args.x_absmax), L.what + ".absmax",
+                0, keep=(self.absmax,)))
 
     # -- helpers --
     def _buf(self, n, h, w, c):
@@ -284,6 +309,7 @@ class Plan:
         p.KH, p.KW, p.stride, p.pad = layer.kh, layer.kw, layer.stride, layer.pad
         p.ldx, p.ldy, p.ldr = ldx, ldy, ldr
         p.flags = flags
+        p.w_absmax = layer.wmax.data_ptr()
         ho, wo = ctypes.c_int32(), ctypes.c_int32()
         _lib.check(self.lib.cnl_conv2d_out_hw(ctypes.byref(p), ctypes.byref(ho), ctypes.byref(wo)), what)
         flops = 2 * self.N * ho.value * wo.value * layer.cout * layer.kh * layer.kw * layer.cin   # direct-conv (algorithmic) flops

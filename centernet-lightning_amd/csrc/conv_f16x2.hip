@@ -1,0 +1,342 @@
+// conv_f16x2.hip — the direct implicit-GEMM convolution of conv_mfma.hip with every fp32 product formed on the fp16 matrix cores
+// (stride-2 3x3 convs, 1x1 downsample / lateral / output convs: models/meta.py:21-47, torchvision BasicBlock.downsample,
+// layers.py:152-177).  Taken by cnl_conv2d_nhwc_f32 when the caller hands over max |x| per image and max |w| (x_absmax / w_absmax).
+//
+// Arithmetic (the split of winograd5.hip, applied to raw activations and weights): each row of the A tile (an output pixel of image
+// n) is scaled by a power of two S_n derived from max |x| of THAT image, the weights by S_w from max |w| (both exact);
+// x S = hi + lo with hi = RN16(x S), lo = RZ16(x S - hi) (the residual is exact in fp32);  x w S_n S_w is accumulated in fp32 as
+// hi lo' + lo hi' + hi hi' (3 x v_mfma_f32_32x32x16_f16; the omitted lo lo' <= 2^-22 |x w|), and the epilogue multiplies row by row
+// by 1 / (S_n S_w).  Error against float64: that of the fp32 matrix-core kernel (tests/test_gpu_conv.py).  A row's scale depends on
+// its own image only, so an image's result never depends on its batch neighbours (batch invariance, shard == full batch).
+//
+// Structure: conv_mfma.hip's — raw fp32 A (patch rows) and B (OHWI weight rows) chunks of 32 channels staged by LDS-DMA into two
+// stages, one barrier per chunk, 4 waves x (TM x TN) accumulator tiles of 32x32, two workgroups per CU.  A wave reads its fp32
+// fragments (two ds_read_b128 per tile and 16-channel group: the K permutation of conv_mfma.hip makes a lane's 8 floats one MFMA
+// operand), splits them in registers (2.5 VALU operations per element: v_fma_mixlo/mixhi_f16, v_fma_mix_f32, v_cvt_pkrtz) and issues
+// 3 MFMAs of 32 cycles where the fp32 kernel issues 8 of 64: 5.3x less matrix time; the split runs beside the co-resident
+// workgroup's MFMAs.  What bounds it then is the L2 -> LDS stream of the tiles (32 flop per staged byte at 128 x 128).
+#include "conv_args.h"
+#include <cstdlib>
+
+namespace cnl_conv {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16_zero() {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const u32x4 zz = {0u, 0u, 0u, 0u};
+    return mfma16(zz, zz, z);
+}
+// (v0, v1) S -> hi pair (RN16, packed) and lo pair (RZ16 of the exact residuals, packed)
+__device__ __forceinline__ void split2(float v0, float v1, float S, unsigned& hi, unsigned& lo) {
+    unsigned pk;
+    float r0, r1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(pk) : "v"(v0), "v"(S));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(pk) : "v"(v1), "v"(S));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(v0), "v"(S), "v"(pk));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(v1), "v"(S), "v"(pk));
+    asm("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
+    hi = pk;
+}
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, float S, u32x4& hi, u32x4& lo) {
+    unsigned h[4], l[4];
+    split2(v0[0], v0[1], S, h[0], l[0]);
+    split2(v0[2], v0[3], S, h[1], l[1]);
+    split2(v1[0], v1[1], S, h[2], l[2]);
+    split2(v1[2], v1[3], S, h[3], l[3]);
+    hi = u32x4{h[0], h[1], h[2], h[3]};
+    lo = u32x4{l[0], l[1], l[2], l[3]};
+}
+// the power of two that puts a tensor of maximum magnitude mx into [2^13, 2^14)  (1 for 0 / Inf / NaN maxima)
+__device__ __forceinline__ float pow2_scale(float mx) {
+    float S = 1.f;
+    if (mx > 0.f && mx < __builtin_inff()) {
+        int e;
+        (void)__builtin_frexpf(mx, &e);            // 2^(e-1) <= mx < 2^e
+        e = 14 - e;
+        S = __builtin_ldexpf(1.f, e < -60 ? -60 : (e > 60 ? 60 : e));
+    }
+    return S;
+}
+
+// KS: compile-time square kernel size (1 or 3).  No input upsampling, no 2x scatter epilogues (those stay on conv_mfma.hip).
+template <int WM, int WN, int TM, int TN, int KS>
+__global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
+    using C = Cfg<WM, WN, TM, TN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sInv = reinterpret_cast<float*>(smem + C::LDS_BYTES);      // [BM] 1 / (S_row S_w)
+    float* sScl = sInv + C::BM;                                       // [BM] S_row
+    int* sImg = reinterpret_cast<int*>(sScl + C::BM);                 // [BM] image of the row (-1 beyond M)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5;
+
+    const unsigned tile = cnl::xcd_remap(blockIdx.x, (unsigned)a.tiles);
+    const int n_tile = tile % a.tiles_n;
+    const int m_tile = tile / a.tiles_n;
+    const int m0 = m_tile * C::BM;
+    const int n0 = n_tile * C::BN;
+
+    // ---- per-lane staging bookkeeping (see conv_mfma.hip) ----
+    const int lrow = lane >> 3;
+    const int pslot = lane & 7;
+    unsigned a_mask[C::A_INSTR], a_base[C::A_INSTR];
+#pragma unroll
+    for (int j = 0; j < C::A_INSTR; ++j) {
+        const int r = (j * C::NW + wave) * 8 + lrow;
+        const int m = m0 + r;
+        const int q = (pslot ^ ((r >> 1) & 7)) * 4;
+        const unsigned n = fast_div((unsigned)m, a.mg_hw, a.sh_hw);
+        const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
+        const unsigned oy = fast_div(rem, a.mg_w, a.sh_w);
+        const unsigned ox = rem - oy * (unsigned)a.Wo;
+        const int iy0 = (int)oy * a.stride - a.pad;
+        const int ix0 = (int)ox * a.stride - a.pad_x;
+        unsigned mask = 0, xb = 0;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) xb |= ((unsigned)(ix0 + kx) < (unsigned)a.WL) ? (1u << kx) : 0u;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) mask |= ((unsigned)(iy0 + ky) < (unsigned)a.HL) ? (xb << (ky * KS)) : 0u;
+        a_mask[j] = m < a.M ? mask : 0u;
+        const int pix = (int)n * a.Hin * a.Win;
+        a_base[j] = (unsigned)(((pix + iy0 * a.Win + ix0) * a.ldx + q) * 4);   // may wrap; used only when the tap is valid
+    }
+    unsigned b_off[C::B_INSTR];
+#pragma unroll
+    for (int j = 0; j < C::B_INSTR; ++j) {
+        const int r = (j * C::NW + wave) * 8 + lrow;
+        const int q = (pslot ^ ((r >> 1) & 7)) * 4;
+        b_off[j] = (unsigned)(((n0 + r) * a.K + q) * 4);   // rows >= Cout land beyond w_bytes -> zeros
+    }
+    unsigned a_voff[C::A_INSTR];
+#define C5_TAP(tap_, ky_, kx_)                                                                                    \
+    do {                                                                                                          \
+        const unsigned bit_ = 1u << (tap_);                                                                       \
+        const unsigned delta_ = (unsigned)((((ky_) * a.Win + (kx_)) * a.ldx) * 4);                                \
+        _Pragma("unroll") for (int j = 0; j < C::A_INSTR; ++j) a_voff[j] = (a_mask[j] & bit_) ? a_base[j] + delta_ : OOB; \
+    } while (0)
+#define C5_ISSUE(stage_, c0_, kbase_)                                                                             \
+    do {                                                                                                          \
+        char* sA_ = smem + (stage_) * C::STAGE_BYTES;                                                             \
+        char* sB_ = sA_ + C::BM * 128;                                                                            \
+        _Pragma("unroll") for (int j = 0; j < C::A_INSTR; ++j)                                                    \
+            dma16(a.x, a.x_bytes, sA_ + (j * C::NW + wave) * 1024, a_voff[j], (unsigned)((c0_) * 4));             \
+        _Pragma("unroll") for (int j = 0; j < C::B_INSTR; ++j)                                                    \
+            dma16(a.w, a.w_bytes, sB_ + (j * C::NW + wave) * 1024, b_off[j], (unsigned)((kbase_) * 4));           \
+    } while (0)
+    int tap = 0, ky = 0, kx = 0, cc = 0;     // position of the chunk being ISSUED
+#define C5_ADVANCE()                                    \
+    do {                                                \
+        if (++cc == a.CC) {                             \
+            cc = 0;                                     \
+            ++tap;                                      \
+            if (++kx == KS) { kx = 0; ++ky; }           \
+            C5_TAP(tap, ky, kx);                        \
+        }                                               \
+    } while (0)
+    C5_TAP(0, 0, 0);
+    C5_ISSUE(0, 0, 0);                       // first chunk in flight before anything else
+
+    // ---- scales: one per row of the tile (its image's), one for the weights ----
+    const float Sw = pow2_scale(*a.wmax);
+    for (int r = threadIdx.x; r < C::BM; r += C::THREADS) {
+        const int m = m0 + r;
+        const unsigned n = fast_div((unsigned)m, a.mg_hw, a.sh_hw);
+        const bool ok = m < a.M;
+        const float S = ok ? pow2_scale(a.xmax[n]) : 1.f;
+        sScl[r] = S;
+        sInv[r] = 1.f / (S * Sw);
+        sImg[r] = ok ? (int)n : -1;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma16_zero();
+
+    // fragment read addresses (bytes inside a stage): row * 128 + ((2*jj + hi) ^ swz) * 16
+    const int swz = (lane >> 1) & 7;
+    const int a_row_byte = (wm * TM * 32 + (lane & 31)) * 128;
+    const int b_row_byte = C::BM * 128 + (wn * TN * 32 + (lane & 31)) * 128;
+    f32x4 ra[2][TM], rb[2][TN];          // the raw fp32 fragments of one 16-channel group (reads 2g, 2g+1)
+    u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+    float sA[TM];
+
+#define C5_READ(stage_ptr_, g_)                                                                                   \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                        \
+            const int sb_ = (((2 * (2 * (g_) + q_) + hi) ^ swz) << 4);                                            \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) ra[q_][i] = lds_read16((stage_ptr_) + a_row_byte + i * 32 * 128 + sb_); \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) rb[q_][j] = lds_read16((stage_ptr_) + b_row_byte + j * 32 * 128 + sb_); \
+        }                                                                                                         \
+    } while (0)
+#define C5_SPLIT()                                                                                                \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) split8(ra[0][i], ra[1][i], sA[i], ah[i], al[i]);           \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) split8(rb[0][j], rb[1][j], Sw, bh[j], bl[j]);              \
+    } while (0)
+#define C5_MFMA()                                                                                                 \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                            \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(ah[i], bl[j], acc[i][j]);           \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                            \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(al[i], bh[j], acc[i][j]);           \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                            \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(ah[i], bh[j], acc[i][j]);           \
+    } while (0)
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk 0 landed (this wave) ...
+    __syncthreads();                                    // ... and everyone's, and the scale tables are written
+#pragma unroll
+    for (int i = 0; i < TM; ++i) sA[i] = sScl[(wm * TM + i) * 32 + (lane & 31)];
+    if (a.KT > 1) {
+        C5_ADVANCE();
+        C5_ISSUE(1, cc * 32, 32);
+    }
+    C5_READ(smem, 0);
+    // One K chunk = two 16-channel groups.  The barrier of chunk kt sits between its two MFMA groups and guarantees (a) every wave
+    // has finished reading chunk kt's stage (group 1's fragments are in registers) -> it may be refilled with chunk kt+2, (b) every
+    // wave's DMA of chunk kt+1 has landed -> it may be read.
+    for (int kt = 0; kt < a.KT; ++kt) {
+        const char* sS = smem + (kt & 1) * C::STAGE_BYTES;
+        const char* sN = smem + ((kt + 1) & 1) * C::STAGE_BYTES;
+        C5_SPLIT();
+        C5_READ(sS, 1);
+        C5_MFMA();
+        C5_SPLIT();
+        if (kt + 1 < a.KT) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 2 < a.KT) {
+                C5_ADVANCE();
+                C5_ISSUE(kt & 1, cc * 32, (kt + 2) * 32);
+            }
+            C5_READ(sN, 0);
+        }
+        C5_MFMA();
+    }
+#undef C5_TAP
+#undef C5_ISSUE
+#undef C5_ADVANCE
+#undef C5_READ
+#undef C5_SPLIT
+#undef C5_MFMA
+
+    // ---- epilogue: row scale back, + bias (+ residual) -> clamp -> (sigmoid) -> NHWC store; max |y| per image ----
+    const float lo = (a.flags & (CNL_RELU | CNL_RELU6)) ? 0.f : -__builtin_inff();
+    const float hi6 = (a.flags & CNL_RELU6) ? 6.f : __builtin_inff();
+    const bool sigm = a.flags & CNL_SIGMOID;
+    const int img0 = sImg[0];
+    float omax = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+        const bool col_ok = col < a.Cout;
+        const float bv = col_ok ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rl = (wm * TM + i) * 32 + 4 * hi;          // this lane's first row inside the tile
+            const int mb = m0 + rl;
+            const unsigned y_voff = (unsigned)((mb * a.ldy + col) * 4);
+            const unsigned r_voff = (unsigned)((mb * a.ldr + col) * 4);
+            float v[16];
+            bool ok[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                ok[r] = col_ok && mb + ro < a.M;
+                v[r] = acc[i][j][r] * sInv[rl + ro] + bv;
+            }
+            if (a.res) {
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rv[r] = buf_load(a.res, a.r_bytes, ok[r] ? r_voff : OOB, (unsigned)(((r & 3) + 8 * (r >> 2)) * a.ldr * 4));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += rv[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fminf(fmaxf(v[r], lo), hi6);
+            if (sigm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                buf_store(v[r], a.y, a.y_bytes, ok[r] ? y_voff : OOB, (unsigned)(((r & 3) + 8 * (r >> 2)) * a.ldy * 4));
+            if (a.ymax) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float av = ok[r] ? fabsf(v[r]) : 0.f;
+                    const int img = sImg[rl + (r & 3) + 8 * (r >> 2)];
+                    if (img == img0) omax = fmaxf(omax, av);
+                    else if (av > 0.f) atomicMax(a.ymax + img, __float_as_uint(av));     // a tile that spans images: rare rows
+                }
+            }
+        }
+    }
+    if (a.ymax) {          // one atomic per wave for the tile's first image
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
+        if (lane == 0 && omax > 0.f) atomicMax(a.ymax + img0, __float_as_uint(omax));
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int KS>
+static int launch_one5(const ConvArgs& a, hipStream_t stream) {
+    using C = Cfg<WM, WN, TM, TN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16x2_kernel<WM, WN, TM, TN, KS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, TM, TN, KS>), dim3(a.tiles), dim3(C::THREADS), C::LDS_BYTES + C::BM * 12, stream, a);
+    return cnl::check_launch("conv_f16x2_kernel");
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_cfg5(const ConvArgs& in, hipStream_t stream) {
+    using C = Cfg<WM, WN, TM, TN>;
+    ConvArgs a = in;
+    const int tiles_m = (a.M + C::BM - 1) / C::BM;
+    a.tiles_n = (a.Cout + C::BN - 1) / C::BN;
+    a.tiles = tiles_m * a.tiles_n;
+    return a.KH == 3 ? launch_one5<WM, WN, TM, TN, 3>(a, stream) : launch_one5<WM, WN, TM, TN, 1>(a, stream);
+}
+
+// which launches the fp16-split kernel covers: the caller handed over both maxima, square 1x1 / 3x3 kernel, no input upsampling,
+// no 2x scatter epilogue; 1x1 convs only where the matrix work dominates (>= 2^20 outputs per image: the 80-class heatmap conv
+// -20 %; the short-K downsample / lateral / box convs are latency- or HBM-bound and lose 5-15 % to the split).  A function of the
+// layer shape per image, never of the batch.  CNL_CONV_F16X2=0 keeps everything on the fp32 matrix cores.
+bool f16x2_eligible(const ConvArgs& a) {
+    static const bool enabled = !(getenv("CNL_CONV_F16X2") && atoi(getenv("CNL_CONV_F16X2")) == 0);
+    static const long long min_out_1x1 = getenv("CNL_CONV_F16X2_MIN1X1") ? atoll(getenv("CNL_CONV_F16X2_MIN1X1")) : (1ll << 20);
+    return enabled && a.xmax && a.wmax && a.KH == a.KW && (a.KH == 1 || a.KH == 3) && a.pad == a.pad_x &&
+           !(a.flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD | CNL_I_SUBPIXEL)) &&
+           (a.KH == 3 || (long long)a.Ho * a.Wo * a.Cout >= min_out_1x1);
+}
+
+int f16x2_launch(const ConvArgs& a, hipStream_t s) {
+    // Tile choice: BN follows Cout; shrink BM when the grid would not fill 256 CUs x 2 workgroups (as conv_mfma.hip).
+    static const int force = getenv("CNL_CONV5_CFG") ? atoi(getenv("CNL_CONV5_CFG")) : 0;      // experiments
+    if (force == 1) return launch_cfg5<4, 1, 2, 2>(a, s);
+    if (force == 2) return launch_cfg5<2, 2, 1, 2>(a, s);
+    if (force == 3) return launch_cfg5<2, 2, 2, 2>(a, s);
+    if (force == 4) return launch_cfg5<4, 1, 1, 3>(a, s);
+    if (a.Cout <= 32) return launch_cfg5<4, 1, 2, 1>(a, s);         // 256 x 32
+    if (a.Cout <= 64) return launch_cfg5<4, 1, 2, 2>(a, s);         // 256 x 64
+    if (a.Cout <= 96) return launch_cfg5<4, 1, 1, 3>(a, s);         // 128 x 96
+    const long long tiles128 = (((long long)a.M + 127) / 128) * ((a.Cout + 127) / 128);
+    if (tiles128 < 512) return launch_cfg5<2, 2, 1, 2>(a, s);       //  64 x 128
+    return launch_cfg5<2, 2, 2, 2>(a, s);                           // 128 x 128
+}
+
+}  // namespace cnl_conv

@@ -27,67 +27,11 @@
 // prologue is kept to a few hundred instructions: magic-number division for (n,oy,ox), compile-time tap
 // loops (KS template), accumulators zeroed by 4 MFMAs instead of 64 v_mov, and the epilogue addresses
 // ride on the buffer instructions' scalar offset (no per-store VALU address math).
-#include "cnl_common.h"
+#include "conv_args.h"
 #include <cstdlib>
 
 namespace cnl_conv {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvArgs {
-    const float* x;
-    const float* w;
-    const float* bias;
-    const float* res;
-    float* y;
-    int N, Hin, Win, Cin, Cout;
-    int KH, KW, stride, pad, pad_x;      // pad = rows, pad_x = columns (equal for every public conv; differ for deconv phases)
-    int sub_dy, sub_dx;                  // CNL_I_SUBPIXEL: phase of the 2x output grid this launch writes
-    int ldx, ldy, ldr;
-    int HL, WL;        // logical input size (2x when CNL_UPSAMPLE_IN)
-    int Ho, Wo, M;     // conv output size, M = N*Ho*Wo
-    int CC, KT, K;     // Cin/32, KH*KW*CC, KH*KW*Cin
-    unsigned x_bytes, w_bytes, y_bytes, r_bytes;
-    unsigned flags;
-    int tiles_n, tiles;
-    unsigned mg_hw, sh_hw, mg_w, sh_w;   // magic division by Ho*Wo and by Wo (exact for n < 2^31)
-    long long* trace;                    // CNL_TRACE builds only: per-workgroup phase timestamps
-};
-
-constexpr unsigned CNL_I_SUBPIXEL = 1u << 16;   // internal: y[n, 2oy+sub_dy, 2ox+sub_dx, :] = act(conv + bias) (+ residual there)
-constexpr unsigned OOB = 0xFFFFFFF0u;   // voffset that is always >= num_records -> DMA writes zeros / store dropped
-
-template <int WM, int WN, int TM, int TN>
-struct Cfg {
-    static constexpr int NW = WM * WN;
-    static constexpr int THREADS = NW * 64;
-    static constexpr int BM = WM * TM * 32;
-    static constexpr int BN = WN * TN * 32;
-    static constexpr int A_INSTR = BM / (NW * 8);   // buffer_load..lds instructions per wave for A
-    static constexpr int B_INSTR = BN / (NW * 8);
-    static constexpr int STAGE_BYTES = (BM + BN) * 128;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
-    static_assert(NW == 4, "kernel is declared __launch_bounds__(256, 2)");
-    static_assert(BM % (NW * 8) == 0 && BN % (NW * 8) == 0, "tile rows must split evenly over waves");
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-
-// amdgcn builtins are wrapped in NON-template device functions: called with template-dependent arguments
-// directly inside the kernel template they make hipcc's host pass silently drop the kernel's host stub.
-__device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* lds_dst, unsigned voffset, unsigned soffset) {
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 0, 0);
-}
-__device__ __forceinline__ float buf_load(const float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset, soffset, 0));
-}
-__device__ __forceinline__ void buf_store(float v, float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voffset, soffset, CNL_NT_STORES);
-}
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -95,12 +39,6 @@ __device__ __forceinline__ f32x16 mfma_zero() {        // 16 zeroed accumulator 
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     return __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, z, 0, 0, 0);
 }
-__device__ __forceinline__ f32x4 lds_read16(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
-// n / d for n < 2^31 with host-computed (magic, shift); shift == 0xFF encodes d == 1
-__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, unsigned shift) {
-    return shift == 0xFFu ? n : (__umulhi(n, magic) >> shift);
-}
-
 // Epilogue for one 32x32 accumulator tile: + bias (+ residual) -> max(.,lo) -> (sigmoid) -> NHWC store.
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 // `voff` = byte offset of (row 0 of this lane, col); the row's r-dependent part goes in the scalar offset.
@@ -503,6 +441,7 @@ static int finish_and_launch(ConvArgs& a, bool out4x, const char* who, hipStream
 #ifdef CNL_TRACE
     if (const char* e = getenv("CNL_TRACE_PTR")) a.trace = (long long*)strtoull(e, nullptr, 0);
 #endif
+    if (f16x2_eligible(a)) return f16x2_launch(a, s);               // conv_f16x2.hip: the caller handed over max |x|, max |w|
     // Tile choice: BN follows Cout; shrink BM when the grid would not fill 256 CUs x 2 workgroups.
     if (a.Cout <= 32) return launch_cfg<4, 1, 2, 1>(a, s);          // 256 x 32
     if (a.Cout <= 64) return launch_cfg<4, 1, 2, 2>(a, s);          // 256 x 64
@@ -519,6 +458,18 @@ extern "C" int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32
     *H_out = (p->H_in * up + 2 * p->pad - p->KH) / p->stride + 1;
     *W_out = (p->W_in * up + 2 * p->pad - p->KW) / p->stride + 1;
     return CNL_OK;
+}
+
+extern "C" int cnl_conv2d_kernel(const cnl_conv_params* p) {
+    CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv2d_kernel: null params");
+    ConvArgs a;
+    a.KH = p->KH; a.KW = p->KW; a.pad = a.pad_x = p->pad; a.flags = p->flags; a.Cout = p->Cout;
+    a.xmax = p->x_absmax; a.wmax = p->w_absmax;
+    int32_t ho = 0, wo = 0;
+    const int rc = cnl_conv2d_out_hw(p, &ho, &wo);
+    if (rc != CNL_OK) return rc;
+    a.Ho = ho; a.Wo = wo;
+    return f16x2_eligible(a) ? CNL_CONV_F16X2 : CNL_CONV_F32;
 }
 
 extern "C" int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream) {
@@ -547,6 +498,7 @@ extern "C" int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream) {
     a.sub_dy = a.sub_dx = 0;
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
     a.flags = p->flags;
+    a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
     const int up = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
     a.HL = p->H_in * up; a.WL = p->W_in * up;
     a.Ho = (a.HL + 2 * p->pad - p->KH) / p->stride + 1;
@@ -601,6 +553,7 @@ extern "C" int cnl_deconv2x_nhwc_f32(const cnl_deconv_params* p, void* stream) {
             a.sub_dy = dy; a.sub_dx = dx;
             a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
             a.flags = p->flags | CNL_I_SUBPIXEL;
+            a.xmax = a.wmax = nullptr; a.ymax = nullptr;
             a.HL = p->H_in; a.WL = p->W_in;
             a.Ho = p->H_in; a.Wo = p->W_in;
             const int rc = finish_and_launch(a, true, "cnl_deconv2x_nhwc_f32", (hipStream_t)stream);

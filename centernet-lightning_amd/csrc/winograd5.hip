@@ -601,6 +601,20 @@ int cnl_wino5_transform_weights(const float* w_ohwi, const float* u_f32, size_t 
     return cnl::check_launch("weights5_kernel");
 }
 
+extern "C" int cnl_absmax_per_image_f32(const float* x, int32_t N, int64_t pixels, int32_t C, int32_t ld, float* out, void* stream) {
+    CNL_REQUIRE(x && out, CNL_E_BAD_ARG, "cnl_absmax_per_image_f32: null pointer");
+    CNL_REQUIRE(N > 0 && N <= 65535 && pixels > 0 && C > 0, CNL_E_BAD_ARG, "cnl_absmax_per_image_f32: N in 1..65535, pixels and C positive");
+    CNL_REQUIRE(C % 4 == 0 && ld % 4 == 0 && ld >= C && ((uintptr_t)x & 15) == 0, CNL_E_UNSUPPORTED,
+                "cnl_absmax_per_image_f32: C=%d, ld=%d must be multiples of 4 (ld >= C) and x 16-byte aligned", C, ld);
+    CNL_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, (hipStream_t)stream));
+    const long long vec4 = (long long)pixels * (C / 4);
+    const long long want = (vec4 + 256 * 16 - 1) / (256 * 16);
+    const unsigned mgrid = (unsigned)(want < 1 ? 1 : (want > 64 ? 64 : want));
+    hipLaunchKernelGGL(cnl_wino5::absmax_kernel, dim3(mgrid, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, (long)pixels, C, ld,
+                       reinterpret_cast<unsigned*>(out));
+    return cnl::check_launch("absmax_kernel");
+}
+
 // Launch (arguments already validated by cnl_conv3x3_winograd_f32); u5 = the fp16-split weights, scal = the layer's scalars.
 int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream) {
     using namespace cnl_wino5;

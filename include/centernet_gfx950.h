@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 3   /* 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 4   /* 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -80,9 +80,23 @@ typedef struct cnl_conv_params {
      * channels is a valid, slightly conservative bound.                                                                        */
     const float* x_absmax;
     float* y_absmax;
+    /* cnl_conv2d_nhwc_f32 only: device pointer to ONE float, max |w| of this layer's weights (e.g. computed once when the weights
+     * are loaded), or NULL.  With both x_absmax and w_absmax the 1x1 / 3x3 convs without up-sampling flags form each fp32 product
+     * on the fp16 matrix cores from scaled two-way splits of both operands (csrc/conv_f16x2.hip: same error against float64 as
+     * the fp32 matrix-core kernel, 2-3x faster) and honour y_absmax; without them the fp32 matrix-core kernel runs.             */
+    const float* w_absmax;
 } cnl_conv_params;
 
 int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream);
+
+/* Which kernel cnl_conv2d_nhwc_f32 takes for *p (a function of the hints, kernel size and flags only — never of the batch). */
+#define CNL_CONV_F32 2     /* fp32 matrix cores (csrc/conv_mfma.hip); ignores y_absmax                                    */
+#define CNL_CONV_F16X2 5   /* fp16 matrix cores, scaled two-way split (csrc/conv_f16x2.hip); writes y_absmax when given   */
+int cnl_conv2d_kernel(const cnl_conv_params* p);
+
+/* out[n] = max |x[n, :, 0:C]| over the `pixels` pixels of image n (pixel stride ld floats; C % 4 == 0, ld % 4 == 0, x 16-byte
+ * aligned): the x_absmax hint for callers whose producer does not report it.  Zeroes out[] first (stream-ordered).            */
+int cnl_absmax_per_image_f32(const float* x, int32_t N, int64_t pixels, int32_t C, int32_t ld, float* out, void* stream);
 
 /* Output spatial size of the conv itself (before CNL_UPSAMPLE_OUT_ADD doubles it). */
 int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);

@@ -19,8 +19,9 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0, x_off=0):
-    """x_nchw: CPU tensor. Returns NCHW CPU output of cnl_conv2d_nhwc_f32."""
+def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0, x_off=0, hints=False):
+    """x_nchw: CPU tensor. Returns NCHW CPU output of cnl_conv2d_nhwc_f32.  hints: hand over max |x| per image (from
+    cnl_absmax_per_image_f32) and max |w|, which selects the fp16-split kernel where it applies; then returns (out, kernel, y_absmax)."""
     lib = _lib.load()
     N, Cin, H, W = x_nchw.shape
     Cout, _, KH, KW = w_oihw.shape
@@ -46,8 +47,17 @@ def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0
     if residual is not None:
         rd = residual.permute(0, 2, 3, 1).contiguous().cuda()
         p.residual, p.ldr = rd.data_ptr(), Cout
+    if hints:
+        xm = torch.full((N,), float("nan"), device="cuda")
+        _lib.check(lib.cnl_absmax_per_image_f32(p.x, N, H * W, Cin, ldx, xm.data_ptr(), _stream()), "absmax")
+        wm = wd.abs().max().reshape(1).contiguous()
+        ym = torch.zeros(N, device="cuda")
+        p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), wm.data_ptr(), ym.data_ptr()
     _lib.check(lib.cnl_conv2d_nhwc_f32(ctypes.byref(p), _stream()), "conv")
     torch.cuda.synchronize()
+    if hints:
+        assert torch.equal(xm.cpu(), x_nchw.abs().amax(dim=(1, 2, 3)))
+        return y.cpu().permute(0, 3, 1, 2), lib.cnl_conv2d_kernel(ctypes.byref(p)), ym.cpu()
     return y.cpu().permute(0, 3, 1, 2)
 
 
@@ -110,6 +120,110 @@ def test_conv_matches_cpu(case):
     assert out.shape == ref.shape
     assert not torch.isnan(out).any()
     torch.testing.assert_close(out, ref, rtol=RTOL, atol=ATOL)
+
+
+F16X2_CASES = [c for c in CASES if not (c[7] & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD))] + [
+    (3, 128, 19, 34, 256, 3, 2, CNL_RELU, False),          # 608x1088 frames: tiles span images (10 x 17 = 170 rows per image)
+    (5, 64, 3, 5, 96, 1, 1, 0, True),                      # several images inside one tile
+    (2, 512, 16, 16, 256, 1, 1, 0, False),                 # FPN lateral
+    (1, 256, 128, 128, 80, 1, 1, CNL_SIGMOID, False),      # the 80-class heatmap conv at its real size: a 1x1 the rule sends to the split kernel
+]
+_MIN1X1_LIB = []
+
+
+def _lib_all_1x1_split():
+    """A private copy of the library that sends every 1x1 conv with hints to the fp16-split kernel (CNL_CONV_F16X2_MIN1X1=0 is read
+    at its first conv call): covers the KS = 1 template on ragged / multi-image tiles that the per-image size rule keeps on fp32."""
+    import os
+    if not _MIN1X1_LIB:
+        os.environ["CNL_CONV_F16X2_MIN1X1"] = "0"
+        lib = _fresh_lib(0)
+        os.environ.pop("CNL_WINO", None)
+        x = torch.zeros(1, 4, 4, 32, device="cuda")
+        w = torch.zeros(32, 1, 1, 32, device="cuda")
+        p = ConvParams()
+        p.x, p.w, p.bias, p.y = x.data_ptr(), w.data_ptr(), w.data_ptr(), torch.empty(1, 4, 4, 32, device="cuda").data_ptr()
+        p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.ldx, p.ldy = 1, 4, 4, 32, 32, 1, 1, 1, 0, 32, 32
+        p.x_absmax = p.w_absmax = x.data_ptr()
+        assert lib.cnl_conv2d_kernel(ctypes.byref(p)) == 5         # first call: the environment is read here
+        torch.cuda.synchronize()
+        os.environ.pop("CNL_CONV_F16X2_MIN1X1", None)
+        _MIN1X1_LIB.append(lib)
+    return _MIN1X1_LIB[0]
+
+
+def _f16x2_on():
+    import os
+    return os.environ.get("CNL_CONV_F16X2", "1") != "0"
+
+
+@pytest.mark.parametrize("case", F16X2_CASES, ids=lambda c: "N{}c{}_{}x{}_o{}k{}s{}f{}r{}".format(*[int(v) for v in c]))
+def test_conv_f16x2_matches_cpu(case, monkeypatch):
+    """The same layers through the fp16-split kernel (x_absmax / w_absmax handed over): same tolerance as the fp32 matrix-core
+    kernel, and the max |y| per image it reports is exactly the maximum of what it stored."""
+    N, Cin, H, W, Cout, k, stride, flags, use_res = case
+    if k == 1 and _f16x2_on() and (H // stride) * (W // stride) * Cout < (1 << 20):
+        x, w, b = mk(N, Cin, H, W, Cout, k, seed=1)
+        assert run_conv(x, w, b, stride, flags & ~CNL_SIGMOID, hints=True)[1] == 2     # the size rule keeps small 1x1 convs on fp32 ...
+        monkeypatch.setattr(_lib, "_lib", _lib_all_1x1_split())                      # ... cover the template anyway
+    x, w, b = mk(N, Cin, H, W, Cout, k, seed=Cin * 7 + Cout + H)
+    x[N - 1] *= 37.0                                       # images of different magnitude: a row's scale is its own image's
+    ref_nores = ref_conv(x, w, b, stride, flags & ~(CNL_RELU | CNL_SIGMOID))
+    res = torch.randn(ref_nores.shape, generator=torch.Generator().manual_seed(5)) if use_res else None
+    ref = ref_conv(x, w, b, stride, flags, res)
+    out, kernel, ymax = run_conv(x, w, b, stride, flags, res, hints=True)
+    assert kernel == (5 if _f16x2_on() else 2)
+    assert out.shape == ref.shape and not torch.isnan(out).any()
+    torch.testing.assert_close(out, ref, rtol=RTOL, atol=ATOL * max(1.0, ref.abs().max().item() / 10))
+    if kernel == 5:
+        assert torch.equal(ymax, out.abs().amax(dim=(1, 2, 3)))
+
+
+def test_conv_f16x2_exact_on_small_integers_and_batch_invariant():
+    """Integers up to 2^10 split exactly (hi = x S, lo = 0), so every product and partial sum is exact: the fp16-split kernel must
+    reproduce the integer result bit for bit.  And an image's rows are scaled by its own maximum: its output is the same bits
+    alone or beside images 1e5 x larger / smaller."""
+    if not _f16x2_on():
+        pytest.skip("CNL_CONV_F16X2=0 pins the fp32 matrix core")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-8, 9, (2, 64, 9, 9), generator=g).float()
+    w = torch.randint(-4, 5, (96, 64, 3, 3), generator=g).float()
+    b = torch.randint(-4, 5, (96,), generator=g).float()
+    out, kernel, _ = run_conv(x, w, b, 2, 0, hints=True)
+    assert kernel == 5 and torch.equal(out, ref_conv(x, w, b, 2, 0))
+    x, w, b = mk(3, 128, 10, 17, 128, 3, seed=21)
+    x[0] *= 1e5
+    x[2] *= 1e-5
+    full, _, _ = run_conv(x, w, b, 2, CNL_RELU, hints=True)
+    for n in range(3):
+        alone, _, _ = run_conv(x[n:n + 1], w, b, 2, CNL_RELU, hints=True)
+        assert torch.equal(alone[0], full[n]), n
+
+
+def test_conv_f16x2_error_not_above_fp32_mfma():
+    """Error against float64 of the fp16-split direct kernel <= 1.25 x that of the fp32 matrix-core kernel on a K = 2304 layer, also
+    with channels spanning six decades and with all-tiny / all-huge tensors."""
+    if not _f16x2_on():
+        pytest.skip("CNL_CONV_F16X2=0 pins the fp32 matrix core")
+    g = torch.Generator().manual_seed(11)
+    for case in ("plain", "spread", "tiny", "huge"):
+        x = torch.randn(1, 256, 32, 32, generator=g).clamp_min(0)
+        if case == "spread":
+            x = x * torch.pow(10.0, torch.randint(-3, 4, (1, 256, 1, 1), generator=g).float())
+        elif case == "tiny":
+            x = x * 1e-12
+        elif case == "huge":
+            x = x * 1e12
+        w = torch.randn(256, 256, 3, 3, generator=g) * (2.0 / (256 * 9)) ** 0.5
+        b = torch.zeros(256)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=2, padding=1)
+        e32 = (run_conv(x, w, b, 2, 0).double() - ref).abs().max().item()
+        out, kernel, _ = run_conv(x, w, b, 2, 0, hints=True)
+        assert kernel == 5 and torch.isfinite(out).all()
+        e16 = (out.double() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        assert e16 <= 1.25 * e32 + 1e-7 * scale, (case, e16, e32, scale)
+        assert e16 < 2e-5 * scale, (case, e16, scale)
 
 
 def test_conv_reads_channel_slice_of_wider_buffer():

@@ -27,6 +27,11 @@ SHAPES = {
     "c4l3": (16, 38, 68, 256, 256, 3, 1, CNL_RELU, False),
     "c4l2": (16, 76, 136, 128, 128, 3, 1, CNL_RELU, False),
     "c4head": (16, 152, 272, 256, 256, 3, 1, CNL_RELU, False),
+    "l2s2": (32, 128, 128, 64, 128, 3, 2, CNL_RELU, False),
+    "l3s2": (32, 64, 64, 128, 256, 3, 2, CNL_RELU, False),
+    "l4s2": (32, 32, 32, 256, 512, 3, 2, CNL_RELU, False),
+    "l3down": (32, 64, 64, 128, 256, 1, 2, 0, False),
+    "lat512": (32, 16, 16, 512, 256, 1, 1, 0, False),
     "out80": (32, 128, 128, 256, 80, 1, 1, CNL_SIGMOID, False),
     "out4": (32, 128, 128, 256, 4, 1, 1, 0, False),
 }
@@ -37,6 +42,7 @@ def main():
     ap.add_argument("names", nargs="*", default=["head256"])
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--winograd", action="store_true")
+    ap.add_argument("--hints", action="store_true", help="hand over x_absmax / w_absmax (fp16-split direct kernel where it applies)")
     args = ap.parse_args()
     lib = _lib.load()
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -70,6 +76,11 @@ def main():
             p.w = u.data_ptr()
             p.flags = flags & 5            # RELU | UPSAMPLE_IN
             fn = lib.cnl_conv3x3_winograd_f32
+        if args.hints and not args.winograd:
+            xm = x.abs().amax(dim=(1, 2, 3)).contiguous()
+            wm = w.abs().max().reshape(1).contiguous()
+            ym = torch.zeros(N, device="cuda")
+            p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), wm.data_ptr(), ym.data_ptr()
         for _ in range(2):
             _lib.check(fn(ctypes.byref(p), stream))
         torch.cuda.synchronize()
