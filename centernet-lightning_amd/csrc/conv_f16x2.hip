@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     const float hi6 = (a.flags & CNL_RELU6) ? 6.f : __builtin_inff();
     const bool sigm = a.flags & CNL_SIGMOID;
     const int img0 = sImg[0];
-    float omax = 0.f;
+    float omax = 0.f, omax1 = 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -277,15 +277,20 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
                     const float av = ok[r] ? fabsf(v[r]) : 0.f;
                     const int img = sImg[rl + (r & 3) + 8 * (r >> 2)];
                     if (img == img0) omax = fmaxf(omax, av);
-                    else if (av > 0.f) atomicMax(a.ymax + img, __float_as_uint(av));     // a tile that spans images: rare rows
+                    else if (img == img0 + 1) omax1 = fmaxf(omax1, av);                  // a tile that spans two images
+                    else if (av > 0.f) atomicMax(a.ymax + img, __float_as_uint(av));     // maps smaller than the tile: rare rows
                 }
             }
         }
     }
-    if (a.ymax) {          // one atomic per wave for the tile's first image
+    if (a.ymax) {          // one atomic per wave for the tile's first image and one for the next
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
+        for (int o = 32; o > 0; o >>= 1) {
+            omax = fmaxf(omax, __shfl_xor(omax, o, 64));
+            omax1 = fmaxf(omax1, __shfl_xor(omax1, o, 64));
+        }
         if (lane == 0 && omax > 0.f) atomicMax(a.ymax + img0, __float_as_uint(omax));
+        if (lane == 0 && omax1 > 0.f) atomicMax(a.ymax + img0 + 1, __float_as_uint(omax1));
     }
 }
 

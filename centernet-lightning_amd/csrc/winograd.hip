@@ -521,7 +521,7 @@ static int wino_choice(const cnl_conv_params* p) {
     static const int forced = getenv("CNL_WINO") ? atoi(getenv("CNL_WINO")) : 0;
     static const int min_cin5 = getenv("CNL_W5_MINCIN") ? atoi(getenv("CNL_W5_MINCIN")) : 128;
     static const int min_cout5 = getenv("CNL_W5_MINCOUT") ? atoi(getenv("CNL_W5_MINCOUT")) : 512;
-    static const int max_cin7 = getenv("CNL_W7_MAXCIN") ? atoi(getenv("CNL_W7_MAXCIN")) : 128;
+    static const int max_cin7 = getenv("CNL_W7_MAXCIN") ? atoi(getenv("CNL_W7_MAXCIN")) : 0;      // opt-in: see below
     const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
     const int H = p->H_in * upf, W = p->W_in * upf, CoutP = (p->Cout + 63) / 64 * 64;
     const int items_per_image = ((H + 15) / 16) * ((W + 15) / 16) * (CoutP / 64);
@@ -529,8 +529,9 @@ static int wino_choice(const cnl_conv_params* p) {
     if (p->Cin % 16) return 2;
     if (forced >= 3 && forced <= 7) return forced;
     if (items_per_image >= 8 && (p->Cin >= min_cin5 || p->Cout >= min_cout5)) {
-        // short channel loops (<= 8 chunks of 16): the item prologue / epilogue weigh most, and a second wave per SIMD hides them
-        // (winograd7.hip: -3 .. -4 % against both other forms at Cin = 64 and 128; +1.5 % at Cin = 256, +5 % at 512)
+        // winograd7.hip (two waves per SIMD) is NOT dispatched by default: -3 .. -4 % on the short channel loops of 512x512 inputs
+        // (Cin = 64, 128; 4 work items per CU), but +7 % on the same layers of 608x1088 frames (12 items per CU) and +64 % on their
+        // fused first head blocks (64 -> 768): CNL_W7_MAXCIN=128 reproduces the former
         if (p->Cin <= max_cin7) return 7;
         // the 8x16-pixel x 128-cout work items of winograd6.hip: where the channel loop is short and the couts many, and on maps
         // that 16-row blocks pad more than 8-row blocks (19x34, 38x68, 152x272 of 608x1088 frames: -1 .. -4 %)
