@@ -191,7 +191,7 @@ def main():
     ap.add_argument("--layers", action="store_true", help="also print the per-layer conv table to stderr")
     ap.add_argument("--oracle-check", action="store_true", help="add max |heatmap - CPU oracle| of this configuration (one oracle pass)")
     ap.add_argument("--no-fp32-mfma-leg", action="store_true",
-                    help="skip the extra short run with every conv on the fp32 matrix core (CNL_WINO=2 CNL_CONV_F16X2=0), reported beside `value`")
+                    help="skip the extra short run with every conv on the fp32 matrix core (CNL_WINO=2 CNL_CONV_F16X2=0 CNL_STEM_F16X2=0), reported beside `value`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -347,7 +347,7 @@ def main():
         if world == 1 and not args.no_fp32_mfma_leg and not os.environ.get("CNL_WINO"):
             # the same job with every 3x3 layer on the fp32 matrix core (the kernel choice is read once per process: child process)
             import subprocess
-            env = dict(os.environ, CNL_WINO="2", CNL_CONV_F16X2="0")
+            env = dict(os.environ, CNL_WINO="2", CNL_CONV_F16X2="0", CNL_STEM_F16X2="0")
             cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(max(args.steps // 2, 3)), "--warmup", str(min(args.warmup, 3)),
                    "--config", args.config, "--batch", str(B), "--height", str(H), "--width", str(W), "--k", str(args.k),
                    "--no-cpu-baseline", "--no-fp32-mfma-leg", "--oracle-check"]
@@ -357,7 +357,7 @@ def main():
                 result["fp32_mfma_only"] = {"value": alt["value"], "unit": alt["unit"], "ms_per_step": alt["ms_per_step"], "steps": alt["steps"],
                                             "roofline_frac_of_fp32_mfma_peak": alt["roofline"]["frac"],
                                             "max_abs_err_heatmap_vs_cpu_oracle": alt.get("oracle_check", {}).get("max_abs_err_heatmap"),
-                                            "note": "CNL_WINO=2 CNL_CONV_F16X2=0: every conv on v_mfma_f32_32x32x2_f32 (no split operands anywhere)"}
+                                            "note": "CNL_WINO=2 CNL_CONV_F16X2=0 CNL_STEM_F16X2=0: every conv on v_mfma_f32_32x32x2_f32 (no split operands anywhere)"}
             except Exception as e:      # reported, never fatal: `value` above is the measurement
                 result["fp32_mfma_only"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

@@ -31,16 +31,16 @@ __device__ __forceinline__ f32x16 mfma16_zero() {
     const u32x4 zz = {0u, 0u, 0u, 0u};
     return mfma16(zz, zz, z);
 }
-// (v0, v1) S -> hi pair (RN16, packed) and lo pair (RZ16 of the exact residuals, packed)
+// (v0, v1) S -> hi pair (RN16, packed) and lo pair (RZ16 of the exact residuals, packed).  Plain C on purpose: the compiler folds it
+// into v_fma_mixlo/mixhi_f16, v_fma_mix_f32 and v_cvt_pkrtz_f16_f32, and — unlike with inline asm — its hazard recognizer then sees
+// VALU instructions and keeps the two wait states gfx950 needs between a VALU write and an MFMA reading that register.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2(float v0, float v1, float S, unsigned& hi, unsigned& lo) {
-    unsigned pk;
-    float r0, r1;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(pk) : "v"(v0), "v"(S));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(pk) : "v"(v1), "v"(S));
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(v0), "v"(S), "v"(pk));
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(v1), "v"(S), "v"(pk));
-    asm("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
-    hi = pk;
+    const _Float16 h0 = (_Float16)__builtin_fmaf(v0, S, 0.f), h1 = (_Float16)__builtin_fmaf(v1, S, 0.f);
+    const float r0 = __builtin_fmaf(v0, S, -(float)h0), r1 = __builtin_fmaf(v1, S, -(float)h1);
+    const f16x2 hv = {h0, h1};
+    hi = __builtin_bit_cast(unsigned, hv);
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, float S, u32x4& hi, u32x4& lo) {
     unsigned h[4], l[4];

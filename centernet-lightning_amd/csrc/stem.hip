@@ -177,12 +177,19 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
 }  // namespace cnl_stem
 using namespace cnl_stem;
 
-extern "C" size_t cnl_stem_packed_weight_floats(void) { return (size_t)ST_KP * 64; }
+// stem_f16x2.hip: the same conv on the fp16 matrix cores; its split weights ride behind the fp32 image in the packed buffer
+size_t cnl_stem5_extra_floats();
+int cnl_stem5_pack(const float* w_ohwi, float* extra, void* stream);
+int cnl_stem5_launch(const float* x, long sn, int sc, int sh, int sw, unsigned img_bytes, const float* extra, const float* bias, float* y,
+                     int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y, unsigned blocks, void* stream);
+
+extern "C" size_t cnl_stem_packed_weight_floats(void) { return (size_t)ST_KP * 64 + cnl_stem5_extra_floats(); }
 
 extern "C" int cnl_stem_pack_weights_f32(const float* w_ohwi, float* w_packed, void* stream) {
     CNL_REQUIRE(w_ohwi && w_packed, CNL_E_BAD_ARG, "cnl_stem_pack_weights_f32: null pointer");
     hipLaunchKernelGGL(stem_pack_kernel, dim3((ST_KP * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_ohwi, w_packed);
-    return cnl::check_launch("stem_pack_kernel");
+    const int rc = cnl::check_launch("stem_pack_kernel");
+    return rc != CNL_OK ? rc : cnl_stem5_pack(w_ohwi, w_packed + ST_KP * 64, stream);
 }
 
 extern "C" int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
@@ -197,6 +204,10 @@ extern "C" int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int6
     const int tiles_x = (Wo + ST_TW - 1) / ST_TW, tiles_y = (Ho + ST_TH - 1) / ST_TH;
     const long long blocks = (long long)N * tiles_x * tiles_y;
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_stem_conv7x7_f32: grid too large");
+    static const bool f16x2 = !(getenv("CNL_STEM_F16X2") && atoi(getenv("CNL_STEM_F16X2")) == 0);      // 0: fp32 matrix cores
+    if (f16x2)
+        return cnl_stem5_launch(x, (long)sn, (int)sc, (int)sh, (int)sw, (unsigned)img_bytes, w + ST_KP * 64, bias, y, N, H, W, Ho, Wo,
+                                tiles_x, tiles_y, (unsigned)blocks, stream);
     static bool attr_done = false;
     const int lds = ST_LDS_BYTES;
     if (!attr_done) {

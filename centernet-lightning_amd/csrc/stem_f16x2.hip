@@ -1,0 +1,260 @@
+// stem_f16x2.hip — the ResNet stem Conv2d(3,64,7,s2,p3)+BN(folded)+ReLU of stem.hip with every fp32 product formed on the fp16
+// matrix cores (torchvision resnet.conv1/bn1/relu through backbone.forward_features: reference models/meta.py:42).
+//
+// Arithmetic: winograd5.hip's scaled two-way split.  The weights are split once (cnl_stem_pack_weights_f32: S_w from max |w|); the
+// input patch of a workgroup is scaled by a power of two S_x derived from the maximum of THAT patch (an output depends on its own
+// image only, and on nothing outside the tile's patch: batch-invariant by construction, no pass over the input, no hint);
+// x S = hi + lo (hi = RN16, lo = RZ16 of the exact residual), hi lo' + lo hi' + hi hi' accumulated in fp32, epilogue x 1/(S_x S_w).
+//
+// Structure: stem.hip's LDS-side im2col (the workgroup stages the (2*16+5) x (2*32+5) x 3 patch of its 16x32 output tile by 4-byte
+// LDS-DMA from whatever strides the caller has), but K is laid out in groups of 8 for v_mfma_f32_32x32x16_f16: group g = 3 ky + q
+// holds t = 8q .. 8q+7 of kernel row ky (t = kx*3 + c; t >= 21 are pads: zero weights, and the A operand is masked there because
+// the patch slot holds a neighbouring pixel and 0 x inf would not be 0); 21 groups + one all-zero = 11 steps of 16 instead of 77 of
+// 2.  A lane's operand is 8 consecutive patch floats (four ds_read_b64) split in registers (2.5 VALU per element); the split weights
+// sit in LDS as [piece][group][cout][8] so a lane's operand is one ds_read_b128.  Per step and wave: 4 rows x 2 cout groups x 3
+// MFMAs of 32 cycles against 88 x 64 in stem.hip — the kernel becomes bound by its 537 MB of output.
+#include "cnl_common.h"
+#include <cstdlib>
+
+namespace cnl_stem5 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TH = 16, TW = 32;                       // output tile (4 rows per wave)
+constexpr int PR = 2 * TH + 5;                        // patch rows (37)
+constexpr int PC = 2 * TW + 5;                        // patch cols (69)
+constexpr int RS = 256;                               // patch row stride in floats: 207 used (+ 3 pad reads); 1 KB = 4 DMA instructions
+constexpr int NG = 21;                                // K groups of 8 that hold weights (7 kernel rows x 3)
+constexpr int STEPS = 11;                             // 22 groups / 2 lane halves
+constexpr int W_PIECE_BYTES = NG * 64 * 16;           // 21504: one piece (hi or lo) of the split weights
+constexpr int W_BYTES = 2 * W_PIECE_BYTES;            // 43008 = 42 x 1 KB
+constexpr int PATCH_BYTES = PR * RS * 4;              // 37888
+constexpr int LDS_BYTES = PATCH_BYTES + W_BYTES + 64; // 80960 -> 2 workgroups / CU
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void dma4(const float* base, unsigned bytes, float* lds_dst, unsigned voffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 4, voffset, 0, 0, 0);
+}
+__device__ __forceinline__ void dma16(const void* base, unsigned bytes, char* lds_dst, unsigned voffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// (v0, v1) S -> hi pair (RN16, packed) and lo pair (RZ16 of the exact residuals, packed).  Plain C on purpose (the compiler folds it
+// into v_fma_mixlo/mixhi_f16, v_fma_mix_f32, v_cvt_pkrtz): with inline asm the hazard recognizer does not see VALU instructions,
+// and this kernel reuses an MFMA's operand registers for the next row's split a few instructions after the MFMA issues.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float v0, float v1, float S, unsigned& hi, unsigned& lo) {
+    const _Float16 h0 = (_Float16)__builtin_fmaf(v0, S, 0.f), h1 = (_Float16)__builtin_fmaf(v1, S, 0.f);
+    const float r0 = __builtin_fmaf(v0, S, -(float)h0), r1 = __builtin_fmaf(v1, S, -(float)h1);
+    const f16x2 hv = {h0, h1};
+    hi = __builtin_bit_cast(unsigned, hv);
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+}
+// the power of two that puts a tensor of maximum magnitude mx into [2^13, 2^14)  (1 for 0 / Inf / NaN maxima)
+__device__ __forceinline__ float pow2_scale(float mx) {
+    float S = 1.f;
+    if (mx > 0.f && mx < __builtin_inff()) {
+        int e;
+        (void)__builtin_frexpf(mx, &e);
+        e = 14 - e;
+        S = __builtin_ldexpf(1.f, e < -60 ? -60 : (e > 60 ? 60 : e));
+    }
+    return S;
+}
+
+// w_split: [piece][group][cout][8] fp16 (W_BYTES), scal[0] = S_w
+__global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const float* __restrict__ x, long sn, int sc, int sh, int sw,
+                                                            unsigned x_img_bytes, const void* __restrict__ w_split,
+                                                            const float* __restrict__ scal, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int N, int H, int W, int Ho, int Wo, int tiles_x,
+                                                            int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* patch = reinterpret_cast<float*>(smem);
+    char* wl = smem + PATCH_BYTES;
+    float* red = reinterpret_cast<float*>(smem + PATCH_BYTES + W_BYTES);      // [4] per-wave patch maxima
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, hi = lane >> 5, px = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+
+    // ---- staging by LDS-DMA (see stem.hip) ----
+#ifndef S5_EXP
+#define S5_EXP 0
+#endif
+    if (S5_EXP != 2)
+    for (int q = wave; q < W_BYTES / 1024; q += 4) dma16(w_split, (unsigned)W_BYTES, wl + q * 1024, (unsigned)(q * 1024 + lane * 16));
+    const float* xn = x + (long)n * sn;
+    unsigned lane_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int f = q * 64 + lane;
+        const int col = f / 3, c = f - col * 3;
+        const int ix = ix0 + col;
+        lane_off[q] = (f < PC * 3 && (unsigned)ix < (unsigned)W) ? (unsigned)((c * sc + ix * sw) * 4) : OOB;
+    }
+    for (int r = wave; r < (S5_EXP == 1 ? 0 : PR); r += 4) {
+        const int iy = iy0 + r;
+        const bool row_ok = (unsigned)iy < (unsigned)H;                       // wave-uniform
+        const unsigned row_off = (unsigned)(iy * sh * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            dma4(xn, x_img_bytes, patch + r * RS + q * 64, (row_ok && lane_off[q] != OOB) ? lane_off[q] + row_off : OOB);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- the patch's scale: max |x| over the staged patch (out-of-image slots hold zeros) ----
+    float mx = 0.f;
+    for (int e = tid; e < (S5_EXP == 5 ? 1 : PR * (RS / 4)); e += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(patch + e * 4);
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    const float Sx = pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    const float inv = 1.f / (Sx * scal[0]);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // lane's A base: output row (wave*4 + i), column px -> patch row 2*(wave*4+i) + ky, floats 6*px + 8q .. + 7
+    const float* pa = patch + (wave * 8) * RS + px * 6;
+    const char* pb = wl + px * 16;                                // + piece * W_PIECE_BYTES + (g * 64 + 32 j) * 16
+#pragma unroll
+    for (int s = 0; s < (S5_EXP == 3 ? 1 : STEPS); ++s) {
+        // group of this lane half: g = 2s + hi; the all-zero group 21 (hi = 1 of the last step) reads group 20's slots and masks all
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int g0 = 2 * s, g1 = (2 * s + 1 < NG) ? 2 * s + 1 : 2 * s;
+        const int ky0 = g0 / 3, q0 = g0 % 3, ky1 = g1 / 3, q1 = g1 % 3;
+        const bool dead1 = 2 * s + 1 >= NG;
+        const int a_off = hi ? (ky1 * RS + 8 * q1) : (ky0 * RS + 8 * q0);              // floats
+        const int b_off = (hi ? g1 : g0) * 64 * 16;                                   // bytes
+        // masks of the packed pairs (e4,e5) and (e6,e7): t = 21, 22, 23 are pads of the groups with q == 2
+        const unsigned m01 = (hi && dead1) ? 0u : 0xFFFFFFFFu;
+        const unsigned m2 = hi ? (dead1 ? 0u : (q1 == 2 ? 0x0000FFFFu : 0xFFFFFFFFu)) : (q0 == 2 ? 0x0000FFFFu : 0xFFFFFFFFu);
+        const unsigned m3 = hi ? ((dead1 || q1 == 2) ? 0u : 0xFFFFFFFFu) : (q0 == 2 ? 0u : 0xFFFFFFFFu);
+        u32x4 bh[2], bl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bh[j] = *reinterpret_cast<const u32x4*>(pb + b_off + j * 32 * 16);
+            bl[j] = *reinterpret_cast<const u32x4*>(pb + W_PIECE_BYTES + b_off + j * 32 * 16);
+            if (dead1) {                                                                // compile-time: last step only
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bh[j][e] &= m01; bl[j][e] &= m01; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* p = pa + (2 * i) * RS + a_off;
+            const f32x2 v0 = *reinterpret_cast<const f32x2*>(p), v1 = *reinterpret_cast<const f32x2*>(p + 2);
+            const f32x2 v2 = *reinterpret_cast<const f32x2*>(p + 4), v3 = *reinterpret_cast<const f32x2*>(p + 6);
+            unsigned h[4], l[4];
+            split2(v0[0], v0[1], Sx, h[0], l[0]);
+            split2(v1[0], v1[1], Sx, h[1], l[1]);
+            split2(v2[0], v2[1], Sx, h[2], l[2]);
+            split2(v3[0], v3[1], Sx, h[3], l[3]);
+            if (dead1) { h[0] &= m01; h[1] &= m01; l[0] &= m01; l[1] &= m01; }
+            if (dead1 || q0 == 2 || q1 == 2) { h[2] &= m2; h[3] &= m3; l[2] &= m2; l[3] &= m3; }
+            const u32x4 ah = {h[0], h[1], h[2], h[3]}, al = {l[0], l[1], l[2], l[3]};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = mfma16(ah, bl[j], acc[i][j]);
+                acc[i][j] = mfma16(al, bh[j], acc[i][j]);
+                acc[i][j] = mfma16(ah, bh[j], acc[i][j]);
+            }
+        }
+    }
+
+    // epilogue: scale back, bias + ReLU, NHWC store (col = lane&31 -> channel, rows -> pixels of the row)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = j * 32 + px;
+        const float bv = bias[co];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oy = oy0 + wave * 4 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (oy < Ho && ox < Wo && (S5_EXP != 4 || acc[i][j][r] == 12345.f)) {
+                    const float v = fmaxf(acc[i][j][r] * inv + bv, 0.f);
+                    __builtin_nontemporal_store(v, &y[(((size_t)n * Ho + oy) * Wo + ox) * 64 + co]);
+                }
+            }
+        }
+    }
+}
+
+// OHWI [64][7][7][3] (BN folded) -> [piece][group][cout][8] fp16 with the power-of-two scale S_w (scal[0]); one workgroup
+__global__ __launch_bounds__(256) void stem_split_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ ws, float* __restrict__ scal) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    float mx = 0.f;
+    for (int e = tid; e < 64 * 147; e += 256) {
+        const float v = fabsf(w[e]);
+        mx = (v < __builtin_inff()) ? fmaxf(mx, v) : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    const float Sw = pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (tid == 0) scal[0] = Sw;
+    for (int e = tid; e < NG * 64 * 8; e += 256) {
+        const int k = e & 7, co = (e >> 3) & 63, g = e >> 9;
+        const int ky = g / 3, t = 8 * (g % 3) + k;
+        const float v = t < 21 ? w[co * 147 + ky * 21 + t] * Sw : 0.f;
+        const _Float16 hv = (_Float16)v;                                     // round to nearest even
+        const float r = v - (float)hv;                                       // exact
+        unsigned lo2;
+        asm("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(lo2) : "v"(r), "v"(0.f));
+        ws[e] = __builtin_bit_cast(unsigned short, hv);
+        ws[NG * 64 * 8 + e] = (unsigned short)(lo2 & 0xFFFFu);
+    }
+}
+
+}  // namespace cnl_stem5
+using namespace cnl_stem5;
+
+// floats appended to the fp32 packed weights: the two fp16 pieces + 4 scalars
+size_t cnl_stem5_extra_floats() { return (size_t)W_BYTES / 4 + 4; }
+
+int cnl_stem5_pack(const float* w_ohwi, float* extra, void* stream) {
+    hipLaunchKernelGGL(stem_split_pack_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w_ohwi,
+                       reinterpret_cast<unsigned short*>(extra), extra + W_BYTES / 4);
+    return cnl::check_launch("stem_split_pack_kernel");
+}
+
+int cnl_stem5_launch(const float* x, long sn, int sc, int sh, int sw, unsigned img_bytes, const float* extra, const float* bias, float* y,
+                     int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y, unsigned blocks, void* stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        CNL_HIP(hipFuncSetAttribute((const void*)stem_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(stem_f16x2_kernel, dim3(blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes,
+                       (const void*)extra, extra + W_BYTES / 4, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y);
+    return cnl::check_launch("stem_f16x2_kernel");
+}

@@ -135,9 +135,11 @@ int cnl_normalize_u8_nhwc_f32(const uint8_t* x, float* y, int32_t N, int32_t H, 
  * ResNet stem: Conv2d(3,64,7,stride=2,padding=3,bias=False)+BN+ReLU (torchvision resnet.conv1/bn1/relu).
  * x is read through explicit element strides (sn,sc,sh,sw) so NCHW-contiguous and channels_last
  * callers are both zero-copy (models/meta.py:97-98 precedent); y is NHWC [N, H/2, W/2, 64].
- * w: the PACKED weight image [154][64] (row k = ky*22 + kx*3 + c; the 22nd row of every ky is zero) that
- * cnl_stem_pack_weights_f32 makes from the OHWI [64][7][7][3] (BN-folded) weights — it is copied into LDS verbatim by LDS-DMA;
- * cnl_stem_packed_weight_floats() = 154*64 sizes it; bias: [64].
+ * w: the PACKED weights that cnl_stem_pack_weights_f32 makes from the OHWI [64][7][7][3] (BN-folded) weights — LDS images copied
+ * verbatim by LDS-DMA: the fp32 image [154][64] (row k = ky*22 + kx*3 + c; the 22nd row of every ky is zero) followed by the
+ * scaled two-way fp16 split [piece][21 groups of 8 k][64][8] and its power-of-two scale (csrc/stem_f16x2.hip: the default kernel
+ * forms each fp32 product on the fp16 matrix cores, input scaled per workgroup patch; CNL_STEM_F16X2=0 in the environment selects
+ * the fp32 matrix-core kernel); cnl_stem_packed_weight_floats() sizes the buffer; bias: [64].
  */
 size_t cnl_stem_packed_weight_floats(void);
 int cnl_stem_pack_weights_f32(const float* w_ohwi, float* w_packed, void* stream);

@@ -275,6 +275,80 @@ def test_stem_matches_cpu(shape, channels_last):
     torch.testing.assert_close(y.cpu().permute(0, 3, 1, 2), ref, rtol=RTOL, atol=ATOL)
 
 
+def _run_stem(lib, x, w, b, channels_last=False):
+    xd = x.cuda()
+    if channels_last:
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = torch.full((lib.cnl_stem_packed_weight_floats(),), float("nan"), device="cuda")
+    _lib.check(lib.cnl_stem_pack_weights_f32(wd.data_ptr(), wp.data_ptr(), _stream()))
+    bd = b.cuda()
+    N, _, H, W = x.shape
+    y = torch.full((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), float("nan"), device="cuda")
+    sn, sc, sh, sw = xd.stride()
+    _lib.check(lib.cnl_stem_conv7x7_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), y.data_ptr(), N, H, W, _stream()))
+    torch.cuda.synchronize()
+    return y.cpu().permute(0, 3, 1, 2)
+
+
+def test_stem_f16x2_exact_on_integers_batch_invariant_and_pad_safe():
+    """The default stem kernel forms its products on the fp16 matrix cores from scaled two-way splits (csrc/stem_f16x2.hip).
+    Small integers split exactly -> bit-exact result; the scale comes from the workgroup's own patch -> an image's output is the
+    same bits alone or beside images 1e5 x larger / smaller; the zero-weight pad entries of its K layout are masked -> a
+    non-finite pixel only reaches the outputs whose 7x7 window contains it."""
+    import os
+    if os.environ.get("CNL_STEM_F16X2", "1") == "0":
+        pytest.skip("CNL_STEM_F16X2=0 pins the fp32 matrix core")
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randint(-8, 9, (2, 3, 37, 70), generator=g).float()
+    w = torch.randint(-4, 5, (64, 3, 7, 7), generator=g).float()
+    b = torch.randint(-4, 5, (64,), generator=g).float()
+    assert torch.equal(_run_stem(lib, x, w, b), F.relu(F.conv2d(x, w, b, stride=2, padding=3)))
+    x = torch.randn(3, 3, 40, 72, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    x[0] *= 1e5
+    x[2] *= 1e-5
+    full = _run_stem(lib, x, w, b, channels_last=True)
+    for n in range(3):
+        assert torch.equal(_run_stem(lib, x[n:n + 1], w, b, channels_last=True)[0], full[n]), n
+    torch.testing.assert_close(full[1], F.relu(F.conv2d(x[1:2], w, b, stride=2, padding=3))[0], rtol=RTOL, atol=ATOL)
+    x = torch.rand(1, 3, 64, 64, generator=g)
+    x[0, 1, 21, 30] = float("inf")
+    out, ref = _run_stem(lib, x, w.abs(), b), F.relu(F.conv2d(x, w.abs(), b, stride=2, padding=3))
+    fin = torch.isfinite(ref)                 # (inside the window the split gives NaN where fp32 gives inf, and fmaxf-ReLU maps NaN to 0)
+    assert (~fin).sum() == 64 * 12 and torch.isfinite(out[fin]).all()
+    torch.testing.assert_close(out[fin], ref[fin], rtol=RTOL, atol=ATOL)
+
+
+def test_stem_f16x2_error_not_above_fp32_mfma():
+    """Error against float64 of the fp16-split stem <= 1.25 x that of the fp32 matrix-core stem (CNL_STEM_F16X2=0 in a private copy
+    of the library), for [0,1) images, normalised images and tiny / huge inputs."""
+    import os
+    if os.environ.get("CNL_STEM_F16X2", "1") == "0":
+        pytest.skip("CNL_STEM_F16X2=0 pins the fp32 matrix core")
+    os.environ["CNL_STEM_F16X2"] = "0"
+    lib32 = _fresh_lib(0)
+    os.environ.pop("CNL_WINO", None)
+    g = torch.Generator().manual_seed(12)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    b = torch.zeros(64)
+    first = True
+    for case, x in (("unit", torch.rand(2, 3, 96, 128, generator=g)), ("normalised", torch.randn(2, 3, 96, 128, generator=g) * 1.2),
+                    ("tiny", torch.rand(1, 3, 64, 64, generator=g) * 1e-12), ("huge", torch.rand(1, 3, 64, 64, generator=g) * 1e12)):
+        ref = F.relu(F.conv2d(x.double(), w.double(), stride=2, padding=3))
+        e32 = (_run_stem(lib32, x, w, b).double() - ref).abs().max().item()
+        if first:
+            os.environ.pop("CNL_STEM_F16X2", None)          # the private copy has read it at its first stem call
+            first = False
+        out = _run_stem(_lib.load(), x, w, b)
+        assert torch.isfinite(out).all()
+        e16 = (out.double() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        assert e16 <= 1.25 * e32 + 1e-7 * scale, (case, e16, e32, scale)
+        assert e32 > 0 and e16 < 2e-5 * scale, (case, e16, e32, scale)
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 32, 32), (1, 64, 17, 23), (1, 8, 6, 6)])
 def test_maxpool_matches_cpu_bit_exact(shape):
     lib = _lib.load()

@@ -191,3 +191,19 @@ def test_collate_is_noop_at_world_size_one():
     assert cl.shard_range(512, 3, 8) == (192, 256)
     with pytest.raises(ValueError):
         cl.shard_range(10, 0, 4)
+
+
+def test_inline_asm_kernels_keep_valu_to_mfma_distance():
+    """gfx950 needs two wait states between a VALU write of a VGPR and an MFMA reading it; the compiler does not look inside inline
+    asm, so the kernels that split operands with asm VALU instructions are checked on their device assembly
+    (tools/mfma_hazard_audit.py).  The checker itself is pinned on a two-line listing with and without the distance."""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import mfma_hazard_audit as audit
+    bad = "v_cvt_pkrtz_f16_f32 v5, v5, v14\nds_read2_b64 v[22:25], v9 offset1:1\nv_mfma_f32_32x32x16_f16 v[50:65], v[2:5], v[6:9], v[50:65]\n"
+    assert audit.audit_asm(bad)[1] and not audit.audit_asm(bad.replace("ds_read2", "s_nop 0\nds_read2"))[1]
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    for name, (total, violations) in audit.audit_files().items():
+        assert total > 90 and not violations, (name, violations[:3])
