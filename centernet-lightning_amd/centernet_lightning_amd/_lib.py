@@ -70,6 +70,8 @@ _SIGNATURES = {
     "cnl_stem_pack_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     "cnl_stem_conv7x7_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                             c_int32, c_int32, c_int32, c_void_p]),
+    "cnl_stem_conv7x7_maxpool_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                            c_int32, c_int32, c_int32, c_void_p]),
     "cnl_maxpool3x3s2_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "cnl_decode_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "cnl_decode_f32": (ctypes.c_int, [POINTER(DecodeParams), c_void_p]),

@@ -382,12 +382,17 @@ class Plan:
             raise ValueError(f"input H, W must be divisible by 32 (got {H}x{W}); docs/implementation.md:52 of the reference")
         # ---- backbone ----
         h2, w2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-        s1 = self._buf(N, h2, w2, 64)
-        self.stem_out = s1
         h4, w4 = (h2 + 2 - 3) // 2 + 1, (w2 + 2 - 3) // 2 + 1
         cur = self._buf(N, h4, w4, 64)
-        self.launches.append(_Launch("stem", None, "stem7x7+bn+relu", 2 * N * h2 * w2 * 64 * 147))
-        self.launches.append(_Launch("maxpool", (s1, cur, N, h2, w2, 64), "maxpool3x3s2"))
+        # the stride-2 feature map is only materialised when a neck consumes it (an FPN with four Fuse levels); otherwise the stem
+        # kernel pools its own tile and the 64-channel map at half resolution never reaches memory (cnl_stem_conv7x7_maxpool_f32)
+        need_s1 = (Wt.neck_kind != "SimpleNeck" and len(Wt.fuse) >= 4) or os.environ.get("CNL_STEM_FUSED_POOL", "1") == "0" or os.environ.get("CNL_STEM_F16X2", "1") == "0"
+        s1 = self._buf(N, h2, w2, 64) if need_s1 else None
+        self.stem_out = s1 if need_s1 else cur
+        self.stem_fused_pool = not need_s1
+        self.launches.append(_Launch("stem", None, "stem7x7+bn+relu" + ("" if need_s1 else "+maxpool3x3s2"), 2 * N * h2 * w2 * 64 * 147))
+        if need_s1:
+            self.launches.append(_Launch("maxpool", (s1, cur, N, h2, w2, 64), "maxpool3x3s2"))
         ch, cw, cc = h4, w4, 64
         feats = {}
         for bi, (c1, c2, down, li) in enumerate(Wt.blocks):
@@ -516,8 +521,9 @@ class Plan:
         for L in self.launches:
             if L.fn == "stem":
                 sn, sc, sh, sw = x.stride()
-                rc = lib.cnl_stem_conv7x7_f32(x.data_ptr(), sn, sc, sh, sw, self._wt_stem_packed.data_ptr(), self._wt_stem.b.data_ptr(),
-                                              self.stem_out.data_ptr(), self.N, self.H, self.W, stream)
+                fn = lib.cnl_stem_conv7x7_maxpool_f32 if self.stem_fused_pool else lib.cnl_stem_conv7x7_f32
+                rc = fn(x.data_ptr(), sn, sc, sh, sw, self._wt_stem_packed.data_ptr(), self._wt_stem.b.data_ptr(),
+                        self.stem_out.data_ptr(), self.N, self.H, self.W, stream)
             elif L.fn == "maxpool":
                 src, dst, n, h, w, c = L.args
                 rc = lib.cnl_maxpool3x3s2_nhwc_f32(src.data_ptr(), dst.data_ptr(), n, h, w, c, stream)

@@ -181,7 +181,7 @@ using namespace cnl_stem;
 size_t cnl_stem5_extra_floats();
 int cnl_stem5_pack(const float* w_ohwi, float* extra, void* stream);
 int cnl_stem5_launch(const float* x, long sn, int sc, int sh, int sw, unsigned img_bytes, const float* extra, const float* bias, float* y,
-                     int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y, unsigned blocks, void* stream);
+                     int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y, unsigned blocks, bool pool, void* stream);
 
 extern "C" size_t cnl_stem_packed_weight_floats(void) { return (size_t)ST_KP * 64 + cnl_stem5_extra_floats(); }
 
@@ -192,22 +192,22 @@ extern "C" int cnl_stem_pack_weights_f32(const float* w_ohwi, float* w_packed, v
     return rc != CNL_OK ? rc : cnl_stem5_pack(w_ohwi, w_packed + ST_KP * 64, stream);
 }
 
-extern "C" int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
-                                    const float* bias, float* y, int32_t N, int32_t H, int32_t W, void* stream) {
-    CNL_REQUIRE(x && w && bias && y, CNL_E_BAD_ARG, "cnl_stem_conv7x7_f32: null tensor pointer");
-    CNL_REQUIRE(N > 0 && H > 0 && W > 0, CNL_E_BAD_ARG, "cnl_stem_conv7x7_f32: non-positive dimension");
-    CNL_REQUIRE(sc > 0 && sh > 0 && sw > 0 && sn >= 0, CNL_E_UNSUPPORTED, "cnl_stem_conv7x7_f32: non-positive strides");
-    CNL_REQUIRE(((uintptr_t)w & 15) == 0, CNL_E_BAD_ARG, "cnl_stem_conv7x7_f32: packed weights must be 16-byte aligned");
+static int stem_launch(const char* who, bool pool, const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
+                       const float* bias, float* y, int32_t N, int32_t H, int32_t W, void* stream) {
+    CNL_REQUIRE(x && w && bias && y, CNL_E_BAD_ARG, "%s: null tensor pointer", who);
+    CNL_REQUIRE(N > 0 && H > 0 && W > 0, CNL_E_BAD_ARG, "%s: non-positive dimension", who);
+    CNL_REQUIRE(sc > 0 && sh > 0 && sw > 0 && sn >= 0, CNL_E_UNSUPPORTED, "%s: non-positive strides", who);
+    CNL_REQUIRE(((uintptr_t)w & 15) == 0, CNL_E_BAD_ARG, "%s: packed weights must be 16-byte aligned", who);
     const unsigned long long img_bytes = (2ull * sc + (unsigned long long)(H - 1) * sh + (unsigned long long)(W - 1) * sw + 1) * 4ull;
-    CNL_REQUIRE(img_bytes < 0xFFFFFF00ull, CNL_E_UNSUPPORTED, "cnl_stem_conv7x7_f32: one image spans >= 4 GiB");
+    CNL_REQUIRE(img_bytes < 0xFFFFFF00ull, CNL_E_UNSUPPORTED, "%s: one image spans >= 4 GiB", who);
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     const int tiles_x = (Wo + ST_TW - 1) / ST_TW, tiles_y = (Ho + ST_TH - 1) / ST_TH;
     const long long blocks = (long long)N * tiles_x * tiles_y;
-    CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_stem_conv7x7_f32: grid too large");
+    CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "%s: grid too large", who);
     static const bool f16x2 = !(getenv("CNL_STEM_F16X2") && atoi(getenv("CNL_STEM_F16X2")) == 0);      // 0: fp32 matrix cores
-    if (f16x2)
+    if (f16x2 || pool)           // (the fused max-pool exists in the fp16-split kernel only)
         return cnl_stem5_launch(x, (long)sn, (int)sc, (int)sh, (int)sw, (unsigned)img_bytes, w + ST_KP * 64, bias, y, N, H, W, Ho, Wo,
-                                tiles_x, tiles_y, (unsigned)blocks, stream);
+                                tiles_x, tiles_y, (unsigned)blocks, pool, stream);
     static bool attr_done = false;
     const int lds = ST_LDS_BYTES;
     if (!attr_done) {
@@ -217,6 +217,16 @@ extern "C" int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int6
     hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, (long)sn, (int)sc,
                        (int)sh, (int)sw, (unsigned)img_bytes, w, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y);
     return cnl::check_launch("stem_conv_kernel");
+}
+
+extern "C" int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
+                                    const float* bias, float* y, int32_t N, int32_t H, int32_t W, void* stream) {
+    return stem_launch("cnl_stem_conv7x7_f32", false, x, sn, sc, sh, sw, w, bias, y, N, H, W, stream);
+}
+
+extern "C" int cnl_stem_conv7x7_maxpool_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
+                                            const float* bias, float* y, int32_t N, int32_t H, int32_t W, void* stream) {
+    return stem_launch("cnl_stem_conv7x7_maxpool_f32", true, x, sn, sc, sh, sw, w, bias, y, N, H, W, stream);
 }
 
 extern "C" int cnl_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {

@@ -70,7 +70,12 @@ __device__ __forceinline__ float pow2_scale(float mx) {
     return S;
 }
 
-// w_split: [piece][group][cout][8] fp16 (W_BYTES), scal[0] = S_w
+// w_split: [piece][group][cout][8] fp16 (W_BYTES), scal[0] = S_w.
+// POOL: y is the output of MaxPool2d(3, s2, p1) applied to the conv output ([N, Hp, Wp, 64], ZERO-FILLED by the caller's launch
+// function): the workgroup pools its 16x32 conv tile through LDS; the 7x15 pooled cells whose 3x3 window lies inside the tile are
+// stored, the border cells (whose window continues in a neighbouring tile) are merged with atomic max on the bit pattern — exact
+// and order-independent, the values being post-ReLU (>= +0).  The 537 MB conv output never exists.
+template <bool POOL>
 __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const float* __restrict__ x, long sn, int sc, int sh, int sw,
                                                             unsigned x_img_bytes, const void* __restrict__ w_split,
                                                             const float* __restrict__ scal, const float* __restrict__ bias,
@@ -187,23 +192,111 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const float* __restr
         }
     }
 
-    // epilogue: scale back, bias + ReLU, NHWC store (col = lane&31 -> channel, rows -> pixels of the row)
+    if constexpr (!POOL) {
+        // epilogue: scale back, bias + ReLU, NHWC store (col = lane&31 -> channel, rows -> pixels of the row)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = j * 32 + px;
-        const float bv = bias[co];
+        for (int j = 0; j < 2; ++j) {
+            const int co = j * 32 + px;
+            const float bv = bias[co];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int oy = oy0 + wave * 4 + i;
+            for (int i = 0; i < 4; ++i) {
+                const int oy = oy0 + wave * 4 + i;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (oy < Ho && ox < Wo && (S5_EXP != 4 || acc[i][j][r] == 12345.f)) {
-                    const float v = fmaxf(acc[i][j][r] * inv + bv, 0.f);
-                    __builtin_nontemporal_store(v, &y[(((size_t)n * Ho + oy) * Wo + ox) * 64 + co]);
+                for (int r = 0; r < 16; ++r) {
+                    const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (oy < Ho && ox < Wo && (S5_EXP != 4 || acc[i][j][r] == 12345.f)) {
+                        const float v = fmaxf(acc[i][j][r] * inv + bv, 0.f);
+                        __builtin_nontemporal_store(v, &y[(((size_t)n * Ho + oy) * Wo + ox) * 64 + co]);
+                    }
                 }
             }
         }
+    } else {
+        // epilogue with the max-pool, in registers.  A lane holds, per conv row, the columns c0 .. c0+3 of four groups (c0 = 8g + 4hi):
+        // pooled column 4g+2hi+1 = max of columns c0+1 .. c0+3 is lane-local, pooled column 4g+2hi = max(c0-1, c0, c0+1) takes c0-1
+        // from the other lane half (one xor-32 shuffle per group); a wave holds conv rows 4w .. 4w+3: pooled row 2w+1 (rows 4w+1 .. 4w+3)
+        // is wave-local, pooled row 2w = max(4w-1, 4w, 4w+1) takes the column-pooled row 4w-1 from the previous wave through LDS.
+        // Pooled row 0 / column 0 (window continues in the tile above / left) and row 8 / column 16 (only the first row / column of the
+        // window is in this tile) are merged across workgroups with atomic max; invalid conv positions (outside the image) count as 0.
+        float* X = reinterpret_cast<float*>(smem);                     // [j][wave][9][64 lanes]: column-pooled conv row 4w+3
+        const int Hp = (Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1;        // MaxPool2d(3, 2, 1) output size
+        const int rows_ok = Ho - oy0, cols_ok = Wo - ox0;              // conv rows / cols of the tile inside the image
+        const int py0 = oy0 >> 1, px0 = ox0 >> 1;
+        // column pooling of 16 values (one conv row, or the maximum of several): out[0..3] = pooled columns 4g+2hi, out[4..7] = 4g+2hi+1,
+        // out[8] = column 31 alone (lane half 1; pooled column 16)
+#define S5_COLPOOL(in_, out_)                                                                                     \
+        do {                                                                                                      \
+            float s_[4];                                                                                          \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) s_[g] = __shfl_xor((in_)[4 * g + 3], 32, 64);           \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                       \
+                const float nb_ = hi ? s_[g] : (g ? s_[g ? g - 1 : 0] : 0.f);                                     \
+                (out_)[g] = fmaxf(fmaxf((in_)[4 * g], (in_)[4 * g + 1]), nb_);                                    \
+                (out_)[4 + g] = fmaxf(fmaxf((in_)[4 * g + 1], (in_)[4 * g + 2]), (in_)[4 * g + 3]);               \
+            }                                                                                                     \
+            (out_)[8] = hi ? (in_)[15] : 0.f;                                                                     \
+        } while (0)
+        __syncthreads();                                               // everyone is done with the LDS images
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float bv = bias[j * 32 + px];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r] * inv + bv;
+                    const bool ok = wave * 4 + i < rows_ok && (r & 3) + 8 * (r >> 2) + 4 * hi < cols_ok;
+                    acc[i][j][r] = (ok && v > 0.f) ? v : 0.f;            // ReLU; never -0 or NaN
+                }
+            float in3[16], p3[9];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) in3[r] = acc[3][j][r];
+            S5_COLPOOL(in3, p3);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) X[((j * 4 + wave) * 9 + k) * 64 + lane] = p3[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float in_o[16], in_e[16], po[9], pe[9];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                in_o[r] = fmaxf(fmaxf(acc[1][j][r], acc[2][j][r]), acc[3][j][r]);
+                in_e[r] = fmaxf(acc[0][j][r], acc[1][j][r]);
+            }
+            S5_COLPOOL(in_o, po);
+            S5_COLPOOL(in_e, pe);
+            if (wave > 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) pe[k] = fmaxf(pe[k], X[((j * 4 + wave - 1) * 9 + k) * 64 + lane]);
+            }
+            float* yc = y + (size_t)n * Hp * Wp * 64 + j * 32 + px;
+            // rows: 0 = pooled row 2w (even), 1 = pooled row 2w+1 (odd), 2 = pooled row 8 (wave 3 only: its conv row 15 alone)
+#pragma unroll
+            for (int rw = 0; rw < 3; ++rw) {
+                if (rw == 2 && wave != 3) continue;
+                const int pr = rw == 2 ? 8 : 2 * wave + rw;
+                const int gy = py0 + pr;
+                if (gy >= Hp) continue;
+                const bool row_border = pr == 0 || pr == 8;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int pc = k == 8 ? 16 : (4 * (k & 3) + 2 * hi + (k >> 2));
+                    const int gx = px0 + pc;
+                    float m;
+                    if (rw == 2) m = X[((j * 4 + 3) * 9 + k) * 64 + lane];      // own column-pooled row 15
+                    else m = rw ? po[k] : pe[k];
+                    if (k == 8 && !hi) continue;
+                    if (gx >= Wp) continue;
+                    float* dst = yc + ((size_t)gy * Wp + gx) * 64;
+                    if (row_border || pc == 0 || pc == 16) {
+                        if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
+                    } else {
+                        __builtin_nontemporal_store(m, dst);
+                    }
+                }
+            }
+        }
+#undef S5_COLPOOL
     }
 }
 
@@ -248,13 +341,21 @@ int cnl_stem5_pack(const float* w_ohwi, float* extra, void* stream) {
 }
 
 int cnl_stem5_launch(const float* x, long sn, int sc, int sh, int sw, unsigned img_bytes, const float* extra, const float* bias, float* y,
-                     int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y, unsigned blocks, void* stream) {
+                     int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y, unsigned blocks, bool pool, void* stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        CNL_HIP(hipFuncSetAttribute((const void*)stem_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CNL_HIP(hipFuncSetAttribute((const void*)stem_f16x2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CNL_HIP(hipFuncSetAttribute((const void*)stem_f16x2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_done = true;
     }
-    hipLaunchKernelGGL(stem_f16x2_kernel, dim3(blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes,
-                       (const void*)extra, extra + W_BYTES / 4, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y);
+    if (pool) {                  // the border cells are merged with atomic max: start from +0 everywhere
+        const size_t Hp = (size_t)(Ho - 1) / 2 + 1, Wp = (size_t)(Wo - 1) / 2 + 1;
+        CNL_HIP(hipMemsetAsync(y, 0, (size_t)N * Hp * Wp * 64 * sizeof(float), (hipStream_t)stream));
+        hipLaunchKernelGGL(stem_f16x2_kernel<true>, dim3(blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes,
+                           (const void*)extra, extra + W_BYTES / 4, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y);
+    } else {
+        hipLaunchKernelGGL(stem_f16x2_kernel<false>, dim3(blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes,
+                           (const void*)extra, extra + W_BYTES / 4, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y);
+    }
     return cnl::check_launch("stem_f16x2_kernel");
 }

@@ -321,6 +321,40 @@ def test_stem_f16x2_exact_on_integers_batch_invariant_and_pad_safe():
     torch.testing.assert_close(out[fin], ref[fin], rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 64, 64), (1, 3, 70, 134), (3, 3, 32, 96), (1, 3, 6, 10)])
+def test_stem_with_fused_maxpool_is_bit_identical_to_two_launches(shape):
+    """cnl_stem_conv7x7_maxpool_f32 pools the conv tile inside the stem kernel (border cells merged across workgroups with atomic
+    max): the same bits as cnl_stem_conv7x7_f32 + cnl_maxpool3x3s2_nhwc_f32, for full, ragged and tiny images and both layouts."""
+    import os
+    if os.environ.get("CNL_STEM_F16X2", "1") == "0":
+        pytest.skip("the two-launch path would run the fp32 stem")
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(*shape, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    b = torch.randn(64, generator=g) * 0.1
+    N, _, H, W = shape
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = torch.empty((lib.cnl_stem_packed_weight_floats(),), device="cuda")
+    _lib.check(lib.cnl_stem_pack_weights_f32(wd.data_ptr(), wp.data_ptr(), _stream()))
+    bd = b.cuda()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    for cl_ in (False, True):
+        xd = x.cuda().contiguous(memory_format=torch.channels_last) if cl_ else x.cuda()
+        sn, sc, sh, sw = xd.stride()
+        y1 = torch.empty((N, Ho, Wo, 64), device="cuda")
+        y2 = torch.empty((N, Hp, Wp, 64), device="cuda")
+        yf = torch.full((N, Hp, Wp, 64), float("nan"), device="cuda")
+        _lib.check(lib.cnl_stem_conv7x7_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), y1.data_ptr(), N, H, W, _stream()))
+        _lib.check(lib.cnl_maxpool3x3s2_nhwc_f32(y1.data_ptr(), y2.data_ptr(), N, Ho, Wo, 64, _stream()))
+        _lib.check(lib.cnl_stem_conv7x7_maxpool_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), yf.data_ptr(), N, H, W, _stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(yf, y2), (shape, cl_)
+        ref = F.max_pool2d(F.relu(F.conv2d(x, w, b, stride=2, padding=3)), 3, 2, 1)
+        torch.testing.assert_close(yf.cpu().permute(0, 3, 1, 2), ref, rtol=RTOL, atol=ATOL)
+
+
 def test_stem_f16x2_error_not_above_fp32_mfma():
     """Error against float64 of the fp16-split stem <= 1.25 x that of the fp32 matrix-core stem (CNL_STEM_F16X2=0 in a private copy
     of the library), for [0,1) images, normalised images and tiny / huge inputs."""
