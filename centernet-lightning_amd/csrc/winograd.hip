@@ -528,7 +528,8 @@ static int wino_choice(const cnl_conv_params* p) {
     if (forced == 1 || forced == 2) return forced;
     if (p->Cin % 16) return 2;
     if (forced >= 3 && forced <= 7) return forced;
-    if (items_per_image >= 8 && (p->Cin >= min_cin5 || p->Cout >= min_cout5)) {
+    static const int min_items5 = getenv("CNL_W5_MINITEMS") ? atoi(getenv("CNL_W5_MINITEMS")) : 8;
+    if (items_per_image >= min_items5 && (p->Cin >= min_cin5 || p->Cout >= min_cout5)) {
         // winograd7.hip (two waves per SIMD) is NOT dispatched by default: -3 .. -4 % on the short channel loops of 512x512 inputs
         // (Cin = 64, 128; 4 work items per CU), but +7 % on the same layers of 608x1088 frames (12 items per CU) and +64 % on their
         // fused first head blocks (64 -> 768): CNL_W7_MAXCIN=128 reproduces the former
