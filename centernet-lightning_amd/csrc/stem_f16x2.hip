@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const float* __restr
 
     // ---- staging by LDS-DMA (see stem.hip) ----
 #ifndef S5_EXP
-#define S5_EXP 0
+#define S5_EXP 0        // timing builds (results wrong): 1 no patch DMA, 2 no weight DMA, 3 one K step, 4 no stores, 5 no patch scan
 #endif
     if (S5_EXP != 2)
     for (int q = wave; q < W_BYTES / 1024; q += 4) dma16(w_split, (unsigned)W_BYTES, wl + q * 1024, (unsigned)(q * 1024 + lane * 16));
@@ -149,8 +149,6 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const float* __restr
 #pragma unroll
     for (int s = 0; s < (S5_EXP == 3 ? 1 : STEPS); ++s) {
         // group of this lane half: g = 2s + hi; the all-zero group 21 (hi = 1 of the last step) reads group 20's slots and masks all
-        constexpr int dummy = 0;
-        (void)dummy;
         const int g0 = 2 * s, g1 = (2 * s + 1 < NG) ? 2 * s + 1 : 2 * s;
         const int ky0 = g0 / 3, q0 = g0 % 3, ky1 = g1 / 3, q1 = g1 % 3;
         const bool dead1 = 2 * s + 1 >= NG;
