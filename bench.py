@@ -329,9 +329,9 @@ def main():
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",
-            "dtype_note": "fp32 in / fp32 accumulate / fp32 out; the long-channel 3x3 layers form each fp32 product on the fp16 matrix cores from "
+            "dtype_note": "fp32 in / fp32 accumulate / fp32 out; the long-channel 3x3 layers, the stride-2 / heatmap direct convs and the stem form each fp32 product on the fp16 matrix cores from "
                           "a two-way fp16 split of both (power-of-two scaled) operands (3 cross terms, error <= the fp32 MFMA's: tools/bf16x3_probe.hip, "
-                          "tests/test_gpu_conv.py::test_winograd_split_kernels_error_not_above_fp32_mfma)",
+                          "tests/test_gpu_conv.py::test_winograd_split_kernels_error_not_above_fp32_mfma, test_conv_f16x2_error_not_above_fp32_mfma, test_stem_f16x2_error_not_above_fp32_mfma; fp32_mfma_only = the same job with no split operands anywhere)",
             "data": "synthetic (seeded rand images; random-init weights of the named architecture)",
             "config": {"workload": f"BASELINE C{'1' if args.config == 'simple' else ('4' if tracking else '2/3')}: ResNet34 + {args.config} neck, "
                                    f"{B} img/GPU x {H}x{W}, heads {'2+4+reid64' if tracking else '80+4'} (w256), k={args.k}, nms 3",
