@@ -93,7 +93,7 @@ def conv_kernel_profile(model, x, reps=3):
     plan = eng.plans[(n_sub, x.shape[2], x.shape[3], True)]
     lib = plan.lib
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    convs = [L for L in plan.launches if L.fn in (lib.cnl_conv2d_nhwc_f32, lib.cnl_conv3x3_winograd_f32)]
+    convs = [L for L in plan.launches if L.fn in (lib.cnl_conv2d_nhwc_f32, lib.cnl_conv3x3_winograd_f32, lib.cnl_conv3x3_up2_nhwc_f32)]
     acc = [0.0] * len(convs)
     for _ in range(reps):
         model(x)                                        # refresh inputs of every layer
@@ -110,6 +110,8 @@ def conv_kernel_profile(model, x, reps=3):
         for i, (e0, e1) in enumerate(evs):
             acc[i] += e0.elapsed_time(e1)
     def kind(L):
+        if L.fn is lib.cnl_conv3x3_up2_nhwc_f32:        # four sub-pixel phase convs on the direct kernels
+            return "direct_f16x2" if lib.cnl_conv3x3_up2_kernel(ctypes.byref(L.args)) == 5 else "direct"
         if L.fn is not lib.cnl_conv3x3_winograd_f32:
             return "direct_f16x2" if lib.cnl_conv2d_kernel(ctypes.byref(L.args)) == 5 else "direct"
         return {3: "winograd_bf16x3", 5: "winograd_f16x2"}.get(lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)), "winograd_f32")

@@ -53,6 +53,10 @@ _SIGNATURES = {
     "cnl_conv3x3_winograd_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
     "cnl_conv3x3_winograd_kernel": (ctypes.c_int, [POINTER(ConvParams)]),
     "cnl_conv2d_kernel": (ctypes.c_int, [POINTER(ConvParams)]),
+    "cnl_up2_weight_floats": (c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    "cnl_up2_pack_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int32, ctypes.c_int32, c_void_p]),
+    "cnl_conv3x3_up2_nhwc_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
+    "cnl_conv3x3_up2_kernel": (ctypes.c_int, [POINTER(ConvParams)]),
     "cnl_absmax_per_image_f32": (ctypes.c_int, [c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_void_p, c_void_p]),
     "cnl_winograd_weight_floats": (c_size_t, [c_int32, c_int32]),
     "cnl_winograd_transform_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),

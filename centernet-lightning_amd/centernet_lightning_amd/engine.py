@@ -64,6 +64,28 @@ class _Layer:
                            "cnl_winograd_transform_weights_f32")
 
 
+def _layer_wants_up2(self):
+    """cnl_conv3x3_up2_nhwc_f32 instead of Winograd for this layer when its input is nearest-2x upsampled: measured on 64 -> 512
+    @64^2 -> 128^2 (861 vs 1062 us); the small neck layers (256 -> 128 @16^2: 130 vs 50 us) stay on Winograd.  Shape only."""
+    return (os.environ.get("CNL_UP2", "1") != "0" and self.kh == 3 and self.kw == 3 and self.stride == 1 and self.cin % 32 == 0
+            and self.cin <= 64 and self.cout >= 256 and self.w.is_cuda)
+
+
+def _layer_up2(self):
+    if getattr(self, "_up2", None) is None:
+        lib = _lib.load()
+        with torch.cuda.device(self.w.device):
+            self._up2 = torch.empty((lib.cnl_up2_weight_floats(self.cin, self.cout),), device=self.w.device, dtype=torch.float32)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.w.device).cuda_stream)
+            _lib.check(lib.cnl_up2_pack_weights_f32(self.w.data_ptr(), self._up2.data_ptr(), self.cin, self.cout, stream), "cnl_up2_pack_weights_f32")
+            self.up2_wmax = self._up2.abs().max().reshape(1).contiguous()
+    return self._up2
+
+
+_Layer.wants_up2 = _layer_wants_up2
+_Layer.up2 = _layer_up2
+
+
 class _SepLayer:
     """make_conv(conv_type="separable") (layers.py:56-69) packed: depthwise weight [3][3][C] (tap-major) + bias with BN folded,
     and the pointwise half as a 1x1 _Layer."""
@@ -238,7 +260,7 @@ class Plan:
         whole story: the consumer's input buffer has exactly one writer in the plan, that writer runs an fp16-split kernel (the
         ones that report max |y|) and it writes every channel of the buffer.  A 3x3 direct conv without such a producer (the
         stride-2 conv after layer1) gets an explicit cnl_absmax_per_image_f32 pass: cheaper than what the split kernel saves."""
-        lib, wino, direct = self.lib, self.lib.cnl_conv3x3_winograd_f32, self.lib.cnl_conv2d_nhwc_f32
+        lib, wino, direct, up2 = self.lib, self.lib.cnl_conv3x3_winograd_f32, self.lib.cnl_conv2d_nhwc_f32, self.lib.cnl_conv3x3_up2_nhwc_f32
         self.absmax = None
         if os.environ.get("CNL_ABSMAX_HANDOVER", "1") == "0":      # debugging: every fp16-split Winograd launch makes its own pass,
             return                                                 # every direct conv stays on the fp32 matrix cores
@@ -252,10 +274,10 @@ class Plan:
                 unsafe.update(id(t) for t in L.keep if isinstance(t, torch.Tensor))
 
         def would_split(L):             # a direct conv that takes the fp16-split kernel once it has both hints
-            if L.fn is not direct or not L.args.w_absmax:
+            if (L.fn is not direct and L.fn is not up2) or not L.args.w_absmax:
                 return False
             saved, L.args.x_absmax = L.args.x_absmax, L.args.w_absmax      # any non-null pointer: the choice looks at presence only
-            k = lib.cnl_conv2d_kernel(ctypes.byref(L.args))
+            k = (lib.cnl_conv2d_kernel if L.fn is direct else lib.cnl_conv3x3_up2_kernel)(ctypes.byref(L.args))
             L.args.x_absmax = saved
             return k == 5
 
@@ -318,6 +340,13 @@ class Plan:
             p.w = layer.u.data_ptr()
             fn = self.lib.cnl_conv3x3_winograd_f32
             what += " [winograd]"
+        if (flags & CNL_UPSAMPLE_IN) and not (flags & ~(CNL_RELU | CNL_UPSAMPLE_IN)) and residual is None and layer.wants_up2():
+            # short channel loop, many couts, conv on the nearest-2x upsampled input (the fused first head blocks behind the simple
+            # neck): four 2x2 sub-pixel phase convs on the low-resolution input (fp16-split direct kernel) beat Winograd there
+            p.w = layer.up2().data_ptr()
+            p.w_absmax = layer.up2_wmax.data_ptr()
+            fn = self.lib.cnl_conv3x3_up2_nhwc_f32
+            what = what.replace(" [winograd]", "") + " [sub-pixel phases]"
         self.launches.append(_Launch(fn, p, what, flops, keep=(x, y, residual, layer)))
         return p, ho.value, wo.value
 

@@ -63,14 +63,17 @@ __device__ __forceinline__ float pow2_scale(float mx) {
     return S;
 }
 
-// KS: compile-time square kernel size (1 or 3).  No input upsampling, no 2x scatter epilogues (those stay on conv_mfma.hip).
-template <int WM, int WN, int TM, int TN, int KS>
+// KS: compile-time square kernel size (1, 2 or 3).  SUB: the launch is one sub-pixel phase of a conv on the nearest-2x upsampled input
+// (cnl_conv3x3_up2_nhwc_f32): row m = (n, oy, ox) is stored at pixel (2 oy + sub_dy, 2 ox + sub_dx) of the 2x output grid; pad (rows)
+// and pad_x (columns) differ between phases.  No CNL_UPSAMPLE_IN gather, no CNL_UPSAMPLE_OUT_ADD epilogue (those stay on conv_mfma.hip).
+template <int WM, int WN, int TM, int TN, int KS, bool SUB>
 __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     using C = Cfg<WM, WN, TM, TN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sInv = reinterpret_cast<float*>(smem + C::LDS_BYTES);      // [BM] 1 / (S_row S_w)
     float* sScl = sInv + C::BM;                                       // [BM] S_row
     int* sImg = reinterpret_cast<int*>(sScl + C::BM);                 // [BM] image of the row (-1 beyond M)
+    unsigned* sPix = reinterpret_cast<unsigned*>(sImg + C::BM);       // [BM] SUB: destination pixel of the row in the 2x output grid
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -153,6 +156,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
         sScl[r] = S;
         sInv[r] = 1.f / (S * Sw);
         sImg[r] = ok ? (int)n : -1;
+        if constexpr (SUB) {
+            const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
+            const unsigned oy = fast_div(rem, a.mg_w, a.sh_w);
+            const unsigned ox = rem - oy * (unsigned)a.Wo;
+            sPix[r] = (n * 2u * (unsigned)a.Ho + 2u * oy + (unsigned)a.sub_dy) * (2u * (unsigned)a.Wo) + 2u * ox + (unsigned)a.sub_dx;   // < 2^30: 4 GiB rule
+        }
     }
 
     f32x16 acc[TM][TN];
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
                 ok[r] = col_ok && mb + ro < a.M;
                 v[r] = acc[i][j][r] * sInv[rl + ro] + bv;
             }
-            if (a.res) {
+            if (!SUB && a.res) {
                 float rv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -268,9 +277,15 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
             }
+            if constexpr (SUB) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                buf_store(v[r], a.y, a.y_bytes, ok[r] ? y_voff : OOB, (unsigned)(((r & 3) + 8 * (r >> 2)) * a.ldy * 4));
+                for (int r = 0; r < 16; ++r)
+                    buf_store(v[r], a.y, a.y_bytes, ok[r] ? (sPix[rl + (r & 3) + 8 * (r >> 2)] * (unsigned)a.ldy + (unsigned)col) * 4u : OOB, 0u);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    buf_store(v[r], a.y, a.y_bytes, ok[r] ? y_voff : OOB, (unsigned)(((r & 3) + 8 * (r >> 2)) * a.ldy * 4));
+            }
             if (a.ymax) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -294,16 +309,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, int KS>
+template <int WM, int WN, int TM, int TN, int KS, bool SUB>
 static int launch_one5(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<WM, WN, TM, TN>;
     static bool attr_done = false;
     if (!attr_done) {
-        CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16x2_kernel<WM, WN, TM, TN, KS>),
+        CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16x2_kernel<WM, WN, TM, TN, KS, SUB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, TM, TN, KS>), dim3(a.tiles), dim3(C::THREADS), C::LDS_BYTES + C::BM * 12, stream, a);
+    hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, TM, TN, KS, SUB>), dim3(a.tiles), dim3(C::THREADS), C::LDS_BYTES + C::BM * 16, stream, a);
     return cnl::check_launch("conv_f16x2_kernel");
 }
 
@@ -314,7 +329,8 @@ static int launch_cfg5(const ConvArgs& in, hipStream_t stream) {
     const int tiles_m = (a.M + C::BM - 1) / C::BM;
     a.tiles_n = (a.Cout + C::BN - 1) / C::BN;
     a.tiles = tiles_m * a.tiles_n;
-    return a.KH == 3 ? launch_one5<WM, WN, TM, TN, 3>(a, stream) : launch_one5<WM, WN, TM, TN, 1>(a, stream);
+    if (a.flags & CNL_I_SUBPIXEL) return launch_one5<WM, WN, TM, TN, 2, true>(a, stream);
+    return a.KH == 3 ? launch_one5<WM, WN, TM, TN, 3, false>(a, stream) : launch_one5<WM, WN, TM, TN, 1, false>(a, stream);
 }
 
 // which launches the fp16-split kernel covers: the caller handed over both maxima, square 1x1 / 3x3 kernel, no input upsampling,
@@ -324,9 +340,9 @@ static int launch_cfg5(const ConvArgs& in, hipStream_t stream) {
 bool f16x2_eligible(const ConvArgs& a) {
     static const bool enabled = !(getenv("CNL_CONV_F16X2") && atoi(getenv("CNL_CONV_F16X2")) == 0);
     static const long long min_out_1x1 = getenv("CNL_CONV_F16X2_MIN1X1") ? atoll(getenv("CNL_CONV_F16X2_MIN1X1")) : (1ll << 20);
-    return enabled && a.xmax && a.wmax && a.KH == a.KW && (a.KH == 1 || a.KH == 3) && a.pad == a.pad_x &&
-           !(a.flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD | CNL_I_SUBPIXEL)) &&
-           (a.KH == 3 || (long long)a.Ho * a.Wo * a.Cout >= min_out_1x1);
+    if (!(enabled && a.xmax && a.wmax) || (a.flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD))) return false;
+    if (a.flags & CNL_I_SUBPIXEL) return a.KH == 2 && a.KW == 2 && !a.res;       // the phases of cnl_conv3x3_up2_nhwc_f32
+    return a.KH == a.KW && (a.KH == 1 || a.KH == 3) && a.pad == a.pad_x && (a.KH == 3 || (long long)a.Ho * a.Wo * a.Cout >= min_out_1x1);
 }
 
 int f16x2_launch(const ConvArgs& a, hipStream_t s) {

@@ -507,6 +507,97 @@ extern "C" int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream) {
 }
 
 /*
+ * 3x3 / stride 1 / pad 1 convolution on the NEAREST-2x UPSAMPLED input (make_upsample(nearest) + ConvBnAct: layers.py:99,72-77;
+ * the first head block behind the simple neck) as four sub-pixel phases on the LOW-resolution input: rows 2y and 2y+1 of the
+ * upsampled image are both row y, so for output row 2y+a the three kernel rows collapse onto two input rows —
+ *   a = 0: rows y-1, y with weights w[0], w[1]+w[2];   a = 1: rows y, y+1 with weights w[0]+w[1], w[2]   (columns alike) —
+ * i.e. four 2x2 convolutions with pre-summed weights: 16 instead of 36 multiplies per 2x2 output block (the same 2.25x as
+ * Winograd F(2x2,3x3)), each an ordinary implicit GEMM with K = 4 Cin writing one phase of the 2x output grid.
+ */
+namespace cnl_conv {
+__global__ __launch_bounds__(256) void up2_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout) {
+    const long total = 16l * Cin * Cout;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int ci = (int)(e % Cin);
+        long t = e / Cin;
+        const int kx2 = (int)(t & 1), ky2 = (int)((t >> 1) & 1);
+        t >>= 2;
+        const int co = (int)(t % Cout), ph = (int)(t / Cout);
+        const int a = ph >> 1, b = ph & 1;
+        // kernel rows / columns that land on tap ky2 / kx2 of phase a / b
+        const int ky_lo = a ? (ky2 ? 2 : 0) : (ky2 ? 1 : 0), ky_hi = a ? (ky2 ? 2 : 1) : (ky2 ? 2 : 0);
+        const int kx_lo = b ? (kx2 ? 2 : 0) : (kx2 ? 1 : 0), kx_hi = b ? (kx2 ? 2 : 1) : (kx2 ? 2 : 0);
+        float acc = 0.f;
+        for (int ky = ky_lo; ky <= ky_hi; ++ky)
+            for (int kx = kx_lo; kx <= kx_hi; ++kx) acc += w[((long)(co * 3 + ky) * 3 + kx) * Cin + ci];
+        wp[e] = acc;
+    }
+}
+}  // namespace cnl_conv
+
+extern "C" size_t cnl_up2_weight_floats(int32_t Cin, int32_t Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)16 * Cin * Cout;
+}
+
+extern "C" int cnl_up2_pack_weights_f32(const float* w_ohwi, float* w_packed, int32_t Cin, int32_t Cout, void* stream) {
+    CNL_REQUIRE(w_ohwi && w_packed && Cin > 0 && Cout > 0, CNL_E_BAD_ARG, "cnl_up2_pack_weights_f32: null pointer / non-positive size");
+    const long total = 16l * Cin * Cout;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(up2_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_ohwi, w_packed, Cin, Cout);
+    return cnl::check_launch("up2_pack_kernel");
+}
+
+static int up2_args(const cnl_conv_params* p, const char* who) {
+    CNL_REQUIRE(p, CNL_E_BAD_ARG, "%s: null params", who);
+    CNL_REQUIRE(p->x && p->w && p->bias && p->y, CNL_E_BAD_ARG, "%s: null tensor pointer", who);
+    CNL_REQUIRE(p->N > 0 && p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG, "%s: non-positive dimension", who);
+    CNL_REQUIRE(p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1, CNL_E_UNSUPPORTED, "%s: 3x3 / stride 1 / pad 1 only", who);
+    CNL_REQUIRE(p->Cin % 32 == 0, CNL_E_UNSUPPORTED, "%s: Cin=%d is not a multiple of 32", who, p->Cin);
+    CNL_REQUIRE(p->ldx >= p->Cin && p->ldy >= p->Cout && p->ldx % 4 == 0, CNL_E_BAD_ARG, "%s: pixel strides ldx=%d ldy=%d too small / misaligned",
+                who, p->ldx, p->ldy);
+    CNL_REQUIRE(((uintptr_t)p->x & 15) == 0 && ((uintptr_t)p->w & 15) == 0, CNL_E_BAD_ARG, "%s: x and w must be 16-byte aligned", who);
+    CNL_REQUIRE((p->flags & CNL_UPSAMPLE_IN) && !(p->flags & ~(uint32_t)(CNL_RELU | CNL_RELU6 | CNL_UPSAMPLE_IN)), CNL_E_UNSUPPORTED,
+                "%s: flags must be CNL_UPSAMPLE_IN (| CNL_RELU | CNL_RELU6)", who);
+    CNL_REQUIRE(!p->residual, CNL_E_UNSUPPORTED, "%s: residual not supported", who);
+    return CNL_OK;
+}
+
+static void up2_phase(const cnl_conv_params* p, int dy, int dx, ConvArgs& a) {
+    a.x = p->x; a.w = p->w + (size_t)(dy * 2 + dx) * p->Cout * 4 * p->Cin; a.bias = p->bias; a.res = nullptr; a.y = p->y;
+    a.N = p->N; a.Hin = p->H_in; a.Win = p->W_in; a.Cin = p->Cin; a.Cout = p->Cout;
+    a.KH = a.KW = 2; a.stride = 1; a.pad = dy ? 0 : 1; a.pad_x = dx ? 0 : 1;
+    a.sub_dy = dy; a.sub_dx = dx;
+    a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = 0;
+    a.flags = (p->flags & (CNL_RELU | CNL_RELU6)) | CNL_I_SUBPIXEL;
+    a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
+    a.HL = p->H_in; a.WL = p->W_in;
+    a.Ho = p->H_in; a.Wo = p->W_in;
+}
+
+extern "C" int cnl_conv3x3_up2_kernel(const cnl_conv_params* p) {
+    const int rc = up2_args(p, "cnl_conv3x3_up2_kernel");
+    if (rc != CNL_OK) return rc;
+    ConvArgs a;
+    up2_phase(p, 0, 0, a);
+    return f16x2_eligible(a) ? CNL_CONV_F16X2 : CNL_CONV_F32;
+}
+
+extern "C" int cnl_conv3x3_up2_nhwc_f32(const cnl_conv_params* p, void* stream) {
+    const int rc0 = up2_args(p, "cnl_conv3x3_up2_nhwc_f32");
+    if (rc0 != CNL_OK) return rc0;
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            ConvArgs a;
+            up2_phase(p, dy, dx, a);
+            const int rc = finish_and_launch(a, true, "cnl_conv3x3_up2_nhwc_f32", (hipStream_t)stream);
+            if (rc != CNL_OK) return rc;
+        }
+    return CNL_OK;
+}
+
+/*
  * Stride-2 transposed convolution as four sub-pixel phases, each an ordinary correlation over the input written to one of the
  * four positions of the 2x output grid (no zero-stuffing, no col2im): out[2y+dy, 2x+dx] = sum over the taps ky == (dy+p) mod 2,
  * kx == (dx+p) mod 2 of in[y + (dy+p-ky)/2, x + (dx+p-kx)/2] . w[ky][kx].

@@ -94,6 +94,21 @@ int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream);
 #define CNL_CONV_F16X2 5   /* fp16 matrix cores, scaled two-way split (csrc/conv_f16x2.hip); writes y_absmax when given   */
 int cnl_conv2d_kernel(const cnl_conv_params* p);
 
+/*
+ * 3x3 / stride 1 / pad 1 conv on the nearest-2x upsampled input (nn.Upsample(scale_factor=2) + ConvBnAct: models/layers.py:99,72-77;
+ * the first head block behind the simple neck, models/meta.py:24-26) computed as four 2x2 sub-pixel phase convolutions on the
+ * LOW-resolution input (16 instead of 36 multiplies per 2x2 output block; see csrc/conv_mfma.hip).  Same cnl_conv_params as
+ * cnl_conv2d_nhwc_f32 with flags = CNL_UPSAMPLE_IN (| CNL_RELU | CNL_RELU6), KH = KW = 3, stride 1, pad 1, no residual; H_in / W_in
+ * are the LOW-resolution size, y is [N, 2 H_in, 2 W_in, Cout].  p->w: the phase weights [4][Cout][2][2][Cin] made once by
+ * cnl_up2_pack_weights_f32 from the OHWI [Cout][3][3][Cin] weights (cnl_up2_weight_floats = 16 Cin Cout floats); w_absmax, if
+ * given, is max |.| of the PACKED weights.  With x_absmax and w_absmax the phases run on the fp16-split kernel
+ * (cnl_conv3x3_up2_kernel reports CNL_CONV_F16X2) and y_absmax is honoured; otherwise on the fp32 matrix cores.
+ */
+size_t cnl_up2_weight_floats(int32_t Cin, int32_t Cout);
+int cnl_up2_pack_weights_f32(const float* w_ohwi, float* w_packed, int32_t Cin, int32_t Cout, void* stream);
+int cnl_conv3x3_up2_nhwc_f32(const cnl_conv_params* p, void* stream);
+int cnl_conv3x3_up2_kernel(const cnl_conv_params* p);
+
 /* out[n] = max |x[n, :, 0:C]| over the `pixels` pixels of image n (pixel stride ld floats; C % 4 == 0, ld % 4 == 0, x 16-byte
  * aligned): the x_absmax hint for callers whose producer does not report it.  Zeroes out[] first (stream-ordered).            */
 int cnl_absmax_per_image_f32(const float* x, int32_t N, int64_t pixels, int32_t C, int32_t ld, float* out, void* stream);

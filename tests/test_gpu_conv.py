@@ -226,6 +226,51 @@ def test_conv_f16x2_error_not_above_fp32_mfma():
         assert e16 < 2e-5 * scale, (case, e16, scale)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 12, 20, 96, CNL_RELU), (1, 32, 7, 5, 160, 0), (3, 128, 9, 12, 64, CNL_RELU), (2, 64, 64, 64, 128, CNL_RELU)],
+                         ids=lambda c: "N{}c{}_{}x{}_o{}f{}".format(*[int(v) for v in c]))
+@pytest.mark.parametrize("hints", [False, True])
+def test_conv3x3_on_upsampled_input_as_subpixel_phases(case, hints):
+    """cnl_conv3x3_up2_nhwc_f32: the 3x3 conv on the nearest-2x upsampled input as four 2x2 phase convs on the low-resolution input
+    with pre-summed weights (fp32 matrix cores without hints, fp16-split kernel with them) against conv2d(interpolate(x))."""
+    N, Cin, H, W, Cout, flags = case
+    lib = _lib.load()
+    x, w, b = mk(N, Cin, H, W, Cout, 3, seed=Cin + Cout + H)
+    x[N - 1] *= 29.0
+    ref = ref_conv(x, w, b, 1, flags | CNL_UPSAMPLE_IN)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = torch.full((lib.cnl_up2_weight_floats(Cin, Cout),), float("nan"), device="cuda")
+    _lib.check(lib.cnl_up2_pack_weights_f32(wd.data_ptr(), wp.data_ptr(), Cin, Cout, _stream()))
+    bd = b.cuda()
+    y = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), device="cuda")
+    p = ConvParams()
+    p.x, p.w, p.bias, p.y = xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr()
+    p.N, p.H_in, p.W_in, p.Cin, p.Cout = N, H, W, Cin, Cout
+    p.KH, p.KW, p.stride, p.pad = 3, 3, 1, 1
+    p.ldx, p.ldy, p.flags = Cin, Cout, flags | CNL_UPSAMPLE_IN
+    if hints:
+        xm = x.abs().amax(dim=(1, 2, 3)).cuda()
+        wm = wp.abs().max().reshape(1)
+        ym = torch.zeros(N, device="cuda")
+        p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), wm.data_ptr(), ym.data_ptr()
+    import os
+    split = hints and os.environ.get("CNL_CONV_F16X2", "1") != "0"
+    assert lib.cnl_conv3x3_up2_kernel(ctypes.byref(p)) == (5 if split else 2)
+    _lib.check(lib.cnl_conv3x3_up2_nhwc_f32(ctypes.byref(p), _stream()), "up2")
+    torch.cuda.synchronize()
+    out = y.cpu().permute(0, 3, 1, 2)
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out, ref, rtol=RTOL, atol=ATOL * max(1.0, ref.abs().max().item() / 10))
+    if split:
+        assert torch.equal(ym.cpu(), out.abs().amax(dim=(1, 2, 3)))
+        for n in range(N):                                   # batch invariance: image n alone gives the same bits
+            p.N, p.x, p.y = 1, xd[n].data_ptr(), y.data_ptr()
+            p.x_absmax, p.y_absmax = xm[n:].data_ptr(), ym.data_ptr()
+            _lib.check(lib.cnl_conv3x3_up2_nhwc_f32(ctypes.byref(p), _stream()), "up2")
+            torch.cuda.synchronize()
+            assert torch.equal(y[0].cpu().permute(2, 0, 1), out[n]), n
+
+
 def test_conv_reads_channel_slice_of_wider_buffer():
     """heads read their 256-channel slice out of the fused 512-channel first-block buffer (ldx > Cin, x offset)."""
     x, w, b = mk(1, 64, 8, 8, 64, 3, seed=3)

@@ -27,6 +27,8 @@ SHAPES = {
     "c4l3": (16, 38, 68, 256, 256, 3, 1, CNL_RELU, False),
     "c4l2": (16, 76, 136, 128, 128, 3, 1, CNL_RELU, False),
     "c4head": (16, 152, 272, 256, 256, 3, 1, CNL_RELU, False),
+    "neckup1": (32, 16, 16, 256, 128, 3, 1, CNL_RELU | CNL_UPSAMPLE_IN, False),
+    "neckup2": (32, 32, 32, 128, 64, 3, 1, CNL_RELU | CNL_UPSAMPLE_IN, False),
     "l2s2": (32, 128, 128, 64, 128, 3, 2, CNL_RELU, False),
     "l3s2": (32, 64, 64, 128, 256, 3, 2, CNL_RELU, False),
     "l4s2": (32, 32, 32, 256, 512, 3, 2, CNL_RELU, False),
@@ -42,6 +44,7 @@ def main():
     ap.add_argument("names", nargs="*", default=["head256"])
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--winograd", action="store_true")
+    ap.add_argument("--up2", action="store_true", help="3x3 convs with CNL_UPSAMPLE_IN through cnl_conv3x3_up2_nhwc_f32 (sub-pixel phases)")
     ap.add_argument("--hints", action="store_true", help="hand over x_absmax / w_absmax (fp16-split direct kernel where it applies)")
     args = ap.parse_args()
     lib = _lib.load()
@@ -76,6 +79,15 @@ def main():
             p.w = u.data_ptr()
             p.flags = flags & 5            # RELU | UPSAMPLE_IN
             fn = lib.cnl_conv3x3_winograd_f32
+        if args.up2:
+            if not (flags & CNL_UPSAMPLE_IN) or k != 3:
+                continue
+            wp = torch.empty(lib.cnl_up2_weight_floats(Cin, Cout), device="cuda")
+            _lib.check(lib.cnl_up2_pack_weights_f32(w.data_ptr(), wp.data_ptr(), Cin, Cout, stream))
+            p.w = wp.data_ptr()
+            p.flags = flags & 5
+            fn = lib.cnl_conv3x3_up2_nhwc_f32
+            w = wp
         if args.hints and not args.winograd:
             xm = x.abs().amax(dim=(1, 2, 3)).contiguous()
             wm = w.abs().max().reshape(1).contiguous()
