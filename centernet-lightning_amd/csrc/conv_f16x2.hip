@@ -12,7 +12,7 @@
 // Structure: conv_mfma.hip's — raw fp32 A (patch rows) and B (OHWI weight rows) chunks of 32 channels staged by LDS-DMA into two
 // stages, one barrier per chunk, 4 waves x (TM x TN) accumulator tiles of 32x32, two workgroups per CU.  A wave reads its fp32
 // fragments (two ds_read_b128 per tile and 16-channel group: the K permutation of conv_mfma.hip makes a lane's 8 floats one MFMA
-// operand), splits them in registers (2.5 VALU operations per element: v_fma_mixlo/mixhi_f16, v_fma_mix_f32, v_cvt_pkrtz) and issues
+// operand), splits them in registers (3 VALU operations per element, compiler-scheduled: v_fma_mixlo/mixhi_f16, v_fma_mix_f32, v_cvt_pkrtz) and issues
 // 3 MFMAs of 32 cycles where the fp32 kernel issues 8 of 64: 5.3x less matrix time; the split runs beside the co-resident
 // workgroup's MFMAs.  What bounds it then is the L2 -> LDS stream of the tiles (32 flop per staged byte at 128 x 128).
 #include "conv_args.h"

@@ -10,7 +10,7 @@
 // LDS-DMA from whatever strides the caller has), but K is laid out in groups of 8 for v_mfma_f32_32x32x16_f16: group g = 3 ky + q
 // holds t = 8q .. 8q+7 of kernel row ky (t = kx*3 + c; t >= 21 are pads: zero weights, and the A operand is masked there because
 // the patch slot holds a neighbouring pixel and 0 x inf would not be 0); 21 groups + one all-zero = 11 steps of 16 instead of 77 of
-// 2.  A lane's operand is 8 consecutive patch floats (four ds_read_b64) split in registers (2.5 VALU per element); the split weights
+// 2.  A lane's operand is 8 consecutive patch floats (four ds_read_b64) split in registers (3 VALU per element); the split weights
 // sit in LDS as [piece][group][cout][8] so a lane's operand is one ds_read_b128.  Per step and wave: 4 rows x 2 cout groups x 3
 // MFMAs of 32 cycles against 88 x 64 in stem.hip — the kernel becomes bound by its 537 MB of output.
 #include "cnl_common.h"
