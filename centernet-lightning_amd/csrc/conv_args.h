@@ -29,6 +29,7 @@ struct ConvArgs {
     const float* xmax;                   // fp16-split kernel (conv_f16x2.hip): per-image max |x| (N floats), max |w| (1 float),
     const float* wmax;
     unsigned* ymax;                      // and where max |y| per image is folded into (or null)
+    const float* wscale;                 // sub-pixel phases (SUB): the power-of-two scale of the PRE-SPLIT weights a.w points to
 };
 
 constexpr unsigned CNL_I_SUBPIXEL = 1u << 16;   // internal: y[n, 2oy+sub_dy, 2ox+sub_dx, :] = act(conv + bias) (+ residual there)

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     C5_ISSUE(0, 0, 0);                       // first chunk in flight before anything else
 
     // ---- scales: one per row of the tile (its image's), one for the weights ----
-    const float Sw = pow2_scale(*a.wmax);
+    const float Sw = SUB ? *a.wscale : pow2_scale(*a.wmax);       // SUB: the weights were split when they were packed
     for (int r = threadIdx.x; r < C::BM; r += C::THREADS) {
         const int m = m0 + r;
         const unsigned n = fast_div((unsigned)m, a.mg_hw, a.sh_hw);
@@ -182,14 +182,23 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     do {                                                                                                          \
         _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                        \
             const int sb_ = (((2 * (2 * (g_) + q_) + hi) ^ swz) << 4);                                            \
+            /* SUB: B rows hold fp16 pieces, slot (2 (2 g + hi) + piece) = this lane's 8 halves of piece q_ */   \
+            const int sbb_ = SUB ? (((2 * (2 * (g_) + hi) + q_) ^ swz) << 4) : sb_;                               \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) ra[q_][i] = lds_read16((stage_ptr_) + a_row_byte + i * 32 * 128 + sb_); \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) rb[q_][j] = lds_read16((stage_ptr_) + b_row_byte + j * 32 * 128 + sb_); \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) rb[q_][j] = lds_read16((stage_ptr_) + b_row_byte + j * 32 * 128 + sbb_); \
         }                                                                                                         \
     } while (0)
 #define C5_SPLIT()                                                                                                \
     do {                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) split8(ra[0][i], ra[1][i], sA[i], ah[i], al[i]);           \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) split8(rb[0][j], rb[1][j], Sw, bh[j], bl[j]);              \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                          \
+            if constexpr (SUB) {                                                                                  \
+                bh[j] = __builtin_bit_cast(u32x4, rb[0][j]);                                                      \
+                bl[j] = __builtin_bit_cast(u32x4, rb[1][j]);                                                      \
+            } else {                                                                                              \
+                split8(rb[0][j], rb[1][j], Sw, bh[j], bl[j]);                                                     \
+            }                                                                                                     \
+        }                                                                                                         \
     } while (0)
 #define C5_MFMA()                                                                                                 \
     do {                                                                                                          \
@@ -340,9 +349,9 @@ static int launch_cfg5(const ConvArgs& in, hipStream_t stream) {
 bool f16x2_eligible(const ConvArgs& a) {
     static const bool enabled = !(getenv("CNL_CONV_F16X2") && atoi(getenv("CNL_CONV_F16X2")) == 0);
     static const long long min_out_1x1 = getenv("CNL_CONV_F16X2_MIN1X1") ? atoll(getenv("CNL_CONV_F16X2_MIN1X1")) : (1ll << 20);
-    if (!(enabled && a.xmax && a.wmax) || (a.flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD))) return false;
-    if (a.flags & CNL_I_SUBPIXEL) return a.KH == 2 && a.KW == 2 && !a.res;       // the phases of cnl_conv3x3_up2_nhwc_f32
-    return a.KH == a.KW && (a.KH == 1 || a.KH == 3) && a.pad == a.pad_x && (a.KH == 3 || (long long)a.Ho * a.Wo * a.Cout >= min_out_1x1);
+    if (!(enabled && a.xmax) || (a.flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD))) return false;
+    if (a.flags & CNL_I_SUBPIXEL) return a.KH == 2 && a.KW == 2 && !a.res && a.wscale;       // the phases of cnl_conv3x3_up2_nhwc_f32
+    return a.wmax && a.KH == a.KW && (a.KH == 1 || a.KH == 3) && a.pad == a.pad_x && (a.KH == 3 || (long long)a.Ho * a.Wo * a.Cout >= min_out_1x1);
 }
 
 int f16x2_launch(const ConvArgs& a, hipStream_t s) {

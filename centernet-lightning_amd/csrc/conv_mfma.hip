@@ -464,7 +464,7 @@ extern "C" int cnl_conv2d_kernel(const cnl_conv_params* p) {
     CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv2d_kernel: null params");
     ConvArgs a;
     a.KH = p->KH; a.KW = p->KW; a.pad = a.pad_x = p->pad; a.flags = p->flags; a.Cout = p->Cout;
-    a.xmax = p->x_absmax; a.wmax = p->w_absmax;
+    a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.wscale = nullptr; a.res = p->residual;
     int32_t ho = 0, wo = 0;
     const int rc = cnl_conv2d_out_hw(p, &ho, &wo);
     if (rc != CNL_OK) return rc;
@@ -498,7 +498,7 @@ extern "C" int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream) {
     a.sub_dy = a.sub_dx = 0;
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
     a.flags = p->flags;
-    a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
+    a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax); a.wscale = nullptr;
     const int up = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
     a.HL = p->H_in * up; a.WL = p->W_in * up;
     a.Ho = (a.HL + 2 * p->pad - p->KH) / p->stride + 1;
@@ -533,11 +533,53 @@ __global__ __launch_bounds__(256) void up2_pack_kernel(const float* __restrict__
         wp[e] = acc;
     }
 }
+// the packed phase weights once more as scaled fp16 pieces in the B-row layout of conv_f16x2.hip's sub-pixel variant: per cout row
+// and 32-k chunk 8 slots of 16 bytes, slot (2 (2 g + h) + piece) = the 8 halves lane half h multiplies in 16-k group g
+// (k = 16 g + 4 h + e for e < 4, 16 g + 8 + 4 h + e - 4 for e >= 4: the K permutation of the A fragments).  One workgroup: max |w| ->
+// S_w = 2^(14 - e) -> hi = RN16(w S_w), lo = RZ16(w S_w - hi).  scal[0] = S_w.
+__global__ __launch_bounds__(1024) void up2_split_kernel(const float* __restrict__ wp, unsigned short* __restrict__ ws, float* __restrict__ scal, long total) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    float mx = 0.f;
+    for (long e = tid; e < total; e += 1024) {
+        const float v = fabsf(wp[e]);
+        mx = (v < __builtin_inff()) ? fmaxf(mx, v) : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = 0.f;
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, red[i]);
+    float Sw = 1.f;
+    if (mx > 0.f) {
+        int ex;
+        (void)__builtin_frexpf(mx, &ex);
+        ex = 14 - ex;
+        Sw = __builtin_ldexpf(1.f, ex < -60 ? -60 : (ex > 60 ? 60 : ex));
+    }
+    if (tid == 0) scal[0] = Sw;
+    for (long e = tid; e < total; e += 1024) {          // e = (row-chunk index) * 32 + kk over the fp32 layout [..][K] (K % 32 == 0)
+        const int kk = (int)(e & 31);
+        const long rc = e >> 5;
+        const int g = kk >> 4, r16 = kk & 15;
+        const int h = (r16 >> 2) & 1, el = (r16 & 3) + ((r16 >> 3) << 2);      // inverse of k = 16 g + 4 h + e (e < 4) / 16 g + 8 + 4 h + e - 4
+        const float v = wp[e] * Sw;
+        const _Float16 hv = (_Float16)v;
+        const float r = v - (float)hv;
+        unsigned lo2;
+        asm("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(lo2) : "v"(r), "v"(0.f));
+        const long base = rc * 64 + (2 * (2 * g + h)) * 8 + el;               // in halves: 64 per row-chunk, 8 per slot
+        ws[base] = __builtin_bit_cast(unsigned short, hv);
+        ws[base + 8] = (unsigned short)(lo2 & 0xFFFFu);
+    }
+}
 }  // namespace cnl_conv
 
+// [fp32 phase weights 16 Cin Cout][their fp16 split, same size][4 scalars]
 extern "C" size_t cnl_up2_weight_floats(int32_t Cin, int32_t Cout) {
     if (Cin <= 0 || Cout <= 0) return 0;
-    return (size_t)16 * Cin * Cout;
+    return (size_t)32 * Cin * Cout + 4;
 }
 
 extern "C" int cnl_up2_pack_weights_f32(const float* w_ohwi, float* w_packed, int32_t Cin, int32_t Cout, void* stream) {
@@ -545,8 +587,11 @@ extern "C" int cnl_up2_pack_weights_f32(const float* w_ohwi, float* w_packed, in
     const long total = 16l * Cin * Cout;
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    CNL_REQUIRE(Cin % 32 == 0, CNL_E_UNSUPPORTED, "cnl_up2_pack_weights_f32: Cin=%d is not a multiple of 32", Cin);
     hipLaunchKernelGGL(up2_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_ohwi, w_packed, Cin, Cout);
-    return cnl::check_launch("up2_pack_kernel");
+    hipLaunchKernelGGL(up2_split_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_packed, reinterpret_cast<unsigned short*>(w_packed + total),
+                       w_packed + 2 * total, total);
+    return cnl::check_launch("up2_pack_kernel / up2_split_kernel");
 }
 
 static int up2_args(const cnl_conv_params* p, const char* who) {
@@ -565,7 +610,9 @@ static int up2_args(const cnl_conv_params* p, const char* who) {
 }
 
 static void up2_phase(const cnl_conv_params* p, int dy, int dx, ConvArgs& a) {
+    const size_t total = (size_t)16 * p->Cin * p->Cout;          // floats of the fp32 phase weights; the fp16 split follows, then S_w
     a.x = p->x; a.w = p->w + (size_t)(dy * 2 + dx) * p->Cout * 4 * p->Cin; a.bias = p->bias; a.res = nullptr; a.y = p->y;
+    a.wscale = p->w + 2 * total;
     a.N = p->N; a.Hin = p->H_in; a.Win = p->W_in; a.Cin = p->Cin; a.Cout = p->Cout;
     a.KH = a.KW = 2; a.stride = 1; a.pad = dy ? 0 : 1; a.pad_x = dx ? 0 : 1;
     a.sub_dy = dy; a.sub_dx = dx;
@@ -574,6 +621,7 @@ static void up2_phase(const cnl_conv_params* p, int dy, int dx, ConvArgs& a) {
     a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
     a.HL = p->H_in; a.WL = p->W_in;
     a.Ho = p->H_in; a.Wo = p->W_in;
+    if (f16x2_eligible(a)) a.w += total;                          // the fp16-split kernel multiplies the pre-split copy
 }
 
 extern "C" int cnl_conv3x3_up2_kernel(const cnl_conv_params* p) {
@@ -644,7 +692,7 @@ extern "C" int cnl_deconv2x_nhwc_f32(const cnl_deconv_params* p, void* stream) {
             a.sub_dy = dy; a.sub_dx = dx;
             a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
             a.flags = p->flags | CNL_I_SUBPIXEL;
-            a.xmax = a.wmax = nullptr; a.ymax = nullptr;
+            a.xmax = a.wmax = a.wscale = nullptr; a.ymax = nullptr;
             a.HL = p->H_in; a.WL = p->W_in;
             a.Ho = p->H_in; a.Wo = p->W_in;
             const int rc = finish_and_launch(a, true, "cnl_deconv2x_nhwc_f32", (hipStream_t)stream);

@@ -99,10 +99,11 @@ int cnl_conv2d_kernel(const cnl_conv_params* p);
  * the first head block behind the simple neck, models/meta.py:24-26) computed as four 2x2 sub-pixel phase convolutions on the
  * LOW-resolution input (16 instead of 36 multiplies per 2x2 output block; see csrc/conv_mfma.hip).  Same cnl_conv_params as
  * cnl_conv2d_nhwc_f32 with flags = CNL_UPSAMPLE_IN (| CNL_RELU | CNL_RELU6), KH = KW = 3, stride 1, pad 1, no residual; H_in / W_in
- * are the LOW-resolution size, y is [N, 2 H_in, 2 W_in, Cout].  p->w: the phase weights [4][Cout][2][2][Cin] made once by
- * cnl_up2_pack_weights_f32 from the OHWI [Cout][3][3][Cin] weights (cnl_up2_weight_floats = 16 Cin Cout floats); w_absmax, if
- * given, is max |.| of the PACKED weights.  With x_absmax and w_absmax the phases run on the fp16-split kernel
- * (cnl_conv3x3_up2_kernel reports CNL_CONV_F16X2) and y_absmax is honoured; otherwise on the fp32 matrix cores.
+ * are the LOW-resolution size, y is [N, 2 H_in, 2 W_in, Cout].  p->w: the buffer cnl_up2_pack_weights_f32 fills from the OHWI
+ * [Cout][3][3][Cin] weights (Cin % 32 == 0; cnl_up2_weight_floats sizes it): the phase weights [4][Cout][2][2][Cin] in fp32, the
+ * same as scaled two-way fp16 split in the kernel's LDS row layout, and the scale.  With x_absmax the phases run on the fp16-split
+ * kernel with the pre-split weights (cnl_conv3x3_up2_kernel reports CNL_CONV_F16X2; w_absmax is not needed) and y_absmax is
+ * honoured; otherwise on the fp32 matrix cores.
  */
 size_t cnl_up2_weight_floats(int32_t Cin, int32_t Cout);
 int cnl_up2_pack_weights_f32(const float* w_ohwi, float* w_packed, int32_t Cin, int32_t Cout, void* stream);
