@@ -39,13 +39,13 @@ import centernet_lightning_amd as cl  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16), 16x the fp32 MFMA rate
 F16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense fp16 = bf16 rate
-# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_final8.txt: 29 winograd5 launches): per kernel, mean
+# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_final9.txt: 29 winograd5 launches): per kernel, mean
 # FETCH_SIZE x 2 (gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md §HBM) + mean WRITE_SIZE over the launches
 # of a C1 step (fp16-split Winograd: 186.2 MB x 2 + 146.6 MB = 518.9 MB).  Other configs: not profiled -> null.
 MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("simple", 32, 512, 512, "cnl_conv::conv_mfma_kernel"): 237.0e6,
                                      ("simple", 32, 512, 512, "cnl_wino2::winograd2_kernel"): 328.9e6,
                                      ("simple", 32, 512, 512, "cnl_wino3::winograd3_kernel"): 731.5e6,
-                                     ("simple", 32, 512, 512, "cnl_wino5::winograd5_kernel"): 484.2e6}
+                                     ("simple", 32, 512, 512, "cnl_wino5::winograd5_kernel"): 484.3e6}
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 
 
@@ -309,7 +309,7 @@ def main():
                     "kernel_ms_per_step": round(ms_d, 3), "algorithmic_gflop_per_step": round(fl_d / 1e9, 2),
                     "avg_launch_us": round(ms_d * 1e3 / max(n_d, 1), 2)}
         roof["traffic"] = MEASURED_TRAFFIC_BYTES_PER_LAUNCH.get((args.config, B, H, W, roof["kernel"].split(" ")[0]))
-        roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic_final8.txt: 29 winograd5 launches)"
+        roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic_final9.txt: 29 winograd5 launches)"
         dom = "winograd_f16x2" if "wino5" in roof["kernel"] else "winograd_bf16x3" if "wino3" in roof["kernel"] else ("winograd_f32" if "wino2" in roof["kernel"] else "direct")
         roof["algorithmic_bytes_per_launch"] = round(conv_bytes.get(dom, 0) / max(roof["launches_per_step"], 1))
         roof["other_kernels"] = {"cnl_wino2::winograd2_kernel (fp32 MFMA)": {"launches_per_step": n_w, "kernel_ms_per_step": round(ms_w, 3),
