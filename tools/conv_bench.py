@@ -19,6 +19,8 @@ SHAPES = {
     "layer1": (32, 128, 128, 64, 64, 3, 1, CNL_RELU, False),
     "layer1res": (32, 128, 128, 64, 64, 3, 1, CNL_RELU, True),
     "layer2": (32, 64, 64, 128, 128, 3, 1, CNL_RELU, True),
+    "layer2n64": (64, 64, 64, 128, 128, 3, 1, CNL_RELU, True),
+    "layer2n8": (8, 64, 64, 128, 128, 3, 1, CNL_RELU, True),
     "layer3": (32, 32, 32, 256, 256, 3, 1, CNL_RELU, True),
     "layer4": (32, 16, 16, 512, 512, 3, 1, CNL_RELU, True),
     "big256px": (8, 256, 256, 64, 64, 3, 1, CNL_RELU, False),
