@@ -27,6 +27,7 @@ SHAPES = {
     "neck0": (32, 16, 16, 512, 256, 3, 1, CNL_RELU, False),
     "c4l4": (16, 19, 34, 512, 512, 3, 1, CNL_RELU, False),
     "c4l3": (16, 38, 68, 256, 256, 3, 1, CNL_RELU, False),
+    "c4l1": (16, 152, 272, 64, 64, 3, 1, CNL_RELU, True),
     "c4l2": (16, 76, 136, 128, 128, 3, 1, CNL_RELU, False),
     "c4head": (16, 152, 272, 256, 256, 3, 1, CNL_RELU, False),
     "neckup1": (32, 16, 16, 256, 128, 3, 1, CNL_RELU | CNL_UPSAMPLE_IN, False),
