@@ -6,21 +6,33 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
 
   step      = one pass of the hot path over one synthetic batch per GPU:
               CenterNet.forward (ResNet-34 -> neck -> heads, sigmoid) + gather_detection2d (k=100, nms 3)
-              [+ all-gather of the packed detections when N > 1].  Inputs are resident in HBM.
+              [+ the all-gather of the packed detections when N > 1: started on a side stream after the decode and collected one
+              step later (collate.Collator), i.e. overlapped with the next batch's forward; the last one is drained inside the
+              timed region].  Inputs are resident in HBM.
   workload  = BASELINE.json configs[1] (C1): ResNet34 + simple upsample neck, batch 32 per GPU, 512x512, 80 classes
-              (`--config fpn --batch 64` = C2/C3, `--config tracking --batch 32 --height 608 --width 1088` = C4).
+              (`--config fpn --batch 64` = C2/C3, `--config tracking --batch 32 --height 608 --width 1088` = C4).  At N = 1 the
+              default run appends short C2 and C4 lines under `also` (5 steps each).
   value     = total images / max-over-ranks wall time of the K timed steps (weak scaling: batch per GPU fixed).
-  roofline  = the dominant kernel by time, measured with HIP events on the launch stream around every launch of one step.  The
-              3x3/s1 layers run Winograd F(2x2,3x3) on one of two multiplier arrays, chosen per layer SHAPE (include/centernet_gfx950.h):
-              `cnl_wino5::winograd5_kernel` (Cin >= 128 or Cout >= 512: fp32 operands scaled by a per-tensor power of two and split
-              into two fp16 pieces, three fp16 MFMAs per product, fp32 accumulation — fp32-grade accuracy on the 16x faster fp16
-              matrix core; peak = 2.5 PFLOP/s dense fp16) or `cnl_wino2::winograd2_kernel` (fp32 MFMA, peak 157.3).  `achieved` counts the matrix-core flops the kernel EXECUTES
-              (direct-conv flops x 16/36, x 3 for the split), so `frac` is an honest hardware fraction; `effective_tflops` is the same
-              time against the direct-conv (algorithmic) flops.  The other conv kernels are reported under `other_kernels`.
-  dtype     = "f32": inputs, weights, accumulation and outputs are fp32 and every product is formed to fp32 accuracy (the dropped
-              split terms are <= 2^-24 relative); `cpu_baseline.sample` carries the max |GPU - CPU oracle| of this very run.
-  cpu_baseline = the CPU oracle (oracle/ref_cpu.py + oracle/decode_ref.py: the plain PyTorch restatement of the
-              reference path — kind "port") timed on this box's host cores on a bounded sample; rank 0, N=1 only.
+  roofline  = the dominant kernel by time, measured with HIP events on the launch stream around every conv launch of one step.
+              The long 3x3 layers form every fp32 product on the fp16 matrix cores (scaled two-way fp16 split, three MFMAs per
+              product, fp32 accumulation), as Winograd F(4x4,3x3) (`cnl_wino8::winograd8_kernel`) where its 32x16-pixel work items
+              tile the map, else F(2x2,3x3) (`cnl_wino5/6`); peak = 2.5 PFLOP/s dense fp16.  `achieved` counts the matrix-core flops
+              the kernel EXECUTES (direct-conv flops x 36/144 [F(4x4)] or 16/36 [F(2x2)], x 3 for the split), so `frac` is an honest
+              hardware fraction — Winograd trades executed flops for transform work, which is why `effective_tflops` (the same time
+              against the direct-conv, i.e. algorithmic, flops) is reported beside it.  `traffic` is NOT measured in this run: it is
+              the rocprofv3 PMC figure of the named profiles/ file (null where no profile of that configuration exists).
+  variants  = the same job in the other arithmetic classes of the plan (KernelOptions.algo; in-process, short runs):
+              f2 = no F(4x4) (every kernel's error at or below the fp32 matrix core's), f32 = fp32 matrix cores only.
+  accuracy  = max |feature - float64 oracle| / max |float64 oracle| at the neck output and at each head's last 256-channel block
+              output (what out_conv reads), for auto / f2 / f32 and for the CPU fp32 oracle itself, on 2 images of the bench shape.
+              (The post-sigmoid heatmap hides feature error by ~3 orders of magnitude; it is reported too.)  Backbone / ConvBnAct
+              parity is "unpinned" by the reference itself (torchvision / vision_toolbox absent): the oracle is this repo's restatement.
+  decode    = decode p50 on the forward's own outputs: bytes that must move, GB/s, fraction of 8 TB/s; with a separate sigmoid pass
+              in front (what a caller holding logits pays) and without (the path: sigmoid is the heatmap conv's epilogue).
+  cpu_baseline = the CPU oracle (oracle/ref_cpu.py + oracle/decode_ref.py: the plain PyTorch restatement of the reference path —
+              kind "port") timed on this box's host cores: C0 exactly (1x3x512x512) and the bench config at N = 8, 2 warm-ups +
+              5 timed passes each (bounded by a time budget), median; decode p50 on the CPU beside the GPU's.  Rank 0, N = 1 only,
+              AFTER all GPU legs (so that the GPU work of the run is contiguous).
 """
 import argparse
 import json
@@ -37,16 +49,24 @@ import torch.distributed as dist  # noqa: E402
 import centernet_lightning_amd as cl  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
-BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16), 16x the fp32 MFMA rate
-F16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense fp16 = bf16 rate
-# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_final9.txt: 29 winograd5 launches): per kernel, mean
-# FETCH_SIZE x 2 (gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md §HBM) + mean WRITE_SIZE over the launches
-# of a C1 step (fp16-split Winograd: 186.2 MB x 2 + 146.6 MB = 518.9 MB).  Other configs: not profiled -> null.
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("simple", 32, 512, 512, "cnl_conv::conv_mfma_kernel"): 237.0e6,
-                                     ("simple", 32, 512, 512, "cnl_wino2::winograd2_kernel"): 328.9e6,
-                                     ("simple", 32, 512, 512, "cnl_wino3::winograd3_kernel"): 731.5e6,
-                                     ("simple", 32, 512, 512, "cnl_wino5::winograd5_kernel"): 484.3e6}
+F16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense fp16 / bf16 (v_mfma_f32_32x32x16_f16)
+HBM_PEAK_GBPS = 8000.0            # same guide: HBM3E spec peak (6.29 TB/s measured float4 copy)
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 [gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md §HBM]
+# + WRITE_SIZE, mean over the kernel's launches of one step).  From committed profiles — NOT measured by this run.
+PROFILED_TRAFFIC = {
+    ("simple", 32, 512, 512, "winograd_f16x2"): (484.3e6, "profiles/r01_pmc_traffic_final9.txt (29 winograd5 launches of a C1 step)"),
+    ("simple", 32, 512, 512, "winograd_f32"): (328.9e6, "profiles/r01_pmc_traffic_final9.txt"),
+}
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
+KIND_NAMES = {"winograd_f4": "cnl_wino8::winograd8_kernel (Winograd F(4x4,3x3); fp32 operands scaled per image by a power of two and split into 2 fp16 pieces, "
+                             "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
+              "winograd_f16x2": "cnl_wino5::winograd5_kernel / cnl_wino6::winograd6_kernel (Winograd F(2x2,3x3); the same split arithmetic)",
+              "winograd_f32": "cnl_wino2::winograd2_kernel (Winograd F(2x2,3x3), fp32 v_mfma_f32_32x32x2_f32)",
+              "direct_f16x2": "cnl_conv::conv_f16x2_kernel (direct implicit GEMM, fp16 matrix cores, scaled two-way split)",
+              "direct": "cnl_conv::conv_mfma_kernel (direct implicit GEMM, fp32 v_mfma_f32_32x32x2_f32)"}
+# executed matrix flops / direct-conv flops, and the peak they run against
+EXEC = {"winograd_f4": (36.0 / 144.0 * 3.0, F16_MFMA_PEAK_TFLOPS), "winograd_f16x2": (16.0 / 36.0 * 3.0, F16_MFMA_PEAK_TFLOPS),
+        "winograd_f32": (16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS), "direct_f16x2": (3.0, F16_MFMA_PEAK_TFLOPS), "direct": (1.0, FP32_MFMA_PEAK_TFLOPS)}
 
 
 def synthetic_weights_(model, seed=0):
@@ -73,110 +93,260 @@ def synthetic_weights_(model, seed=0):
     return model
 
 
-def step(model, x, tracking, k):
-    out = model(x)
-    dets = model.gather_tracking2d(out, num_detections=k) if tracking else model.gather_detection2d(out, num_detections=k)
-    return model.collate(dets)
+def build_model(config, **options):
+    torch.manual_seed(0)
+    model = synthetic_weights_(cl.build_centernet(os.path.join(ROOT, "centernet-lightning_amd", "configs", CONFIGS[config])))
+    if options:
+        model.set_kernel_options(**options)
+    return model.cuda()
+
+
+def run_steps(model, x, tracking, k, steps, collator):
+    """`steps` passes of the hot path; the all-gather of step i is collected during step i+1 and the last one drained."""
+    pending, out = None, None
+    for _ in range(steps):
+        o = model(x)
+        dets = model.gather_tracking2d(o, num_detections=k) if tracking else model.gather_detection2d(o, num_detections=k)
+        h = collator.submit(dets)
+        if pending is not None:
+            out = collator.result(pending)
+        pending = h
+    if pending is not None:
+        out = collator.result(pending)
+    return out
+
+
+def timed(model, x, tracking, k, warmup, steps, collator, barrier):
+    with torch.no_grad():
+        run_steps(model, x, tracking, k, warmup, collator)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(model, x, tracking, k, steps, collator)
+        barrier()
+        return time.perf_counter() - t0
 
 
 def conv_kernel_profile(model, x, reps=3):
-    """HIP-event timing of every conv launch of one forward (events on torch's current stream == the launch
-    stream).  Returns (sum of conv durations per step [ms], conv flops per step, launches per step, per-layer rows)."""
+    """HIP-event timing of every conv launch of one forward (events on torch's current stream == the launch stream).
+    Returns per-launch rows (what, algorithmic flops, ms, kind, algorithmic bytes), scaled to the whole batch."""
     import ctypes
     eng = model._engine
     model(x)                                            # make sure the plan exists
-    # batches whose activations would exceed the kernels' 4 GiB addressing run as equal sub-batches (Engine.forward): time one
-    # sub-batch and scale
+    # batches whose activations would exceed the kernels' 4 GiB addressing run as equal sub-batches (Engine.forward): time one and scale
     n_sub = eng.sub_batch(x.shape[0], x.shape[2], x.shape[3])
     scale = x.shape[0] / n_sub
     x = x[:n_sub]
-    plan = eng.plans[(n_sub, x.shape[2], x.shape[3], True)]
+    plan = eng.plan_for(x, sigmoid=True)
     lib = plan.lib
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     convs = [L for L in plan.launches if L.fn in (lib.cnl_conv2d_nhwc_f32, lib.cnl_conv3x3_winograd_f32, lib.cnl_conv3x3_up2_nhwc_f32)]
     acc = [0.0] * len(convs)
     for _ in range(reps):
-        model(x)                                        # refresh inputs of every layer
         torch.cuda.synchronize()
         evs = []
-        for L in convs:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            rc = L.fn(ctypes.byref(L.args), stream)
-            e1.record()
+        if plan.absmax is not None:
+            plan.absmax.zero_()
+        for L in plan.launches:                         # replay the WHOLE plan in order (buffers are reused by liveness), timing the convs
+            e0 = e1 = None
+            if L in convs:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            rc = plan.launch(L, x, stream)
             assert rc == 0, L.what
-            evs.append((e0, e1))
+            if e0 is not None:
+                e1.record()
+                evs.append((e0, e1))
         torch.cuda.synchronize()
         for i, (e0, e1) in enumerate(evs):
             acc[i] += e0.elapsed_time(e1)
+
     def kind(L):
         if L.fn is lib.cnl_conv3x3_up2_nhwc_f32:        # four sub-pixel phase convs on the direct kernels
             return "direct_f16x2" if lib.cnl_conv3x3_up2_kernel(ctypes.byref(L.args)) == 5 else "direct"
         if L.fn is not lib.cnl_conv3x3_winograd_f32:
             return "direct_f16x2" if lib.cnl_conv2d_kernel(ctypes.byref(L.args)) == 5 else "direct"
-        return {3: "winograd_bf16x3", 5: "winograd_f16x2"}.get(lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)), "winograd_f32")
-    rows = [(L.what, L.flops * scale, acc[i] / reps * scale, kind(L)) for i, L in enumerate(convs)]
-    # algorithmic HBM bytes of a conv launch: input + weights + bias + output (+ residual), each touched once
-    nbytes = 0
-    bytes_by_kind = {}
-    for L in convs:
+        return {5: "winograd_f16x2", 8: "winograd_f4"}.get(lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)), "winograd_f32")
+
+    rows = []
+    for i, L in enumerate(convs):
         p = L.args
         up_in = 2 if p.flags & 4 else 1
         ho = (p.H_in * up_in + 2 * p.pad - p.KH) // p.stride + 1
         wo = (p.W_in * up_in + 2 * p.pad - p.KW) // p.stride + 1
-        up_out = 4 if p.flags & 8 else 1
-        out_px = p.N * ho * wo * up_out
-        b_ = 4 * (p.N * p.H_in * p.W_in * p.Cin + p.Cout * p.KH * p.KW * p.Cin + p.Cout + out_px * p.Cout
-                  + (out_px * p.Cout if p.residual else 0))
-        nbytes += b_
-        bytes_by_kind[kind(L)] = bytes_by_kind.get(kind(L), 0) + b_ * scale
-    return sum(r[2] for r in rows), sum(r[1] for r in rows), len(rows), rows, bytes_by_kind
+        out_px = p.N * ho * wo * (4 if p.flags & 8 else 1)
+        # algorithmic HBM bytes of a conv launch: input + weights + bias + output (+ residual), each touched once
+        nbytes = 4 * (p.N * p.H_in * p.W_in * p.Cin + p.Cout * p.KH * p.KW * p.Cin + p.Cout + out_px * p.Cout + (out_px * p.Cout if p.residual else 0))
+        rows.append((L.what, L.flops * scale, acc[i] / reps * scale, kind(L), nbytes * scale))
+    return rows, plan
 
 
-def cpu_baseline(model, tracking, k, H, W, budget_s=20.0):
-    """Oracle leg: CPU restatement of forward + decode on a bounded sample of the same workload."""
+def roofline_block(rows, config, B, H, W):
+    agg = {}
+    for what, fl, ms, kd, nb in rows:
+        a = agg.setdefault(kd, [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += fl; a[3] += nb
+    dom = max(agg, key=lambda k_: agg[k_][1])
+    n, ms, fl, nb = agg[dom]
+    ratio, peak = EXEC[dom]
+    exec_tf = fl * ratio / (ms * 1e-3) / 1e12
+    traffic = PROFILED_TRAFFIC.get((config, B, H, W, dom))
+    roof = {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": round(exec_tf, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(exec_tf / peak, 4),
+            "achieved_counts": f"EXECUTED matrix-core flops = direct-conv flops x {ratio:.4f} (Winograd multiplies x split terms); the algorithmic rate is effective_tflops",
+            "effective_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+            "effective_frac_of_fp32_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3),
+            "launches_per_step": n, "kernel_ms_per_step": round(ms, 3), "algorithmic_gflop_per_step": round(fl / 1e9, 2),
+            "avg_launch_us": round(ms * 1e3 / n, 2),
+            "algorithmic_bytes_per_launch": round(nb / n),
+            "traffic": traffic[0] if traffic else None,
+            "traffic_source": (traffic[1] + " — rocprofv3 PMC of an earlier run of this command, not measured here") if traffic else
+                              "no PMC profile of this kernel / configuration committed yet (see profiles/)",
+            "sustained_clock_note": "power-limited DVFS: the split-operand kernels hold 1.8-2.0 GHz of 2.4 (profiles/r01_winograd_clocks.txt)"}
+    roof["other_kernels"] = {KIND_NAMES[k_].split(" (")[0]: {"launches_per_step": v[0], "kernel_ms_per_step": round(v[1], 3),
+                                                            "effective_tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0,
+                                                            "executed_frac_of_its_peak": round(v[2] * EXEC[k_][0] / (v[1] * 1e-3) / 1e12 / EXEC[k_][1], 4) if v[1] else 0.0}
+                             for k_, v in agg.items() if k_ != dom}
+    conv_ms, conv_fl = sum(r[2] for r in rows), sum(r[1] for r in rows)
+    stack = {"algorithmic_gflop_per_step": round(conv_fl / 1e9, 2), "kernel_ms_per_step": round(conv_ms, 3),
+             "effective_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
+    return roof, stack
+
+
+def p50_ms(fn, reps=30, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    lat = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        lat.append(e0.elapsed_time(e1))
+    lat.sort()
+    return lat[len(lat) // 2]
+
+
+def decode_block(model, x, tracking, k):
+    with torch.no_grad():
+        out = model(x)
+        logits = model.get_encoded_outputs(x)
+        gather = model.gather_tracking2d if tracking else model.gather_detection2d
+        p_wo = p50_ms(lambda: gather(out, num_detections=k))
+        rest = tuple(out[1:])
+        p_w = p50_ms(lambda: gather((torch.sigmoid(logits["heatmap"]),) + rest, num_detections=k))
+    N, C, h, w = out[0].shape
+    E = out[2].shape[1] if tracking else 0
+    must = N * (4 * C * h * w + k * (16 + 4 * E) + k * (4 + 8 + 8 + 16 + 4 * E))      # SURVEY.md §8d: heatmap once + k gathers + outputs
+    gbps = must / (p_wo * 1e-3) / 1e9
+    return {"p50_ms_without_sigmoid": round(p_wo, 4), "p50_ms_with_separate_sigmoid_pass": round(p_w, 4),
+            "must_move_bytes": must, "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4),
+            "note": "without = the path (sigmoid is the heatmap out_conv's epilogue); with = torch.sigmoid(logits) + decode, what a caller "
+                    "holding logits pays; HIP events around gather_detection2d on the forward's own outputs, median of 30"}
+
+
+def feature_errors(config, x2, algo):
+    """max |feature - float64 oracle| / max |float64 oracle| at the neck output and each head's last-block output + the heatmap."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_cpu
+    model = build_model(config, algo=algo, reuse_buffers=False) if algo != "cpu" else build_model(config)
+    sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
+    out64, _, neck64, heads64 = ref_cpu.forward_float64(sd, x2, sigmoid=True, return_intermediates="heads")
+    if algo == "cpu":
+        out, _, neck, heads = ref_cpu.forward(sd, x2, sigmoid=True, return_intermediates="heads")
+        heat = out["heatmap"]
+    else:
+        with torch.no_grad():
+            heat = model(x2.cuda())[0].cpu()
+        torch.cuda.synchronize()
+        plan = model._engine.plan_for(x2.cuda(), sigmoid=True)
+        nb, _, _, nc, nup = plan.neck_out
+        neck = plan.tensor(nb)[..., :nc].permute(0, 3, 1, 2).cpu()
+        if nup:
+            neck = torch.nn.functional.interpolate(neck, scale_factor=2, mode="nearest")
+        heads = {name: plan.tensor(buf)[..., off:off + c].permute(0, 3, 1, 2).cpu() for name, (buf, ld, off, c, _, _, _) in plan.head_features.items()}
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    e = {"neck": rel(neck, neck64)}
+    for name in heads64:
+        e["head." + name] = rel(heads[name], heads64[name])
+    e["heatmap_abs"] = float((heat.double() - out64["heatmap"]).abs().max())
+    return {k_: float(f"{v:.3e}") for k_, v in e.items()}
+
+
+def cpu_baseline(model, config, tracking, k, H, W, gpu_decode_p50_ms, budget_s=45.0):
+    """Oracle leg: the CPU restatement of forward + decode, C0 exactly and the bench config at N = 8."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import decode_ref
     import ref_cpu
     sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
-    n = 2
-    x = torch.rand(n, 3, H, W, generator=torch.Generator().manual_seed(1234))
-    cores = torch.get_num_threads()
+    cores = os.cpu_count()
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
 
-    def one():
+    def one(x):
         o = ref_cpu.forward(sd, x, sigmoid=True)
-        d = decode_ref.decode_detections(o["heatmap"].numpy(), o["box_2d"].numpy(), k, 3,
-                                         reid=o["reid"].numpy() if tracking else None)
-        return o, d
-
-    t0 = time.perf_counter()
-    o, d = one()                                        # warm-up (also used as the checker below)
-    warm = time.perf_counter() - t0
-    iters, spent = 0, 0.0
-    while iters < 1 or (spent + warm < budget_s and iters < 5):
         t0 = time.perf_counter()
-        one()
-        spent += time.perf_counter() - t0
-        iters += 1
-    # checker: the HIP path on the same sample
-    with torch.no_grad():
-        out = model(x.cuda())
-    err = float((out[0].cpu() - o["heatmap"]).abs().max())
-    return {"value": round(n * iters / spent, 3), "unit": "images/s", "cores": cores, "kind": "port", "max_abs_err_heatmap": err,
-            "sample": f"{iters} timed passes of oracle/ref_cpu.forward + decode_ref on {n}x3x{H}x{W} (same weights), "
-                      f"torch {torch.__version__} CPU fp32, {cores} threads; max |heatmap_gpu - heatmap_cpu| = {err:.2e}"}
+        decode_ref.decode_detections(o["heatmap"].numpy(), o["box_2d"].numpy(), k, 3, reid=o["reid"].numpy() if tracking else None)
+        return time.perf_counter() - t0
+
+    def leg(n, h, w, budget):
+        x = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(1234))
+        best = None
+        for threads in sorted({cores, max(1, cores // 2)}, reverse=True):      # all hardware threads, and one per physical core (SMT-2 hosts)
+            torch.set_num_threads(threads)
+            t0 = time.perf_counter()
+            one(x)
+            one(x)                                                             # 2 warm-ups
+            warm = time.perf_counter() - t0
+            ts, dec = [], []
+            while len(ts) < 5 and (len(ts) < 3 or sum(ts) + warm < budget / 2):
+                t0 = time.perf_counter()
+                dec.append(one(x))
+                ts.append(time.perf_counter() - t0)
+            ts.sort(); dec.sort()
+            r = {"threads": threads, "images_per_s": round(n / ts[len(ts) // 2], 3), "timed_passes": len(ts), "decode_p50_ms": round(dec[len(dec) // 2] * 1e3, 3)}
+            if best is None or r["images_per_s"] > best["images_per_s"]:
+                other, best = best, r
+            else:
+                other = r
+        best["other_thread_setting"] = other
+        torch.set_num_threads(cores)
+        return best
+
+    c0 = leg(1, 512, 512, budget_s * 0.3)
+    cn = leg(8, H, W, budget_s * 0.7)
+    return {"value": cn["images_per_s"], "unit": "images/s", "cores": cn["threads"], "kind": "port",
+            "os_cpu_count": cores, "cpu_model": cpu_model,
+            "sample": f"oracle/ref_cpu.forward + decode_ref.decode_detections (same weights) on 8x3x{H}x{W}, 2 warm-ups + {cn['timed_passes']} timed passes, median; "
+                      f"torch {torch.__version__} CPU fp32, {cn['threads']} threads (best of {cores} / {max(1, cores // 2)})",
+            "bench_config_N8": cn, "C0_1x3x512x512": c0,
+            "decode_p50_ms": {"cpu_N8": cn["decode_p50_ms"], "cpu_N1_C0": c0["decode_p50_ms"], "gpu_full_batch": gpu_decode_p50_ms}}
 
 
-def oracle_check(model, H, W):
-    """max |heatmap_gpu - heatmap_cpu| on a 2-image sample: one pass of the CPU oracle, no timing (the checker, not the product)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ref_cpu
-    sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
-    x = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(1234))
-    o = ref_cpu.forward(sd, x, sigmoid=True)
+def short_line(config, B, H, W, k, steps=5, warmup=2):
+    """A short run of another BASELINE configuration (driver-visible C2 / C4 numbers)."""
+    tracking = config == "tracking"
+    model = build_model(config)
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1234)).cuda()
+    sync = torch.cuda.synchronize
+    el = timed(model, x, tracking, k, warmup, steps, cl.Collator(), sync)
     with torch.no_grad():
-        out = model(x.cuda())
-    return float((out[0].cpu() - o["heatmap"]).abs().max())
+        rows, plan = conv_kernel_profile(model, x, reps=2)
+    roof, stack = roofline_block(rows, config, B, H, W)
+    eng = model._engine
+    return {"config": {"workload": f"ResNet34 + {config} neck, {B} img x {H}x{W}, k={k}"}, "value": round(B * steps / el, 2), "unit": "images/s",
+            "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 3),
+            "roofline": {kk: roof[kk] for kk in ("kernel", "achieved", "peak", "frac", "effective_tflops", "launches_per_step", "kernel_ms_per_step")},
+            "conv_stack": stack,
+            "activation_arena_MB": {"with_liveness_reuse": round(plan.arena_bytes / 1e6, 1), "every_buffer_separate": round(plan.bytes_without_reuse / 1e6, 1),
+                                    "sub_batch": eng.sub_batch(B, H, W)}}
 
 
 def main():
@@ -189,11 +359,12 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--algo", choices=["auto", "f2", "f32"], default="auto", help="KernelOptions.algo of the measured job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the f2 / f32 legs")
+    ap.add_argument("--no-also", action="store_true", help="skip the short C2 / C4 lines")
+    ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer conv table to stderr")
-    ap.add_argument("--oracle-check", action="store_true", help="add max |heatmap - CPU oracle| of this configuration (one oracle pass)")
-    ap.add_argument("--no-fp32-mfma-leg", action="store_true",
-                    help="skip the extra short run with every conv on the fp32 matrix core (CNL_WINO=2 CNL_CONV_F16X2=0 CNL_STEM_F16X2=0), reported beside `value`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -217,158 +388,108 @@ def main():
             dist.init_process_group(backend)
 
     tracking = args.config == "tracking"
-    torch.manual_seed(0)
-    model = synthetic_weights_(cl.build_centernet(os.path.join(ROOT, "centernet-lightning_amd", "configs", CONFIGS[args.config]))).cuda()
+    model = build_model(args.config, algo=args.algo)
     B, H, W = args.batch, args.height, args.width
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1234 + rank)).cuda()
+    collator = cl.Collator()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step(model, x, tracking, args.k)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(model, x, tracking, args.k)
-        barrier()
-        elapsed = time.perf_counter() - t0
+    elapsed = timed(model, x, tracking, args.k, args.warmup, args.steps, collator, barrier)
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the collate step alone, synchronously (pack + all-gather + unpack), for the record: median of 10
+        with torch.no_grad():
+            o = model(x)
+            dets = model.gather_tracking2d(o, num_detections=args.k) if tracking else model.gather_detection2d(o, num_detections=args.k)
+            cts = []
+            for _ in range(10):
+                barrier()
+                t0 = time.perf_counter()
+                collator.result(collator.submit(dets))
+                torch.cuda.synchronize()
+                cts.append(time.perf_counter() - t0)
+            cts.sort()
+            collate_ms = cts[len(cts) // 2] * 1e3
 
-    result = None
     if rank == 0:
         with torch.no_grad():
-            conv_ms, conv_flops, n_launch, rows, conv_bytes = conv_kernel_profile(model, x)
-            # decode-only latency (p50) on the forward's own outputs
-            out = model(x)
-            lat = []
-            for _ in range(30):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                (model.gather_tracking2d if tracking else model.gather_detection2d)(out, num_detections=args.k)
-                e1.record()
-                torch.cuda.synchronize()
-                lat.append(e0.elapsed_time(e1))
-            lat.sort()
-        def agg(kind):
-            sel = [r for r in rows if r[3] == kind]
-            ms = sum(r[2] for r in sel)
-            fl = sum(r[1] for r in sel)
-            return len(sel), ms, fl
-        n_w, ms_w, fl_w = agg("winograd_f32")
-        n_b, ms_b, fl_b = agg("winograd_bf16x3")
-        n_h, ms_h, fl_h = agg("winograd_f16x2")
-        n_d, ms_d, fl_d = agg("direct")
-        n_d5, ms_d5, fl_d5 = agg("direct_f16x2")
-        direct_tf = fl_d / (ms_d * 1e-3) / 1e12 if ms_d else 0.0
-        f32_exec_tf = fl_w * (16.0 / 36.0) / (ms_w * 1e-3) / 1e12 if ms_w else 0.0
-        if ms_h >= ms_b and ms_h >= ms_w and ms_h >= ms_d:
-            # dominant: Winograd on the fp16 matrix cores (scaled two-way split, 3 MFMAs per product); HIP events around the entry
-            # point include the absmax pass over the input that fixes the scale
-            exec_tf = fl_h * (16.0 / 36.0) * 3.0 / (ms_h * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "cnl_wino5::winograd5_kernel (F(2x2,3x3); fp32 operands scaled by a power of two and split into 2 fp16 "
-                                               "pieces, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; incl. cnl_wino6::winograd6_kernel and cnl_wino7::winograd7_kernel, its 128-cout and two-waves-per-SIMD forms, and the few absmax_kernel passes)",
-                    "achieved": round(exec_tf, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(exec_tf / F16_MFMA_PEAK_TFLOPS, 4),
-                    "achieved_counts": "executed fp16 matrix-core flops = direct-conv flops x 16/36 (Winograd) x 3 (split terms)",
-                    "effective_tflops": round(fl_h / (ms_h * 1e-3) / 1e12, 2),
-                    "launches_per_step": n_h, "kernel_ms_per_step": round(ms_h, 3),
-                    "algorithmic_gflop_per_step": round(fl_h / 1e9, 2), "avg_launch_us": round(ms_h * 1e3 / n_h, 2),
-                    "sustained_clock_note": "power-limited DVFS: the split-operand kernels hold 1.8-2.0 GHz of 2.4 (tools/clk_probe.sh)"}
-        elif ms_b >= ms_w and ms_b >= ms_d:      # dominant kernel: Winograd on the bf16 matrix cores (exact 3-way split, 6 MFMAs per product)
-            exec_tf = fl_b * (16.0 / 36.0) * 6.0 / (ms_b * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "cnl_wino3::winograd3_kernel (F(2x2,3x3); fp32 operands split exactly into 3 bf16 pieces, "
-                                               "6 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)",
-                    "achieved": round(exec_tf, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(exec_tf / BF16_MFMA_PEAK_TFLOPS, 4),
-                    "achieved_counts": "executed bf16 matrix-core flops = direct-conv flops x 16/36 (Winograd) x 6 (split terms)",
-                    "effective_tflops": round(fl_b / (ms_b * 1e-3) / 1e12, 2),
-                    "launches_per_step": n_b, "kernel_ms_per_step": round(ms_b, 3),
-                    "algorithmic_gflop_per_step": round(fl_b / 1e9, 2), "avg_launch_us": round(ms_b * 1e3 / n_b, 2),
-                    "sustained_clock_note": "the chip sustains ~1.6-1.65 GHz under this kernel (power-limited DVFS; tools/wino3_trace.py): "
-                                            "bf16 ceiling at that clock ~1.7 PFLOP/s"}
-        elif ms_w >= ms_d:          # dominant kernel: Winograd on the fp32 matrix cores
-            roof = {"bound": "mfma", "kernel": "cnl_wino2::winograd2_kernel (F(2x2,3x3), fp32 v_mfma_f32_32x32x2_f32)",
-                    "achieved": round(f32_exec_tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(f32_exec_tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "achieved_counts": "executed matrix-core flops = direct-conv flops x 16/36",
-                    "effective_tflops": round(fl_w / (ms_w * 1e-3) / 1e12, 2),
-                    "launches_per_step": n_w, "kernel_ms_per_step": round(ms_w, 3),
-                    "algorithmic_gflop_per_step": round(fl_w / 1e9, 2), "avg_launch_us": round(ms_w * 1e3 / n_w, 2),
-                    "sustained_clock_note": "chip sustains ~2.1 GHz under this load (DVFS; profiles/r01_mfma_peak_onbox.txt), i.e. ~140 TFLOP/s ceiling"}
-        else:
-            roof = {"bound": "mfma", "kernel": "cnl_conv::conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
-                    "achieved": round(direct_tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(direct_tf / FP32_MFMA_PEAK_TFLOPS, 4), "launches_per_step": n_d,
-                    "kernel_ms_per_step": round(ms_d, 3), "algorithmic_gflop_per_step": round(fl_d / 1e9, 2),
-                    "avg_launch_us": round(ms_d * 1e3 / max(n_d, 1), 2)}
-        roof["traffic"] = MEASURED_TRAFFIC_BYTES_PER_LAUNCH.get((args.config, B, H, W, roof["kernel"].split(" ")[0]))
-        roof["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic_final9.txt: 29 winograd5 launches)"
-        dom = "winograd_f16x2" if "wino5" in roof["kernel"] else "winograd_bf16x3" if "wino3" in roof["kernel"] else ("winograd_f32" if "wino2" in roof["kernel"] else "direct")
-        roof["algorithmic_bytes_per_launch"] = round(conv_bytes.get(dom, 0) / max(roof["launches_per_step"], 1))
-        roof["other_kernels"] = {"cnl_wino2::winograd2_kernel (fp32 MFMA)": {"launches_per_step": n_w, "kernel_ms_per_step": round(ms_w, 3),
-                                                                             "achieved_tflops_executed": round(f32_exec_tf, 2),
-                                                                             "frac_of_fp32_mfma_peak": round(f32_exec_tf / FP32_MFMA_PEAK_TFLOPS, 4)},
-                                 "cnl_wino3::winograd3_kernel (bf16 MFMA, exact 3-way split)": {"launches_per_step": n_b, "kernel_ms_per_step": round(ms_b, 3)},
-                                 "cnl_wino5::winograd5_kernel (fp16 MFMA, scaled 2-way split)": {"launches_per_step": n_h, "kernel_ms_per_step": round(ms_h, 3)},
-                                 "cnl_conv::conv_mfma_kernel": {"launches_per_step": n_d, "kernel_ms_per_step": round(ms_d, 3),
-                                                                "achieved_tflops": round(direct_tf, 2)},
-                                 "cnl_conv::conv_f16x2_kernel (direct conv, fp16 MFMA, scaled 2-way split)": {
-                                     "launches_per_step": n_d5, "kernel_ms_per_step": round(ms_d5, 3),
-                                     "effective_tflops": round(fl_d5 / (ms_d5 * 1e-3) / 1e12, 2) if ms_d5 else 0.0}}
-        ms_per_step = elapsed / args.steps * 1e3
+            rows, plan = conv_kernel_profile(model, x)
+        roof, stack = roofline_block(rows, args.config, B, H, W)
+        dec = decode_block(model, x, tracking, args.k)
+        eng = model._engine
         result = {
             "metric": "images/sec @512x512 ResNet34 CenterNet forward + gather_detection2d",
             "value": round(world * B * args.steps / elapsed, 2),
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3),
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",
-            "dtype_note": "fp32 in / fp32 accumulate / fp32 out; the long-channel 3x3 layers, the stride-2 / heatmap direct convs and the stem form each fp32 product on the fp16 matrix cores from "
-                          "a two-way fp16 split of both (power-of-two scaled) operands (3 cross terms, error <= the fp32 MFMA's: tools/bf16x3_probe.hip, "
-                          "tests/test_gpu_conv.py::test_winograd_split_kernels_error_not_above_fp32_mfma, test_conv_f16x2_error_not_above_fp32_mfma, test_stem_f16x2_error_not_above_fp32_mfma; fp32_mfma_only = the same job with no split operands anywhere)",
+            "dtype_note": "fp32 in / fp32 accumulate / fp32 out; where it pays, each fp32 product is formed on the fp16 matrix cores from a two-way fp16 split of "
+                          "both (power-of-two scaled) operands (3 cross terms); KernelOptions.algo = " + args.algo + " (auto: Winograd F(4x4,3x3) on the long 3x3 layers; "
+                          "f2: F(2x2) only — every kernel's error at or below the fp32 MFMA's; f32: fp32 matrix cores only): see `variants` and `accuracy`",
             "data": "synthetic (seeded rand images; random-init weights of the named architecture)",
             "config": {"workload": f"BASELINE C{'1' if args.config == 'simple' else ('4' if tracking else '2/3')}: ResNet34 + {args.config} neck, "
                                    f"{B} img/GPU x {H}x{W}, heads {'2+4+reid64' if tracking else '80+4'} (w256), k={args.k}, nms 3",
-                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of detections" if world > 1 else "")},
+                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of detections (side stream, one step behind)" if world > 1 else "")},
             "roofline": roof,
-            "conv_stack": {"algorithmic_gflop_per_step": round(conv_flops / 1e9, 2), "kernel_ms_per_step": round(conv_ms, 3),
-                           "effective_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2)},
-            "decode_p50_ms": round(lat[len(lat) // 2], 4),
+            "conv_stack": stack,
+            "decode": dec,
+            "decode_p50_ms": dec["p50_ms_without_sigmoid"],
+            "activation_arena_MB": {"with_liveness_reuse": round(plan.arena_bytes / 1e6, 1), "every_buffer_separate": round(plan.bytes_without_reuse / 1e6, 1),
+                                    "sub_batch": eng.sub_batch(B, H, W)},
         }
+        if world > 1:
+            result["collate_ms"] = round(collate_ms, 4)
+            result["collate_note"] = "pack + all_gather_into_tensor + unpack run synchronously, median of 10 (inside `value` the gather runs on a side stream behind the next forward)"
         if args.layers:
-            for what, fl, ms, _kind in rows:
-                print(f"{what:44s} {fl / 1e9:10.2f} GFLOP {ms * 1e3:10.1f} us {fl / (ms * 1e-3) / 1e12 if ms else 0:8.1f} TF", file=sys.stderr)
-        if world == 1 and not args.no_fp32_mfma_leg and not os.environ.get("CNL_WINO"):
-            # the same job with every 3x3 layer on the fp32 matrix core (the kernel choice is read once per process: child process)
-            import subprocess
-            env = dict(os.environ, CNL_WINO="2", CNL_CONV_F16X2="0", CNL_STEM_F16X2="0")
-            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(max(args.steps // 2, 3)), "--warmup", str(min(args.warmup, 3)),
-                   "--config", args.config, "--batch", str(B), "--height", str(H), "--width", str(W), "--k", str(args.k),
-                   "--no-cpu-baseline", "--no-fp32-mfma-leg", "--oracle-check"]
-            try:
-                out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
-                alt = json.loads(out)
-                result["fp32_mfma_only"] = {"value": alt["value"], "unit": alt["unit"], "ms_per_step": alt["ms_per_step"], "steps": alt["steps"],
-                                            "roofline_frac_of_fp32_mfma_peak": alt["roofline"]["frac"],
-                                            "max_abs_err_heatmap_vs_cpu_oracle": alt.get("oracle_check", {}).get("max_abs_err_heatmap"),
-                                            "note": "CNL_WINO=2 CNL_CONV_F16X2=0 CNL_STEM_F16X2=0: every conv on v_mfma_f32_32x32x2_f32 (no split operands anywhere)"}
-            except Exception as e:      # reported, never fatal: `value` above is the measurement
-                result["fp32_mfma_only"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(model, tracking, args.k, H, W)
-            result["accuracy"] = {"max_abs_err_heatmap_vs_cpu_oracle": result["cpu_baseline"]["max_abs_err_heatmap"],
-                                  "same_with_every_layer_on_the_fp32_mfma": result.get("fp32_mfma_only", {}).get("max_abs_err_heatmap_vs_cpu_oracle"),
-                                  "tolerance": 1e-4, "sample": "2 images of the bench shape, same weights"}
-        elif world == 1 and args.oracle_check:
-            result["oracle_check"] = {"max_abs_err_heatmap": oracle_check(model, H, W)}
+            for what, fl, ms, kd, _nb in rows:
+                print(f"{what:44s} {kd:16s} {fl / 1e9:10.2f} GFLOP {ms * 1e3:10.1f} us {fl / (ms * 1e-3) / 1e12 if ms else 0:8.1f} TF", file=sys.stderr)
+        if world == 1:
+            sync = torch.cuda.synchronize
+            if not args.no_variants:
+                result["variants"] = {}
+                for algo in ("f2", "f32"):
+                    if algo == args.algo:
+                        continue
+                    try:
+                        m2 = build_model(args.config, algo=algo)
+                        st = max(args.steps // 2, 3)
+                        el = timed(m2, x, tracking, args.k, min(args.warmup, 3), st, cl.Collator(), sync)
+                        with torch.no_grad():
+                            r2, _ = conv_kernel_profile(m2, x, reps=2)
+                        rf2, _ = roofline_block(r2, args.config, B, H, W)
+                        result["variants"][algo] = {"value": round(B * st / el, 2), "unit": "images/s", "ms_per_step": round(el / st * 1e3, 3), "steps": st,
+                                                    "dominant_kernel": rf2["kernel"].split(" (")[0], "roofline_frac": rf2["frac"], "effective_tflops": rf2["effective_tflops"]}
+                        del m2
+                    except Exception as e:      # reported, never fatal: `value` above is the measurement
+                        result["variants"][algo] = {"error": repr(e)}
+            if not args.no_also and args.config == "simple" and (B, H, W) == (32, 512, 512):
+                result["also"] = []
+                for cfg, b_, h_, w_, k_ in (("fpn", 64, 512, 512, 100), ("tracking", 32, 608, 1088, 100)):
+                    try:
+                        result["also"].append(short_line(cfg, b_, h_, w_, k_))
+                    except Exception as e:
+                        result["also"].append({"config": cfg, "error": repr(e)})
+            torch.cuda.empty_cache()
+            if not args.no_accuracy:
+                x2 = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(4242))
+                try:
+                    acc = {a: feature_errors(args.config, x2, a) for a in ("auto", "f2", "f32", "cpu")}
+                    result["accuracy"] = {"max_err_over_max_ref_vs_float64_oracle": acc, "tolerance": 1e-4,
+                                          "sample": f"2 images of the bench shape, same weights; 'cpu' = the CPU fp32 oracle's own distance from float64",
+                                          "parity_note": "backbone + ConvBnAct parity is unpinned by the reference (torchvision / vision_toolbox absent): the oracle is this repo's restatement; "
+                                                         "decode / head wiring / neck options are pinned by goldens generated from the reference (tests/golden/)"}
+                except Exception as e:
+                    result["accuracy"] = {"error": repr(e)}
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline(model, args.config, tracking, args.k, H, W, dec["p50_ms_without_sigmoid"])
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

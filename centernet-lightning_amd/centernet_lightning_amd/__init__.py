@@ -6,10 +6,10 @@ is in libcenternet_gfx950.so (hand-written HIP kernels, C ABI in include/centern
 """
 from .config import load_config
 from .models import CenterNet, DetectionOutput, TrackingOutput, build_centernet
-from .collate import (all_gather_records, collate_detections, pack_detections, shard_range, unpack_detections)
+from .collate import (Collator, all_gather_records, collate_detections, pack_detections, shard_range, unpack_detections)
 from .tracker import Tracker, Track, TrackState, build_tracker, match_with_threshold
 from . import decode, formats
 
 __all__ = ["CenterNet", "build_centernet", "load_config", "DetectionOutput", "TrackingOutput", "decode",
-           "collate_detections", "all_gather_records", "pack_detections", "unpack_detections", "shard_range",
+           "collate_detections", "Collator", "all_gather_records", "pack_detections", "unpack_detections", "shard_range",
            "Tracker", "Track", "TrackState", "build_tracker", "match_with_threshold", "formats"]

@@ -16,8 +16,12 @@ CNL_UPSAMPLE_IN = 1 << 2
 CNL_UPSAMPLE_OUT_ADD = 1 << 3
 CNL_RELU6 = 1 << 4
 
+# cnl_conv_params.algo: the arithmetic class a launch may use (include/centernet_gfx950.h)
+CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_FORCE = 0, 1, 2, 100
+CNL_WINO_F32, CNL_WINO_F16X2, CNL_WINO_F16X2_F4 = 2, 5, 8
+
 CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4
-ABI_VERSION = 4          # CNL_ABI_VERSION of include/centernet_gfx950.h
+ABI_VERSION = 5          # CNL_ABI_VERSION of include/centernet_gfx950.h
 
 
 class ConvParams(Structure):
@@ -25,7 +29,7 @@ class ConvParams(Structure):
                 ("N", c_int32), ("H_in", c_int32), ("W_in", c_int32), ("Cin", c_int32), ("Cout", c_int32),
                 ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
                 ("ldx", c_int32), ("ldy", c_int32), ("ldr", c_int32), ("flags", c_uint32),
-                ("x_absmax", c_void_p), ("y_absmax", c_void_p), ("w_absmax", c_void_p)]
+                ("x_absmax", c_void_p), ("y_absmax", c_void_p), ("w_absmax", c_void_p), ("algo", c_uint32)]
 
 
 class DeconvParams(Structure):
@@ -73,7 +77,7 @@ _SIGNATURES = {
     "cnl_stem_packed_weight_floats": (c_size_t, []),
     "cnl_stem_pack_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     "cnl_stem_conv7x7_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
-                                            c_int32, c_int32, c_int32, c_void_p]),
+                                            c_int32, c_int32, c_int32, c_uint32, c_void_p]),
     "cnl_stem_conv7x7_maxpool_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                             c_int32, c_int32, c_int32, c_void_p]),
     "cnl_maxpool3x3s2_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

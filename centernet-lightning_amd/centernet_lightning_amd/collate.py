@@ -31,8 +31,9 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def pack_detections(dets: dict) -> torch.Tensor:
-    """dict(bboxes|boxes [N,k,4], scores [N,k], labels [N,k] i64 [, embeddings [N,k,E]]) -> record [N,k,6+E] (HIP)."""
+def pack_detections(dets: dict, out: torch.Tensor = None) -> torch.Tensor:
+    """dict(bboxes|boxes [N,k,4], scores [N,k], labels [N,k] i64 [, embeddings [N,k,E]]) -> record [N,k,6+E] (HIP); `out`: a
+    preallocated record to fill instead of a fresh one."""
     lib = _lib.load()
     boxes = dets["bboxes"] if "bboxes" in dets else dets["boxes"]
     scores, labels, emb = dets["scores"], dets["labels"], dets.get("embeddings")
@@ -43,7 +44,9 @@ def pack_detections(dets: dict) -> torch.Tensor:
     boxes, scores, labels = boxes.contiguous(), scores.contiguous(), labels.contiguous()
     emb = emb.contiguous() if emb is not None else None
     with torch.cuda.device(boxes.device):
-        rec = torch.empty((N, k, RECORD_FIELDS + E), device=boxes.device, dtype=torch.float32)
+        rec = out if out is not None else torch.empty((N, k, RECORD_FIELDS + E), device=boxes.device, dtype=torch.float32)
+        if tuple(rec.shape) != (N, k, RECORD_FIELDS + E) or rec.dtype != torch.float32 or not rec.is_contiguous():
+            raise ValueError(f"pack_detections: out must be a contiguous float32 [{N},{k},{RECORD_FIELDS + E}] tensor")
         _lib.check(lib.cnl_pack_detections_f32(boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(),
                                                emb.data_ptr() if emb is not None else None, rec.data_ptr(), N, k, E,
                                                _stream(boxes.device)), "cnl_pack_detections_f32")
@@ -93,3 +96,96 @@ def collate_detections(dets: dict, group=None, force: bool = False) -> dict:
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return dets
     return unpack_detections(all_gather_records(pack_detections(dets), group, force), box_key=box_key)
+
+
+class Collator:
+    """Pipelined collation for a steady stream of batches ("all-gather on a side stream, overlapped with the next
+    batch"): submit() packs this rank's detections into a PERSISTENT record slot and starts the all-gather of that slot on a side
+    stream behind an event; result() makes the caller's stream wait for the gather's event and unpacks.  With `depth` slots the
+    gather of batch i runs while batch i+1 .. i+depth-1 are computed; nothing is allocated per step after the first.
+
+        c = Collator(); pending = None
+        for x in batches:
+            h = c.submit(model.gather_detection2d(model(x)))
+            if pending is not None: use(c.result(pending))
+            pending = h
+        use(c.result(pending))
+
+    World size 1 (or no process group) is the reference's shortcut (eval/coco.py:11-13): the detections pass through untouched.
+    CPU record tensors (the gloo protocol tests) take the same path without streams."""
+
+    def __init__(self, group=None, depth: int = 2, force: bool = False):
+        self.group, self.depth, self.force = group, max(1, int(depth)), force
+        self._slots = {}            # (shape, device) -> list of [rec, out, done_event] per slot
+        self._next = 0
+        self._side = None
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
+
+    def _slot(self, shape, device, dtype):
+        key = (tuple(shape), str(device))
+        slots = self._slots.get(key)
+        if slots is None:
+            world = dist.get_world_size(self.group)
+            slots = []
+            for _ in range(self.depth):
+                rec = torch.empty(shape, device=device, dtype=dtype)
+                out = torch.empty((world * shape[0],) + tuple(shape[1:]), device=device, dtype=dtype)
+                slots.append([rec, out, torch.cuda.Event() if device.type == "cuda" else None, False])
+            self._slots[key] = slots
+        i = self._next % self.depth
+        self._next += 1
+        return slots[i]
+
+    def _claim(self, shape, device, dtype):
+        """Next slot; the caller's stream first waits for the slot's previous gather (it is about to overwrite its source)."""
+        slot = self._slot(shape, device, dtype)
+        if slot[2] is not None and slot[3]:
+            torch.cuda.current_stream(device).wait_event(slot[2])
+        slot[3] = True
+        return slot
+
+    def submit_records(self, rec: torch.Tensor, _slot=None):
+        """Start the all-gather of a packed record [N_local,k,R]; returns a handle for result_records()."""
+        if not self._active():
+            return ("local", rec)
+        slot = _slot
+        if slot is None:
+            slot = self._claim(rec.shape, rec.device, rec.dtype)
+            slot[0].copy_(rec)
+        if rec.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(rec.device)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(rec.device))
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                dist.all_gather_into_tensor(slot[1], slot[0], group=self.group)
+                slot[2].record(self._side)
+        else:
+            dist.all_gather_into_tensor(slot[1], slot[0], group=self.group)
+        return ("gathered", slot)
+
+    def result_records(self, handle) -> torch.Tensor:
+        kind, payload = handle
+        if kind == "local":
+            return payload
+        if payload[2] is not None:
+            torch.cuda.current_stream(payload[1].device).wait_event(payload[2])
+        return payload[1]
+
+    def submit(self, dets: dict):
+        if not self._active():
+            return ("dets", dets)
+        box_key = "bboxes" if "bboxes" in dets else "boxes"
+        scores, emb = dets["scores"], dets.get("embeddings")
+        N, k = scores.shape
+        slot = self._claim((N, k, RECORD_FIELDS + (emb.shape[-1] if emb is not None else 0)), scores.device, torch.float32)
+        pack_detections(dets, out=slot[0])                       # straight into the persistent record
+        return ("records", self.submit_records(slot[0], _slot=slot), box_key)
+
+    def result(self, handle) -> dict:
+        if handle[0] == "dets":
+            return handle[1]
+        return unpack_detections(self.result_records(handle[1]), box_key=handle[2])

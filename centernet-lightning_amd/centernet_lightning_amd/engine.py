@@ -12,16 +12,46 @@ Fusions relative to the reference's op-per-layer graph (results identical up to 
   * first 3x3 block of every head (same input, meta.py:46) -> one conv with concatenated Cout
   * heatmap .sigmoid() (centernet.py:205)                 -> epilogue of the heatmap out_conv
 """
+import bisect
 import ctypes
-import os
 from collections import OrderedDict
+from dataclasses import dataclass
 
 import torch
 
 from . import _lib
-from ._lib import CNL_RELU, CNL_RELU6, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD, ConvParams, DeconvParams
+from ._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_RELU, CNL_RELU6, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD,
+                   CNL_WINO_F16X2, CNL_WINO_F16X2_F4, ConvParams, DeconvParams)
 
 BN_EPS_DEFAULT = 1e-5
+
+
+@dataclass(frozen=True)
+class KernelOptions:
+    """What the launch plan may use — an explicit, per-model choice (CenterNet.set_kernel_options), part of the plan key; the library
+    reads nothing from the environment.
+      algo             "auto": fastest fp32-grade kernels (fp16-split matrix cores, Winograd F(4x4,3x3) on the long 3x3 layers);
+                       "f2":   the same without F(4x4): every kernel's error vs float64 is at or below the fp32 matrix core's;
+                       "f32":  fp32 matrix cores only (no split operands, no hints).
+      winograd         False: every conv on the direct implicit-GEMM kernels (A/B and parity checks)
+      up2              the fused first head blocks behind a nearest upsample as four sub-pixel phase convs
+      absmax_handover  per-image max |y| handed from producer to consumer launches (else each fp16-split Winograd launch makes
+                       its own pass and the direct convs stay on the fp32 matrix cores)
+      stem_fused_pool  the 3x3/2 max-pool inside the stem kernel
+      reuse_buffers    activation buffers share one arena by liveness; False keeps every intermediate (tests read them)"""
+    algo: str = "auto"
+    winograd: bool = True
+    up2: bool = True
+    absmax_handover: bool = True
+    stem_fused_pool: bool = True
+    reuse_buffers: bool = True
+
+    @property
+    def algo_id(self):
+        try:
+            return {"auto": CNL_ALGO_AUTO, "f2": CNL_ALGO_F2, "f32": CNL_ALGO_F32}[self.algo]
+        except KeyError:
+            raise ValueError(f"KernelOptions.algo must be 'auto', 'f2' or 'f32', got {self.algo!r}") from None
 
 
 def fold_conv_bn(conv_w, conv_b, bn=None):
@@ -37,12 +67,6 @@ def fold_conv_bn(conv_w, conv_b, bn=None):
     return w.permute(0, 2, 3, 1).contiguous(), b.contiguous()
 
 
-def winograd_enabled():
-    """3x3 / stride-1 layers run through the Winograd F(2x2,3x3) kernel unless CNL_WINOGRAD=0 (then every conv takes the
-    direct implicit-GEMM kernel; same results up to fp32 rounding)."""
-    return os.environ.get("CNL_WINOGRAD", "1") != "0"
-
-
 class _Layer:
     """One packed conv layer: folded OHWI weight + bias on the device (+ the Winograd-transformed weight for
     3x3 / stride-1 layers, produced once by cnl_winograd_transform_weights_f32)."""
@@ -54,7 +78,7 @@ class _Layer:
         self.pad = (self.kh - 1) // 2
         self.wmax = w_ohwi.abs().max().reshape(1).contiguous()      # cnl_conv_params.w_absmax (fp16-split direct kernel)
         self.u = None
-        if self.kh == 3 and self.kw == 3 and stride == 1 and self.cin % 8 == 0 and w_ohwi.is_cuda and winograd_enabled():
+        if self.kh == 3 and self.kw == 3 and stride == 1 and self.cin % 8 == 0 and w_ohwi.is_cuda:
             lib = _lib.load()
             n = lib.cnl_winograd_weight_floats(self.cin, self.cout)
             with torch.cuda.device(w_ohwi.device):
@@ -67,8 +91,8 @@ class _Layer:
 def _layer_wants_up2(self):
     """cnl_conv3x3_up2_nhwc_f32 instead of Winograd for this layer when its input is nearest-2x upsampled: measured on 64 -> 512
     @64^2 -> 128^2 (861 vs 1062 us); the small neck layers (256 -> 128 @16^2: 130 vs 50 us) stay on Winograd.  Shape only."""
-    return (os.environ.get("CNL_UP2", "1") != "0" and self.kh == 3 and self.kw == 3 and self.stride == 1 and self.cin % 32 == 0
-            and self.cin <= 64 and self.cout >= 256 and self.w.is_cuda)
+    return (self.kh == 3 and self.kw == 3 and self.stride == 1 and self.cin % 32 == 0 and self.cin <= 64 and self.cout >= 256
+            and self.w.is_cuda)
 
 
 def _layer_up2(self):
@@ -166,6 +190,9 @@ class PackedWeights:
     """Device-resident, BN-folded weights of a CenterNet model (rebuilt whenever parameters change)."""
 
     def __init__(self, model, device):
+        # what the packed copy was made from: (tensor, version at packing time); Engine.forward rebuilds when a parameter or buffer was
+        # replaced or written in place since (load_state_dict on a submodule, optimizer steps, manual edits)
+        self._sources = [(t, t._version, t.data_ptr()) for t in list(model.parameters()) + list(model.buffers())]
         bb, neck, heads = model.backbone, model.neck, model.heads
         dev = lambda t: t.to(device)
         L = lambda conv, bn=None, stride=None: _Layer(*map(dev, fold_conv_bn(conv.weight, conv.bias, bn)),
@@ -231,6 +258,34 @@ class PackedWeights:
             self.fused_first = _Layer(w, b)
 
 
+    def stale(self):
+        """A source tensor was written in place (load_state_dict on a submodule, manual edits: version counter) or moved since packing."""
+        for t, v0, p0 in self._sources:
+            if t._version != v0 or t.data_ptr() != p0:
+                return True
+        return False
+
+
+_VBASE = 1 << 60        # virtual addresses of plan buffers while the plan is being built (far above any device pointer)
+
+
+class _VBuf:
+    """An activation buffer of the plan: shape + a virtual address range while the launch list is assembled; bound to its slice of
+    the plan's arena by Plan._bind (data_ptr() then returns the real address)."""
+    __slots__ = ("shape", "nbytes", "vbase", "offset", "real", "first", "last")
+
+    def __init__(self, shape, vbase):
+        self.shape = tuple(shape)
+        n = 1
+        for d in shape:
+            n *= d
+        self.nbytes = (n * 4 + 255) // 256 * 256
+        self.vbase, self.offset, self.real, self.first, self.last = vbase, None, None, None, None
+
+    def data_ptr(self):
+        return self.real if self.real is not None else self.vbase
+
+
 class _Launch:
     """One C-ABI call of the plan: `args` is a params struct (passed by reference) or a tuple of scalar / pointer arguments."""
     __slots__ = ("fn", "args", "what", "flops", "keep")
@@ -240,18 +295,119 @@ class _Launch:
 
 
 class Plan:
-    """Activation buffers + launch list for one (N, H, W, input strides, sigmoid) signature."""
+    """Activation arena + launch list for one (N, H, W, sigmoid, options, stream) signature.  A Plan is SINGLE-STREAM: its arena, its
+    absmax slots and the output pointers patched per call are private state; Engine keeps one plan per stream, so forwards on
+    different streams never share any of it."""
 
-    def __init__(self, weights: PackedWeights, N, H, W, device, sigmoid):
+    def __init__(self, weights: PackedWeights, N, H, W, device, sigmoid, options: KernelOptions = KernelOptions()):
         self.lib = _lib.load()
-        self.N, self.H, self.W, self.device, self.sigmoid = N, H, W, device, sigmoid
+        self.N, self.H, self.W, self.device, self.sigmoid, self.options = N, H, W, device, sigmoid, options
+        self.algo = options.algo_id
         self.launches = []
         self.buffers = []
+        self._vnext = _VBASE
         self.outputs = OrderedDict()      # name -> (NHWC buffer tensor [N,h,w,C])
         self.out_params = {}              # name -> ConvParams writing that output (y patched per call)
         self.stem_args = None
         self._build(weights)
         self._wire_absmax()
+        self._bind()
+
+    def _bind(self):
+        """Liveness-based placement of the activation buffers in ONE arena: a buffer lives from the first to the last launch that
+        mentions it; buffers whose lifetimes do not overlap share memory (launches are stream-ordered).  Then every virtual address
+        baked into the launch arguments is translated.  reuse_buffers=False gives each buffer its own range (tests read
+        intermediates after the run)."""
+        bases = [b.vbase for b in self.buffers]
+
+        def owner(addr):
+            if not isinstance(addr, int) or addr < _VBASE:
+                return None
+            i = bisect.bisect_right(bases, addr) - 1
+            b = self.buffers[i]
+            assert b.vbase <= addr < b.vbase + b.nbytes + 256, "virtual address outside every plan buffer"
+            return b
+
+        def pointers(L):
+            if isinstance(L.args, (ConvParams, DeconvParams)):
+                return [(L.args, f) for f in ("x", "y", "residual")]
+            if isinstance(L.args, list):
+                return [(L.args, i) for i in range(len(L.args))]
+            return []
+
+        def get(holder, key):
+            return getattr(holder, key) if isinstance(key, str) else holder[key]
+
+        fresh_y = {id(p_) for p_, _ in self.out_params.values()}          # their y is patched per call
+        for i, L in enumerate(self.launches):
+            used = [t for t in L.keep if isinstance(t, _VBuf)]
+            for holder, key in pointers(L):
+                if isinstance(key, str) and key == "y" and id(holder) in fresh_y:
+                    continue
+                b = owner(get(holder, key))
+                if b is not None:
+                    used.append(b)
+            for b in used:
+                b.first = i if b.first is None else b.first
+                b.last = i
+        self.bytes_without_reuse = sum(b.nbytes for b in self.buffers)
+        live = [b for b in self.buffers if b.first is not None]
+        if self.options.reuse_buffers:
+            free, top, active = [], 0, []                  # free: [(offset, size)], active: buffers placed and not yet expired
+            for b in sorted(live, key=lambda b_: b_.first):
+                for a_ in [a_ for a_ in active if a_.last < b.first]:
+                    active.remove(a_)
+                    free.append((a_.offset, a_.nbytes))
+                free.sort()
+                merged = []
+                for off, sz in free:                       # coalesce neighbours
+                    if merged and merged[-1][0] + merged[-1][1] == off:
+                        merged[-1] = (merged[-1][0], merged[-1][1] + sz)
+                    else:
+                        merged.append((off, sz))
+                if merged and merged[-1][0] + merged[-1][1] == top:      # a free tail gives the arena back
+                    top = merged.pop()[0]
+                free = merged
+                fit = [(sz, off) for off, sz in free if sz >= b.nbytes]
+                if fit:
+                    sz, off = min(fit)                     # best fit
+                    free.remove((off, sz))
+                    if sz > b.nbytes:
+                        free.append((off + b.nbytes, sz - b.nbytes))
+                    b.offset = off
+                else:
+                    b.offset = top
+                    top += b.nbytes
+                active.append(b)
+            total = max((b.offset + b.nbytes for b in live), default=0)
+        else:
+            total = 0
+            for b in live:
+                b.offset = total
+                total += b.nbytes
+        self.arena_bytes = total
+        self.arena = torch.empty((total // 4 + 64,), device=self.device, dtype=torch.float32)
+        base = self.arena.data_ptr()
+        for L in self.launches:
+            for holder, key in pointers(L):
+                v = get(holder, key)
+                b = owner(v)
+                if b is not None and b.offset is not None:
+                    new = base + b.offset + (v - b.vbase)
+                    if isinstance(key, str):
+                        setattr(holder, key, new)
+                    else:
+                        holder[key] = new
+        for b in live:
+            b.real = base + b.offset
+
+    def tensor(self, buf):
+        """The [N, h, w, C] view of a plan buffer in the arena (valid until a later launch reuses the range: build the plan with
+        KernelOptions(reuse_buffers=False) to read intermediates after a run)."""
+        n = 1
+        for d in buf.shape:
+            n *= d
+        return self.arena[buf.offset // 4: buf.offset // 4 + n].view(buf.shape)
 
     def _wire_absmax(self):
         """Hand the per-image maximum magnitude of a tensor from the launch that produces it to the fp16-split launches that
@@ -262,8 +418,8 @@ class Plan:
         stride-2 conv after layer1) gets an explicit cnl_absmax_per_image_f32 pass: cheaper than what the split kernel saves."""
         lib, wino, direct, up2 = self.lib, self.lib.cnl_conv3x3_winograd_f32, self.lib.cnl_conv2d_nhwc_f32, self.lib.cnl_conv3x3_up2_nhwc_f32
         self.absmax = None
-        if os.environ.get("CNL_ABSMAX_HANDOVER", "1") == "0":      # debugging: every fp16-split Winograd launch makes its own pass,
-            return                                                 # every direct conv stays on the fp32 matrix cores
+        if not self.options.absmax_handover or self.algo == CNL_ALGO_F32:   # every fp16-split Winograd launch makes its own pass,
+            return                                                        # every direct conv stays on the fp32 matrix cores
         writers, unsafe = {}, set()
         fresh_y = {id(p) for p, _ in self.out_params.values()}      # output convs: y is a fresh tensor per call (keep[1] is a placeholder)
         for L in self.launches:
@@ -271,7 +427,7 @@ class Plan:
                 if id(L.args) not in fresh_y:
                     writers.setdefault(id(L.keep[1]), []).append(L)
             else:                       # other launches: anything they hold may be written by them
-                unsafe.update(id(t) for t in L.keep if isinstance(t, torch.Tensor))
+                unsafe.update(id(t) for t in L.keep if isinstance(t, (torch.Tensor, _VBuf)))
 
         def would_split(L):             # a direct conv that takes the fp16-split kernel once it has both hints
             if (L.fn is not direct and L.fn is not up2) or not L.args.w_absmax:
@@ -285,7 +441,7 @@ class Plan:
         for L in self.launches:         # plan order: a direct conv only reports max |y| if it got its own hint
             if not isinstance(L.args, ConvParams):
                 continue
-            is_wino5 = L.fn is wino and lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)) == 5
+            is_wino5 = L.fn is wino and lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)) in (CNL_WINO_F16X2, CNL_WINO_F16X2_F4)
             if not is_wino5 and not would_split(L):
                 continue
             x = L.keep[0]
@@ -309,12 +465,13 @@ class Plan:
             a = L.args
             L.args.x_absmax = self.absmax.data_ptr() + 4 * i * self.N
             self.launches.insert(self.launches.index(L), _Launch(
-                lib.cnl_absmax_per_image_f32, (a.x, self.N, a.H_in * a.W_in, a.Cin, a.ldx, L.args.x_absmax), L.what + ".absmax",
-                0, keep=(self.absmax,)))
+                lib.cnl_absmax_per_image_f32, [a.x, self.N, a.H_in * a.W_in, a.Cin, a.ldx, L.args.x_absmax], L.what + ".absmax",
+                0, keep=(self.absmax, L.keep[0])))
 
     # -- helpers --
     def _buf(self, n, h, w, c):
-        t = torch.empty((n, h, w, c), device=self.device, dtype=torch.float32)
+        t = _VBuf((n, h, w, c), self._vnext)
+        self._vnext += t.nbytes + 4096
         self.buffers.append(t)
         return t
 
@@ -331,16 +488,18 @@ class Plan:
         p.KH, p.KW, p.stride, p.pad = layer.kh, layer.kw, layer.stride, layer.pad
         p.ldx, p.ldy, p.ldr = ldx, ldy, ldr
         p.flags = flags
+        p.algo = self.algo
         p.w_absmax = layer.wmax.data_ptr()
         ho, wo = ctypes.c_int32(), ctypes.c_int32()
         _lib.check(self.lib.cnl_conv2d_out_hw(ctypes.byref(p), ctypes.byref(ho), ctypes.byref(wo)), what)
         flops = 2 * self.N * ho.value * wo.value * layer.cout * layer.kh * layer.kw * layer.cin   # direct-conv (algorithmic) flops
         fn = self.lib.cnl_conv2d_nhwc_f32
-        if layer.u is not None and not (flags & (CNL_UPSAMPLE_OUT_ADD | CNL_SIGMOID)) and (4 * x_off) % 16 == 0:
+        if self.options.winograd and layer.u is not None and not (flags & (CNL_UPSAMPLE_OUT_ADD | CNL_SIGMOID)) and (4 * x_off) % 16 == 0:
             p.w = layer.u.data_ptr()
             fn = self.lib.cnl_conv3x3_winograd_f32
             what += " [winograd]"
-        if (flags & CNL_UPSAMPLE_IN) and not (flags & ~(CNL_RELU | CNL_UPSAMPLE_IN)) and residual is None and layer.wants_up2():
+        if (self.options.up2 and (flags & CNL_UPSAMPLE_IN) and not (flags & ~(CNL_RELU | CNL_UPSAMPLE_IN)) and residual is None
+                and layer.wants_up2()):
             # short channel loop, many couts, conv on the nearest-2x upsampled input (the fused first head blocks behind the simple
             # neck): four 2x2 sub-pixel phase convs on the low-resolution input (fp16-split direct kernel) beat Winograd there
             p.w = layer.up2().data_ptr()
@@ -354,8 +513,8 @@ class Plan:
         """Separable conv (layers.py:56-69): depthwise 3x3 + BN + ReLU6 -> pointwise 1x1 + BN + ReLU6."""
         t = self._buf(self.N, xh, xw, layer.cin)
         self.launches.append(_Launch(self.lib.cnl_depthwise3x3_nhwc_f32,
-                                     (x.data_ptr(), layer.dw_w.data_ptr(), layer.dw_b.data_ptr(), t.data_ptr(), self.N, xh, xw,
-                                      layer.cin, ldx, layer.cin, CNL_RELU6), what + ".dw", 0, keep=(x, t, layer)))
+                                     [x.data_ptr(), layer.dw_w.data_ptr(), layer.dw_b.data_ptr(), t.data_ptr(), self.N, xh, xw,
+                                      layer.cin, ldx, layer.cin, CNL_RELU6], what + ".dw", 0, keep=(x, t, layer)))
         self._conv(layer.pw, t, xh, xw, layer.cin, y, ldy, CNL_RELU6, what=what + ".pw")
         return xh, xw
 
@@ -367,8 +526,8 @@ class Plan:
         kk = layer.k * layer.k
         col = self._buf(self.N, xh, xw, kk * layer.cin)
         self.launches.append(_Launch(self.lib.cnl_deform_sample_nhwc_f32,
-                                     (x.data_ptr(), om.data_ptr(), col.data_ptr(), self.N, xh, xw, layer.cin, ldx, no, layer.k,
-                                      int(layer.has_mask)), what + ".sample", 0, keep=(x, om, col)))
+                                     [x.data_ptr(), om.data_ptr(), col.data_ptr(), self.N, xh, xw, layer.cin, ldx, no, layer.k,
+                                      int(layer.has_mask)], what + ".sample", 0, keep=(x, om, col)))
         self._conv(layer.gemm, col, xh, xw, kk * layer.cin, y, ldy, CNL_RELU, what=what + ".deform_conv (GEMM)")
         return xh, xw
 
@@ -387,8 +546,8 @@ class Plan:
         """nn.Upsample x2 (0 nearest / 1 bilinear) materialised, + optional Fuse sum.  Returns the new buffer."""
         y = self._buf(self.N, 2 * xh, 2 * xw, c)
         self.launches.append(_Launch(self.lib.cnl_upsample2x_nhwc_f32,
-                                     (x.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(), self.N, xh, xw,
-                                      c, ldx, ldr, c, mode), what, 0, keep=(x, y, residual)))
+                                     [x.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(), self.N, xh, xw,
+                                      c, ldx, ldr, c, mode], what, 0, keep=(x, y, residual)))
         return y
 
     def _deconv(self, layer, x, xh, xw, ldx, what, residual=None, ldr=0):
@@ -415,13 +574,14 @@ class Plan:
         cur = self._buf(N, h4, w4, 64)
         # the stride-2 feature map is only materialised when a neck consumes it (an FPN with four Fuse levels); otherwise the stem
         # kernel pools its own tile and the 64-channel map at half resolution never reaches memory (cnl_stem_conv7x7_maxpool_f32)
-        need_s1 = (Wt.neck_kind != "SimpleNeck" and len(Wt.fuse) >= 4) or os.environ.get("CNL_STEM_FUSED_POOL", "1") == "0" or os.environ.get("CNL_STEM_F16X2", "1") == "0"
+        need_s1 = (Wt.neck_kind != "SimpleNeck" and len(Wt.fuse) >= 4) or not self.options.stem_fused_pool or self.algo == CNL_ALGO_F32
         s1 = self._buf(N, h2, w2, 64) if need_s1 else None
         self.stem_out = s1 if need_s1 else cur
         self.stem_fused_pool = not need_s1
-        self.launches.append(_Launch("stem", None, "stem7x7+bn+relu" + ("" if need_s1 else "+maxpool3x3s2"), 2 * N * h2 * w2 * 64 * 147))
+        self.launches.append(_Launch("stem", None, "stem7x7+bn+relu" + ("" if need_s1 else "+maxpool3x3s2"), 2 * N * h2 * w2 * 64 * 147,
+                                     keep=(self.stem_out,)))
         if need_s1:
-            self.launches.append(_Launch("maxpool", (s1, cur, N, h2, w2, 64), "maxpool3x3s2"))
+            self.launches.append(_Launch("maxpool", (s1, cur, N, h2, w2, 64), "maxpool3x3s2", keep=(s1, cur)))
         ch, cw, cc = h4, w4, 64
         feats = {}
         for bi, (c1, c2, down, li) in enumerate(Wt.blocks):
@@ -506,6 +666,7 @@ class Plan:
         self.out_hw = (oh_, ow_)
 
         # ---- heads ----
+        self.head_features = {}
         first = {}
         if Wt.fused_first is not None:
             tot = Wt.fused_first.cout
@@ -528,6 +689,7 @@ class Plan:
                 y = self._buf(N, oh_, ow_, layer.cout)
                 self._conv(layer, x, xh, xw, ldx, y, layer.cout, CNL_RELU | up, what=f"heads.{name}.block", x_off=xoff)
                 x, ldx, xoff, xc, xh, xw, up = y, layer.cout, 0, layer.cout, oh_, ow_, 0
+            self.head_features[name] = (x, ldx, xoff, xc, xh, xw, up)      # what out_conv reads (tests: feature-level parity gate)
             outl = Wt.head_out[name]
             flags = up | (CNL_SIGMOID if (name == "heatmap" and self.sigmoid) else 0)
             # output buffer is allocated fresh per call (ownership passes to the caller); patched in run()
@@ -548,21 +710,27 @@ class Plan:
         if self.absmax is not None:
             self.absmax.zero_()                                # the producers fold max |y| into these with atomic max
         for L in self.launches:
-            if L.fn == "stem":
-                sn, sc, sh, sw = x.stride()
-                fn = lib.cnl_stem_conv7x7_maxpool_f32 if self.stem_fused_pool else lib.cnl_stem_conv7x7_f32
-                rc = fn(x.data_ptr(), sn, sc, sh, sw, self._wt_stem_packed.data_ptr(), self._wt_stem.b.data_ptr(),
-                        self.stem_out.data_ptr(), self.N, self.H, self.W, stream)
-            elif L.fn == "maxpool":
-                src, dst, n, h, w, c = L.args
-                rc = lib.cnl_maxpool3x3s2_nhwc_f32(src.data_ptr(), dst.data_ptr(), n, h, w, c, stream)
-            elif isinstance(L.args, tuple):
-                rc = L.fn(*L.args, stream)
-            else:
-                rc = L.fn(ctypes.byref(L.args), stream)
+            rc = self.launch(L, x, stream)
             if rc != 0:
                 _lib.check(rc, L.what)
         return OrderedDict((k, v.permute(0, 3, 1, 2)) for k, v in outs.items())
+
+    def launch(self, L, x, stream):
+        """Issue ONE launch of the plan (x: the forward's input, read by the stem only).  Returns the C ABI's return code."""
+        lib = self.lib
+        if L.fn == "stem":
+            sn, sc, sh, sw = x.stride()
+            if self.stem_fused_pool:
+                return lib.cnl_stem_conv7x7_maxpool_f32(x.data_ptr(), sn, sc, sh, sw, self._wt_stem_packed.data_ptr(), self._wt_stem.b.data_ptr(),
+                                                        self.stem_out.data_ptr(), self.N, self.H, self.W, stream)
+            return lib.cnl_stem_conv7x7_f32(x.data_ptr(), sn, sc, sh, sw, self._wt_stem_packed.data_ptr(), self._wt_stem.b.data_ptr(),
+                                            self.stem_out.data_ptr(), self.N, self.H, self.W, self.algo, stream)
+        if L.fn == "maxpool":
+            src, dst, n, h, w, c = L.args
+            return lib.cnl_maxpool3x3s2_nhwc_f32(src.data_ptr(), dst.data_ptr(), n, h, w, c, stream)
+        if isinstance(L.args, list):
+            return L.fn(*L.args, stream)
+        return L.fn(ctypes.byref(L.args), stream)
 
     def total_flops(self):
         return sum(L.flops for L in self.launches)
@@ -575,10 +743,18 @@ class Engine:
         self.model = model
         self.weights = None
         self.plans = {}
+        self.options = KernelOptions()
 
     def invalidate(self):
         self.weights = None
         self.plans.clear()
+
+    def set_options(self, **kw):
+        """Replace kernel options (KernelOptions fields); plans are keyed by them, so nothing else needs invalidating."""
+        opts = KernelOptions(**{**self.options.__dict__, **kw})
+        opts.algo_id                                   # validates
+        self.options = opts
+        return opts
 
     def forward(self, x, sigmoid):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
@@ -589,7 +765,7 @@ class Engine:
         if x.dtype != torch.float32:
             raise ValueError(f"expected float32 input, got {x.dtype}")
         dev = x.device
-        if self.weights is None or self.weights_device != dev:
+        if self.weights is None or self.weights_device != dev or self.weights.stale():
             self.weights = PackedWeights(self.model, dev)
             self.weights_device = dev
             self.plans.clear()
@@ -618,11 +794,18 @@ class Engine:
     def _run(self, x, sigmoid):
         dev = x.device
         N, _, H, W = x.shape
-        key = (N, H, W, bool(sigmoid))
+        # one plan per stream: its arena, absmax slots and patched output pointers are private to that stream's launch order
+        key = (N, H, W, bool(sigmoid), self.options, torch.cuda.current_stream(dev).cuda_stream)
         plan = self.plans.get(key)
         if plan is None:
             with torch.cuda.device(dev):
-                plan = Plan(self.weights, N, H, W, dev, bool(sigmoid))
+                plan = Plan(self.weights, N, H, W, dev, bool(sigmoid), self.options)
             self.plans[key] = plan
         with torch.cuda.device(dev):
             return plan.run(x)
+
+    def plan_for(self, x, sigmoid=True):
+        """The (existing) plan a forward of x on the current stream uses — bench / tests introspection."""
+        N, _, H, W = x.shape
+        n_sub = self.sub_batch(N, H, W)
+        return self.plans[(n_sub, H, W, bool(sigmoid), self.options, torch.cuda.current_stream(x.device).cuda_stream)]

@@ -110,8 +110,14 @@ class CenterNet(nn.Module):
         return out
 
     def refresh_weights(self):
-        """Call after mutating parameters in place (re-folds BatchNorm and re-packs OHWI weights)."""
+        """Force re-folding of BatchNorm and re-packing of the OHWI weights.  Not normally needed: the engine notices in-place
+        writes to any parameter / buffer (version counters; e.g. model.backbone.load_state_dict(...)) before the next forward."""
         self._engine.invalidate()
+
+    def set_kernel_options(self, **kw):
+        """Kernel choice of the launch plan, explicit and per model (engine.KernelOptions): algo="auto" | "f2" | "f32", winograd,
+        up2, absmax_handover, stem_fused_pool, reuse_buffers.  The HIP library reads no environment variables."""
+        return self._engine.set_options(**kw)
 
     def train(self, mode: bool = True):
         if mode:

@@ -16,6 +16,20 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+int cu_count(int dev, int* n_cu) {
+    static std::atomic<int> cache[64];          // zero-initialised; one slot per device ordinal
+    int v = cache[dev & 63].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        hipDeviceProp_t prop;
+        hipError_t e_ = hipGetDeviceProperties(&prop, dev);
+        if (e_ != hipSuccess) return fail(CNL_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e_));
+        v = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cache[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    *n_cu = v;
+    return CNL_OK;
+}
+
 }  // namespace cnl
 
 extern "C" int cnl_version(void) { return CNL_ABI_VERSION; }

@@ -1,6 +1,7 @@
 // Shared host-side helpers for libcenternet_gfx950.so (error reporting, launch checks).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -35,6 +36,27 @@ inline int check_launch(const char* what) {
         hipError_t e_ = (call);                                                           \
         if (e_ != hipSuccess) return ::cnl::fail(CNL_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
+
+// One-time, PER-DEVICE launch setup of a kernel (one process may drive several devices: hipFuncSetAttribute applies to the current
+// device only, so a process-wide `static bool done` would leave every later device with the default dynamic-LDS limit and failing
+// launches).  A bit per device ordinal in an atomic word: lock-free, and a lost race merely repeats an idempotent call.  The C ABI
+// returns error codes, which std::call_once cannot carry out of its callable without exceptions — hence the atomic form.
+struct DeviceOnce {
+    std::atomic<unsigned long long> done{0};
+};
+int cu_count(int dev, int* n_cu);      // cnl_api.hip: cached multiProcessorCount of device `dev`
+inline int kernel_setup(DeviceOnce& once, const void* fn, int lds_bytes, int* n_cu = nullptr) {
+    int dev = 0;
+    hipError_t e_ = hipGetDevice(&dev);
+    if (e_ != hipSuccess) return fail(CNL_E_HIP, "hipGetDevice: %s", hipGetErrorString(e_));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(once.done.load(std::memory_order_acquire) & bit)) {
+        e_ = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e_ != hipSuccess) return fail(CNL_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize, %d): %s", lds_bytes, hipGetErrorString(e_));
+        once.done.fetch_or(bit, std::memory_order_release);
+    }
+    return n_cu ? cu_count(dev, n_cu) : CNL_OK;
+}
 
 // XCD-aware, bijective remap of a 1-D block id: the hardware places block b on XCD b % 8; give each
 // XCD a contiguous chunk of logical tile ids so neighbouring tiles share that XCD's private L2.

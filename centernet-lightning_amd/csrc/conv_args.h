@@ -29,6 +29,7 @@ struct ConvArgs {
     const float* xmax;                   // fp16-split kernel (conv_f16x2.hip): per-image max |x| (N floats), max |w| (1 float),
     const float* wmax;
     unsigned* ymax;                      // and where max |y| per image is folded into (or null)
+    unsigned algo;                       // cnl_conv_params.algo (CNL_ALGO_*)
     const float* wscale;                 // sub-pixel phases (SUB): the power-of-two scale of the PRE-SPLIT weights a.w points to
 };
 

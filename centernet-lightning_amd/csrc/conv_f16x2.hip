@@ -321,12 +321,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
 template <int WM, int WN, int TM, int TN, int KS, bool SUB>
 static int launch_one5(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<WM, WN, TM, TN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16x2_kernel<WM, WN, TM, TN, KS, SUB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static cnl::DeviceOnce once;            // one per template instantiation
+    const int rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&conv_f16x2_kernel<WM, WN, TM, TN, KS, SUB>), 160 * 1024);
+    if (rc != CNL_OK) return rc;
     hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, TM, TN, KS, SUB>), dim3(a.tiles), dim3(C::THREADS), C::LDS_BYTES + C::BM * 16, stream, a);
     return cnl::check_launch("conv_f16x2_kernel");
 }
@@ -345,22 +342,17 @@ static int launch_cfg5(const ConvArgs& in, hipStream_t stream) {
 // which launches the fp16-split kernel covers: the caller handed over both maxima, square 1x1 / 3x3 kernel, no input upsampling,
 // no 2x scatter epilogue; 1x1 convs only where the matrix work dominates (>= 2^20 outputs per image: the 80-class heatmap conv
 // -20 %; the short-K downsample / lateral / box convs are latency- or HBM-bound and lose 5-15 % to the split).  A function of the
-// layer shape per image, never of the batch.  CNL_CONV_F16X2=0 keeps everything on the fp32 matrix cores.
+// layer shape per image, never of the batch.  algo = CNL_ALGO_F32 keeps the launch on the fp32 matrix cores; CNL_ALGO_FORCE + 5 takes
+// this kernel for every 1x1 size (tests).
 bool f16x2_eligible(const ConvArgs& a) {
-    static const bool enabled = !(getenv("CNL_CONV_F16X2") && atoi(getenv("CNL_CONV_F16X2")) == 0);
-    static const long long min_out_1x1 = getenv("CNL_CONV_F16X2_MIN1X1") ? atoll(getenv("CNL_CONV_F16X2_MIN1X1")) : (1ll << 20);
-    if (!(enabled && a.xmax) || (a.flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD))) return false;
+    const long long min_out_1x1 = a.algo == CNL_ALGO_FORCE + 5 ? 0 : (1ll << 20);
+    if (a.algo == CNL_ALGO_F32 || !a.xmax || (a.flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD))) return false;
     if (a.flags & CNL_I_SUBPIXEL) return a.KH == 2 && a.KW == 2 && !a.res && a.wscale;       // the phases of cnl_conv3x3_up2_nhwc_f32
     return a.wmax && a.KH == a.KW && (a.KH == 1 || a.KH == 3) && a.pad == a.pad_x && (a.KH == 3 || (long long)a.Ho * a.Wo * a.Cout >= min_out_1x1);
 }
 
 int f16x2_launch(const ConvArgs& a, hipStream_t s) {
     // Tile choice: BN follows Cout; shrink BM when the grid would not fill 256 CUs x 2 workgroups (as conv_mfma.hip).
-    static const int force = getenv("CNL_CONV5_CFG") ? atoi(getenv("CNL_CONV5_CFG")) : 0;      // experiments
-    if (force == 1) return launch_cfg5<4, 1, 2, 2>(a, s);
-    if (force == 2) return launch_cfg5<2, 2, 1, 2>(a, s);
-    if (force == 3) return launch_cfg5<2, 2, 2, 2>(a, s);
-    if (force == 4) return launch_cfg5<4, 1, 1, 3>(a, s);
     if (a.Cout <= 32) return launch_cfg5<4, 1, 2, 1>(a, s);         // 256 x 32
     if (a.Cout <= 64) return launch_cfg5<4, 1, 2, 2>(a, s);         // 256 x 64
     if (a.Cout <= 96) return launch_cfg5<4, 1, 1, 3>(a, s);         // 128 x 96

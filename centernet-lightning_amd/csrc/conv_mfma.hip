@@ -379,14 +379,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 template <int WM, int WN, int TM, int TN, int KS, bool UP_IN>
 int launch_one(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<WM, WN, TM, TN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, KS, UP_IN>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
-    static const int lds_extra = getenv("CNL_LDS_EXTRA") ? atoi(getenv("CNL_LDS_EXTRA")) : 0;   // experiments: force 1 workgroup/CU
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, KS, UP_IN>), dim3(a.tiles), dim3(C::THREADS), C::LDS_BYTES + lds_extra, stream, a);
+    static cnl::DeviceOnce once;            // one per template instantiation
+    const int rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, KS, UP_IN>), 160 * 1024);
+    if (rc != CNL_OK) return rc;
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, KS, UP_IN>), dim3(a.tiles), dim3(C::THREADS), C::LDS_BYTES, stream, a);
     return cnl::check_launch("conv_mfma_kernel");
 }
 
@@ -464,7 +460,7 @@ extern "C" int cnl_conv2d_kernel(const cnl_conv_params* p) {
     CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv2d_kernel: null params");
     ConvArgs a;
     a.KH = p->KH; a.KW = p->KW; a.pad = a.pad_x = p->pad; a.flags = p->flags; a.Cout = p->Cout;
-    a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.wscale = nullptr; a.res = p->residual;
+    a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.wscale = nullptr; a.res = p->residual; a.algo = p->algo;
     int32_t ho = 0, wo = 0;
     const int rc = cnl_conv2d_out_hw(p, &ho, &wo);
     if (rc != CNL_OK) return rc;
@@ -498,7 +494,7 @@ extern "C" int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream) {
     a.sub_dy = a.sub_dx = 0;
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
     a.flags = p->flags;
-    a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax); a.wscale = nullptr;
+    a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax); a.wscale = nullptr; a.algo = p->algo;
     const int up = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
     a.HL = p->H_in * up; a.WL = p->W_in * up;
     a.Ho = (a.HL + 2 * p->pad - p->KH) / p->stride + 1;
@@ -618,7 +614,7 @@ static void up2_phase(const cnl_conv_params* p, int dy, int dx, ConvArgs& a) {
     a.sub_dy = dy; a.sub_dx = dx;
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = 0;
     a.flags = (p->flags & (CNL_RELU | CNL_RELU6)) | CNL_I_SUBPIXEL;
-    a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
+    a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax); a.algo = p->algo;
     a.HL = p->H_in; a.WL = p->W_in;
     a.Ho = p->H_in; a.Wo = p->W_in;
     if (f16x2_eligible(a)) a.w += total;                          // the fp16-split kernel multiplies the pre-split copy
@@ -692,7 +688,7 @@ extern "C" int cnl_deconv2x_nhwc_f32(const cnl_deconv_params* p, void* stream) {
             a.sub_dy = dy; a.sub_dx = dx;
             a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
             a.flags = p->flags | CNL_I_SUBPIXEL;
-            a.xmax = a.wmax = a.wscale = nullptr; a.ymax = nullptr;
+            a.xmax = a.wmax = a.wscale = nullptr; a.ymax = nullptr; a.algo = CNL_ALGO_AUTO;
             a.HL = p->H_in; a.WL = p->W_in;
             a.Ho = p->H_in; a.Wo = p->W_in;
             const int rc = finish_and_launch(a, true, "cnl_deconv2x_nhwc_f32", (hipStream_t)stream);

@@ -193,7 +193,7 @@ extern "C" int cnl_stem_pack_weights_f32(const float* w_ohwi, float* w_packed, v
 }
 
 static int stem_launch(const char* who, bool pool, const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
-                       const float* bias, float* y, int32_t N, int32_t H, int32_t W, void* stream) {
+                       const float* bias, float* y, int32_t N, int32_t H, int32_t W, uint32_t algo, void* stream) {
     CNL_REQUIRE(x && w && bias && y, CNL_E_BAD_ARG, "%s: null tensor pointer", who);
     CNL_REQUIRE(N > 0 && H > 0 && W > 0, CNL_E_BAD_ARG, "%s: non-positive dimension", who);
     CNL_REQUIRE(sc > 0 && sh > 0 && sw > 0 && sn >= 0, CNL_E_UNSUPPORTED, "%s: non-positive strides", who);
@@ -204,29 +204,27 @@ static int stem_launch(const char* who, bool pool, const float* x, int64_t sn, i
     const int tiles_x = (Wo + ST_TW - 1) / ST_TW, tiles_y = (Ho + ST_TH - 1) / ST_TH;
     const long long blocks = (long long)N * tiles_x * tiles_y;
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "%s: grid too large", who);
-    static const bool f16x2 = !(getenv("CNL_STEM_F16X2") && atoi(getenv("CNL_STEM_F16X2")) == 0);      // 0: fp32 matrix cores
-    if (f16x2 || pool)           // (the fused max-pool exists in the fp16-split kernel only)
+    CNL_REQUIRE(algo <= CNL_ALGO_F32, CNL_E_BAD_ARG, "%s: unknown algo %u", who, algo);
+    if (algo != CNL_ALGO_F32 || pool)           // (the fused max-pool exists in the fp16-split kernel only)
         return cnl_stem5_launch(x, (long)sn, (int)sc, (int)sh, (int)sw, (unsigned)img_bytes, w + ST_KP * 64, bias, y, N, H, W, Ho, Wo,
                                 tiles_x, tiles_y, (unsigned)blocks, pool, stream);
-    static bool attr_done = false;
     const int lds = ST_LDS_BYTES;
-    if (!attr_done) {
-        CNL_HIP(hipFuncSetAttribute((const void*)stem_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
-    }
+    static cnl::DeviceOnce once;
+    const int rc = cnl::kernel_setup(once, (const void*)stem_conv_kernel, lds);
+    if (rc != CNL_OK) return rc;
     hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, (long)sn, (int)sc,
                        (int)sh, (int)sw, (unsigned)img_bytes, w, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y);
     return cnl::check_launch("stem_conv_kernel");
 }
 
 extern "C" int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
-                                    const float* bias, float* y, int32_t N, int32_t H, int32_t W, void* stream) {
-    return stem_launch("cnl_stem_conv7x7_f32", false, x, sn, sc, sh, sw, w, bias, y, N, H, W, stream);
+                                    const float* bias, float* y, int32_t N, int32_t H, int32_t W, uint32_t algo, void* stream) {
+    return stem_launch("cnl_stem_conv7x7_f32", false, x, sn, sc, sh, sw, w, bias, y, N, H, W, algo, stream);
 }
 
 extern "C" int cnl_stem_conv7x7_maxpool_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
                                             const float* bias, float* y, int32_t N, int32_t H, int32_t W, void* stream) {
-    return stem_launch("cnl_stem_conv7x7_maxpool_f32", true, x, sn, sc, sh, sw, w, bias, y, N, H, W, stream);
+    return stem_launch("cnl_stem_conv7x7_maxpool_f32", true, x, sn, sc, sh, sw, w, bias, y, N, H, W, CNL_ALGO_AUTO, stream);
 }
 
 extern "C" int cnl_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {

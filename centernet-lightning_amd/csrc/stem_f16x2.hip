@@ -340,12 +340,10 @@ int cnl_stem5_pack(const float* w_ohwi, float* extra, void* stream) {
 
 int cnl_stem5_launch(const float* x, long sn, int sc, int sh, int sw, unsigned img_bytes, const float* extra, const float* bias, float* y,
                      int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y, unsigned blocks, bool pool, void* stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        CNL_HIP(hipFuncSetAttribute((const void*)stem_f16x2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        CNL_HIP(hipFuncSetAttribute((const void*)stem_f16x2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_done = true;
-    }
+    static cnl::DeviceOnce once_plain, once_pool;
+    int rc = cnl::kernel_setup(once_plain, (const void*)stem_f16x2_kernel<false>, LDS_BYTES);
+    if (rc == CNL_OK) rc = cnl::kernel_setup(once_pool, (const void*)stem_f16x2_kernel<true>, LDS_BYTES);
+    if (rc != CNL_OK) return rc;
     if (pool) {                  // the border cells are merged with atomic max: start from +0 everywhere
         const size_t Hp = (size_t)(Ho - 1) / 2 + 1, Wp = (size_t)(Wo - 1) / 2 + 1;
         CNL_HIP(hipMemsetAsync(y, 0, (size_t)N * Hp * Wp * 64 * sizeof(float), (hipStream_t)stream));

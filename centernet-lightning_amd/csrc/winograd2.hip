@@ -398,20 +398,11 @@ int cnl_wino2_launch(const cnl_conv_params* p, size_t u_floats, void* stream) {
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.flags = p->flags;
-    static bool attr_done = false;
-    if (!attr_done) {
-        CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_done = true;
-    }
-    // persistent workgroups: two per CU (76 KB of LDS each), walking the work items with stride gridDim.x
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        CNL_HIP(hipGetDevice(&dev));
-        CNL_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    // persistent workgroups: two per CU (45 KB of LDS each), walking the work items with stride gridDim.x
+    static cnl::DeviceOnce once;
+    int n_cu = 0;
+    const int rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd2_kernel), LDS_BYTES, &n_cu);
+    if (rc != CNL_OK) return rc;
     const unsigned grid = (unsigned)(blocks < 2ll * n_cu ? blocks : 2ll * n_cu);
     hipLaunchKernelGGL(winograd2_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return cnl::check_launch("winograd2_kernel");

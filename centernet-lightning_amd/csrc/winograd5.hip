@@ -14,7 +14,6 @@
 // launch, result left in the layer's weight buffer); the weights carry their own scale, fixed when they are transformed.
 // Structure (work item, wave roles, wave-private single-buffered V, patch DMA, one barrier per chunk): winograd3.hip.
 #include "cnl_common.h"
-#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -615,6 +614,19 @@ extern "C" int cnl_absmax_per_image_f32(const float* x, int32_t N, int64_t pixel
     return cnl::check_launch("absmax_kernel");
 }
 
+// max |x| per image of p's input into scal[16 + n] (the layer's scratch: callers without the x_absmax hint; one such launch at a
+// time per layer — the hint-carrying plan of engine.py never comes here)
+int cnl_wino5_own_absmax(const cnl_conv_params* p, float* scal, void* stream) {
+    CNL_REQUIRE(p->N <= 4096, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: more than 4096 images per launch need x_absmax");
+    CNL_HIP(hipMemsetAsync(scal + 16, 0, sizeof(float) * (size_t)p->N, (hipStream_t)stream));
+    const long long vec4 = (long long)p->H_in * p->W_in * (p->Cin / 4);         // per image
+    const long long want = (vec4 + 256 * 16 - 1) / (256 * 16);                  // >= 16 float4 per thread
+    const unsigned mgrid = (unsigned)(want < 1 ? 1 : (want > 64 ? 64 : want));
+    hipLaunchKernelGGL(cnl_wino5::absmax_kernel, dim3(mgrid, (unsigned)p->N), dim3(256), 0, (hipStream_t)stream, p->x, (long)p->H_in * p->W_in,
+                       p->Cin, p->ldx, reinterpret_cast<unsigned*>(scal + 16));
+    return cnl::check_launch("absmax_kernel");
+}
+
 // Launch (arguments already validated by cnl_conv3x3_winograd_f32); u5 = the fp16-split weights, scal = the layer's scalars.
 int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream) {
     using namespace cnl_wino5;
@@ -641,31 +653,14 @@ int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.flags = p->flags;
-    static const int order_env = getenv("CNL_W5_ORDER") ? atoi(getenv("CNL_W5_ORDER")) : 2;   // measured: 2 best (profiles/r01_winograd_variants.txt)
-    a.order = (order_env == 2 && (a.nb & 1)) ? 0 : order_env;
-    static bool attr_done = false;
-    if (!attr_done) {
-        CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_done = true;
-    }
-    static int n_cu = 0;         // persistent workgroups: one per CU, walking the work items with stride gridDim.x
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        CNL_HIP(hipGetDevice(&dev));
-        CNL_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    a.order = (a.nb & 1) ? 0 : 2;          // pairs of cout blocks fastest: measured best (profiles/r01_winograd_variants.txt)
+    static cnl::DeviceOnce once;
+    int n_cu = 0;                          // persistent workgroups: one per CU, walking the work items with stride gridDim.x
+    int rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd5_kernel), LDS_BYTES, &n_cu);
+    if (rc != CNL_OK) return rc;
     // the scale of the activations: max |x| of this launch's input — handed over by the producer (x_absmax), else one pass over it
     // (stream-ordered before the convolution)
-    if (!p->x_absmax) {
-    CNL_HIP(hipMemsetAsync(scal + 16, 0, sizeof(float) * (size_t)p->N, (hipStream_t)stream));
-    const long long vec4 = (long long)p->H_in * p->W_in * (p->Cin / 4);         // per image
-    const long long want = (vec4 + 256 * 16 - 1) / (256 * 16);                  // >= 16 float4 per thread
-    const unsigned mgrid = (unsigned)(want < 1 ? 1 : (want > 64 ? 64 : want));
-    hipLaunchKernelGGL(absmax_kernel, dim3(mgrid, (unsigned)p->N), dim3(256), 0, (hipStream_t)stream, p->x, (long)p->H_in * p->W_in,
-                       p->Cin, p->ldx, reinterpret_cast<unsigned*>(scal + 16));
-    }
+    if (!p->x_absmax && (rc = cnl_wino5_own_absmax(p, scal, stream)) != CNL_OK) return rc;
     const unsigned grid = (unsigned)(blocks < (long long)n_cu ? blocks : (long long)n_cu);
     hipLaunchKernelGGL(winograd5_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return cnl::check_launch("winograd5_kernel");

@@ -10,7 +10,6 @@
 //   transform work per position slot; V wave-private and single-buffered as in winograd5; LDS 88 KB.
 // Used where Cout is a multiple of 128 (cnl_conv3x3_winograd_f32's dispatch); everything else as winograd5.hip.
 #include "cnl_common.h"
-#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -519,6 +518,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 }  // namespace cnl_wino6
 
 size_t cnl_wino5_weight_bytes(int Cin, int Cout);      // winograd5.hip: the weight layout, scales and scalars are shared
+int cnl_wino5_own_absmax(const cnl_conv_params* p, float* scal, void* stream);
 
 // Launch (arguments already validated by cnl_conv3x3_winograd_f32); u5 = the fp16-split weights, scal = the layer's scalars.
 int cnl_wino6_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream) {
@@ -546,31 +546,12 @@ int cnl_wino6_launch(const cnl_conv_params* p, const void* u5, float* scal, void
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.flags = p->flags;
-    static const int order_env = getenv("CNL_W6_ORDER") ? atoi(getenv("CNL_W6_ORDER")) : 2;   // measured: 2 best (profiles/r01_winograd_variants.txt)
-    a.order = (order_env == 2 && (a.nb & 1)) ? 0 : order_env;
-    static bool attr_done = false;
-    if (!attr_done) {
-        CNL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_done = true;
-    }
-    static int n_cu = 0;         // persistent workgroups: one per CU, walking the work items with stride gridDim.x
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        CNL_HIP(hipGetDevice(&dev));
-        CNL_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    // the scale of the activations: max |x| of this launch's input — handed over by the producer (x_absmax), else one pass over it
-    // (stream-ordered before the convolution)
-    if (!p->x_absmax) {
-    CNL_HIP(hipMemsetAsync(scal + 16, 0, sizeof(float) * (size_t)p->N, (hipStream_t)stream));
-    const long long vec4 = (long long)p->H_in * p->W_in * (p->Cin / 4);         // per image
-    const long long want = (vec4 + 256 * 16 - 1) / (256 * 16);                  // >= 16 float4 per thread
-    const unsigned mgrid = (unsigned)(want < 1 ? 1 : (want > 64 ? 64 : want));
-    hipLaunchKernelGGL(absmax_kernel, dim3(mgrid, (unsigned)p->N), dim3(256), 0, (hipStream_t)stream, p->x, (long)p->H_in * p->W_in,
-                       p->Cin, p->ldx, reinterpret_cast<unsigned*>(scal + 16));
-    }
+    a.order = (a.nb & 1) ? 0 : 2;          // pairs of cout blocks fastest (profiles/r01_winograd_variants.txt)
+    static cnl::DeviceOnce once;
+    int n_cu = 0;                          // persistent workgroups: one per CU, walking the work items with stride gridDim.x
+    int rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd6_kernel), LDS_BYTES, &n_cu);
+    if (rc != CNL_OK) return rc;
+    if (!p->x_absmax && (rc = cnl_wino5_own_absmax(p, scal, stream)) != CNL_OK) return rc;      // winograd5.hip
     const unsigned grid = (unsigned)(blocks < (long long)n_cu ? blocks : (long long)n_cu);
     hipLaunchKernelGGL(winograd6_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return cnl::check_launch("winograd6_kernel");

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 4   /* 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 5   /* 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -35,6 +35,24 @@ enum {
     CNL_E_UNSUPPORTED = -2,  /* shape outside what the gfx950 kernels cover (e.g. Cin % 32 != 0)     */
     CNL_E_WORKSPACE = -3,    /* workspace pointer null / too small (see cnl_decode_workspace_bytes)  */
     CNL_E_HIP = -4           /* a HIP runtime call failed; text in cnl_last_error()                  */
+};
+
+/*
+ * cnl_conv_params.algo / the `algo` argument of cnl_stem_conv7x7_f32: the ARITHMETIC CLASS the caller allows for a launch.  Inside a class
+ * the kernel is a function of the layer shape and the hints alone — never of the batch size, never of the environment.
+ *   CNL_ALGO_AUTO  fastest fp32-grade kernel.  fp32 in / fp32 accumulate / fp32 out everywhere; where it pays, each fp32 product is
+ *                  formed on the fp16 matrix cores from a scaled two-way fp16 split of both operands (three cross terms), and the long
+ *                  3x3 layers may use Winograd F(4x4,3x3) (csrc/winograd8.hip: error ~1e-6 of the layer's largest output, ~4x F(2x2)).
+ *   CNL_ALGO_F2    the same without F(4x4,3x3): every kernel's error against float64 is at or below the fp32 matrix core's.
+ *   CNL_ALGO_F32   fp32 matrix cores only (v_mfma_f32_32x32x2_f32), no split operands anywhere; hints are ignored.
+ *   CNL_ALGO_FORCE + v  tests / A-B measurements: pin kernel variant v (2, 5, 6, 8; 1, 3, 4, 7 in `make experiments` builds) wherever
+ *                  it can run at all.
+ */
+enum {
+    CNL_ALGO_AUTO = 0,
+    CNL_ALGO_F2 = 1,
+    CNL_ALGO_F32 = 2,
+    CNL_ALGO_FORCE = 100
 };
 
 /* epilogue / gather flags of cnl_conv2d_nhwc_f32 */
@@ -85,6 +103,7 @@ typedef struct cnl_conv_params {
      * on the fp16 matrix cores from scaled two-way splits of both operands (csrc/conv_f16x2.hip: same error against float64 as
      * the fp32 matrix-core kernel, 2-3x faster) and honour y_absmax; without them the fp32 matrix-core kernel runs.             */
     const float* w_absmax;
+    uint32_t algo;          /* CNL_ALGO_* (0 = CNL_ALGO_AUTO)                                                                       */
 } cnl_conv_params;
 
 int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream);
@@ -123,16 +142,19 @@ int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);
  * `p->w` must point to the PRE-TRANSFORMED weights produced by cnl_winograd_transform_weights_f32 from the OHWI
  * (BN-folded) weights; flags: CNL_RELU only (upsample / sigmoid variants stay on cnl_conv2d_nhwc_f32). Cin % 8 == 0.
  *
- * Several multiplier arrays serve this entry point, chosen from the layer SHAPE alone (never the batch size): the fp32 matrix
+ * Several multiplier arrays serve this entry point, chosen from the layer SHAPE and p->algo (never the batch size): the fp32 matrix
  * core (csrc/winograd2.hip), or — where the channel loop is long (Cin >= 128 or Cout >= 512, Cin % 16 == 0) — the fp16 matrix core
- * fed with a two-way fp16 split of both fp32 operands under a per-tensor power-of-two scale (three cross terms, fp32
- * accumulation: csrc/winograd5.hip; measured error at or below the fp32 matrix core's, half-precision rate = 16x).  The exact,
- * range-preserving three-way bf16 split (csrc/winograd3.hip) is selectable with CNL_WINO=3; CNL_WINO=2 pins the fp32 matrix
- * core.  cnl_conv3x3_winograd_kernel reports which one a layer takes: CNL_WINO_F32 / CNL_WINO_BF16X3 / CNL_WINO_F16X2.
+ * fed with a two-way fp16 split of both fp32 operands under a per-image power-of-two scale (three cross terms, fp32
+ * accumulation: csrc/winograd5.hip, winograd6.hip; measured error at or below the fp32 matrix core's, half-precision rate = 16x), as
+ * F(2x2,3x3) or, under CNL_ALGO_AUTO on maps that 32x16-pixel work items tile well, F(4x4,3x3) (csrc/winograd8.hip).
+ * cnl_conv3x3_winograd_kernel reports which class a layer takes.  The fp16-split kernels without the x_absmax hint make their own
+ * pass over the input and park the per-image maxima in the layer's weight buffer: such hint-less launches of ONE layer must not
+ * run concurrently on two streams (launches that carry x_absmax — everything engine.py issues — have no hidden state).
  */
 #define CNL_WINO_F32 2
-#define CNL_WINO_BF16X3 3
+#define CNL_WINO_BF16X3 3      /* experiment builds only */
 #define CNL_WINO_F16X2 5
+#define CNL_WINO_F16X2_F4 8
 int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream);
 int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p);            /* CNL_WINO_* for this layer shape, < 0: error code */
 size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout);        /* elements of the transformed weight buffer */
@@ -154,14 +176,14 @@ int cnl_normalize_u8_nhwc_f32(const uint8_t* x, float* y, int32_t N, int32_t H, 
  * w: the PACKED weights that cnl_stem_pack_weights_f32 makes from the OHWI [64][7][7][3] (BN-folded) weights — LDS images copied
  * verbatim by LDS-DMA: the fp32 image [154][64] (row k = ky*22 + kx*3 + c; the 22nd row of every ky is zero) followed by the
  * scaled two-way fp16 split [piece][21 groups of 8 k][64][8] and its power-of-two scale (csrc/stem_f16x2.hip: the default kernel
- * forms each fp32 product on the fp16 matrix cores, input scaled per workgroup patch; CNL_STEM_F16X2=0 in the environment selects
- * the fp32 matrix-core kernel); cnl_stem_packed_weight_floats() sizes the buffer; bias: [64].
+ * forms each fp32 product on the fp16 matrix cores, input scaled per workgroup patch; algo = CNL_ALGO_F32 selects the fp32
+ * matrix-core kernel); cnl_stem_packed_weight_floats() sizes the buffer; bias: [64].
  */
 size_t cnl_stem_packed_weight_floats(void);
 int cnl_stem_pack_weights_f32(const float* w_ohwi, float* w_packed, void* stream);
 int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
                          const float* w, const float* bias, float* y,
-                         int32_t N, int32_t H, int32_t W, void* stream);
+                         int32_t N, int32_t H, int32_t W, uint32_t algo, void* stream);
 
 /* The stem and resnet.maxpool in ONE launch: y = MaxPool2d(3, stride 2, padding 1)(ReLU(BN(conv7x7/2(x)))) as NHWC
  * [N, (Ho-1)/2+1, (Wo-1)/2+1, 64] with Ho = (H-1)/2+1, Wo = (W-1)/2+1; bit-identical to cnl_stem_conv7x7_f32 followed by

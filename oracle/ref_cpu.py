@@ -188,28 +188,42 @@ def head_names(sd):
     return names
 
 
-def head_forward(sd, name, x, stats=None, prefix="heads."):
+def head_forward(sd, name, x, stats=None, prefix="heads.", return_features=False):
+    """GenericHead.forward (meta.py:21-30).  return_features: also the last block's output (what out_conv reads)."""
     q = f"{prefix}{name}."
     i = 1
     while f"{q}block_{i}.conv.weight" in sd:
         x = _conv_bn_relu(x, sd, f"{q}block_{i}.conv", f"{q}block_{i}.bn", stats=stats)
         i += 1
-    return F.conv2d(x, sd[q + "out_conv.weight"], sd[q + "out_conv.bias"])
+    y = F.conv2d(x, sd[q + "out_conv.weight"], sd[q + "out_conv.bias"])
+    return (y, x) if return_features else y
 
 
 @torch.no_grad()
 def forward(sd, x, sigmoid=True, stats=None, return_intermediates=False, upsample_type="nearest"):
     """sd: state_dict (CPU fp32 tensors) with the key layout of centernet_lightning_amd.CenterNet;
-    x: [N,3,H,W] CPU fp32.  Returns OrderedDict(heatmap, box_2d[, reid]) in NCHW."""
+    x: [N,3,H,W] CPU fp32.  Returns OrderedDict(heatmap, box_2d[, reid]) in NCHW.
+    return_intermediates: (out, backbone features, neck output); "heads": additionally the dict of every head's last-block output
+    (the 256-channel tensor its out_conv reads) — the feature-level parity gate of tests/test_gpu_e2e.py compares those."""
     feats = backbone_features(sd, x, stats)
     neck = neck_forward(sd, feats, stats, upsample_type)
-    out = OrderedDict()
+    out, head_feats = OrderedDict(), OrderedDict()
     for name in head_names(sd):
-        y = head_forward(sd, name, neck, stats)
+        y, head_feats[name] = head_forward(sd, name, neck, stats, return_features=True)
         out[name] = y.sigmoid() if (name == "heatmap" and sigmoid) else y
+    if return_intermediates == "heads":
+        return out, feats, neck, head_feats
     if return_intermediates:
         return out, feats, neck
     return out
+
+
+@torch.no_grad()
+def forward_float64(sd, x, **kw):
+    """The same forward in float64 (weights and input promoted): the reference against which fp32 implementations' rounding
+    error is measured (CPU fp32 and the HIP kernels alike)."""
+    sd64 = OrderedDict((k, v.double() if v.is_floating_point() else v) for k, v in sd.items())
+    return forward(sd64, x.double(), **kw)
 
 
 @torch.no_grad()

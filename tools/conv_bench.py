@@ -48,7 +48,10 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--winograd", action="store_true")
     ap.add_argument("--up2", action="store_true", help="3x3 convs with CNL_UPSAMPLE_IN through cnl_conv3x3_up2_nhwc_f32 (sub-pixel phases)")
-    ap.add_argument("--hints", action="store_true", help="hand over x_absmax / w_absmax (fp16-split direct kernel where it applies)")
+    ap.add_argument("--hints", action="store_true", help="hand over x_absmax / w_absmax (fp16-split direct kernel where it applies; Winograd: no own absmax pass)")
+    ap.add_argument("--algo", type=int, default=0, help="cnl_conv_params.algo: 0 auto, 1 F(2x2) only, 2 fp32 matrix cores, 100+v force Winograd variant v")
+    ap.add_argument("--relu-data", action="store_true", help="post-ReLU activations (as inside the network)")
+    ap.add_argument("--check", action="store_true", help="also print max |y - y_fp32mfma| / max |y_fp32mfma| (algo 2 on the same inputs)")
     args = ap.parse_args()
     lib = _lib.load()
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -57,6 +60,8 @@ def main():
         up = 2 if flags & CNL_UPSAMPLE_IN else 1
         Ho, Wo = (H * up + 2 * ((k - 1) // 2) - k) // stride + 1, (W * up + 2 * ((k - 1) // 2) - k) // stride + 1
         x = torch.randn(N, H, W, Cin, device="cuda")
+        if args.relu_data:
+            x.clamp_min_(0)
         if os.environ.get("CNL_BENCH_ZEROS") == "1":            # data-dependent power check: all-zero activations
             x.zero_()
         if os.environ.get("CNL_BENCH_ZEROS") == "2":            # ... and all-zero weights too
@@ -72,7 +77,8 @@ def main():
         p.residual = r.data_ptr() if res else None
         p.N, p.H_in, p.W_in, p.Cin, p.Cout = N, H, W, Cin, Cout
         p.KH, p.KW, p.stride, p.pad = k, k, stride, (k - 1) // 2
-        p.ldx, p.ldy, p.ldr, p.flags = Cin, Cout, Cout, flags | (int(os.environ.get("CNL_DEBUG_FLAGS", "0")))
+        p.ldx, p.ldy, p.ldr, p.flags = Cin, Cout, Cout, flags
+        p.algo = args.algo
         fn = lib.cnl_conv2d_nhwc_f32
         if args.winograd:
             if k != 3 or stride != 1:
@@ -91,6 +97,10 @@ def main():
             p.flags = flags & 5
             fn = lib.cnl_conv3x3_up2_nhwc_f32
             w = wp
+        if args.hints and args.winograd:
+            xm = x.abs().amax(dim=(1, 2, 3)).contiguous()
+            ym = torch.zeros(N, device="cuda")
+            p.x_absmax, p.y_absmax = xm.data_ptr(), ym.data_ptr()
         if args.hints and not args.winograd:
             xm = x.abs().amax(dim=(1, 2, 3)).contiguous()
             wm = w.abs().max().reshape(1).contiguous()
@@ -107,7 +117,15 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
         flops = 2.0 * N * Ho * Wo * Cout * k * k * Cin
-        print(f"{name:10s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s  ({flops / 1e9:.1f} GFLOP)", flush=True)
+        kern = lib.cnl_conv3x3_winograd_kernel(ctypes.byref(p)) if args.winograd else lib.cnl_conv2d_kernel(ctypes.byref(p))
+        extra = ""
+        if args.check:
+            got = y.clone()
+            p.algo = 2
+            _lib.check(fn(ctypes.byref(p), stream))
+            torch.cuda.synchronize()
+            extra = f"  max|y-y32|/max|y32| = {float((got - y).abs().max() / y.abs().max()):.2e}  nan={bool(torch.isnan(got).any())}"
+        print(f"{name:10s} kernel {kern}  {ms * 1e3:9.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s  ({flops / 1e9:.1f} GFLOP){extra}", flush=True)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Static check of the kernels that split operands with inline-asm VALU instructions (winograd3..7.hip): gfx950 needs two wait
+"""Static check of the kernels that split operands with inline-asm VALU instructions (winograd5, 6, 8.hip): gfx950 needs two wait
 states between a VALU write of a VGPR and an MFMA that reads it as SrcA / SrcB.  The compiler keeps that distance for
 instructions it knows, but it does not look inside inline asm — tests/test_gpu_conv.py's stem kernel lost 1.6 % of its outputs to
 exactly this before its split was rewritten in plain C.  Usage: python tools/mfma_hazard_audit.py [file.hip ...]  (exit 1 on a
@@ -12,7 +12,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "centernet-lightning_amd", "csrc")
-ASM_KERNELS = ["winograd3.hip", "winograd4.hip", "winograd5.hip", "winograd6.hip", "winograd7.hip"]
+ASM_KERNELS = ["winograd5.hip", "winograd6.hip", "winograd8.hip"]      # (experiments/winograd3,4,7.hip: python tools/mfma_hazard_audit.py <path>)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-mllvm",
          "-pragma-unroll-threshold=4000000", "-fno-slp-vectorize", "-S", "--cuda-device-only"]      # = csrc/Makefile's for these files
 

@@ -11,7 +11,7 @@ y = torch.empty(32, 256, 256, 64, device="cuda")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 lib.cnl_stem_pack_weights_f32(w.data_ptr(), wp.data_ptr(), st)
 sn, sc, sh, sw = x.stride()
-f = lambda: lib.cnl_stem_conv7x7_f32(x.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), b.data_ptr(), y.data_ptr(), 32, 512, 512, st)
+f = lambda: lib.cnl_stem_conv7x7_f32(x.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), b.data_ptr(), y.data_ptr(), 32, 512, 512, 0, st)
 for _ in range(5): f()
 torch.cuda.synchronize()
 ts = []
