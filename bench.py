@@ -274,7 +274,7 @@ def feature_errors(config, x2, algo):
     return {k_: float(f"{v:.3e}") for k_, v in e.items()}
 
 
-def cpu_baseline(model, config, tracking, k, H, W, gpu_decode_p50_ms, budget_s=45.0):
+def cpu_baseline(model, config, tracking, k, H, W, gpu_decode_p50_ms, budget_s=70.0):
     """Oracle leg: the CPU restatement of forward + decode, C0 exactly and the bench config at N = 8."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import decode_ref
@@ -297,35 +297,46 @@ def cpu_baseline(model, config, tracking, k, H, W, gpu_decode_p50_ms, budget_s=4
         return time.perf_counter() - t0
 
     def leg(n, h, w, budget):
-        x = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(1234))
-        best = None
-        for threads in sorted({cores, max(1, cores // 2)}, reverse=True):      # all hardware threads, and one per physical core (SMT-2 hosts)
-            torch.set_num_threads(threads)
-            t0 = time.perf_counter()
-            one(x)
-            one(x)                                                             # 2 warm-ups
-            warm = time.perf_counter() - t0
-            ts, dec = [], []
-            while len(ts) < 5 and (len(ts) < 3 or sum(ts) + warm < budget / 2):
+        """Best (threads, memory format) found on single probe passes, then 2 warm-ups + 5 timed passes (median) with it.  The
+        reference exposes channels_last itself (models/meta.py:97-98), so both layouts are legitimate forms of its CPU path."""
+        x0 = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(1234))
+        torch.set_num_threads(max(1, cores // 2))
+        one(x0)                                                                 # global warm-up (oneDNN primitive caches, allocator)
+        probes = []
+        t_start = time.perf_counter()
+        for threads in sorted({max(1, cores // 2), max(1, cores // 4), max(1, min(32, cores))}, reverse=True):
+            for cl_ in (False, True):
+                if probes and time.perf_counter() - t_start > budget * 0.45:
+                    break
+                torch.set_num_threads(threads)
+                x = x0.contiguous(memory_format=torch.channels_last) if cl_ else x0
                 t0 = time.perf_counter()
-                dec.append(one(x))
-                ts.append(time.perf_counter() - t0)
-            ts.sort(); dec.sort()
-            r = {"threads": threads, "images_per_s": round(n / ts[len(ts) // 2], 3), "timed_passes": len(ts), "decode_p50_ms": round(dec[len(dec) // 2] * 1e3, 3)}
-            if best is None or r["images_per_s"] > best["images_per_s"]:
-                other, best = best, r
-            else:
-                other = r
-        best["other_thread_setting"] = other
+                one(x)
+                probes.append((time.perf_counter() - t0, threads, cl_))
+        _, threads, cl_ = min(probes)
+        torch.set_num_threads(threads)
+        x = x0.contiguous(memory_format=torch.channels_last) if cl_ else x0
+        one(x)
+        one(x)                                                                  # 2 warm-ups
+        ts, dec = [], []
+        t_start = time.perf_counter()
+        while len(ts) < 5 and (len(ts) < 3 or time.perf_counter() - t_start < budget * 0.5):
+            t0 = time.perf_counter()
+            dec.append(one(x))
+            ts.append(time.perf_counter() - t0)
+        ts.sort(); dec.sort()
         torch.set_num_threads(cores)
-        return best
+        return {"threads": threads, "channels_last": cl_, "images_per_s": round(n / ts[len(ts) // 2], 3), "timed_passes": len(ts),
+                "decode_p50_ms": round(dec[len(dec) // 2] * 1e3, 3),
+                "probes_images_per_s": {f"{t_}thr{'_cl' if c_ else ''}": round(n / s_, 3) for s_, t_, c_ in probes}}
 
     c0 = leg(1, 512, 512, budget_s * 0.3)
     cn = leg(8, H, W, budget_s * 0.7)
     return {"value": cn["images_per_s"], "unit": "images/s", "cores": cn["threads"], "kind": "port",
             "os_cpu_count": cores, "cpu_model": cpu_model,
             "sample": f"oracle/ref_cpu.forward + decode_ref.decode_detections (same weights) on 8x3x{H}x{W}, 2 warm-ups + {cn['timed_passes']} timed passes, median; "
-                      f"torch {torch.__version__} CPU fp32, {cn['threads']} threads (best of {cores} / {max(1, cores // 2)})",
+                      f"torch {torch.__version__} CPU fp32, {cn['threads']} threads{', channels_last' if cn['channels_last'] else ''} "
+                      f"(the best of the probed thread counts / layouts: bench_config_N8.probes_images_per_s); decode = the numpy oracle",
             "bench_config_N8": cn, "C0_1x3x512x512": c0,
             "decode_p50_ms": {"cpu_N8": cn["decode_p50_ms"], "cpu_N1_C0": c0["decode_p50_ms"], "gpu_full_batch": gpu_decode_p50_ms}}
 

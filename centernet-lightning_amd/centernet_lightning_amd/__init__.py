@@ -9,7 +9,8 @@ from .models import CenterNet, DetectionOutput, TrackingOutput, build_centernet
 from .collate import (Collator, all_gather_records, collate_detections, pack_detections, shard_range, unpack_detections)
 from .tracker import Tracker, Track, TrackState, build_tracker, match_with_threshold
 from . import decode, formats
+from .export import TraceableCenterNet, export_onnx, export_torchscript
 
 __all__ = ["CenterNet", "build_centernet", "load_config", "DetectionOutput", "TrackingOutput", "decode",
            "collate_detections", "Collator", "all_gather_records", "pack_detections", "unpack_detections", "shard_range",
-           "Tracker", "Track", "TrackState", "build_tracker", "match_with_threshold", "formats"]
+           "Tracker", "Track", "TrackState", "build_tracker", "match_with_threshold", "formats", "TraceableCenterNet", "export_torchscript", "export_onnx"]

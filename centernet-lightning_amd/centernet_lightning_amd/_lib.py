@@ -74,6 +74,9 @@ _SIGNATURES = {
     "cnl_deform_sample_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                                   c_int32, c_int32, c_void_p]),
     "cnl_normalize_u8_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float), c_void_p]),
+    "cnl_resize_bilinear_u8": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "cnl_stem_conv7x7_u8": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p,
+                                           c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "cnl_stem_packed_weight_floats": (c_size_t, []),
     "cnl_stem_pack_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     "cnl_stem_conv7x7_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,

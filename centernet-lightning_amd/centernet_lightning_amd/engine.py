@@ -696,9 +696,11 @@ class Plan:
             p, _, _ = self._conv(outl, x, xh, xw, ldx, x, outl.cout, flags, what=f"heads.{name}.out_conv", x_off=xoff)
             self.out_params[name] = (p, outl.cout)
 
-    def run(self, x):
-        """x: [N,3,H,W] fp32 on self.device, any strides.  Returns OrderedDict name -> logical-NCHW view of a fresh
-        NHWC tensor (channels_last, zero-copy; precedent models/meta.py:97-98)."""
+    def run(self, x, norm=None):
+        """x: [N,3,H,W] fp32 on self.device, any strides — or, with norm = (mean255, inv_std255) ctypes float[3] arrays, uint8 frames
+        [N,H,W,3] that the stem normalises on the fly.  Returns OrderedDict name -> logical-NCHW view of a fresh NHWC tensor
+        (channels_last, zero-copy; precedent models/meta.py:97-98)."""
+        self._norm = norm
         lib = self.lib
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         outs = OrderedDict()
@@ -719,6 +721,11 @@ class Plan:
         """Issue ONE launch of the plan (x: the forward's input, read by the stem only).  Returns the C ABI's return code."""
         lib = self.lib
         if L.fn == "stem":
+            if x.dtype == torch.uint8:                       # [N,H,W,3] uint8: byte strides of the logical (n, c, y, x) axes
+                sn, sh, sw, sc = x.stride()
+                return lib.cnl_stem_conv7x7_u8(x.data_ptr(), sn, sc, sh, sw, self._norm[0], self._norm[1], self._wt_stem_packed.data_ptr(),
+                                               self._wt_stem.b.data_ptr(), self.stem_out.data_ptr(), self.N, self.H, self.W,
+                                               1 if self.stem_fused_pool else 0, stream)
             sn, sc, sh, sw = x.stride()
             if self.stem_fused_pool:
                 return lib.cnl_stem_conv7x7_maxpool_f32(x.data_ptr(), sn, sc, sh, sw, self._wt_stem_packed.data_ptr(), self._wt_stem.b.data_ptr(),
@@ -756,6 +763,16 @@ class Engine:
         self.options = opts
         return opts
 
+    def forward_u8(self, images, mean255, inv_std255, sigmoid):
+        """uint8 frames [N,H,W,3] -> outputs, normalised inside the stem kernel (no fp32 image in HBM)."""
+        if not (isinstance(images, torch.Tensor) and images.is_cuda):
+            raise RuntimeError("CenterNet (MI355X) runs on HIP devices only: move the frames to 'cuda' (no CPU fallback)")
+        if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3:
+            raise ValueError(f"expected uint8 frames [N,H,W,3], got {images.dtype} {tuple(images.shape)}")
+        if self.options.algo == "f32":
+            raise ValueError("the uint8 stem runs on the fp16-split kernel only: use algo 'auto' / 'f2', or preprocess_uint8() + forward()")
+        return self._dispatch(images, sigmoid, images.shape[0], images.shape[1], images.shape[2], (mean255, inv_std255))
+
     def forward(self, x, sigmoid):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise RuntimeError("CenterNet (MI355X) runs on HIP devices only: move the input to 'cuda' — there is no CPU "
@@ -764,19 +781,22 @@ class Engine:
             raise ValueError(f"expected input of shape [N,3,H,W], got {tuple(x.shape)}")
         if x.dtype != torch.float32:
             raise ValueError(f"expected float32 input, got {x.dtype}")
+        N, _, H, W = x.shape
+        return self._dispatch(x, sigmoid, N, H, W, None)
+
+    def _dispatch(self, x, sigmoid, N, H, W, norm):
         dev = x.device
         if self.weights is None or self.weights_device != dev or self.weights.stale():
             self.weights = PackedWeights(self.model, dev)
             self.weights_device = dev
             self.plans.clear()
-        N, _, H, W = x.shape
         chunk = self.sub_batch(N, H, W)
         if N > chunk:
             # the kernels address each tensor through 32-bit buffer offsets (< 4 GiB per tensor): run contiguous, equally sized
             # sub-batches (images are independent; results are byte-identical to one big batch) and concatenate
-            parts = [self._run(x[i:i + chunk], sigmoid) for i in range(0, N, chunk)]
+            parts = [self._run(x[i:i + chunk], sigmoid, H, W, norm) for i in range(0, N, chunk)]
             return OrderedDict((k, torch.cat([p[k] for p in parts], dim=0)) for k in parts[0])
-        return self._run(x, sigmoid)
+        return self._run(x, sigmoid, H, W, norm)
 
     def sub_batch(self, N, H, W):
         """Images per launch plan: N when it fits the addressing limit, else N split into the fewest equal parts that do."""
@@ -791,9 +811,9 @@ class Engine:
         per_image = max((H // 2) * (W // 2) * 64, (H // 4) * (W // 4) * widest) * 4
         return max(1, (0xF0000000 - (1 << 24)) // per_image)
 
-    def _run(self, x, sigmoid):
+    def _run(self, x, sigmoid, H, W, norm):
         dev = x.device
-        N, _, H, W = x.shape
+        N = x.shape[0]
         # one plan per stream: its arena, absmax slots and patched output pointers are private to that stream's launch order
         key = (N, H, W, bool(sigmoid), self.options, torch.cuda.current_stream(dev).cuda_stream)
         plan = self.plans.get(key)
@@ -802,7 +822,7 @@ class Engine:
                 plan = Plan(self.weights, N, H, W, dev, bool(sigmoid), self.options)
             self.plans[key] = plan
         with torch.cuda.device(dev):
-            return plan.run(x)
+            return plan.run(x, norm)
 
     def plan_for(self, x, sigmoid=True):
         """The (existing) plan a forward of x on the current stream uses — bench / tests introspection."""

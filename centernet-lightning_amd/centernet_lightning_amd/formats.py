@@ -92,13 +92,25 @@ _PREFIXES = ("model.", "module.", "net.")
 _RENAMES = (("output_heads.", "heads."),)
 
 
-def checkpoint_state_dict(ckpt):
+# training-only entries of a reference checkpoint that the inference model has no counterpart for: EmbeddingHead.classifier (the
+# track-id classification layers "used during training only", models/fairmot.py:25-31: Linear / BatchNorm1d / ReLU / Linear ->
+# classifier.{0,1,3}.*) and whatever the loss modules register (loss_function.*)
+_TRAINING_ONLY = (".classifier.", ".loss_function.")
+
+
+def is_training_only_key(key):
+    return any(t in "." + key for t in _TRAINING_ONLY)
+
+
+def checkpoint_state_dict(ckpt, keep_training_only=False):
     """Lightning `.ckpt` (dict with "state_dict") or a bare state_dict -> tensors keyed like this package's CenterNet:
     wrapper prefixes dropped ("model." of GenericModel inside the LightningModule, models/meta.py:66; "module." of DDP),
-    Gen-A's `output_heads.` -> `heads.`."""
+    Gen-A's `output_heads.` -> `heads.`; training-only entries (see _TRAINING_ONLY) dropped unless asked for."""
     sd = ckpt.get("state_dict", ckpt) if isinstance(ckpt, dict) else ckpt
     out = {}
     for k, v in sd.items():
+        if not keep_training_only and is_training_only_key(k):
+            continue
         changed = True
         while changed:
             changed = False
@@ -114,7 +126,8 @@ def checkpoint_state_dict(ckpt):
 
 def load_checkpoint(model, ckpt, strict=True, map_location="cpu"):
     """CenterNet.load_from_checkpoint's weight-loading half (tools/export.py:8): `ckpt` is a path or an already-loaded dict.
-    Returns the (missing, unexpected) key lists; with strict=True a mismatch raises, listing both."""
+    Returns the (missing, unexpected) key lists; with strict=True a mismatch raises, listing both.  Training-only entries of a
+    reference tracking checkpoint (heads.reid.classifier.*, fairmot.py:25-31) are not "unexpected": they are skipped."""
     if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
         ckpt = torch.load(ckpt, map_location=map_location, weights_only=True)
     sd = checkpoint_state_dict(ckpt)

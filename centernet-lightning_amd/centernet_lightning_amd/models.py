@@ -11,6 +11,7 @@ reference tree (models/meta.py:21-47, models/centernet.py:229-304):
 Everything between the input tensor and those outputs runs in libcenternet_gfx950.so (HIP, gfx950).
 There is no CPU path: CPU tensors raise.  Training, datasets and evaluation stay with the reference.
 """
+import ctypes
 import math
 from collections import OrderedDict, namedtuple
 from typing import Any, Dict, Union
@@ -70,6 +71,10 @@ class CenterNet(nn.Module):
         if task == "tracking" and "reid" not in output_heads:
             raise ValueError("task 'tracking' needs a 'reid' head (configs/base_tracking_resnet34_fpn.yaml:26-30)")
         self.task = task
+        # the `model:` section this instance was built from (export.py rebuilds an identical model from it)
+        self.config_section = {"backbone": dict(backbone), "neck": dict(neck), "output_heads": {k: dict(v or {}) for k, v in output_heads.items()},
+                               "task": task, "num_detections": int(num_detections), "nms_kernel": int(nms_kernel), "box_log": bool(box_log),
+                               "box_multiplier": float(box_multiplier)}
         self.backbone = ResNetBackbone(**backbone)
         self.neck = build_neck(neck, self.backbone.out_channels)
         self.output_stride = self.backbone.output_stride // self.neck.upsample_stride      # meta.py:96
@@ -166,6 +171,42 @@ class CenterNet(nn.Module):
                                                      ctypes.c_void_p(torch.cuda.current_stream(images.device).cuda_stream)),
                        "cnl_normalize_u8_nhwc_f32")
         return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def _norm_constants(mean, std):
+        import numpy as np
+        m = np.array(mean, dtype=np.float32) * np.float32(255.0)
+        r = np.reciprocal(np.array(std, dtype=np.float32) * np.float32(255.0), dtype=np.float32)
+        return (ctypes.c_float * 3)(*m.tolist()), (ctypes.c_float * 3)(*r.tolist())
+
+    def resize_uint8(self, images: torch.Tensor, height: int, width: int) -> torch.Tensor:
+        """albumentations A.Resize(height, width) (README.md:84) = cv2.resize(..., INTER_LINEAR) on uint8 frames [N,H,W,C] -> [N,height,width,C]
+        (cnl_resize_bilinear_u8: OpenCV's 8-bit fixed-point rule, bit-exact against oracle/decode_ref.resize_bilinear_u8)."""
+        from . import _lib
+        if not (isinstance(images, torch.Tensor) and images.is_cuda):
+            raise RuntimeError("resize_uint8 runs on HIP devices only (no CPU fallback)")
+        if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] > 4:
+            raise ValueError(f"expected uint8 [N,H,W,C<=4], got {images.dtype} {tuple(images.shape)}")
+        images = images.contiguous()
+        N, H, W, C = images.shape
+        lib = _lib.load()
+        with torch.cuda.device(images.device):
+            out = torch.empty((N, int(height), int(width), C), device=images.device, dtype=torch.uint8)
+            _lib.check(lib.cnl_resize_bilinear_u8(images.data_ptr(), out.data_ptr(), N, H, W, int(height), int(width), C,
+                                                  ctypes.c_void_p(torch.cuda.current_stream(images.device).cuda_stream)), "cnl_resize_bilinear_u8")
+        return out
+
+    def forward_uint8(self, images: torch.Tensor, resize=None, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+        """The reference's inference pre-processing fused into the path (README.md:79-101): uint8 HWC frames [N,H,W,3] ->
+        [A.Resize(*resize) ->] A.Normalize -> forward().  The normalisation happens on the stem kernel's staged patch
+        (cnl_stem_conv7x7_u8), so no fp32 image tensor is ever written: bit-identical to forward(preprocess_uint8(images))."""
+        if resize is not None:
+            images = self.resize_uint8(images, int(resize[0]), int(resize[1]))
+        m, r = self._norm_constants(mean, std)
+        out = self._engine.forward_u8(images.contiguous(), m, r, sigmoid=True)
+        if "reid" in out:
+            return TrackingOutput(out["heatmap"], out["box_2d"], out["reid"])
+        return DetectionOutput(out["heatmap"], out["box_2d"])
 
     # ------------------------------------------------------------------ decode (Gen-A names)
     def gather_detection2d(self, heatmap, box_2d=None, num_detections=100, nms_kernel=3, normalize_bbox=False):

@@ -178,6 +178,11 @@ class ResNetBackbone(nn.Module):
         # `pretrained: True` (configs/base_resnet34.yaml:5) cannot be honoured offline; weights arrive through
         # load_state_dict().  Recorded so callers can see the request.
         self.pretrained_requested = bool(pretrained)
+        if self.pretrained_requested:
+            import warnings
+            warnings.warn("backbone.pretrained=True is recorded but NOT honoured (no network access / no torchvision here): the ResNet "
+                          "backbone is randomly initialised until weights are loaded — model.backbone.load_state_dict(torchvision_sd, "
+                          "strict=False) or formats.load_checkpoint(model, ckpt)", stacklevel=3)
 
 
 class SimpleNeck(nn.Module):

@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void peaks_cminor_kernel(const PeakArgs a) {
     float* red_v = reinterpret_cast<float*>(smem);                  // [R][PXB][CG]
     int* red_c = reinterpret_cast<int*>(red_v + a.R * a.PXB * a.CG);
 
-    int b = blockIdx.x;
+    // XCD-aware tile order: each XCD gets a contiguous range of (x tile, strip) ids, so the halo rows / columns a tile shares with
+    // its neighbours are re-read from that XCD's L2 instead of HBM (the hardware deals consecutive block ids round-robin over XCDs)
+    int b = (int)cnl::xcd_remap(blockIdx.x, gridDim.x);
     const int bx = b % a.tiles_x; b /= a.tiles_x;
     const int by = b % a.strips;
     const int n = b / a.strips;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void peaks_cminor_kernel(const PeakArgs a) {
 // ---- stage 1, generic strides (lanes along x, loop over classes) ----
 template <int P, int R>
 __global__ __launch_bounds__(256) void peaks_generic_kernel(const PeakArgs a) {
-    int b = blockIdx.x;
+    int b = (int)cnl::xcd_remap(blockIdx.x, gridDim.x);
     const int bx = b % a.tiles_x; b /= a.tiles_x;
     const int by = b % a.strips;
     const int n = b / a.strips;
@@ -251,6 +253,7 @@ struct TopkArgs {
     const float* box; long bsn, bsc, bsh, bsw;
     const float* reid; long rsn, rsc, rsh, rsw;
     int HW, W, H, E, k, KP;       // KP = next pow2 >= k
+    int keys_in_lds;              // HW * 4 bytes of dynamic LDS hold the image's score keys (read from memory ONCE)
     int normalize, box_log;
     float mult, stride;
     float* scores; long long* indices; long long* labels; float* boxes; float* emb;
@@ -277,6 +280,7 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
 }
 
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
+    extern __shared__ unsigned lds_keys[];          // [HW] when a.keys_in_lds
     __shared__ unsigned hist[4096];
     __shared__ unsigned wave_tot[TK_THREADS / 64];
     __shared__ unsigned long long cand[1024];
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const float* sc = a.ws_score + (long)n * a.HW;
+    const int KCH = (a.HW + TK_THREADS - 1) / TK_THREADS, KST = KCH | 1;      // indices per thread, LDS row pitch (odd)
 
     // --- radix select: key T of the k-th largest element, digits of 12 / 10 / 10 bits from the top.  (A 12-bit first digit
     // spreads sigmoid scores, which share 1-2 exponents, over 16x more bins than an 8-bit one: far less LDS-atomic contention.) ---
@@ -298,9 +303,20 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         const int per = nbins / TK_THREADS;               // bins per thread in the scan: 4 or 1
         for (int i = tid; i < nbins; i += TK_THREADS) hist[i] = 0;
         __syncthreads();
-        for (int i = tid; i < a.HW; i += TK_THREADS) {
-            const unsigned key = score_key(sc[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (unsigned)(nbins - 1)], 1u);
+        if (a.keys_in_lds && pass > 0) {
+            // keys live in LDS as [thread][KST] (thread t owns indices t*KCH .. t*KCH+KCH-1; the odd row pitch KST keeps both this
+            // loop and the ordered compaction below free of bank conflicts)
+            for (int j = 0; j < KCH; ++j) {
+                if (tid * KCH + j >= a.HW) break;
+                const unsigned key = lds_keys[tid * KST + j];
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (unsigned)(nbins - 1)], 1u);
+            }
+        } else {
+            for (int i = tid; i < a.HW; i += TK_THREADS) {          // coalesced: the only pass over memory when the keys fit in LDS
+                const unsigned key = score_key(sc[i]);
+                if (a.keys_in_lds) lds_keys[(i / KCH) * KST + (i % KCH)] = key;
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (unsigned)(nbins - 1)], 1u);
+            }
         }
         __syncthreads();
         // block-wide suffix sums over the bins from the top: thread t owns bins per*t .. per*t+per-1
@@ -343,11 +359,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     // `need` = number of elements with key == T to take (lowest indices first); the rest have key > T.
 
     // --- ordered compaction: thread t owns the contiguous index range [t*CH, (t+1)*CH); counts packed (gt << 16 | eq) ---
-    const int CH = (a.HW + TK_THREADS - 1) / TK_THREADS;
+    const int CH = KCH;
     const int i0 = tid * CH, i1 = min(i0 + CH, a.HW);
     unsigned cnt = 0;
     for (int i = i0; i < i1; ++i) {
-        const unsigned key = score_key(sc[i]);
+        const unsigned key = a.keys_in_lds ? lds_keys[tid * KST + (i - i0)] : score_key(sc[i]);
         cnt += key > T ? 0x10000u : 0u;
         cnt += key == T ? 1u : 0u;
     }
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     for (int i = tid; i < a.KP; i += TK_THREADS) cand[i] = 0ull;   // padding sorts last
     __syncthreads();
     for (int i = i0; i < i1; ++i) {
-        const unsigned key = score_key(sc[i]);
+        const unsigned key = a.keys_in_lds ? lds_keys[tid * KST + (i - i0)] : score_key(sc[i]);
         const unsigned long long comp = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
         if (key > T) {
             cand[pos_gt++] = comp;
@@ -587,7 +603,14 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
     t.normalize = p->normalize_boxes; t.box_log = p->box_log; t.mult = p->box_multiplier; t.stride = p->stride;
     t.scores = p->scores; t.indices = (long long*)p->indices; t.labels = (long long*)p->labels; t.boxes = p->boxes;
     t.emb = p->emb;
-    hipLaunchKernelGGL(topk_kernel, dim3(p->N), dim3(TK_THREADS), 0, s, t);
+    // 40 KB of static LDS + the keys: one workgroup per CU either way (1024 threads)
+    const size_t kst = (size_t)(((HW + TK_THREADS - 1) / TK_THREADS) | 1);
+    t.keys_in_lds = kst * TK_THREADS * 4 <= 96 * 1024;
+    const size_t key_bytes = t.keys_in_lds ? kst * TK_THREADS * 4 : 0;
+    static cnl::DeviceOnce once;
+    rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&topk_kernel), 96 * 1024);
+    if (rc != CNL_OK) return rc;
+    hipLaunchKernelGGL(topk_kernel, dim3(p->N), dim3(TK_THREADS), key_bytes, s, t);
     return cnl::check_launch("topk_kernel");
 }
 

@@ -14,7 +14,6 @@
 // sit in LDS as [piece][group][cout][8] so a lane's operand is one ds_read_b128.  Per step and wave: 4 rows x 2 cout groups x 3
 // MFMAs of 32 cycles against 88 x 64 in stem.hip — the kernel becomes bound by its 537 MB of output.
 #include "cnl_common.h"
-#include <cstdlib>
 
 namespace cnl_stem5 {
 
@@ -39,6 +38,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 __device__ __forceinline__ void dma4(const float* base, unsigned bytes, float* lds_dst, unsigned voffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 4, voffset, 0, 0, 0);
+}
+// one BYTE per lane, zero-extended to the lane's dword in LDS (uint8 frames)
+__device__ __forceinline__ void dma1(const void* base, unsigned bytes, float* lds_dst, unsigned voffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 1, voffset, 0, 0, 0);
 }
 __device__ __forceinline__ void dma16(const void* base, unsigned bytes, char* lds_dst, unsigned voffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
@@ -71,16 +75,22 @@ __device__ __forceinline__ float pow2_scale(float mx) {
 }
 
 // w_split: [piece][group][cout][8] fp16 (W_BYTES), scal[0] = S_w.
+// U8: x is a uint8 image (strides in bytes) and the first thing the workgroup does with its staged patch is A.Normalize in place —
+// (float(x) - mean255[c]) * inv_std255[c], two roundings, exactly cnl_normalize_u8_nhwc_f32 — inside the pass that scans the patch
+// for its maximum anyway; slots outside the image stay 0 (the conv pads the NORMALISED image).  The fp32 image never exists in HBM.
+struct Norm {
+    float m[3], r[3];
+};
 // POOL: y is the output of MaxPool2d(3, s2, p1) applied to the conv output ([N, Hp, Wp, 64], ZERO-FILLED by the caller's launch
 // function): the workgroup pools its 16x32 conv tile through LDS; the 7x15 pooled cells whose 3x3 window lies inside the tile are
 // stored, the border cells (whose window continues in a neighbouring tile) are merged with atomic max on the bit pattern — exact
 // and order-independent, the values being post-ReLU (>= +0).  The 537 MB conv output never exists.
-template <bool POOL>
-__global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const float* __restrict__ x, long sn, int sc, int sh, int sw,
+template <bool POOL, bool U8>
+__global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restrict__ x, long sn, int sc, int sh, int sw,
                                                             unsigned x_img_bytes, const void* __restrict__ w_split,
                                                             const float* __restrict__ scal, const float* __restrict__ bias,
                                                             float* __restrict__ y, int N, int H, int W, int Ho, int Wo, int tiles_x,
-                                                            int tiles_y) {
+                                                            int tiles_y, const Norm nrm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* patch = reinterpret_cast<float*>(smem);
     char* wl = smem + PATCH_BYTES;
@@ -102,22 +112,26 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const float* __restr
 #endif
     if (S5_EXP != 2)
     for (int q = wave; q < W_BYTES / 1024; q += 4) dma16(w_split, (unsigned)W_BYTES, wl + q * 1024, (unsigned)(q * 1024 + lane * 16));
-    const float* xn = x + (long)n * sn;
+    constexpr int ES = U8 ? 1 : 4;                                             // bytes per input element
+    const char* xn = reinterpret_cast<const char*>(x) + (long)n * sn * ES;
     unsigned lane_off[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int f = q * 64 + lane;
         const int col = f / 3, c = f - col * 3;
         const int ix = ix0 + col;
-        lane_off[q] = (f < PC * 3 && (unsigned)ix < (unsigned)W) ? (unsigned)((c * sc + ix * sw) * 4) : OOB;
+        lane_off[q] = (f < PC * 3 && (unsigned)ix < (unsigned)W) ? (unsigned)((c * sc + ix * sw) * ES) : OOB;
     }
     for (int r = wave; r < (S5_EXP == 1 ? 0 : PR); r += 4) {
         const int iy = iy0 + r;
         const bool row_ok = (unsigned)iy < (unsigned)H;                       // wave-uniform
-        const unsigned row_off = (unsigned)(iy * sh * 4);
+        const unsigned row_off = (unsigned)(iy * sh * ES);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            dma4(xn, x_img_bytes, patch + r * RS + q * 64, (row_ok && lane_off[q] != OOB) ? lane_off[q] + row_off : OOB);
+        for (int q = 0; q < 4; ++q) {
+            const unsigned off = (row_ok && lane_off[q] != OOB) ? lane_off[q] + row_off : OOB;
+            if (U8) dma1(xn, x_img_bytes, patch + r * RS + q * 64, off);
+            else dma4(reinterpret_cast<const float*>(xn), x_img_bytes, patch + r * RS + q * 64, off);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -125,7 +139,23 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const float* __restr
     // ---- the patch's scale: max |x| over the staged patch (out-of-image slots hold zeros) ----
     float mx = 0.f;
     for (int e = tid; e < (S5_EXP == 5 ? 1 : PR * (RS / 4)); e += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(patch + e * 4);
+        float4 v = *reinterpret_cast<const float4*>(patch + e * 4);
+        if (U8) {                        // the slots hold zero-extended bytes: normalise in place
+#pragma clang fp contract(off)           // one rounding per operation: bit-parity with cnl_normalize_u8_nhwc_f32
+            const int r = e >> 6, f0 = (e & 63) * 4;                           // RS / 4 = 64 float4 per patch row
+            const bool row_ok = (unsigned)(iy0 + r) < (unsigned)H;
+            float o[4];
+            const unsigned u[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = f0 + i, col = f / 3, c = f - col * 3;
+                const bool ok = row_ok && f < PC * 3 && (unsigned)(ix0 + col) < (unsigned)W;
+                const float m_ = c == 0 ? nrm.m[0] : (c == 1 ? nrm.m[1] : nrm.m[2]), r_ = c == 0 ? nrm.r[0] : (c == 1 ? nrm.r[1] : nrm.r[2]);
+                o[i] = ok ? ((float)u[i] - m_) * r_ : 0.f;
+            }
+            v = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(patch + e * 4) = v;
+        }
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
 #pragma unroll
@@ -338,20 +368,32 @@ int cnl_stem5_pack(const float* w_ohwi, float* extra, void* stream) {
     return cnl::check_launch("stem_split_pack_kernel");
 }
 
-int cnl_stem5_launch(const float* x, long sn, int sc, int sh, int sw, unsigned img_bytes, const float* extra, const float* bias, float* y,
-                     int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y, unsigned blocks, bool pool, void* stream) {
-    static cnl::DeviceOnce once_plain, once_pool;
-    int rc = cnl::kernel_setup(once_plain, (const void*)stem_f16x2_kernel<false>, LDS_BYTES);
-    if (rc == CNL_OK) rc = cnl::kernel_setup(once_pool, (const void*)stem_f16x2_kernel<true>, LDS_BYTES);
+int cnl_stem5_launch(const void* x, bool u8, const float* mean255, const float* inv_std255, long sn, int sc, int sh, int sw, unsigned img_bytes,
+                     const float* extra, const float* bias, float* y, int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y,
+                     unsigned blocks, bool pool, void* stream) {
+    Norm nrm = {{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
+    if (u8) {
+        for (int c = 0; c < 3; ++c) { nrm.m[c] = mean255[c]; nrm.r[c] = inv_std255[c]; }
+    }
+    static cnl::DeviceOnce once[4];
+    const void* fns[4] = {(const void*)stem_f16x2_kernel<false, false>, (const void*)stem_f16x2_kernel<true, false>,
+                          (const void*)stem_f16x2_kernel<false, true>, (const void*)stem_f16x2_kernel<true, true>};
+    const int which = (u8 ? 2 : 0) + (pool ? 1 : 0);
+    const int rc = cnl::kernel_setup(once[which], fns[which], LDS_BYTES);
     if (rc != CNL_OK) return rc;
     if (pool) {                  // the border cells are merged with atomic max: start from +0 everywhere
         const size_t Hp = (size_t)(Ho - 1) / 2 + 1, Wp = (size_t)(Wo - 1) / 2 + 1;
         CNL_HIP(hipMemsetAsync(y, 0, (size_t)N * Hp * Wp * 64 * sizeof(float), (hipStream_t)stream));
-        hipLaunchKernelGGL(stem_f16x2_kernel<true>, dim3(blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes,
-                           (const void*)extra, extra + W_BYTES / 4, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y);
-    } else {
-        hipLaunchKernelGGL(stem_f16x2_kernel<false>, dim3(blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes,
-                           (const void*)extra, extra + W_BYTES / 4, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y);
     }
+#define S5_LAUNCH(P_, U_)                                                                                                          \
+    hipLaunchKernelGGL((stem_f16x2_kernel<P_, U_>), dim3(blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes, \
+                       (const void*)extra, extra + W_BYTES / 4, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y, nrm)
+    switch (which) {
+        case 0: S5_LAUNCH(false, false); break;
+        case 1: S5_LAUNCH(true, false); break;
+        case 2: S5_LAUNCH(false, true); break;
+        default: S5_LAUNCH(true, true); break;
+    }
+#undef S5_LAUNCH
     return cnl::check_launch("stem_f16x2_kernel");
 }

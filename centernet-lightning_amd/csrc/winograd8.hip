@@ -33,6 +33,12 @@
 #ifndef W8_NT_Y
 #define W8_NT_Y 2
 #endif
+#ifndef W8_EXP
+#define W8_EXP 0      /* timing builds (wrong results): 1 no B loads in the MFMA phase, 2 no input transform, 3 no MFMA phase, 4 no output stores, 5 no epilogue */
+#endif
+#ifndef W8_PK
+#define W8_PK 1       /* packed fp32 fma in the input transform */
+#endif
 
 namespace cnl_wino8 {
 
@@ -95,6 +101,14 @@ __device__ __forceinline__ void buf_store16(f32x4 v, float* base, unsigned bytes
 __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+// The same MFMA with its accumulator pinned to ARCHITECTURAL VGPRs.  The kernel holds 18 accumulator tiles = 288 registers per lane, 32
+// more than the 256 AGPRs; left to itself the compiler keeps two tiles in VGPRs and copies them through AGPRs around their MFMAs (80
+// v_accvgpr moves + result-wait nops per chunk).  The "+v" constraint selects the VGPR form of the instruction for the ninth position of a
+// wave.  The operands come from ds_read / buffer_load (s_waitcnt is inserted on registers, also for inline asm); the s_nop covers the
+// VALU -> MFMA distance in case the compiler moved an operand with v_mov just before (the hazard recognizer does not look inside asm).
+__device__ __forceinline__ void mfma16_vgpr(u32x4 a, u32x4 b, f32x16& c) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
 // split of a channel pair (winograd5.hip): hi = RN16(v S) packed, r = v S - hi exactly, lo = RZ16(r) packed.  The results go to LDS
 // (never straight into an MFMA operand), so the inline asm is outside the VALU -> MFMA hazard window the compiler cannot see into.
 __device__ __forceinline__ unsigned split_hi_lo(float v0, float S) {
@@ -118,11 +132,24 @@ __device__ __forceinline__ float split_res_hi(float v, float S, unsigned pk) {
 }
 __device__ __forceinline__ f32x4 lds_f4(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ u32x4 lds_u4(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+// c * x + y on four channels as two v_pk_fma_f32: the transform phase issues no MFMAs (all four waves transform at the same time), so
+// the packed form — an anti-lever beside MFMAs — simply halves the instruction count of a phase that is bound by instruction issue
+// (one wave per SIMD issues ~one instruction per 4 cycles whatever its width).  IEEE fma per element: bit-identical to fmaf.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 fma4(float c, f32x4 x, f32x4 y) {
+#if W8_PK
+    const f32x2 cc = {c, c};
+    f32x2 lo, hi;
+    const f32x2 xl = {x[0], x[1]}, xh = {x[2], x[3]}, yl = {y[0], y[1]}, yh = {y[2], y[3]};
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(cc), "v"(xl), "v"(yl));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(cc), "v"(xh), "v"(yh));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+#else
     f32x4 r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(c, x[e], y[e]);
     return r;
+#endif
 }
 
 // split four channels of one V element group and store both pieces: dst = this thread's 8 bytes of the (position, piece 0) plane
@@ -225,15 +252,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ---- work item ----
         int n, y0, x0, n0;
         {
+            // Work-item order: tiles of one (image, cout block) fastest, then the cout block, then the image.  xcd_remap gives each XCD a
+            // contiguous range of ids and the persistent workgroups step through it 32 at a time, so the CUs of an XCD multiply the
+            // SAME cout block's weights at about the same time: its slice of U (36 x 2 x 64 x Cin x 2 B = 2.4 MB for Cin = 256, of 9.4 MB
+            // for the layer) stays in that XCD's 4 MB L2.  With cout blocks fastest (what suits F(2x2)'s 4.2 MB of weights) the B
+            // fragments came from the Infinity Cache: 326 us of a 1420 us launch waiting for them (timing builds, profiles/r02).
             unsigned b_ = cnl::xcd_remap(item, (unsigned)a.blocks);
             int nbi, bxi, byi;
-            if (a.nb & 1) {              // cout block fastest
-                nbi = b_ % a.nb; b_ /= a.nb; bxi = b_ % a.bx; b_ /= a.bx; byi = b_ % a.by; n = b_ / a.by;
-            } else {                     // pairs of cout blocks fastest, then the tile, then the pair index (winograd5.hip, order 2)
-                const int np_ = a.nb / 2;
-                const int lo_ = b_ % 2; b_ /= 2; bxi = b_ % a.bx; b_ /= a.bx; byi = b_ % a.by; b_ /= a.by;
-                const int pr_ = b_ % np_; n = b_ / np_; nbi = pr_ * 2 + lo_;
-            }
+            bxi = b_ % a.bx; b_ /= a.bx; byi = b_ % a.by; b_ /= a.by; nbi = b_ % a.nb; n = b_ / a.nb;
             y0 = byi * (4 * TY); x0 = bxi * (4 * TX); n0 = nbi * BN;
         }
         unsigned p_off[10];
@@ -272,7 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned so_ = (unsigned)(cc_) * u_chunk + (unsigned)(9 * wave + (j_)) * u_pos;                    \
         _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_)                                                         \
             _Pragma("unroll") for (int kk_ = 0; kk_ < NP; ++kk_)                                                 \
-                fb[(j_) % 3][g_][kk_] = buf_load16(a.u8, a.u_bytes, u_voff, so_ + (unsigned)g_ * 1024u + (unsigned)kk_ * u_piece); \
+                fb[(j_)][g_][kk_] = buf_load16(a.u8, a.u_bytes, u_voff, so_ + (unsigned)g_ * 1024u + (unsigned)kk_ * u_piece); \
     } while (0)
 #define W8_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -287,42 +313,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][g][r] = 0.f;
-        u32x4 fb[3][2][NP];                             // B fragments: ring of three positions x cout group x piece
+        u32x4 fb[9][2][NP];                             // B fragments of the wave's nine positions x cout group x piece
 
+        W8_LOAD_B(0, 0);
+        W8_LOAD_B(0, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the item's first two patches landed (this wave's part): they are older than these 8 loads
         for (int cc = 0; cc < a.CC; ++cc) {
-            W8_LOAD_B(cc, 0);
-            W8_LOAD_B(cc, 1);
-            // patch cc landed (this wave's part): from chunk 1 on its DMAs are older than B loads that were already consumed; the
-            // first two patches of an item are older than the 8 B loads just issued
-            if (cc == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // patch cc landed (this wave's part): its DMAs were issued at the end of chunk cc-2's MFMA phase, before B loads that
+            // have been consumed since (VMEM returns in order)
             W8_BARRIER();                               // everyone's part; and every wave is done with V of the previous chunk
-            {
+            if (W8_EXP != 2) {
                 const char* src = sP + (cc & 1) * P_BYTES + src0;
                 if (t_half == 0) transform_chunk<0>(src, sV + dstv, S);
                 else transform_chunk<1>(src, sV + dstv, S);
             }
             W8_BARRIER();                               // V complete; the patch buffer of this chunk is free
-            W8_ISSUE_P(cc + 2);
+            // MFMA phase.  The B (weight) fragments are what this kernel waits for: 147 KB per chunk and CU at the ~27 B/clk/CU a
+            // latency-bound stream of two positions in flight reaches (timing builds: 400 us of a 1480 us launch).  The transform's
+            // registers are free now, so ALL remaining positions are requested at once (28 loads per wave in flight: bandwidth-, not
+            // latency-bound) — positions 0 and 1 were requested a phase ago, in the previous MFMA phase's last slots.  Then 9 position
+            // slots x 6 slices of ONE MFMA + at most one memory instruction in its shadow, fenced so that the compiler keeps the
+            // order; A fragments one position ahead; the two cout groups alternate so that consecutive MFMAs never share an accumulator.
+            u32x4 fa[2][NP];
+            if (W8_EXP != 3) {
+                if (W8_EXP != 1) {
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                if (j + 2 < 9) W8_LOAD_B(cc, j + 2);
-                const char* va = sV + (9 * wave + j) * NP * VPIECE + fragA;
-                const u32x4 fa0 = lds_u4(va), fa1 = lds_u4(va + VPIECE);
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    acc[j][g] = mfma16(fa0, fb[j % 3][g][1], acc[j][g]);        // hi lo'
-                    acc[j][g] = mfma16(fa1, fb[j % 3][g][0], acc[j][g]);        // lo hi'
-                    acc[j][g] = mfma16(fa0, fb[j % 3][g][0], acc[j][g]);        // hi hi'
+                    for (int j = 2; j < 9; ++j) W8_LOAD_B(cc, j);
                 }
+                {
+                    const char* va = sV + (9 * wave) * NP * VPIECE + fragA;
+                    fa[0][0] = lds_u4(va);
+                    fa[0][1] = lds_u4(va + VPIECE);
+                }
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int t = k >> 1, g = k & 1;   // terms hi lo', lo hi', hi hi'
+                        if (j == 8) mfma16_vgpr(fa[j & 1][t == 1 ? 1 : 0], fb[j][g][t == 0 ? 1 : 0], acc[j][g]);
+                        else acc[j][g] = mfma16(fa[j & 1][t == 1 ? 1 : 0], fb[j][g][t == 0 ? 1 : 0], acc[j][g]);
+                        if (k < 4 && j >= 7 && W8_EXP != 1 && cc + 1 < a.CC) {        // slots 7 / 8: positions 0 / 1 of the next chunk (their registers are free)
+                            const unsigned so_ = (unsigned)(cc + 1) * u_chunk + (unsigned)(9 * wave + j - 7) * u_pos + (unsigned)(k >> 1) * 1024u + (unsigned)(k & 1) * u_piece;
+                            fb[j - 7][k >> 1][k & 1] = buf_load16(a.u8, a.u_bytes, u_voff, so_);
+                        } else if (k >= 4 && j + 1 < 9) {  // one A fragment of the next position
+                            fa[(j + 1) & 1][k - 4] = lds_u4(sV + ((9 * wave + j + 1) * NP + (k - 4)) * VPIECE + fragA);
+                        }
+                        // the patch two chunks ahead, one LDS-DMA piece per slice from slot 6 slice 4 on: behind the B loads this chunk
+                        // still waits for (VMEM returns in order: a B load younger than a DMA from HBM would wait for it), in the
+                        // shadow of the MFMAs; it lands during the next transform phase
+                        {
+                            const int dslice = (j - 6) * 6 + k - 4;         // 0 .. 13 for (j, k) = (6, 4) .. (8, 5)
+                            if (dslice >= 0 && dslice < 10 && cc + 2 < a.CC)
+                                dma16(a.x, a.x_bytes, sP + (cc & 1) * P_BYTES + (dslice * 256 + wave * 64) * 16, p_off[dslice], (unsigned)((cc + 2) * 64));
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (W8_EXP == 3) W8_ISSUE_P(cc + 2);
         }
 
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the asm MFMAs' results are read by VALU below: past the XDL write -> VALU read distance
         // ---- epilogue: Y = A^T M A ----
         float* sQ = reinterpret_cast<float*>(smem);     // [8 row parts][4 dx][32 tiles][32 couts]
         const int e_cq = tid & 7, e_tile = tid >> 3;
         const int oy = y0 + 4 * (e_tile >> 3), ox = x0 + 4 * (e_tile & 7);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < (W8_EXP == 5 ? 0 : 2); ++g) {
             W8_BARRIER();                               // V (g = 0) / the previous pass's exchange buffer is no longer read
             // stage 1: this wave's positions reduced along x: q[dx] = sum_j A^T[dx][j] M[i][j]
             if ((wave & 1) == 0) {                      // local 0..5 = a full row, 6..8 = columns 0..2 of the next row
@@ -400,7 +458,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         o[e] = fmaxf(yv[dy][e] * inv + bv[e] + rv[e], lo);
                         omax = fmaxf(omax, ok ? fabsf(o[e]) : 0.f);
                     }
-                    buf_store16(o, a.y, a.y_bytes, ok ? y_voff : OOB, so * (unsigned)a.ldy * 4u);
+                    buf_store16(o, a.y, a.y_bytes, (ok && (W8_EXP != 4 || o[0] == 12345.f)) ? y_voff : OOB, so * (unsigned)a.ldy * 4u);
                 }
             }
         }

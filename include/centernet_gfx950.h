@@ -170,6 +170,15 @@ int cnl_normalize_u8_nhwc_f32(const uint8_t* x, float* y, int32_t N, int32_t H, 
                               const float* inv_std255, void* stream);
 
 /*
+ * albumentations A.Resize(height, width) = cv2.resize(img, (W_out, H_out), interpolation=cv2.INTER_LINEAR) on uint8 HWC frames
+ * (README.md:84; datasets/utils.py:24-33 build the same pipeline for training): OpenCV's 8-bit fixed-point bilinear rule (half-pixel
+ * centres, 11-bit coefficients, the two-stage rounding of VResizeLinear<uchar>), restated in csrc/preprocess.hip.
+ * x: [N, H_in, W_in, C] u8 -> y: [N, H_out, W_out, C] u8, C <= 4.
+ */
+int cnl_resize_bilinear_u8(const uint8_t* x, uint8_t* y, int32_t N, int32_t H_in, int32_t W_in, int32_t H_out, int32_t W_out,
+                           int32_t C, void* stream);
+
+/*
  * ResNet stem: Conv2d(3,64,7,stride=2,padding=3,bias=False)+BN+ReLU (torchvision resnet.conv1/bn1/relu).
  * x is read through explicit element strides (sn,sc,sh,sw) so NCHW-contiguous and channels_last
  * callers are both zero-copy (models/meta.py:97-98 precedent); y is NHWC [N, H/2, W/2, 64].
@@ -192,6 +201,15 @@ int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int
 int cnl_stem_conv7x7_maxpool_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
                                  const float* w, const float* bias, float* y,
                                  int32_t N, int32_t H, int32_t W, void* stream);
+
+/* The stem on uint8 frames: x is [N, H, W, 3]-like uint8 addressed through BYTE strides (sn, sc, sh, sw); A.Normalize
+ * — (float(x) - mean255[c]) * inv_std255[c], the arithmetic of cnl_normalize_u8_nhwc_f32, bit for bit — is applied to the staged patch
+ * inside the kernel, so the fp32 image never exists in HBM (3 B/pixel read instead of 12 written + 12 read).  mean255 / inv_std255: HOST
+ * arrays of 3 floats.  fuse_maxpool != 0: y is the pooled map of cnl_stem_conv7x7_maxpool_f32, else the conv output of
+ * cnl_stem_conv7x7_f32.  Bit-identical to cnl_normalize_u8_nhwc_f32 followed by the fp32-input entry points (CNL_ALGO_AUTO).            */
+int cnl_stem_conv7x7_u8(const uint8_t* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* mean255,
+                        const float* inv_std255, const float* w, const float* bias, float* y, int32_t N, int32_t H, int32_t W,
+                        int32_t fuse_maxpool, void* stream);
 
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC (torchvision resnet.maxpool). C % 4 == 0. */
 int cnl_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C,

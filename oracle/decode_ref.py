@@ -154,3 +154,39 @@ def normalize_u8(images_u8, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225
     img = img - m
     img = img * denom
     return img.astype(np.float32)
+
+
+def resize_bilinear_u8(images_u8, out_h, out_w):
+    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_LINEAR) for uint8 images = albumentations A.Resize (README.md:84 of the
+    reference).  OpenCV is absent here: its published 8-bit algorithm (modules/imgproc/src/resize.cpp: resizeGeneric_ with
+    HResizeLinear<uchar,int,short,2048> and VResizeLinear<uchar,int,short>) is restated — "parity unpinned":
+        fx = float32((dx + 0.5) * scale_x - 0.5); sx = floor(fx); fx -= sx; clamp (sx < 0 -> 0, fx = 0; sx >= W-1 -> W-1, fx = 0)
+        alpha = int16(rint([1 - fx, fx] * 2048)); beta likewise from fy (rows clipped instead of fy clamped)
+        D = S[sx] * a0 + S[min(sx+1, W-1)] * a1;   dst = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2
+    images_u8: (N,H,W,C) uint8 -> (N,out_h,out_w,C) uint8."""
+    x = np.asarray(images_u8)
+    N, H, W, C = x.shape
+    sx_scale, sy_scale = 1.0 / (out_w / W), 1.0 / (out_h / H)
+
+    def axis(n_out, n_in, scale, clamp_f):
+        d = np.arange(n_out, dtype=np.float64)
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        if clamp_f:
+            lo, hi = s < 0, s >= n_in - 1
+            f = np.where(lo | hi, np.float32(0), f)
+            s = np.where(lo, 0, np.where(hi, n_in - 1, s))
+        c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int16).astype(np.int64)
+        c1 = np.rint(f * np.float32(2048)).astype(np.int16).astype(np.int64)
+        return s, c0, c1
+
+    sx, a0, a1 = axis(out_w, W, sx_scale, True)
+    sy, b0, b1 = axis(out_h, H, sy_scale, False)
+    x1 = np.minimum(sx + 1, W - 1)
+    y0, y1 = np.clip(sy, 0, H - 1), np.clip(sy + 1, 0, H - 1)
+    xi = x.astype(np.int64)
+    D = xi[:, :, sx, :] * a0[None, None, :, None] + xi[:, :, x1, :] * a1[None, None, :, None]          # (N, H, out_w, C)
+    D0, D1 = D[:, y0], D[:, y1]
+    v = (((b0[None, :, None, None] * (D0 >> 4)) >> 16) + ((b1[None, :, None, None] * (D1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)

@@ -98,3 +98,29 @@ def test_xyxy_to_xywh_and_coco_predictions_gpu():
     assert preds[2]["labels"].dtype == np.int64 and np.array_equal(preds[2]["scores"], dets["scores"][2].cpu().numpy())
     ann = formats.coco_annotations(preds, [0, 1, 2], prediction=True)
     assert len(ann) == 21 and ann[0]["id"] == 1 and ann[-1]["image_id"] == 2 and isinstance(ann[0]["bbox"], list)
+
+
+def test_reference_tracking_checkpoint_with_training_only_keys_loads_strict():
+    """a reference FairMOT checkpoint carries EmbeddingHead.classifier.{0,1,3}.* ("used during training only",
+    fairmot.py:25-31).  They are dropped, not reported as unexpected, so strict loading works; genuinely foreign keys still raise."""
+    import os
+    import torch
+    import centernet_lightning_amd as cl
+    from centernet_lightning_amd import formats
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "centernet-lightning_amd", "configs", "tracking_resnet34_fpn.yaml")
+    model = cl.build_centernet(cfg)
+    sd = {"model." + k: v.clone() for k, v in model.state_dict().items()}
+    E, ids = 64, 800                                         # the reference EmbeddingHead's key set (max_track_ids = 800 in the config)
+    sd.update({"model.heads.reid.classifier.0.weight": torch.zeros(E, E), "model.heads.reid.classifier.1.weight": torch.ones(E),
+               "model.heads.reid.classifier.1.bias": torch.zeros(E), "model.heads.reid.classifier.1.running_mean": torch.zeros(E),
+               "model.heads.reid.classifier.1.running_var": torch.ones(E), "model.heads.reid.classifier.1.num_batches_tracked": torch.tensor(0),
+               "model.heads.reid.classifier.3.weight": torch.zeros(ids, E), "model.heads.reid.classifier.3.bias": torch.zeros(ids)})
+    sd["model.heads.reid.out_conv.bias"] = sd["model.heads.reid.out_conv.bias"] + 1.0
+    missing, unexpected = formats.load_checkpoint(model, {"state_dict": sd}, strict=True)
+    assert missing == [] and unexpected == []
+    assert float(model.heads["reid"].out_conv.bias[0]) == 1.0
+    assert any(formats.is_training_only_key(k) for k in sd) and "heads.reid.classifier.0.weight" in formats.checkpoint_state_dict(sd, keep_training_only=True)
+    sd["model.some_other_module.weight"] = torch.zeros(1)
+    import pytest
+    with pytest.raises(KeyError):
+        formats.load_checkpoint(model, {"state_dict": sd}, strict=True)

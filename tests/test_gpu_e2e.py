@@ -342,3 +342,78 @@ def test_preprocess_uint8_bit_exact_and_feeds_forward():
     b = model.get_encoded_outputs(x.contiguous())
     for k in a:
         assert torch.equal(a[k], b[k])
+
+
+def test_resize_uint8_bit_exact_against_oracle():
+    """cnl_resize_bilinear_u8 = cv2.resize(INTER_LINEAR) on uint8 frames (A.Resize, README.md:84): bit-exact against the numpy restatement
+    of OpenCV's fixed-point rule, for down- and up-scaling, odd sizes and the identity; plus hand-checkable known answers."""
+    model, _ = build("resnet34_simple.yaml")
+    g = torch.Generator().manual_seed(31)
+    for (shape, oh, ow) in [((2, 1080 // 4, 1920 // 4, 3), 128, 128), ((1, 33, 47, 3), 64, 96), ((2, 40, 24, 3), 40, 24),
+                            ((1, 17, 29, 1), 5, 7), ((1, 64, 64, 3), 152, 272)]:
+        u8 = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+        out = model.resize_uint8(u8.cuda(), oh, ow)
+        ref = decode_ref.resize_bilinear_u8(u8.numpy(), oh, ow)
+        assert tuple(out.shape) == (shape[0], oh, ow, shape[3])
+        assert np.array_equal(out.cpu().numpy(), ref), (shape, oh, ow)
+    row = torch.tensor([[[[0], [100]]]], dtype=torch.uint8).cuda()                    # 1 x 2 row -> width 4: 0, 25, 75, 100
+    assert model.resize_uint8(row, 1, 4).flatten().tolist() == [0, 25, 75, 100]
+    const = torch.full((1, 5, 6, 3), 137, dtype=torch.uint8).cuda()
+    assert bool((model.resize_uint8(const, 11, 13) == 137).all())
+
+
+@pytest.mark.parametrize("cfg", ["resnet34_simple.yaml", "resnet34_fpn.yaml"])
+def test_forward_uint8_is_bit_identical_to_normalize_then_forward(cfg):
+    """The uint8 stem (cnl_stem_conv7x7_u8: A.Normalize applied to the staged patch inside the kernel, no fp32 image in HBM) gives the
+    bits of preprocess_uint8() + forward(): same arithmetic, same order.  Ragged sizes exercise the zero padding of the NORMALISED
+    image (an out-of-image slot must stay 0, not (0 - mean) / std)."""
+    model, _ = build(cfg)
+    g = torch.Generator().manual_seed(17)
+    for shape in [(2, 128, 160, 3), (1, 96, 224, 3)]:
+        u8 = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8).cuda()
+        a = model(model.preprocess_uint8(u8))
+        b = model.forward_uint8(u8)
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta, tb), shape
+    frames = torch.randint(0, 256, (2, 270, 480, 3), generator=g, dtype=torch.uint8).cuda()      # "1080p / 4" frames -> A.Resize -> network
+    a = model(model.preprocess_uint8(model.resize_uint8(frames, 128, 128)))
+    b = model.forward_uint8(frames, resize=(128, 128))
+    for ta, tb in zip(a, b):
+        assert torch.equal(ta, tb)
+    dets = model.gather_detection2d(b, num_detections=20)
+    assert tuple(dets["bboxes"].shape) == (2, 20, 4)
+
+
+def test_torchscript_export_traces_saves_and_replays_bit_equal(tmp_path):
+    """tools/export.py:7-12 (to_torchscript(method="trace")): the forward traces to ONE node, centernet_gfx950::forward; the traced
+    module replays bit-equal, survives torch.jit.save / load, and the saved file runs in a FRESH process that merely imports the
+    package (the op rebuilds the model from the embedded config + the saved tensors)."""
+    import subprocess
+    import sys
+    model, _ = build("resnet34_fpn.yaml")
+    x = recipes.images(5, (2, 3, 128, 160)).cuda()
+    ref = model(x)
+    traced = cl.export_torchscript(model, save_path=str(tmp_path / "m.pt"), example_inputs=x)
+    assert "centernet_gfx950::forward" in str(traced.graph)
+    out = traced(x)
+    assert len(out) == 2 and all(torch.equal(a, b) for a, b in zip(out, ref))
+    x2 = recipes.images(6, (1, 3, 96, 96)).cuda()                      # another shape through the same traced module
+    assert all(torch.equal(a, b) for a, b in zip(traced(x2), model(x2)))
+    loaded = torch.jit.load(str(tmp_path / "m.pt"))
+    assert all(torch.equal(a, b) for a, b in zip(loaded(x), ref))
+    torch.save(x.cpu(), tmp_path / "x.pt")
+    torch.save([t.cpu() for t in ref], tmp_path / "ref.pt")
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {os.path.join(os.path.dirname(CONFIGS))!r})\n"
+        "import centernet_lightning_amd\n"
+        f"m = torch.jit.load({str(tmp_path / 'm.pt')!r})\n"
+        f"x = torch.load({str(tmp_path / 'x.pt')!r}).cuda()\n"
+        f"ref = torch.load({str(tmp_path / 'ref.pt')!r})\n"
+        "out = m(x)\n"
+        "assert all(torch.equal(a.cpu(), b) for a, b in zip(out, ref))\n"
+        "print('fresh-process replay ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fresh-process replay ok" in r.stdout, r.stderr[-2000:]
+    with pytest.raises(NotImplementedError):
+        cl.export_onnx(model, "x.onnx")
