@@ -130,9 +130,11 @@ static int wino_choice(const cnl_conv_params* p) {
     if (p->algo == CNL_ALGO_F32 || p->Cin % 16) return 2;
     if (items_per_image >= 8 && (p->Cin >= 128 || p->Cout >= 512)) {
         const long long area = (long long)H * W;
-        if (p->algo == CNL_ALGO_AUTO && p->Cin >= 128 && cnl_wino8_eligible(p)) {
-            // F(4x4): 32x16-pixel items; taken where they pad the map by at most 15 % (128x128, 64x64, 32x32 at 512x512 inputs; 152x272,
-            // 76x136 of 608x1088 frames) — the padding is pure extra work, and below 0.56 / 0.7 it would eat the kernel's advantage
+        if (p->algo == CNL_ALGO_AUTO && p->Cin >= 256 && area >= 64 * 64 && cnl_wino8_eligible(p)) {
+            // F(4x4): 32x16-pixel items.  Measured against kernel 5 / 6 on one box (profiles/r02_winograd8_variants.txt): 0.89-0.93 of
+            // their time on the 256 -> 256 head blocks at 128x128, 0.93-0.97 at 152x272, no gain on the backbone's 32x32 / 64x64 maps
+            // (few items per CU: the per-item prologue / epilogue weigh more) — taken only for the long channel loops on large maps,
+            // where the padding of the map to 32x16-pixel items stays below 15 %
             const long long pad8 = (long long)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32);
             if (pad8 * 100 <= area * 115) return 8;
         }

@@ -36,6 +36,9 @@
 #ifndef W8_EXP
 #define W8_EXP 0      /* timing builds (wrong results): 1 no B loads in the MFMA phase, 2 no input transform, 3 no MFMA phase, 4 no output stores, 5 no epilogue */
 #endif
+#ifndef W8_ORDER
+#define W8_ORDER 2    /* work-item order: 0 cout block fastest, 1 cout block slowest inside an image, 2 pairs of cout blocks fastest */
+#endif
 #ifndef W8_PK
 #define W8_PK 1       /* packed fp32 fma in the input transform */
 #endif
@@ -180,6 +183,9 @@ __device__ __forceinline__ void bt6(const f32x4 t0, const f32x4 t1, const f32x4 
 
 // Input transform of one chunk for this thread's (tile, channel quad): rows 3 HALF .. 3 HALF + 2 of B^T d, all six columns.
 // src = the thread's d[0][0] in the patch image, dst = its 8 bytes in the (position 0, piece 0) plane of V.
+// (Measured and rejected, profiles/r02_winograd8_variants.txt: the same work as two passes over channel pairs — half the live
+// registers, so that weight fragments could be requested DURING the transform — was 13 % slower per transform and bought nothing:
+// the weight stream is bound by the L2 -> CU path, not by the loads in flight.)
 template <int HALF>
 __device__ __forceinline__ void transform_chunk(const char* src, char* dst, const float S) {
     f32x4 t[3][6];
@@ -247,44 +253,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float Su = a.su[0];
 
     float omax = 0.f;
-    unsigned item = blockIdx.x;
-    while (true) {
-        // ---- work item ----
-        int n, y0, x0, n0;
-        {
-            // Work-item order: tiles of one (image, cout block) fastest, then the cout block, then the image.  xcd_remap gives each XCD a
-            // contiguous range of ids and the persistent workgroups step through it 32 at a time, so the CUs of an XCD multiply the
-            // SAME cout block's weights at about the same time: its slice of U (36 x 2 x 64 x Cin x 2 B = 2.4 MB for Cin = 256, of 9.4 MB
-            // for the layer) stays in that XCD's 4 MB L2.  With cout blocks fastest (what suits F(2x2)'s 4.2 MB of weights) the B
-            // fragments came from the Infinity Cache: 326 us of a 1420 us launch waiting for them (timing builds, profiles/r02).
-            unsigned b_ = cnl::xcd_remap(item, (unsigned)a.blocks);
-            int nbi, bxi, byi;
-            bxi = b_ % a.bx; b_ /= a.bx; byi = b_ % a.by; b_ /= a.by; nbi = b_ % a.nb; n = b_ / a.nb;
-            y0 = byi * (4 * TY); x0 = bxi * (4 * TX); n0 = nbi * BN;
-        }
-        unsigned p_off[10];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const int s_ = i * 256 + tid;                       // 16-byte slot of the patch image: (py*4 + quad)*PP + px
-            const int rowq = s_ / PP, pxx = s_ - rowq * PP;
-            const int py = rowq >> 2, q = rowq & 3;
-            const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-            const bool ok = py < PH && pxx < PW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
-            p_off[i] = ok ? (unsigned)((((n * a.Hs + sy) * a.Ws + sx) * a.ldx + q * 4) * 4) : OOB;
-        }
-        const unsigned u_voff = (unsigned)((n0 + (lane & 31)) * 32 + hi * 16);
-        float S = 1.f;
-        {
-            const float mx = 32.f * a.xmax[n];
-            if (mx > 0.f && mx < __builtin_inff()) {
-                int e_;
-                (void)__builtin_frexpf(mx, &e_);                // 2^(e-1) <= mx < 2^e
-                e_ = 15 - e_;
-                S = __builtin_ldexpf(1.f, e_ < -100 ? -100 : (e_ > 100 ? 100 : e_));
-            }
-        }
-        const float inv = 1.f / (S * Su);
+    // ---- work-item state (set by W8_SETUP for the item about to run; the epilogue works on copies) ----
+    int n, y0, x0, n0;
+    unsigned p_off[10], u_voff;
+    float S, inv;
+#define W8_SETUP(item_)                                                                                          \
+    do {                                                                                                         \
+        /* pairs of cout blocks fastest, then the tile, then the pair index (as winograd5.hip): the two workgroups that share an    \
+           input patch run side by side; cout-block-slowest orders (one slice of U per XCD at a time) measured 4 % slower */        \
+        unsigned b_ = cnl::xcd_remap((item_), (unsigned)a.blocks);                                               \
+        int nbi_, bxi_, byi_;                                                                                    \
+        if (W8_ORDER == 0 || (W8_ORDER == 2 && (a.nb & 1))) {       /* cout block fastest */                     \
+            nbi_ = b_ % a.nb; b_ /= a.nb; bxi_ = b_ % a.bx; b_ /= a.bx; byi_ = b_ % a.by; n = b_ / a.by;         \
+        } else if (W8_ORDER == 1) {                                 /* cout block slowest inside an image */     \
+            bxi_ = b_ % a.bx; b_ /= a.bx; byi_ = b_ % a.by; b_ /= a.by; nbi_ = b_ % a.nb; n = b_ / a.nb;         \
+        } else {                                                    /* pairs of cout blocks fastest */           \
+            const int np_ = a.nb / 2;                                                                            \
+            const int lo_ = b_ % 2; b_ /= 2; bxi_ = b_ % a.bx; b_ /= a.bx; byi_ = b_ % a.by; b_ /= a.by;         \
+            const int pr_ = b_ % np_; n = b_ / np_; nbi_ = pr_ * 2 + lo_;                                        \
+        }                                                                                                        \
+        y0 = byi_ * (4 * TY); x0 = bxi_ * (4 * TX); n0 = nbi_ * BN;                                              \
+        _Pragma("unroll") for (int i = 0; i < 10; ++i) {                                                         \
+            const int s_ = i * 256 + tid;              /* 16-byte slot of the patch image: (py*4 + quad)*PP + px */ \
+            const int rowq_ = s_ / PP, pxx_ = s_ - rowq_ * PP;                                                   \
+            const int py_ = rowq_ >> 2, q_ = rowq_ & 3;                                                          \
+            const int iy_ = y0 - 1 + py_, ix_ = x0 - 1 + pxx_;                                                   \
+            const bool ok_ = py_ < PH && pxx_ < PW && (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W; \
+            const int sy_ = up ? (iy_ >> 1) : iy_, sx_ = up ? (ix_ >> 1) : ix_;                                  \
+            p_off[i] = ok_ ? (unsigned)((((n * a.Hs + sy_) * a.Ws + sx_) * a.ldx + q_ * 4) * 4) : OOB;           \
+        }                                                                                                        \
+        u_voff = (unsigned)((n0 + (lane & 31)) * 32 + hi * 16);                                                  \
+        S = 1.f;                                                                                                 \
+        {                                                                                                        \
+            const float mx_ = 32.f * a.xmax[n];                                                                  \
+            if (mx_ > 0.f && mx_ < __builtin_inff()) {                                                           \
+                int e_;                                                                                          \
+                (void)__builtin_frexpf(mx_, &e_);            /* 2^(e-1) <= mx < 2^e */                           \
+                e_ = 15 - e_;                                                                                    \
+                S = __builtin_ldexpf(1.f, e_ < -100 ? -100 : (e_ > 100 ? 100 : e_));                             \
+            }                                                                                                    \
+        }                                                                                                        \
+        inv = 1.f / (S * Su);                                                                                    \
+    } while (0)
 #define W8_ISSUE_P(cc_)                                                                                          \
     do {                                                                                                         \
         if ((cc_) < a.CC) {                                                                                      \
@@ -293,19 +303,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 dma16(a.x, a.x_bytes, d_ + (i * 256 + wave * 64) * 16, p_off[i], (unsigned)((cc_) * 64));        \
         }                                                                                                        \
     } while (0)
+    // the four B fragments of position j_ of chunk cc_ into ring buffer (j_) % 3
 #define W8_LOAD_B(cc_, j_)                                                                                       \
     do {                                                                                                         \
         const unsigned so_ = (unsigned)(cc_) * u_chunk + (unsigned)(9 * wave + (j_)) * u_pos;                    \
         _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_)                                                         \
             _Pragma("unroll") for (int kk_ = 0; kk_ < NP; ++kk_)                                                 \
-                fb[(j_)][g_][kk_] = buf_load16(a.u8, a.u_bytes, u_voff, so_ + (unsigned)g_ * 1024u + (unsigned)kk_ * u_piece); \
+                fb[(j_) % 3][g_][kk_] = buf_load16(a.u8, a.u_bytes, u_voff, so_ + (unsigned)g_ * 1024u + (unsigned)kk_ * u_piece); \
     } while (0)
 #define W8_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+    unsigned item = blockIdx.x;
+    while (true) {
+        W8_SETUP(item);
         W8_BARRIER();                                   // the previous item's epilogue is done with the exchange buffer
         W8_ISSUE_P(0);
         W8_ISSUE_P(1);
-
         f32x16 acc[9][2];
 #pragma unroll
         for (int j = 0; j < 9; ++j)
@@ -313,14 +326,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][g][r] = 0.f;
-        u32x4 fb[9][2][NP];                             // B fragments of the wave's nine positions x cout group x piece
-
+        u32x4 fb[3][2][NP];                             // B fragments: ring of three positions x cout group x piece
         W8_LOAD_B(0, 0);
         W8_LOAD_B(0, 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the item's first two patches landed (this wave's part): they are older than these 8 loads
+        // the item's first two patches landed (this wave's part): their DMAs are older than these 8 loads (VMEM returns in order)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         for (int cc = 0; cc < a.CC; ++cc) {
-            // patch cc landed (this wave's part): its DMAs were issued at the end of chunk cc-2's MFMA phase, before B loads that
-            // have been consumed since (VMEM returns in order)
+            // patch cc landed (this wave's part): its DMAs were issued in the last slices of chunk cc-2's MFMA phase, before B loads
+            // that have been consumed since
             W8_BARRIER();                               // everyone's part; and every wave is done with V of the previous chunk
             if (W8_EXP != 2) {
                 const char* src = sP + (cc & 1) * P_BYTES + src0;
@@ -328,18 +341,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 else transform_chunk<1>(src, sV + dstv, S);
             }
             W8_BARRIER();                               // V complete; the patch buffer of this chunk is free
-            // MFMA phase.  The B (weight) fragments are what this kernel waits for: 147 KB per chunk and CU at the ~27 B/clk/CU a
-            // latency-bound stream of two positions in flight reaches (timing builds: 400 us of a 1480 us launch).  The transform's
-            // registers are free now, so ALL remaining positions are requested at once (28 loads per wave in flight: bandwidth-, not
-            // latency-bound) — positions 0 and 1 were requested a phase ago, in the previous MFMA phase's last slots.  Then 9 position
-            // slots x 6 slices of ONE MFMA + at most one memory instruction in its shadow, fenced so that the compiler keeps the
-            // order; A fragments one position ahead; the two cout groups alternate so that consecutive MFMAs never share an accumulator.
+            W8_ISSUE_P(cc + 2);                         // the patch two chunks ahead, into the buffer this chunk's transform has read
+            // MFMA phase: 9 position slots x 6 slices of ONE MFMA + at most one memory instruction issued in its shadow, fenced so
+            // that the compiler keeps the software pipeline (left alone it sinks every B load to just before its first use: one L2
+            // round trip per MFMA pair).  B fragments two positions ahead (ring of three; slots 7 / 8 fetch positions 0 / 1 of the
+            // NEXT chunk, which then have the whole transform phase to arrive), A fragments one position ahead; the two cout
+            // groups alternate so that consecutive MFMAs never share an accumulator.  What the phase waits for is the weight stream
+            // itself — 147 KB per chunk and CU at the ~27 B/clk/CU the L2 -> CU path delivers, whatever the number of loads in flight
+            // (all nine positions requested at once: slower) and whatever the work-item order (profiles/r02_winograd8_variants.txt).
             u32x4 fa[2][NP];
             if (W8_EXP != 3) {
-                if (W8_EXP != 1) {
-#pragma unroll
-                    for (int j = 2; j < 9; ++j) W8_LOAD_B(cc, j);
-                }
                 {
                     const char* va = sV + (9 * wave) * NP * VPIECE + fragA;
                     fa[0][0] = lds_u4(va);
@@ -351,43 +362,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int k = 0; k < 6; ++k) {
                         __builtin_amdgcn_sched_barrier(0);
                         const int t = k >> 1, g = k & 1;   // terms hi lo', lo hi', hi hi'
-                        if (j == 8) mfma16_vgpr(fa[j & 1][t == 1 ? 1 : 0], fb[j][g][t == 0 ? 1 : 0], acc[j][g]);
-                        else acc[j][g] = mfma16(fa[j & 1][t == 1 ? 1 : 0], fb[j][g][t == 0 ? 1 : 0], acc[j][g]);
-                        if (k < 4 && j >= 7 && W8_EXP != 1 && cc + 1 < a.CC) {        // slots 7 / 8: positions 0 / 1 of the next chunk (their registers are free)
-                            const unsigned so_ = (unsigned)(cc + 1) * u_chunk + (unsigned)(9 * wave + j - 7) * u_pos + (unsigned)(k >> 1) * 1024u + (unsigned)(k & 1) * u_piece;
-                            fb[j - 7][k >> 1][k & 1] = buf_load16(a.u8, a.u_bytes, u_voff, so_);
+                        if (j == 8) mfma16_vgpr(fa[j & 1][t == 1 ? 1 : 0], fb[j % 3][g][t == 0 ? 1 : 0], acc[j][g]);
+                        else acc[j][g] = mfma16(fa[j & 1][t == 1 ? 1 : 0], fb[j % 3][g][t == 0 ? 1 : 0], acc[j][g]);
+                        if (k < 4 && W8_EXP != 1) {        // one B fragment of the position after next
+                            const int jn = (j + 2) % 9;
+                            const int cn = cc + (j + 2 >= 9 ? 1 : 0);
+                            if (j + 2 < 9 || cn < a.CC) {
+                                const unsigned so_ = (unsigned)cn * u_chunk + (unsigned)(9 * wave + jn) * u_pos + (unsigned)(k >> 1) * 1024u + (unsigned)(k & 1) * u_piece;
+                                fb[jn % 3][k >> 1][k & 1] = buf_load16(a.u8, a.u_bytes, u_voff, so_);
+                            }
                         } else if (k >= 4 && j + 1 < 9) {  // one A fragment of the next position
                             fa[(j + 1) & 1][k - 4] = lds_u4(sV + ((9 * wave + j + 1) * NP + (k - 4)) * VPIECE + fragA);
-                        }
-                        // the patch two chunks ahead, one LDS-DMA piece per slice from slot 6 slice 4 on: behind the B loads this chunk
-                        // still waits for (VMEM returns in order: a B load younger than a DMA from HBM would wait for it), in the
-                        // shadow of the MFMAs; it lands during the next transform phase
-                        {
-                            const int dslice = (j - 6) * 6 + k - 4;         // 0 .. 13 for (j, k) = (6, 4) .. (8, 5)
-                            if (dslice >= 0 && dslice < 10 && cc + 2 < a.CC)
-                                dma16(a.x, a.x_bytes, sP + (cc & 1) * P_BYTES + (dslice * 256 + wave * 64) * 16, p_off[dslice], (unsigned)((cc + 2) * 64));
                         }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (W8_EXP == 3) W8_ISSUE_P(cc + 2);
         }
-
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the asm MFMAs' results are read by VALU below: past the XDL write -> VALU read distance
-        // ---- epilogue: Y = A^T M A ----
-        float* sQ = reinterpret_cast<float*>(smem);     // [8 row parts][4 dx][32 tiles][32 couts]
+
+        // ---- epilogue: Y = A^T M A.  Stage 1 (registers): each wave reduces its positions along x — a full row of six or a half row;
+        // the eight row parts meet through LDS (one cout group per pass: [8 parts][4 dx][32 tiles][32 couts] = 128 KB over V and the
+        // patch buffers); stage 2: thread = (tile, 4 couts) finishes A^T . A.  (Measured and rejected: four 64 KB passes that leave the
+        // patch buffers free for the next item's first patches during the epilogue — the extra barriers cost more than the hidden
+        // HBM latency saved, profiles/r02_winograd8_variants.txt.) ----
+        const int en = n, ey0 = y0, ex0 = x0, en0 = n0;
+        const float einv = inv;
+        const unsigned next = item + gridDim.x;
+        const bool more = next < (unsigned)a.blocks;
+        float* sQ = reinterpret_cast<float*>(smem);
         const int e_cq = tid & 7, e_tile = tid >> 3;
-        const int oy = y0 + 4 * (e_tile >> 3), ox = x0 + 4 * (e_tile & 7);
+        const int oy = ey0 + 4 * (e_tile >> 3), ox = ex0 + 4 * (e_tile & 7);
 #pragma unroll
         for (int g = 0; g < (W8_EXP == 5 ? 0 : 2); ++g) {
             W8_BARRIER();                               // V (g = 0) / the previous pass's exchange buffer is no longer read
-            // stage 1: this wave's positions reduced along x: q[dx] = sum_j A^T[dx][j] M[i][j]
-            if ((wave & 1) == 0) {                      // local 0..5 = a full row, 6..8 = columns 0..2 of the next row
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int tl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    float* q = sQ + ((2 * wave) * 4 * 32 + tl) * 32 + (lane & 31);
+            for (int r = 0; r < 16; ++r) {
+                const int tl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float* q = sQ + ((2 * wave) * 4 * 32 + tl) * 32 + (lane & 31);          // [part][dx][tile][cout]: + part * 4096 + dx * 1024
+                if ((wave & 1) == 0) {                  // local 0..5 = a full row, 6..8 = columns 0..2 of the next row
                     const float m0 = acc[0][g][r], m1 = acc[1][g][r], m2 = acc[2][g][r], m3 = acc[3][g][r], m4 = acc[4][g][r], m5 = acc[5][g][r];
                     const float sa = m1 + m2, da = m1 - m2, sb = m3 + m4, db = m3 - m4;
                     q[0 * 1024] = (m0 + sa) + sb;
@@ -400,12 +413,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     q[5 * 1024] = PA * da2;
                     q[6 * 1024] = A2 * sa2;
                     q[7 * 1024] = A3 * da2;
-                }
-            } else {                                    // local 0..2 = columns 3..5 of a row, 3..8 = the next full row
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int tl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    float* q = sQ + ((2 * wave) * 4 * 32 + tl) * 32 + (lane & 31);
+                } else {                                // local 0..2 = columns 3..5 of a row, 3..8 = the next full row
                     const float n3 = acc[0][g][r], n4 = acc[1][g][r], n5 = acc[2][g][r];
                     const float sb2 = n3 + n4, db2 = n3 - n4;
                     q[0 * 1024] = sb2;
@@ -420,17 +428,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     q[7 * 1024] = __builtin_fmaf(A3, da, __builtin_fmaf(B3, db, m5));
                 }
             }
-            // this thread's output columns, bias and residual of the pass (requested before the barrier)
-            const int col = n0 + g * 32 + e_cq * 4;
+            // this thread's output columns, bias and addresses of the pass (requested before the barrier)
+            const int col = en0 + g * 32 + e_cq * 4;
             const bool col_ok = col < a.Cout;
             f32x4 bv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) bv[e] = col_ok ? a.bias[col + e] : 0.f;
-            const unsigned pix = (unsigned)((n * a.H + oy) * a.W + ox);
+            const unsigned pix = (unsigned)((en * a.H + oy) * a.W + ox);
             const unsigned y_voff = (pix * (unsigned)a.ldy + (unsigned)col) * 4u;
             const unsigned r_voff = (pix * (unsigned)a.ldr + (unsigned)col) * 4u;
             W8_BARRIER();
-            // stage 2: thread = (tile, 4 couts): rows 1 and 4 arrive in two parts; Y[dy][dx] = sum_i A^T[dy][i] q[i][dx]
+            // stage 2: rows 1 and 4 arrive in two parts; Y[dy][dx] = sum_i A^T[dy][i] q[i][dx]
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) {
                 f32x4 p[8];
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        o[e] = fmaxf(yv[dy][e] * inv + bv[e] + rv[e], lo);
+                        o[e] = fmaxf(yv[dy][e] * einv + bv[e] + rv[e], lo);
                         omax = fmaxf(omax, ok ? fabsf(o[e]) : 0.f);
                     }
                     buf_store16(o, a.y, a.y_bytes, (ok && (W8_EXP != 4 || o[0] == 12345.f)) ? y_voff : OOB, so * (unsigned)a.ldy * 4u);
@@ -465,13 +473,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (a.ymax) {          // max |y| of this item into its image's slot: one atomic per wave and item
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
-            if (lane == 0 && omax > 0.f) atomicMax(a.ymax + n, __float_as_uint(omax));
+            if (lane == 0 && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
             omax = 0.f;
         }
-        const unsigned next = item + gridDim.x;
-        if (next >= (unsigned)a.blocks) break;
+        if (!more) break;
         item = next;
     }
+#undef W8_SETUP
 #undef W8_ISSUE_P
 #undef W8_LOAD_B
 #undef W8_BARRIER

@@ -486,7 +486,7 @@ def test_winograd_split_kernels_exact_on_small_integers():
     for v in (5, 6):
         assert torch.equal(run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + v, want=5), ref_conv(x, w, b, 1, 0)), v
     assert torch.equal(run_winograd(x, w, b, 0, algo=CNL_ALGO_F2, want=5), ref_conv(x, w, b, 1, 0))
-    out = run_winograd(x, w, b, 0, algo=CNL_ALGO_AUTO, want=8)                    # F(4x4): integers up to ~4e3, error << 0.5
+    out = run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + 8, want=8)               # F(4x4): integers up to ~4e3, error << 0.5
     assert (out - ref_conv(x, w, b, 1, 0)).abs().max().item() < 2e-2
 
 
@@ -498,7 +498,7 @@ def test_winograd_is_batch_invariant_across_magnitudes():
     x = torch.randn(3, 256, 32, 32, generator=g).clamp_min(0) * torch.tensor([1.0, 1e-3, 300.0]).view(3, 1, 1, 1)
     w = torch.randn(128, 256, 3, 3, generator=g) * (2.0 / (256 * 9)) ** 0.5
     b = torch.randn(128, generator=g)
-    for algo, want in ((CNL_ALGO_AUTO, 8), (CNL_ALGO_F2, 5), (CNL_ALGO_F32, 2)):
+    for algo, want in ((CNL_ALGO_FORCE + 8, 8), (CNL_ALGO_F2, 5), (CNL_ALGO_F32, 2)):
         full = run_winograd(x, w, b, CNL_RELU, algo=algo, want=want)
         for i in range(3):
             assert torch.equal(full[i:i + 1], run_winograd(x[i:i + 1], w, b, CNL_RELU, algo=algo)), (algo, i)
@@ -626,3 +626,24 @@ def test_winograd_split_kernels_error_not_above_fp32_mfma():
             assert err[v] <= 1.25 * err[2] + 1e-7 * scale, (case, v, err, scale)
         assert err[8] <= 4e-6 * scale and err[8] <= 8 * err[2] + 1e-7 * scale, (case, err, scale)
         assert err[2] < 2e-5 * scale, (case, err, scale)
+
+
+def test_winograd_dispatch_is_a_function_of_shape_and_algo_only():
+    """cnl_conv3x3_winograd_kernel: the kernel class follows the layer shape and the caller's algo — never the batch size, never the
+    environment.  F(4x4) only under CNL_ALGO_AUTO, on long channel loops (Cin >= 256) over large maps."""
+    lib = _lib.load()
+
+    def kind(N, Cin, H, W, Cout, algo):
+        p = ConvParams()
+        p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.ldx, p.ldy, p.flags, p.algo = N, H, W, Cin, Cout, 3, 3, 1, 1, Cin, Cout, 0, algo
+        return lib.cnl_conv3x3_winograd_kernel(ctypes.byref(p))
+
+    for N in (1, 7, 32):
+        assert kind(N, 256, 128, 128, 256, CNL_ALGO_AUTO) == 8          # head blocks
+        assert kind(N, 256, 152, 272, 256, CNL_ALGO_AUTO) == 8          # ... of 608 x 1088 frames
+        assert kind(N, 256, 128, 128, 256, CNL_ALGO_F2) == 5
+        assert kind(N, 256, 128, 128, 256, CNL_ALGO_F32) == 2
+        assert kind(N, 256, 32, 32, 256, CNL_ALGO_AUTO) == 5            # layer3: F(2x2)
+        assert kind(N, 128, 64, 64, 128, CNL_ALGO_AUTO) == 5            # layer2
+        assert kind(N, 64, 128, 128, 64, CNL_ALGO_AUTO) == 2            # layer1: fp32 matrix cores
+        assert kind(N, 24, 128, 128, 64, CNL_ALGO_AUTO) == 2            # Cin % 16 != 0
