@@ -15,16 +15,16 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
   value     = total images / max-over-ranks wall time of the K timed steps (weak scaling: batch per GPU fixed).
   roofline  = the dominant kernel by time, measured with HIP events on the launch stream around every conv launch of one step.
               The long 3x3 layers form every fp32 product on the fp16 matrix cores (scaled two-way fp16 split, three MFMAs per
-              product, fp32 accumulation), as Winograd F(4x4,3x3) (`cnl_wino8::winograd8_kernel`) where its 32x16-pixel work items
-              tile the map, else F(2x2,3x3) (`cnl_wino5/6`); peak = 2.5 PFLOP/s dense fp16.  `achieved` counts the matrix-core flops
+              product, fp32 accumulation) as Winograd F(2x2,3x3) (`cnl_wino5/6`; with --algo f4 the 256-channel layers over large maps
+              as F(4x4,3x3), `cnl_wino8::winograd8_kernel`); peak = 2.5 PFLOP/s dense fp16.  `achieved` counts the matrix-core flops
               the kernel EXECUTES (direct-conv flops x 36/144 [F(4x4)] or 16/36 [F(2x2)], x 3 for the split), so `frac` is an honest
               hardware fraction — Winograd trades executed flops for transform work, which is why `effective_tflops` (the same time
               against the direct-conv, i.e. algorithmic, flops) is reported beside it.  `traffic` is NOT measured in this run: it is
               the rocprofv3 PMC figure of the named profiles/ file (null where no profile of that configuration exists).
   variants  = the same job in the other arithmetic classes of the plan (KernelOptions.algo; in-process, short runs):
-              f2 = no F(4x4) (every kernel's error at or below the fp32 matrix core's), f32 = fp32 matrix cores only.
+              f4 = additionally Winograd F(4x4,3x3) on the 256-channel layers over large maps (opt-in), f32 = fp32 matrix cores only.
   accuracy  = max |feature - float64 oracle| / max |float64 oracle| at the neck output and at each head's last 256-channel block
-              output (what out_conv reads), for auto / f2 / f32 and for the CPU fp32 oracle itself, on 2 images of the bench shape.
+              output (what out_conv reads), for auto / f4 / f32 and for the CPU fp32 oracle itself, on 2 images of the bench shape.
               (The post-sigmoid heatmap hides feature error by ~3 orders of magnitude; it is reported too.)  Backbone / ConvBnAct
               parity is "unpinned" by the reference itself (torchvision / vision_toolbox absent): the oracle is this repo's restatement.
   decode    = decode p50 on the forward's own outputs: bytes that must move, GB/s, fraction of 8 TB/s; with a separate sigmoid pass
@@ -304,9 +304,9 @@ def cpu_baseline(model, config, tracking, k, H, W, gpu_decode_p50_ms, budget_s=7
         one(x0)                                                                 # global warm-up (oneDNN primitive caches, allocator)
         probes = []
         t_start = time.perf_counter()
-        for threads in sorted({max(1, cores // 2), max(1, cores // 4), max(1, min(32, cores))}, reverse=True):
+        for threads in sorted({max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, min(32, cores)), max(1, min(16, cores))}):    # fewest first: on many-core hosts oneDNN scales negatively here
             for cl_ in (False, True):
-                if probes and time.perf_counter() - t_start > budget * 0.45:
+                if probes and time.perf_counter() - t_start > budget * 0.5:
                     break
                 torch.set_num_threads(threads)
                 x = x0.contiguous(memory_format=torch.channels_last) if cl_ else x0
@@ -370,7 +370,7 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--algo", choices=["auto", "f2", "f32"], default="auto", help="KernelOptions.algo of the measured job")
+    ap.add_argument("--algo", choices=["auto", "f4", "f32"], default="auto", help="KernelOptions.algo of the measured job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the f2 / f32 legs")
     ap.add_argument("--no-also", action="store_true", help="skip the short C2 / C4 lines")
@@ -443,8 +443,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",
             "dtype_note": "fp32 in / fp32 accumulate / fp32 out; where it pays, each fp32 product is formed on the fp16 matrix cores from a two-way fp16 split of "
-                          "both (power-of-two scaled) operands (3 cross terms); KernelOptions.algo = " + args.algo + " (auto: Winograd F(4x4,3x3) on the long 3x3 layers; "
-                          "f2: F(2x2) only — every kernel's error at or below the fp32 MFMA's; f32: fp32 matrix cores only): see `variants` and `accuracy`",
+                          "both (power-of-two scaled) operands (3 cross terms); KernelOptions.algo = " + args.algo + " (auto: every kernel's error at or below the fp32 MFMA's; "
+                          "f4: additionally Winograd F(4x4,3x3) on the 256-channel layers over large maps; f32: fp32 matrix cores only): see `variants` and `accuracy`",
             "data": "synthetic (seeded rand images; random-init weights of the named architecture)",
             "config": {"workload": f"BASELINE C{'1' if args.config == 'simple' else ('4' if tracking else '2/3')}: ResNet34 + {args.config} neck, "
                                    f"{B} img/GPU x {H}x{W}, heads {'2+4+reid64' if tracking else '80+4'} (w256), k={args.k}, nms 3",
@@ -466,7 +466,7 @@ def main():
             sync = torch.cuda.synchronize
             if not args.no_variants:
                 result["variants"] = {}
-                for algo in ("f2", "f32"):
+                for algo in ("f4", "f32"):
                     if algo == args.algo:
                         continue
                     try:
@@ -492,7 +492,7 @@ def main():
             if not args.no_accuracy:
                 x2 = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(4242))
                 try:
-                    acc = {a: feature_errors(args.config, x2, a) for a in ("auto", "f2", "f32", "cpu")}
+                    acc = {a: feature_errors(args.config, x2, a) for a in ("auto", "f4", "f32", "cpu")}
                     result["accuracy"] = {"max_err_over_max_ref_vs_float64_oracle": acc, "tolerance": 1e-4,
                                           "sample": f"2 images of the bench shape, same weights; 'cpu' = the CPU fp32 oracle's own distance from float64",
                                           "parity_note": "backbone + ConvBnAct parity is unpinned by the reference (torchvision / vision_toolbox absent): the oracle is this repo's restatement; "

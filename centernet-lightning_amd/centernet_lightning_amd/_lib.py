@@ -17,7 +17,7 @@ CNL_UPSAMPLE_OUT_ADD = 1 << 3
 CNL_RELU6 = 1 << 4
 
 # cnl_conv_params.algo: the arithmetic class a launch may use (include/centernet_gfx950.h)
-CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_FORCE = 0, 1, 2, 100
+CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_F4, CNL_ALGO_FORCE = 0, 1, 2, 3, 100
 CNL_WINO_F32, CNL_WINO_F16X2, CNL_WINO_F16X2_F4 = 2, 5, 8
 
 CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4

@@ -20,7 +20,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_RELU, CNL_RELU6, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD,
+from ._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_F4, CNL_RELU, CNL_RELU6, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD,
                    CNL_WINO_F16X2, CNL_WINO_F16X2_F4, ConvParams, DeconvParams)
 
 BN_EPS_DEFAULT = 1e-5
@@ -30,8 +30,10 @@ BN_EPS_DEFAULT = 1e-5
 class KernelOptions:
     """What the launch plan may use — an explicit, per-model choice (CenterNet.set_kernel_options), part of the plan key; the library
     reads nothing from the environment.
-      algo             "auto": fastest fp32-grade kernels (fp16-split matrix cores, Winograd F(4x4,3x3) on the long 3x3 layers);
-                       "f2":   the same without F(4x4): every kernel's error vs float64 is at or below the fp32 matrix core's;
+      algo             "auto": fp32-grade kernels on the fp16-split matrix cores where they pay (every kernel's error vs float64 at or
+                       below the fp32 matrix core's; "f2" is a synonym);
+                       "f4":   the same plus Winograd F(4x4,3x3) on the long 3x3 layers over large maps (error ~4x F(2x2)'s, still ~1e-6 of
+                               the layer maximum; opt-in: measured within +-5 % of "auto" on MI355X);
                        "f32":  fp32 matrix cores only (no split operands, no hints).
       winograd         False: every conv on the direct implicit-GEMM kernels (A/B and parity checks)
       up2              the fused first head blocks behind a nearest upsample as four sub-pixel phase convs
@@ -49,9 +51,9 @@ class KernelOptions:
     @property
     def algo_id(self):
         try:
-            return {"auto": CNL_ALGO_AUTO, "f2": CNL_ALGO_F2, "f32": CNL_ALGO_F32}[self.algo]
+            return {"auto": CNL_ALGO_AUTO, "f2": CNL_ALGO_F2, "f4": CNL_ALGO_F4, "f32": CNL_ALGO_F32}[self.algo]
         except KeyError:
-            raise ValueError(f"KernelOptions.algo must be 'auto', 'f2' or 'f32', got {self.algo!r}") from None
+            raise ValueError(f"KernelOptions.algo must be 'auto', 'f2', 'f4' or 'f32', got {self.algo!r}") from None
 
 
 def fold_conv_bn(conv_w, conv_b, bn=None):

@@ -11,7 +11,7 @@
 //                     terms, fp32 accumulation: error at or below the fp32 MFMA's), 16x16-pixel x 64-cout work items;
 //   6  winograd6.hip  the same on 8x16-pixel x 128-cout work items (short channel loop with many couts, or maps that 16-row blocks pad);
 //   8  winograd8.hip  F(4x4,3x3) with the same split: 0.56x the matrix work and split work per output, error ~4x kernel 5's
-//                     (~1e-6 of the layer maximum) — long channel loops on maps its 32x16-pixel items tile well, CNL_ALGO_AUTO only.
+//                     (~1e-6 of the layer maximum) — long channel loops on large maps its 32x16-pixel items tile well, CNL_ALGO_F4 only.
 // The 16x16-pixel-block fp32 kernel this file used to hold, the exact three-way bf16 split (winograd3/4) and the two-waves-per-SIMD
 // form of 5 (winograd7) are measured-and-superseded variants: experiments/ (`make experiments`, algo = CNL_ALGO_FORCE + variant).
 #include "cnl_common.h"
@@ -130,7 +130,7 @@ static int wino_choice(const cnl_conv_params* p) {
     if (p->algo == CNL_ALGO_F32 || p->Cin % 16) return 2;
     if (items_per_image >= 8 && (p->Cin >= 128 || p->Cout >= 512)) {
         const long long area = (long long)H * W;
-        if (p->algo == CNL_ALGO_AUTO && p->Cin >= 256 && area >= 64 * 64 && cnl_wino8_eligible(p)) {
+        if (p->algo == CNL_ALGO_F4 && p->Cin >= 256 && area >= 64 * 64 && cnl_wino8_eligible(p)) {
             // F(4x4): 32x16-pixel items.  Measured against kernel 5 / 6 on one box (profiles/r02_winograd8_variants.txt): 0.89-0.93 of
             // their time on the 256 -> 256 head blocks at 128x128, 0.93-0.97 at 152x272, no gain on the backbone's 32x32 / 64x64 maps
             // (few items per CU: the per-item prologue / epilogue weigh more) — taken only for the long channel loops on large maps,
@@ -166,7 +166,7 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 "cnl_conv3x3_winograd_f32: Cin %% 8 != 0 or bad pixel stride");
     CNL_REQUIRE(((uintptr_t)p->x & 15) == 0 && ((uintptr_t)p->w & 15) == 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unaligned x / u");
     CNL_REQUIRE(!p->residual || p->ldr >= p->Cout, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: ldr < Cout");
-    CNL_REQUIRE(p->algo <= CNL_ALGO_F32 || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 8), CNL_E_BAD_ARG,
+    CNL_REQUIRE(p->algo <= CNL_ALGO_F4 || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 8), CNL_E_BAD_ARG,
                 "cnl_conv3x3_winograd_f32: unknown algo %u", p->algo);
     const int choice = wino_choice(p);
     const WeightLayout L(p->Cin, p->Cout);

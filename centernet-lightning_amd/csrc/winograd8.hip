@@ -36,6 +36,9 @@
 #ifndef W8_EXP
 #define W8_EXP 0      /* timing builds (wrong results): 1 no B loads in the MFMA phase, 2 no input transform, 3 no MFMA phase, 4 no output stores, 5 no epilogue */
 #endif
+#ifndef W8_NT_X
+#define W8_NT_X 0     /* cache policy (aux) of the patch DMA loads: 2 = nt (streaming: do not displace the weights in L2) */
+#endif
 #ifndef W8_ORDER
 #define W8_ORDER 2    /* work-item order: 0 cout block fastest, 1 cout block slowest inside an image, 2 pairs of cout blocks fastest */
 #endif
@@ -91,7 +94,7 @@ static_assert(Q_BYTES <= LDS_BYTES, "epilogue exchange buffer must fit");
 
 __device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* lds_dst, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 0, W8_NT_X);
 }
 __device__ __forceinline__ u32x4 buf_load16(const void* base, unsigned bytes, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);

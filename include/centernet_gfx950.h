@@ -40,11 +40,14 @@ enum {
 /*
  * cnl_conv_params.algo / the `algo` argument of cnl_stem_conv7x7_f32: the ARITHMETIC CLASS the caller allows for a launch.  Inside a class
  * the kernel is a function of the layer shape and the hints alone — never of the batch size, never of the environment.
- *   CNL_ALGO_AUTO  fastest fp32-grade kernel.  fp32 in / fp32 accumulate / fp32 out everywhere; where it pays, each fp32 product is
- *                  formed on the fp16 matrix cores from a scaled two-way fp16 split of both operands (three cross terms), and the long
- *                  3x3 layers may use Winograd F(4x4,3x3) (csrc/winograd8.hip: error ~1e-6 of the layer's largest output, ~4x F(2x2)).
- *   CNL_ALGO_F2    the same without F(4x4,3x3): every kernel's error against float64 is at or below the fp32 matrix core's.
+ *   CNL_ALGO_AUTO  the default.  fp32 in / fp32 accumulate / fp32 out everywhere; where it pays, each fp32 product is formed on the fp16
+ *                  matrix cores from a scaled two-way fp16 split of both operands (three cross terms): every kernel's error against
+ *                  float64 is at or below the fp32 matrix core's (tests/test_gpu_conv.py pins that per kernel).
+ *   CNL_ALGO_F2    synonym of CNL_ALGO_AUTO (Winograd tiles no larger than F(2x2,3x3)).
  *   CNL_ALGO_F32   fp32 matrix cores only (v_mfma_f32_32x32x2_f32), no split operands anywhere; hints are ignored.
+ *   CNL_ALGO_F4    AUTO, plus Winograd F(4x4,3x3) (csrc/winograd8.hip) on the long 3x3 layers over large maps: 0.56x the matrix work,
+ *                  error ~1e-6 of the layer's largest output (~4x F(2x2)).  Opt-in: on MI355X it is bound by the same weight stream
+ *                  from the L2 / Infinity Cache as the F(2x2) kernels and ends up within +-5 % of them.
  *   CNL_ALGO_FORCE + v  tests / A-B measurements: pin kernel variant v (2, 5, 6, 8; 1, 3, 4, 7 in `make experiments` builds) wherever
  *                  it can run at all.
  */
@@ -52,6 +55,7 @@ enum {
     CNL_ALGO_AUTO = 0,
     CNL_ALGO_F2 = 1,
     CNL_ALGO_F32 = 2,
+    CNL_ALGO_F4 = 3,
     CNL_ALGO_FORCE = 100
 };
 
@@ -146,7 +150,7 @@ int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);
  * core (csrc/winograd2.hip), or — where the channel loop is long (Cin >= 128 or Cout >= 512, Cin % 16 == 0) — the fp16 matrix core
  * fed with a two-way fp16 split of both fp32 operands under a per-image power-of-two scale (three cross terms, fp32
  * accumulation: csrc/winograd5.hip, winograd6.hip; measured error at or below the fp32 matrix core's, half-precision rate = 16x), as
- * F(2x2,3x3) or, under CNL_ALGO_AUTO on maps that 32x16-pixel work items tile well, F(4x4,3x3) (csrc/winograd8.hip).
+ * F(2x2,3x3) or, under CNL_ALGO_F4 on large maps that 32x16-pixel work items tile well, F(4x4,3x3) (csrc/winograd8.hip).
  * cnl_conv3x3_winograd_kernel reports which class a layer takes.  The fp16-split kernels without the x_absmax hint make their own
  * pass over the input and park the per-image maxima in the layer's weight buffer: such hint-less launches of ONE layer must not
  * run concurrently on two streams (launches that carry x_absmax — everything engine.py issues — have no hidden state).

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from centernet_lightning_amd import _lib
-from centernet_lightning_amd._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_FORCE, CNL_RELU, CNL_SIGMOID, CNL_UPSAMPLE_IN,
+from centernet_lightning_amd._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_F4, CNL_ALGO_FORCE, CNL_RELU, CNL_SIGMOID, CNL_UPSAMPLE_IN,
                                           CNL_UPSAMPLE_OUT_ADD, ConvParams)
 
 pytestmark = pytest.mark.gpu
@@ -630,7 +630,7 @@ def test_winograd_split_kernels_error_not_above_fp32_mfma():
 
 def test_winograd_dispatch_is_a_function_of_shape_and_algo_only():
     """cnl_conv3x3_winograd_kernel: the kernel class follows the layer shape and the caller's algo — never the batch size, never the
-    environment.  F(4x4) only under CNL_ALGO_AUTO, on long channel loops (Cin >= 256) over large maps."""
+    environment.  F(4x4) only under CNL_ALGO_F4, on long channel loops (Cin >= 256) over large maps."""
     lib = _lib.load()
 
     def kind(N, Cin, H, W, Cout, algo):
@@ -639,11 +639,12 @@ def test_winograd_dispatch_is_a_function_of_shape_and_algo_only():
         return lib.cnl_conv3x3_winograd_kernel(ctypes.byref(p))
 
     for N in (1, 7, 32):
-        assert kind(N, 256, 128, 128, 256, CNL_ALGO_AUTO) == 8          # head blocks
-        assert kind(N, 256, 152, 272, 256, CNL_ALGO_AUTO) == 8          # ... of 608 x 1088 frames
+        assert kind(N, 256, 128, 128, 256, CNL_ALGO_F4) == 8            # head blocks, F(4x4) allowed
+        assert kind(N, 256, 152, 272, 256, CNL_ALGO_F4) == 8            # ... of 608 x 1088 frames
+        assert kind(N, 256, 128, 128, 256, CNL_ALGO_AUTO) == 5          # the default never takes F(4x4)
         assert kind(N, 256, 128, 128, 256, CNL_ALGO_F2) == 5
         assert kind(N, 256, 128, 128, 256, CNL_ALGO_F32) == 2
-        assert kind(N, 256, 32, 32, 256, CNL_ALGO_AUTO) == 5            # layer3: F(2x2)
+        assert kind(N, 256, 32, 32, 256, CNL_ALGO_F4) == 5              # layer3: F(2x2) even when F(4x4) is allowed
         assert kind(N, 128, 64, 64, 128, CNL_ALGO_AUTO) == 5            # layer2
         assert kind(N, 64, 128, 128, 64, CNL_ALGO_AUTO) == 2            # layer1: fp32 matrix cores
         assert kind(N, 24, 128, 128, 64, CNL_ALGO_AUTO) == 2            # Cin % 16 != 0
