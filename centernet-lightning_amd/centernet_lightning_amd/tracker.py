@@ -9,7 +9,9 @@ track table itself — per-track embedding and box live in HBM and are updated t
 come to the host, where the Hungarian assignment runs on scipy exactly as in the reference (tracker.py:28), and the short
 match list goes back.  The reference instead copies every frame's k x (6+E) detections to the host (tracker.py:107).
 
-Not supported (raises): `use_kalman=True` (filterpy, third-party, absent), callable `reid_cost` / `box_cost`.
+`use_kalman=True` (tracker.py:243-262, 281-323): the per-track 8-state filter is a float64 numpy restatement of filterpy's
+KalmanFilter (third-party, absent) on the host, beside the life cycle; the filtered boxes are uploaded to the device table.
+Not supported (raises): `reid_cost` other than "cosine", callable `reid_cost` / `box_cost`.
 There is no CPU fallback: without the HIP library or a GPU, `update` raises.
 """
 import ctypes
@@ -48,12 +50,52 @@ def match_with_threshold(cost_matrix, threshold):
     return matches, unmatched_row, unmatched_col
 
 
+class BoxKalman:
+    """The 8-state constant-velocity Kalman filter the reference builds per track with filterpy (tracker.py:243-262, 281-301, 317-323):
+    state = box corners x1 y1 x2 y2 + their velocities, measurement = the corners.  filterpy is third-party and absent from the image;
+    its published predict / update equations (filterpy/kalman/kalman_filter.py: x = Fx, P = FPF' + Q;  y = z - Hx, S = HPH' + R,
+    K = PH'S^-1, x += Ky, P = (I-KH)P(I-KH)' + KRK') are restated in float64 numpy — "parity unpinned" (no reference test pins it)."""
+
+    def __init__(self, bbox):
+        self.x = np.zeros(8)
+        self.x[:4] = bbox
+        self.F = np.eye(8)
+        self.F[:4, 4:] = np.eye(4)
+        self.H = np.eye(4, 8)
+        wh = np.asarray(bbox[2:], np.float64) - np.asarray(bbox[:2], np.float64)
+        std = np.tile(wh, 4)                                  # adapted from DeepSORT (tracker.py:256-260)
+        std[:4] /= 10
+        std[4:] /= 16
+        self.P = np.diag(std ** 2)
+
+    def predict(self):
+        wh = self.x[2:4] - self.x[:2]
+        std = np.tile(wh, 4)                                  # tracker.py:284-289
+        std[:4] /= 20
+        std[4:] /= 160
+        self.x = self.F @ self.x
+        self.P = self.F @ self.P @ self.F.T + np.diag(np.square(std))
+
+    def update(self, z):
+        wh = self.x[2:4] - self.x[:2]
+        R = np.diag((np.tile(wh, 2) / 20) ** 2)               # tracker.py:318-320
+        y = np.asarray(z, np.float64) - self.H @ self.x
+        PHT = self.P @ self.H.T
+        S = self.H @ PHT + R
+        K = PHT @ np.linalg.inv(S)
+        self.x = self.x + K @ y
+        I_KH = np.eye(8) - K @ self.H
+        self.P = I_KH @ self.P @ I_KH.T + K @ R @ K.T
+        return self.x[:4].copy()
+
+
 class Track:
     """Host record of one track (tracker.py:217-347).  bbox / label live here (they are reported every frame); the embedding
     lives in the tracker's device table and is fetched on access."""
 
-    def __init__(self, tracker, track_id, bbox, label, min_birth_age=2, max_inactive_age=30, smoothing_factor=0.9):
+    def __init__(self, tracker, track_id, bbox, label, min_birth_age=2, max_inactive_age=30, smoothing_factor=0.9, use_kalman=False):
         self._tracker = tracker
+        self.kf = BoxKalman(bbox) if use_kalman else None
         self._row = -1
         self.track_id = track_id
         self.state = TrackState.UNCONFIRMED
@@ -89,7 +131,14 @@ class Track:
         elif self.state == TrackState.INACTIVE:
             self.state = TrackState.ACTIVE
             self.inactive_age = 0
-        self.bbox = bbox
+        # tracker.py:311-323: the detection's box, or the filtered state when the track carries a Kalman filter
+        self.bbox = bbox if self.kf is None else self.kf.update(bbox)
+
+    def kalman_predict(self):
+        """tracker.py:281-290 (called at the end of every Tracker.update; `bbox` keeps the last UPDATED state, as in the reference,
+        where it is a view of the array that filterpy's predict replaces)."""
+        if self.kf is not None:
+            self.kf.predict()
 
     def update_unmatched(self):
         if self.state == TrackState.UNCONFIRMED:
@@ -115,9 +164,6 @@ class Tracker:
         self.model = model
         if model is None:
             warnings.warn("A model was not provided. Only `.update()` will work")
-        if use_kalman:
-            raise NotImplementedError("use_kalman=True needs filterpy's KalmanFilter (third-party, not in this image); "
-                                      "the MI355X tracker covers the reference default use_kalman=False")
         if reid_cost != "cosine":
             raise ValueError(f"reid_cost={reid_cost!r}: only 'cosine' (the reference default) has a gfx950 kernel")
         if box_cost not in _BOX_MODES:
@@ -130,7 +176,7 @@ class Tracker:
         self.box_cost = box_cost
         self.box_threshold = box_threshold
         self.smoothing_factor = smoothing_factor
-        self.use_kalman = False
+        self.use_kalman = bool(use_kalman)
         self.max_inactive_age = max_inactive_age
         self.min_birth_age = min_birth_age
         self._device = torch.device(device) if device is not None else None
@@ -271,7 +317,8 @@ class Tracker:
         for det_idx in unmatched_dets:
             src = int(det_index[det_idx])
             self.tracks.append(Track(self, self.next_track_id, h_box[src], h_label[src], min_birth_age=self.min_birth_age,
-                                     max_inactive_age=self.max_inactive_age, smoothing_factor=self.smoothing_factor))
+                                     max_inactive_age=self.max_inactive_age, smoothing_factor=self.smoothing_factor,
+                                     use_kalman=self.use_kalman))
             self.next_track_id += 1
             old_rows.append(-1)
             row_det[len(self.tracks) - 1] = src
@@ -292,6 +339,14 @@ class Tracker:
             self._spare, (self._emb, self._box) = ((self._emb, self._box) if self._emb is not None else None), (new_emb, new_box)
         for r, t in enumerate(self.tracks):
             t._row = r
+        if self.use_kalman and T_new:
+            # the device table's boxes are the detections' (cnl_track_apply_f32); a Kalman track's box is its filtered state, computed on
+            # the host with the rest of the life cycle (8x8 float64 algebra per track): upload the T x 4 boxes (16 B per track)
+            boxes = np.asarray([np.asarray(t.bbox, np.float64) for t in self.tracks], np.float32).reshape(T_new, 4)
+            with torch.cuda.device(dev):
+                self._box[:T_new].copy_(torch.from_numpy(boxes), non_blocking=False)
+            for t in self.tracks:
+                t.kalman_predict()
 
     def track_embeddings(self):
         """Device view [T, E] of the live track table (row order = self.tracks)."""

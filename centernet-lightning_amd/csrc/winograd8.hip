@@ -39,6 +39,13 @@
 #ifndef W8_NT_X
 #define W8_NT_X 0     /* cache policy (aux) of the patch DMA loads: 2 = nt (streaming: do not displace the weights in L2) */
 #endif
+// Channel-chunk rotation: work item (tile, cout block) walks the channel chunks starting at a chunk that depends on its tile position,
+// so that the CUs of an XCD do not all ask for the same weight lines in the same chunk period.  The start is a function of the tile
+// position inside the image and the cout block only — an image's result never depends on its batch neighbours.
+#ifndef W8_ROTATE
+#define W8_ROTATE 0
+#endif
+#define W8_ROT(c_) (W8_ROTATE ? (((c_) + rot) >= a.CC ? ((c_) + rot - a.CC) : ((c_) + rot)) : (c_))
 #ifndef W8_ORDER
 #define W8_ORDER 2    /* work-item order: 0 cout block fastest, 1 cout block slowest inside an image, 2 pairs of cout blocks fastest */
 #endif
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     float omax = 0.f;
     // ---- work-item state (set by W8_SETUP for the item about to run; the epilogue works on copies) ----
-    int n, y0, x0, n0;
+    int n, y0, x0, n0, rot;
     unsigned p_off[10], u_voff;
     float S, inv;
 #define W8_SETUP(item_)                                                                                          \
@@ -276,6 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int pr_ = b_ % np_; n = b_ / np_; nbi_ = pr_ * 2 + lo_;                                        \
         }                                                                                                        \
         y0 = byi_ * (4 * TY); x0 = bxi_ * (4 * TX); n0 = nbi_ * BN;                                              \
+        rot = W8_ROTATE ? (bxi_ + 5 * byi_ + 3 * nbi_) % a.CC : 0;                                               \
         _Pragma("unroll") for (int i = 0; i < 10; ++i) {                                                         \
             const int s_ = i * 256 + tid;              /* 16-byte slot of the patch image: (py*4 + quad)*PP + px */ \
             const int rowq_ = s_ / PP, pxx_ = s_ - rowq_ * PP;                                                   \
@@ -303,13 +311,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if ((cc_) < a.CC) {                                                                                      \
             char* d_ = sP + ((cc_) & 1) * P_BYTES;                                                               \
             _Pragma("unroll") for (int i = 0; i < 10; ++i)                                                       \
-                dma16(a.x, a.x_bytes, d_ + (i * 256 + wave * 64) * 16, p_off[i], (unsigned)((cc_) * 64));        \
+                dma16(a.x, a.x_bytes, d_ + (i * 256 + wave * 64) * 16, p_off[i], (unsigned)(W8_ROT(cc_) * 64));  \
         }                                                                                                        \
     } while (0)
     // the four B fragments of position j_ of chunk cc_ into ring buffer (j_) % 3
 #define W8_LOAD_B(cc_, j_)                                                                                       \
     do {                                                                                                         \
-        const unsigned so_ = (unsigned)(cc_) * u_chunk + (unsigned)(9 * wave + (j_)) * u_pos;                    \
+        const unsigned so_ = (unsigned)W8_ROT(cc_) * u_chunk + (unsigned)(9 * wave + (j_)) * u_pos;              \
         _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_)                                                         \
             _Pragma("unroll") for (int kk_ = 0; kk_ < NP; ++kk_)                                                 \
                 fb[(j_) % 3][g_][kk_] = buf_load16(a.u8, a.u_bytes, u_voff, so_ + (unsigned)g_ * 1024u + (unsigned)kk_ * u_piece); \
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             const int jn = (j + 2) % 9;
                             const int cn = cc + (j + 2 >= 9 ? 1 : 0);
                             if (j + 2 < 9 || cn < a.CC) {
-                                const unsigned so_ = (unsigned)cn * u_chunk + (unsigned)(9 * wave + jn) * u_pos + (unsigned)(k >> 1) * 1024u + (unsigned)(k & 1) * u_piece;
+                                const unsigned so_ = (unsigned)W8_ROT(cn) * u_chunk + (unsigned)(9 * wave + jn) * u_pos + (unsigned)(k >> 1) * 1024u + (unsigned)(k & 1) * u_piece;
                                 fb[jn % 3][k >> 1][k & 1] = buf_load16(a.u8, a.u_bytes, u_voff, so_);
                             }
                         } else if (k >= 4 && j + 1 < 9) {  // one A fragment of the next position

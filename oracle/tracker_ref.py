@@ -14,7 +14,9 @@ Parity status: PINNED.  tests/golden/track_*.npz hold cost matrices and per-fram
 reference's own `Tracker.update`, `box_iou_distance_matrix`, `box_giou_distance_matrix` (imported in the build container by
 oracle/make_golden_tracker.py); tests/test_oracle_tracker.py checks this restatement against them.
 
-Not restated: the Kalman option (`use_kalman=True`, filterpy — absent from the image).
+The Kalman option (`use_kalman=True`): filterpy is absent from the image, so its KalmanFilter cannot be run to pin this part —
+BoxKalman restates filterpy's published predict / update equations with the reference's matrices and noise schedule
+(tracker.py:243-262, 281-323): "parity unpinned" for the filter; known-answer checks in tests/test_oracle_tracker.py.
 
 Reference quirk kept on purpose (results must be identical): matches index the *thresholded* detection arrays, but
 `update_matched` is fed `bboxes[det_idx]` / `embeddings[det_idx]` from the UNfiltered arrays (tracker.py:171).  The two agree
@@ -87,10 +89,50 @@ class TrackState(Enum):
     TO_DELETE = auto()
 
 
-class Track:
-    """tracker.py:217-347 without the Kalman branch."""
+class BoxKalman:
+    """The 8-state constant-velocity Kalman filter the reference builds per track with filterpy (tracker.py:243-262, 281-301, 317-323):
+    state = box corners x1 y1 x2 y2 + their velocities, measurement = the corners.  filterpy is third-party and absent from the image;
+    its published predict / update equations (filterpy/kalman/kalman_filter.py: x = Fx, P = FPF' + Q;  y = z - Hx, S = HPH' + R,
+    K = PH'S^-1, x += Ky, P = (I-KH)P(I-KH)' + KRK') are restated in float64 numpy — "parity unpinned" (no reference test pins it)."""
 
-    def __init__(self, track_id, bbox, label, embedding, min_birth_age=2, max_inactive_age=30, smoothing_factor=0.9):
+    def __init__(self, bbox):
+        self.x = np.zeros(8)
+        self.x[:4] = bbox
+        self.F = np.eye(8)
+        self.F[:4, 4:] = np.eye(4)
+        self.H = np.eye(4, 8)
+        wh = np.asarray(bbox[2:], np.float64) - np.asarray(bbox[:2], np.float64)
+        std = np.tile(wh, 4)                                  # adapted from DeepSORT (tracker.py:256-260)
+        std[:4] /= 10
+        std[4:] /= 16
+        self.P = np.diag(std ** 2)
+
+    def predict(self):
+        wh = self.x[2:4] - self.x[:2]
+        std = np.tile(wh, 4)                                  # tracker.py:284-289
+        std[:4] /= 20
+        std[4:] /= 160
+        self.x = self.F @ self.x
+        self.P = self.F @ self.P @ self.F.T + np.diag(np.square(std))
+
+    def update(self, z):
+        wh = self.x[2:4] - self.x[:2]
+        R = np.diag((np.tile(wh, 2) / 20) ** 2)               # tracker.py:318-320
+        y = np.asarray(z, np.float64) - self.H @ self.x
+        PHT = self.P @ self.H.T
+        S = self.H @ PHT + R
+        K = PHT @ np.linalg.inv(S)
+        self.x = self.x + K @ y
+        I_KH = np.eye(8) - K @ self.H
+        self.P = I_KH @ self.P @ I_KH.T + K @ R @ K.T
+        return self.x[:4].copy()
+
+
+class Track:
+    """tracker.py:217-347."""
+
+    def __init__(self, track_id, bbox, label, embedding, min_birth_age=2, max_inactive_age=30, smoothing_factor=0.9, use_kalman=False):
+        self.kf = BoxKalman(bbox) if use_kalman else None
         self.track_id = track_id
         self.state = TrackState.UNCONFIRMED
         self.birth_age = 0
@@ -113,7 +155,7 @@ class Track:
         elif self.state == TrackState.INACTIVE:
             self.state = TrackState.ACTIVE
             self.inactive_age = 0
-        self.bbox = bbox
+        self.bbox = bbox if self.kf is None else self.kf.update(bbox)
         embedding = embedding / np.linalg.norm(embedding)
         self.embedding = (1 - self.smoothing_factor) * self.embedding + self.smoothing_factor * embedding
 
@@ -133,8 +175,9 @@ class Tracker:
     """tracker.py:45-201 (`update` only — the model-driven `step_batch` lives in the product)."""
 
     def __init__(self, detection_threshold=0.3, reid_cost="cosine", reid_threshold=0.2, box_cost="iou", box_threshold=0.5,
-                 smoothing_factor=0.5, max_inactive_age=30, min_birth_age=2):
+                 smoothing_factor=0.5, max_inactive_age=30, min_birth_age=2, use_kalman=False):
         assert reid_cost == "cosine"
+        self.use_kalman = use_kalman
         self.detection_threshold = detection_threshold
         self.reid_threshold = reid_threshold
         self.box_cost = BOX_COSTS[box_cost] if box_cost is not None else None
@@ -173,9 +216,12 @@ class Tracker:
         for d in unmatched_dets:
             self.tracks.append(Track(self.next_track_id, det_bboxes[d], det_labels[d], det_embeddings[d],
                                      min_birth_age=self.min_birth_age, max_inactive_age=self.max_inactive_age,
-                                     smoothing_factor=self.smoothing_factor))
+                                     smoothing_factor=self.smoothing_factor, use_kalman=self.use_kalman))
             self.next_track_id += 1
         self.tracks = [t for t in self.tracks if not t.to_delete]
+        for t in self.tracks:                                   # tracker.py:199-201
+            if t.kf is not None:
+                t.kf.predict()
         self.frame += 1
 
     def active(self):

@@ -101,8 +101,7 @@ def test_product_tracker_host_surface(configs_dir):
         t = cl.build_tracker(os.path.join(configs_dir, "tracking_resnet34_fpn.yaml"))
         assert (t.num_detections, t.detection_threshold, t.reid_threshold, t.box_cost, t.box_threshold) == (300, 0.3, 0.2, "iou", 0.5)
         assert (t.smoothing_factor, t.max_inactive_age, t.min_birth_age, t.frame, t.next_track_id, t.tracks) == (0.5, 30, 2, 0, 0, [])
-        with pytest.raises(NotImplementedError):
-            cl.Tracker(use_kalman=True)
+        assert cl.Tracker(use_kalman=True).use_kalman is True          # tracker.py:243-262: host-side filter (BoxKalman)
         with pytest.raises(ValueError):
             cl.Tracker(reid_cost="euclidean")
         with pytest.raises(ValueError):
@@ -122,3 +121,22 @@ def test_product_tracker_host_surface(configs_dir):
     tr.update_unmatched(); tr.update_unmatched(); tr.update_unmatched(); assert tr.to_delete
     t2 = cl.Track(None, 1, np.zeros(4), 0)
     t2.update_unmatched(); assert t2.to_delete
+
+
+def test_box_kalman_known_answers():
+    """BoxKalman (filterpy restated): a measurement equal to the state leaves the state; repeated measurements of a box moving at constant
+    velocity make the velocity estimate converge to it; the covariance stays symmetric positive definite; predict moves the corners by
+    the velocities."""
+    box = np.array([0.2, 0.3, 0.4, 0.6])
+    kf = tracker_ref.BoxKalman(box)
+    assert np.allclose(kf.update(box), box) and np.allclose(kf.x[4:], 0)
+    v = np.array([0.01, -0.005, 0.01, -0.005])
+    kf = tracker_ref.BoxKalman(box)
+    for t in range(1, 60):
+        kf.predict()
+        kf.update(box + v * t)
+    assert np.allclose(kf.x[4:], v, atol=2e-4) and np.allclose(kf.x[:4], box + v * 59, atol=2e-3)
+    assert np.allclose(kf.P, kf.P.T) and np.all(np.linalg.eigvalsh(kf.P) > 0)
+    before = kf.x.copy()
+    kf.predict()
+    assert np.allclose(kf.x[:4], before[:4] + before[4:]) and np.allclose(kf.x[4:], before[4:])
