@@ -67,6 +67,8 @@ _SIGNATURES = {
     "cnl_deconv2x_nhwc_f32": (ctypes.c_int, [POINTER(DeconvParams), c_void_p]),
     "cnl_deconv_phase_geometry": (ctypes.c_int, [c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
     "cnl_deconv_weight_floats": (c_size_t, [c_int32, c_int32, c_int32]),
+    "cnl_fuse_sum_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                             c_int32, c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int32, c_void_p]),
     "cnl_upsample2x_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                                c_int32, c_int32, c_void_p]),
     "cnl_depthwise3x3_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,

@@ -188,6 +188,23 @@ def _identity_layer(c, device, gain=1.0):
     return _Layer(eye, torch.zeros(c, device=device))
 
 
+class _FuseNode:
+    """A general Fuse node (params.FuseNode; layers.py:138-177) packed: per-input 1x1 projections, raw relu'd fusion weights + their
+    denominator (layers.py:164-167), the resize of the last input and the output conv."""
+
+    def __init__(self, mod, L, C, device):
+        self.proj = [L(p) if isinstance(p, torch.nn.Conv2d) else None for p in mod.project]
+        self.down = mod.resize_kind == "down"
+        self.upsample_type = mod.upsample_type
+        self.gains, self.den = None, 1.0
+        if mod.weights is not None:
+            wts = torch.relu(mod.weights.detach().float().cpu())
+            self.gains = [float(v) for v in wts]
+            self.den = float(wts.sum() + 1e-6)                 # fp32, like torch.sum(weights) + eps
+        self.deconv = _DeconvLayer(mod.resize, device) if (not self.down and self.upsample_type == "conv_transpose") else None
+        self.out_conv = C(mod.output_conv)
+
+
 class PackedWeights:
     """Device-resident, BN-folded weights of a CenterNet model (rebuilt whenever parameters change)."""
 
@@ -224,6 +241,13 @@ class PackedWeights:
         if self.neck_kind == "SimpleNeck":
             self.neck_layers = [C(m) for m in neck.layers]
             self.neck_ups = [_DeconvLayer(u, device) if self.upsample_type == "conv_transpose" else None for u in neck.upsamples]
+        elif self.neck_kind == "IDANeck":
+            self.fuse = []                                   # (the stem's stride-2 map is not read: len(fuse) < 4)
+            self.stages = [[_FuseNode(f, L, C, device) for f in st] for st in neck.stages]
+        elif self.neck_kind == "BiFPNNeck":
+            self.fuse = []
+            self.bifpn = [([_FuseNode(f, L, C, device) for f in lay.td],
+                           [_FuseNode(f, L, C, device) for f in lay.bu] if lay.bu is not None else None) for lay in neck.bifpn]
         else:
             self.top = L(neck.top_conv)
             self.fuse = []
@@ -564,6 +588,56 @@ class Plan:
         self.launches.append(_Launch(self.lib.cnl_deconv2x_nhwc_f32, p, what, flops, keep=(x, y, residual, layer)))
         return y
 
+    def _fuse_node(self, nd, ins, what):
+        """One general Fuse node (layers.py:160-177): ins = [(buffer, h, w, c), ...], the last one at half ("up") or double ("down")
+        resolution.  Lowering: 1x1 projections where the node has them; then
+          * two inputs, nearest "up", unweighted, last input projected: project -> upsample -> + in0 in the epilogue of that ONE 1x1
+            conv (CNL_UPSAMPLE_OUT_ADD), like the FPN levels;
+          * anything else: cnl_fuse_sum_nhwc_f32 (gains, up to three inputs, the last resized on the fly; a conv_transpose resize is
+            materialised first by cnl_deconv2x_nhwc_f32);
+        then the output conv.  Returns (buffer, h, w, c)."""
+        N = self.N
+        oh, ow = ins[0][1], ins[0][2]
+        lh, lw = ins[-1][1], ins[-1][2]
+        if (not nd.down and (oh, ow) != (2 * lh, 2 * lw)) or (nd.down and (2 * oh, 2 * ow) != (lh, lw)) or any((h, w) != (oh, ow) for _, h, w, _ in ins[:-1]):
+            raise ValueError(f"{what}: input sizes {[(h, w) for _, h, w, _ in ins]} do not fit a Fuse node with resize={'down' if nd.down else 'up'}")
+        fused_up = (len(ins) == 2 and not nd.down and nd.upsample_type == "nearest" and nd.gains is None and nd.proj[-1] is not None)
+        cur = []
+        for j, (b, h, w, c) in enumerate(ins):
+            pj = nd.proj[j]
+            if pj is not None and not (fused_up and j == len(ins) - 1):
+                t = self._buf(N, h, w, pj.cout)
+                self._conv(pj, b, h, w, c, t, pj.cout, 0, what=f"{what}.project.{j}")
+                b, c = t, pj.cout
+            cur.append((b, h, w, c))
+        oc = cur[0][3]
+        fused = self._buf(N, oh, ow, oc)
+        if fused_up:
+            lb, _, _, lc = cur[-1]
+            lay = nd.proj[-1]
+            if lay.cout != oc:
+                raise ValueError(f"{what}: channel mismatch {lay.cout} vs {oc}")
+            self._conv(lay, lb, lh, lw, lc, fused, oc, CNL_UPSAMPLE_OUT_ADD, residual=cur[0][0], ldr=oc, what=f"{what}.project+up+sum")
+        else:
+            if any(c != oc for _, _, _, c in cur):
+                raise ValueError(f"{what}: channel mismatch {[c for _, _, _, c in cur]}")
+            lb = cur[-1][0]
+            if nd.down:
+                mode = 2
+            elif nd.deconv is not None:
+                lb, mode = self._deconv(nd.deconv, lb, lh, lw, oc, f"{what}.resize (conv_transpose)"), 3
+            else:
+                mode = 1 if nd.upsample_type == "bilinear" else 0
+            g = nd.gains if nd.gains is not None else [1.0] * len(cur)
+            in1 = cur[1][0] if len(cur) == 3 else None
+            self.launches.append(_Launch(self.lib.cnl_fuse_sum_nhwc_f32,
+                                         [cur[0][0].data_ptr(), in1.data_ptr() if in1 is not None else None, lb.data_ptr(), fused.data_ptr(),
+                                          N, oh, ow, oc, oc, oc, oc, oc, g[0], g[1] if len(cur) == 3 else 0.0, g[-1], nd.den, mode],
+                                         f"{what}.sum ({'max-pool down' if nd.down else nd.upsample_type})", 0, keep=(cur[0][0], in1, lb, fused)))
+        y = self._buf(N, oh, ow, nd.out_conv.cout)
+        self._block(nd.out_conv, fused, oh, ow, oc, y, nd.out_conv.cout, f"{what}.output_conv")
+        return (y, oh, ow, nd.out_conv.cout)
+
     def _build(self, Wt):
         N, H, W = self.N, self.H, self.W
         self._wt_stem = Wt.stem
@@ -620,6 +694,29 @@ class Plan:
                     up = CNL_UPSAMPLE_IN                          # nearest: folded into the consumer
             neck, nh, nw, nc, neck_up = x, xh, xw, xc, up          # a pending final nearest upsample is folded into the heads
             oh_, ow_ = (2 * nh, 2 * nw) if up else (nh, nw)
+        elif Wt.neck_kind == "IDANeck":
+            levels = list(self.features[1:])
+            for s_, stage in enumerate(Wt.stages):
+                levels = [self._fuse_node(nd, [levels[i], levels[i + 1]], f"neck.stages.{s_}.{i}") for i, nd in enumerate(stage)]
+            neck, nh, nw, nc = levels[0]
+            neck_up, oh_, ow_ = 0, nh, nw
+        elif Wt.neck_kind == "BiFPNNeck":
+            ins = list(self.features[1:])
+            for l_, (tds, bus) in enumerate(Wt.bifpn):
+                n_ = len(ins)
+                td = [None] * (n_ - 1) + [ins[-1]]
+                for i in range(n_ - 2, -1, -1):
+                    td[i] = self._fuse_node(tds[i], [ins[i], td[i + 1]], f"neck.bifpn.{l_}.td.{i}")
+                if bus is None:
+                    ins = td
+                    continue
+                outs = [td[0]]
+                for i in range(1, n_ - 1):
+                    outs.append(self._fuse_node(bus[i - 1], [ins[i], td[i], outs[i - 1]], f"neck.bifpn.{l_}.bu.{i - 1}"))
+                outs.append(self._fuse_node(bus[n_ - 2], [ins[-1], outs[-1]], f"neck.bifpn.{l_}.bu.{n_ - 2}"))
+                ins = outs
+            neck, nh, nw, nc = ins[0]
+            neck_up, oh_, ow_ = 0, nh, nw
         else:
             top, th, tw, tc = self.features[-1]
             top_pending = Wt.top                      # level 0 starts with `top = top_conv(c5)` (not yet materialised)

@@ -247,6 +247,86 @@ class FPNNeck(nn.Module):
         self.fuse = nn.ModuleList(fuse)
 
 
+class FuseNode(nn.Module):
+    """layers.py:138-177 `Fuse(in_channels, out, resize, upsample, downsample, conv_type, weighted_fusion)` for any number of inputs —
+    the node IDA and BiFPN necks are made of: 1x1 projections WITH bias where channels differ (:152), the LAST input resized (:154-156;
+    "down" is always MaxPool2d(2, 2): the reference passes `downsample=` where make_downsample expects `downsample_type=`, :118/:156,
+    so the choice never arrives), plain or weighted sum (:163-171), output conv (:158).  Key names equal the reference module's."""
+
+    def __init__(self, in_channels, out, resize="up", upsample="nearest", conv_type="normal", weighted_fusion=False, deconv_kernel=3,
+                 deconv_init_bilinear=True, **conv_kw):
+        super().__init__()
+        if resize not in ("up", "down"):
+            raise ValueError(f"Fuse resize={resize!r}: 'up' or 'down' (layers.py:144)")
+        self.resize_kind, self.upsample_type, self.conv_type = resize, upsample, conv_type
+        self.weights = nn.Parameter(torch.ones(len(in_channels)), requires_grad=True) if weighted_fusion else None
+        self.project = nn.ModuleList([nn.Conv2d(c, out, 1) if c != out else nn.Identity() for c in in_channels])
+        self.resize = DeconvBn(out, deconv_kernel, deconv_init_bilinear) if (resize == "up" and upsample == "conv_transpose") else nn.Identity()
+        self.output_conv = make_conv_params(out, out, conv_type, **conv_kw)
+
+
+class IDANeck(nn.Module):
+    """"Iteratively fuse consecutive feature maps from backbone until there is only 1 feature map left" (docs/implementation.md:43; the
+    class is missing from the reference tree — tests/test_necks.py:61-62 is an empty test).  Defined on the reference's Fuse node over the
+    features at strides 4 .. 32: stage s maps the levels to [Fuse([c_i, c_{i+1}], out=c_i, "up")(level_i, level_{i+1})]; three stages
+    leave one map with the stride-4 feature's channel count at stride 4.  State keys: neck.stages.{s}.{i}.<Fuse keys>."""
+
+    def __init__(self, backbone_channels, upsample_type="nearest", conv_type="normal", weighted_fusion=False, deconv_kernel=3,
+                 deconv_init_bilinear=True, **conv_kw):
+        super().__init__()
+        _check_neck_options(upsample_type, conv_type)
+        self.upsample_type, self.conv_type, self.weighted_fusion = upsample_type, conv_type, bool(weighted_fusion)
+        ch = list(backbone_channels[1:])                      # strides 4, 8, 16, 32
+        self.out_channels = ch[0]
+        self.upsample_stride = 2 ** (len(ch) - 1)
+        stages = []
+        while len(ch) > 1:
+            stages.append(nn.ModuleList([FuseNode([ch[i], ch[i + 1]], ch[i], "up", upsample_type, conv_type, weighted_fusion, deconv_kernel,
+                                                  deconv_init_bilinear, **conv_kw) for i in range(len(ch) - 1)]))
+            ch = ch[:-1]
+        self.stages = nn.ModuleList(stages)
+
+
+class _BiFPNLayer(nn.Module):
+    def __init__(self, in_ch, C, last, kw):
+        super().__init__()
+        n = len(in_ch)
+        # td[i], i = 0 .. n-2: Fuse([in_i, td_{i+1}], C, "up"); td_{n-1} is the input itself
+        self.td = nn.ModuleList([FuseNode([in_ch[i], C if i < n - 2 else in_ch[n - 1]], C, "up", **kw) for i in range(n - 1)])
+        # bu[i-1], i = 1 .. n-1: Fuse([in_i, td_i, out_{i-1}], C, "down"); the coarsest level has no td node of its own
+        self.bu = None if last else nn.ModuleList(
+            [FuseNode([in_ch[i], C, C], C, "down", **kw) for i in range(1, n - 1)] + [FuseNode([in_ch[n - 1], C], C, "down", **kw)])
+
+
+class BiFPNNeck(nn.Module):
+    """EfficientDet's BiFPN (docs/implementation.md:42; class missing from the reference tree, tests/test_necks.py:58-59 is empty), on the
+    reference's Fuse node over the features at strides 4 .. 32.  Per layer: top-down td_i = Fuse([in_i, td_{i+1}], C, "up"), then
+    bottom-up out_i = Fuse([in_i, td_i, out_{i-1}], C, "down") (out_0 = td_0; the coarsest level fuses [in, out_{below}]).  The neck
+    returns out_0 of the last layer, so the last layer builds no bottom-up nodes.  `num_channels` = C, `num_layers` >= 1.
+    State keys: neck.bifpn.{l}.td.{i}.* / neck.bifpn.{l}.bu.{i}.*."""
+
+    def __init__(self, backbone_channels, num_channels=64, num_layers=3, upsample_type="nearest", conv_type="normal",
+                 weighted_fusion=False, deconv_kernel=3, deconv_init_bilinear=True, **conv_kw):
+        super().__init__()
+        _check_neck_options(upsample_type, conv_type)
+        if int(num_layers) < 1 or int(num_channels) < 4 or int(num_channels) % 4:
+            raise ValueError(f"bifpn: num_layers={num_layers} (>= 1), num_channels={num_channels} (a positive multiple of 4)")
+        self.upsample_type, self.conv_type, self.weighted_fusion = upsample_type, conv_type, bool(weighted_fusion)
+        self.num_channels, self.num_layers = int(num_channels), int(num_layers)
+        self.out_channels = self.num_channels
+        in_ch = list(backbone_channels[1:])
+        self.upsample_stride = 2 ** (len(in_ch) - 1)
+        kw = dict(upsample=upsample_type, conv_type=conv_type, weighted_fusion=weighted_fusion, deconv_kernel=deconv_kernel,
+                  deconv_init_bilinear=deconv_init_bilinear, **conv_kw)
+        layers = []
+        for l in range(self.num_layers):
+            last = l == self.num_layers - 1
+            layers.append(_BiFPNLayer(in_ch, self.num_channels, last, kw))
+            # what the next layer reads: out_0 .. out_{n-1}, all C channels
+            in_ch = [self.num_channels] * len(in_ch)
+        self.bifpn = nn.ModuleList(layers)
+
+
 def _check_neck_options(upsample_type, conv_type):
     if upsample_type not in UPSAMPLE_TYPES:
         raise ValueError(f"upsample_type={upsample_type!r}: expected one of {UPSAMPLE_TYPES} (layers.py:84)")
@@ -278,4 +358,8 @@ def build_neck(cfg, backbone_channels):
         return SimpleNeck(backbone_channels, **cfg)
     if name == "fpn":
         return FPNNeck(backbone_channels, **cfg)
-    raise ValueError(f"neck '{name}' is outside the MI355X hot-path scope (supported: simple, fpn)")
+    if name == "ida":
+        return IDANeck(backbone_channels, **cfg)
+    if name == "bifpn":
+        return BiFPNNeck(backbone_channels, **cfg)
+    raise ValueError(f"neck '{name}': expected one of simple, fpn, bifpn, ida (README.md:70 of the reference)")

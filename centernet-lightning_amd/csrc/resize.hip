@@ -1,5 +1,6 @@
 // resize.hip — the HBM-bound halves of the remaining neck options:
 //   upsample2x_kernel   nn.Upsample(scale_factor=2, mode="nearest"|"bilinear") (+ the Fuse sum)   models/layers.py:99, 160-174
+//   fuse_sum_kernel     the general Fuse node's sum: up to three inputs, gains, the last one resized up / max-pooled  models/layers.py:160-175
 //   depthwise3x3_kernel depthwise 3x3 + folded BN + ReLU6 of conv_type="separable"                 models/layers.py:58-62
 // Both stream NHWC float4s: one thread per (output pixel, 4 channels); neighbouring pixels' re-reads hit L2.
 #include "cnl_common.h"
@@ -79,6 +80,59 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const float* __restri
     }
 }
 
+// Fuse.forward's sum for the general node (layers.py:160-175): y = (g0 . in0 [+ g1 . in1] + gl . resize(last)) / den, the LAST input
+// resized on the fly: 0 nearest x2, 1 bilinear x2 (last is H/2 x W/2), 2 MaxPool2d(2, 2) (last is 2H x 2W), 3 same size.
+__global__ __launch_bounds__(256) void fuse_sum_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                       const float* __restrict__ last, float* __restrict__ y, int N, int H, int W, int C4,
+                                                       int ld0, int ld1, int ldl, int ldy, float g0, float g1, float gl, float den,
+                                                       int mode) {
+    const long total = (long)N * H * W * C4;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int c = (int)(t % C4) * 4;
+        const long opix = t / C4;
+        const int ox = (int)(opix % W);
+        const int oy = (int)((opix / W) % H);
+        const int n = (int)(opix / ((long)W * H));
+        f32x4 v;
+        if (mode == 3) {
+            v = *reinterpret_cast<const f32x4*>(last + opix * ldl + c);
+        } else if (mode == 2) {
+            const float* p = last + (((long)n * 2 * H + 2 * oy) * 2 * W + 2 * ox) * ldl + c;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + ldl);
+            const f32x4 cc = *reinterpret_cast<const f32x4*>(p + (long)2 * W * ldl), d = *reinterpret_cast<const f32x4*>(p + (long)2 * W * ldl + ldl);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {          // ATen max_pool2d propagates NaN
+                float m = a[i];
+                m = (b[i] > m || b[i] != b[i]) ? b[i] : m;
+                m = (cc[i] > m || cc[i] != cc[i]) ? cc[i] : m;
+                m = (d[i] > m || d[i] != d[i]) ? d[i] : m;
+                v[i] = m;
+            }
+        } else {
+            const int Hs = H >> 1, Ws = W >> 1;
+            const float* xn = last + (long)n * Hs * Ws * ldl + c;
+            if (mode == 0) {
+                v = *reinterpret_cast<const f32x4*>(xn + ((long)(oy >> 1) * Ws + (ox >> 1)) * ldl);
+            } else {
+                const float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
+                const int y0 = (int)sy, x0 = (int)sx;
+                const int y1 = y0 + (y0 < Hs - 1), x1 = x0 + (x0 < Ws - 1);
+                const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+                const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(xn + ((long)y0 * Ws + x0) * ldl);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(xn + ((long)y0 * Ws + x1) * ldl);
+                const f32x4 cc = *reinterpret_cast<const f32x4*>(xn + ((long)y1 * Ws + x0) * ldl);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(xn + ((long)y1 * Ws + x1) * ldl);
+                v = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * cc + lx1 * d);
+            }
+        }
+        f32x4 acc = *reinterpret_cast<const f32x4*>(in0 + opix * ld0 + c) * g0;
+        if (in1) acc = acc + *reinterpret_cast<const f32x4*>(in1 + opix * ld1 + c) * g1;
+        acc = (acc + v * gl) / den;
+        *reinterpret_cast<f32x4*>(y + opix * ldy + c) = acc;
+    }
+}
+
 static unsigned grid_for(long total) {
     long b = (total + 255) / 256;
     if (b > 256 * 32) b = 256 * 32;
@@ -100,6 +154,23 @@ extern "C" int cnl_upsample2x_nhwc_f32(const float* x, const float* residual, fl
     hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, residual, y, N, H_in, W_in, C / 4,
                        ldx, ldr, ldy, mode);
     return cnl::check_launch("upsample2x_kernel");
+}
+
+extern "C" int cnl_fuse_sum_nhwc_f32(const float* in0, const float* in1, const float* last, float* y, int32_t N, int32_t H, int32_t W,
+                                     int32_t C, int32_t ld0, int32_t ld1, int32_t ldl, int32_t ldy, float g0, float g1, float gl,
+                                     float den, int32_t mode, void* stream) {
+    CNL_REQUIRE(in0 && last && y, CNL_E_BAD_ARG, "cnl_fuse_sum_nhwc_f32: null tensor pointer");
+    CNL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, CNL_E_BAD_ARG, "cnl_fuse_sum_nhwc_f32: non-positive dimension");
+    CNL_REQUIRE(mode >= 0 && mode <= 3, CNL_E_UNSUPPORTED, "cnl_fuse_sum_nhwc_f32: mode %d (0 nearest up, 1 bilinear up, 2 max-pool down, 3 none)", mode);
+    CNL_REQUIRE(mode >= 2 || (H % 2 == 0 && W % 2 == 0), CNL_E_BAD_ARG, "cnl_fuse_sum_nhwc_f32: an upsampled input needs even output H, W (%dx%d)", H, W);
+    CNL_REQUIRE(C % 4 == 0 && ld0 % 4 == 0 && ldl % 4 == 0 && ldy % 4 == 0 && ld0 >= C && ldl >= C && ldy >= C && (!in1 || (ld1 % 4 == 0 && ld1 >= C)),
+                CNL_E_UNSUPPORTED, "cnl_fuse_sum_nhwc_f32: C and the pixel strides must be multiples of 4 (C=%d)", C);
+    CNL_REQUIRE((((uintptr_t)in0 | (uintptr_t)in1 | (uintptr_t)last | (uintptr_t)y) & 15) == 0, CNL_E_BAD_ARG, "cnl_fuse_sum_nhwc_f32: 16-byte alignment");
+    CNL_REQUIRE(den != 0.f, CNL_E_BAD_ARG, "cnl_fuse_sum_nhwc_f32: den == 0");
+    const long total = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(fuse_sum_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in0, in1, last, y, N, H, W, C / 4, ld0, ld1,
+                       ldl, ldy, g0, g1, gl, den, mode);
+    return cnl::check_launch("fuse_sum_kernel");
 }
 
 extern "C" int cnl_depthwise3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int32_t N, int32_t H, int32_t W,

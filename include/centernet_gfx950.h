@@ -304,6 +304,18 @@ size_t cnl_deconv_weight_floats(int32_t Cin, int32_t Cout, int32_t K);
 int cnl_upsample2x_nhwc_f32(const float* x, const float* residual, float* y, int32_t N, int32_t H_in, int32_t W_in, int32_t C,
                             int32_t ldx, int32_t ldr, int32_t ldy, int32_t mode, void* stream);
 
+/* The sum of a general Fuse node (reference models/layers.py:160-175; nodes with three inputs and/or resize="down" — BiFPN's bottom-up
+ * path — and weighted_fusion with any resize):
+ *     y = (g0 * in0 [+ g1 * in1] + gl * resize(last)) / den          in1 == NULL for a two-input node
+ * in0 / in1 / y are [N, H, W, C] NHWC with pixel strides ld0 / ld1 / ldy; `last` is resized on the fly by `mode`:
+ *   0  nn.Upsample(2, "nearest")   last is [N, H/2, W/2, C]       1  nn.Upsample(2, "bilinear", align_corners=False)   same shape
+ *   2  nn.MaxPool2d(2, 2)          last is [N, 2H, 2W, C]         3  none (already resized, e.g. by cnl_deconv2x_nhwc_f32)
+ * Unweighted fusion: g* = den = 1 (bit-exact plain sum); weighted (layers.py:164-167): g_j = relu(w_j), den = sum_j relu(w_j) + 1e-6.
+ * C and the strides multiples of 4, pointers 16-byte aligned.  HBM-bound: reads each input once, writes y once. */
+int cnl_fuse_sum_nhwc_f32(const float* in0, const float* in1, const float* last, float* y, int32_t N, int32_t H, int32_t W, int32_t C,
+                          int32_t ld0, int32_t ld1, int32_t ldl, int32_t ldy, float g0, float g1, float gl, float den, int32_t mode,
+                          void* stream);
+
 /*
  * conv_type="separable", depthwise half (layers.py:58-62): nn.Conv2d(C, C, 3, padding=1, groups=C, bias=False) + BN + ReLU6.
  * w: [3][3][C] (tap-major, BN scale folded), bias [C]; flags: CNL_RELU | CNL_RELU6.  C % 4 == 0.  The pointwise half is

@@ -161,8 +161,73 @@ def fuse_forward(sd, q, skip, top, upsample_type="nearest", stats=None, eps=1e-6
     return make_conv_forward(o, sd, q + "output_conv", stats)
 
 
+def fuse_forward_n(sd, q, inputs, resize="up", upsample_type="nearest", stats=None, eps=1e-6):
+    """Fuse.forward (layers.py:138-177) for any number of inputs: every input projected by its 1x1 conv where one exists, the LAST one
+    resized — "up": make_upsample (:154), "down": make_downsample (:156) — then the plain or weighted sum and the output conv.
+    Reference quirk kept: Fuse passes `downsample=` (not `downsample_type=`) to make_downsample (:156), where it disappears into
+    **kwargs (:118), so the down path is ALWAYS nn.MaxPool2d(2, 2) whatever the `downsample` argument says."""
+    out = list(inputs)
+    for j in range(len(out)):
+        if f"{q}project.{j}.weight" in sd:
+            out[j] = F.conv2d(out[j], sd[f"{q}project.{j}.weight"], sd[f"{q}project.{j}.bias"])
+    if resize == "up":
+        out[-1] = make_upsample_forward(out[-1], sd, q + "resize", upsample_type, stats)
+    else:
+        out[-1] = F.max_pool2d(out[-1], 2, 2)
+    if q + "weights" in sd:
+        w = F.relu(sd[q + "weights"])
+        o = torch.stack([out[j] * w[j] for j in range(len(out))], dim=-1)
+        o = torch.sum(o, dim=-1) / (torch.sum(w) + eps)
+    else:
+        o = torch.stack(out, dim=-1).sum(dim=-1)
+    return make_conv_forward(o, sd, q + "output_conv", stats)
+
+
+def ida_forward(sd, feats, stats=None, upsample_type="nearest"):
+    """IDANeck — "iteratively fuse consecutive feature maps from backbone until there is only 1 feature map left"
+    (docs/implementation.md:43; the class itself is missing from the reference tree, tests/test_necks.py:61-62 is empty).  Defined here
+    on the reference's own Fuse node: levels = features at strides 4, 8, 16, 32; stage s replaces them by
+    [Fuse([c_i, c_{i+1}], out = c_i, "up")(level_i, level_{i+1})]; after three stages one 64-channel map at stride 4 is left."""
+    levels = list(feats[1:])
+    s = 0
+    while len(levels) > 1:
+        levels = [fuse_forward_n(sd, f"neck.stages.{s}.{i}.", [levels[i], levels[i + 1]], "up", upsample_type, stats) for i in range(len(levels) - 1)]
+        s += 1
+    return levels[0]
+
+
+def bifpn_forward(sd, feats, stats=None, upsample_type="nearest"):
+    """BiFPNNeck (docs/implementation.md:42: EfficientDet's BiFPN; class missing from the reference tree, tests/test_necks.py:58-59 is
+    empty).  Defined here on the reference's Fuse node over the features at strides 4 .. 32 (P2 .. P5), per layer:
+        top-down   td_3 = in_3;  td_i = Fuse([in_i, td_{i+1}], C, "up")                        i = 2, 1, 0
+        bottom-up  out_0 = td_0; out_i = Fuse([in_i, td_i, out_{i-1}], C, "down")              i = 1, 2;   out_3 = Fuse([in_3, out_2], C, "down")
+    The neck's output is out_0 of the last layer, so the last layer has no bottom-up nodes (nothing reads them)."""
+    ins = list(feats[1:])
+    l = 0
+    has = lambda prefix: any(k.startswith(prefix) for k in sd)
+    while has(f"neck.bifpn.{l}.td.0."):
+        q = f"neck.bifpn.{l}."
+        td = [None, None, None, ins[3]]
+        for i in (2, 1, 0):
+            td[i] = fuse_forward_n(sd, f"{q}td.{i}.", [ins[i], td[i + 1]], "up", upsample_type, stats)
+        if has(f"{q}bu.0."):
+            outs = [td[0], None, None, None]
+            for i in (1, 2):
+                outs[i] = fuse_forward_n(sd, f"{q}bu.{i - 1}.", [ins[i], td[i], outs[i - 1]], "down", upsample_type, stats)
+            outs[3] = fuse_forward_n(sd, f"{q}bu.2.", [ins[3], outs[2]], "down", upsample_type, stats)
+            ins = outs
+        else:
+            ins = [td[0], td[1], td[2], td[3]]
+        l += 1
+    return ins[0]
+
+
 def neck_forward(sd, feats, stats=None, upsample_type="nearest"):
     """`upsample_type` distinguishes "nearest" from "bilinear" (neither has parameters); "conv_transpose" is read off the keys."""
+    if any(k.startswith("neck.stages.0.0.") for k in sd):      # IDA
+        return ida_forward(sd, feats, stats, upsample_type)
+    if any(k.startswith("neck.bifpn.0.td.0.") for k in sd):    # BiFPN
+        return bifpn_forward(sd, feats, stats, upsample_type)
     if "neck.top_conv.weight" in sd:                           # FPN
         top = F.conv2d(feats[-1], sd["neck.top_conv.weight"], sd["neck.top_conv.bias"])
         i = 0

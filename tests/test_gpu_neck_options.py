@@ -173,6 +173,40 @@ def test_deform_sample_matches_torchvision_rule(shape, K, has_mask):
     assert lib.cnl_deform_sample_nhwc_f32(xd.data_ptr(), omd.data_ptr(), col.data_ptr(), N, H, W, C, C, om.shape[1], 4, 1, None) == _lib.CNL_E_UNSUPPORTED
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("three", [False, True])
+def test_fuse_sum_kernel(mode, three):
+    """cnl_fuse_sum_nhwc_f32 against the reference Fuse.forward's arithmetic (layers.py:160-175) written with torch ops: plain sum
+    bit-exact, weighted sum within 2 ulp-ish (same operation order, division included)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(10 * mode + three)
+    N, C, H, W = 2, 24, 12, 20
+    a, b = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H, W, generator=g)
+    lshape = {0: (H // 2, W // 2), 1: (H // 2, W // 2), 2: (2 * H, 2 * W), 3: (H, W)}[mode]
+    last = torch.randn(N, C, *lshape, generator=g)
+    res = {0: lambda t: F.interpolate(t, scale_factor=2, mode="nearest"), 1: lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False),
+           2: lambda t: F.max_pool2d(t, 2, 2), 3: lambda t: t}[mode](last)
+    ins = [a, b, res] if three else [a, res]
+    y = torch.full((N, H, W, C), float("nan"), device="cuda")
+    ad, bd, ld = nhwc(a), nhwc(b), nhwc(last)
+    call = lambda g0, g1, gl, den: _lib.check(lib.cnl_fuse_sum_nhwc_f32(ad.data_ptr(), bd.data_ptr() if three else None, ld.data_ptr(), y.data_ptr(),
+                                                                        N, H, W, C, C, C, C, C, g0, g1, gl, den, mode, None))
+    call(1.0, 1.0, 1.0, 1.0)
+    want = torch.stack(ins, dim=-1).sum(dim=-1)
+    if mode == 1:                                               # ATen's CPU bilinear kernel orders the four-tap blend differently
+        torch.testing.assert_close(nchw(y), want, rtol=1e-6, atol=1e-6)
+    else:
+        assert torch.equal(nchw(y), want)
+    wts = torch.relu(torch.tensor([0.7, -0.2, 1.9] if three else [0.7, 1.9]))
+    call(float(wts[0]), float(wts[1]) if three else 0.0, float(wts[-1]), float(wts.sum() + 1e-6))
+    want = torch.sum(torch.stack([t * wts[j] for j, t in enumerate(ins)], dim=-1), dim=-1) / (torch.sum(wts) + 1e-6)
+    torch.testing.assert_close(nchw(y), want, rtol=1e-6, atol=1e-6)
+    if mode < 2:
+        assert lib.cnl_fuse_sum_nhwc_f32(ad.data_ptr(), None, ld.data_ptr(), y.data_ptr(), N, 11, W, C, C, C, C, C, 1.0, 0.0, 1.0, 1.0, mode, None) == _lib.CNL_E_BAD_ARG
+    assert lib.cnl_fuse_sum_nhwc_f32(ad.data_ptr(), None, ld.data_ptr(), y.data_ptr(), N, H, W, C, C, C, C, C, 1.0, 0.0, 1.0, 1.0, 4, None) == _lib.CNL_E_UNSUPPORTED
+    assert lib.cnl_fuse_sum_nhwc_f32(ad.data_ptr(), None, ld.data_ptr(), y.data_ptr(), N, H, W, 22, C, C, C, C, 1.0, 0.0, 1.0, 1.0, mode, None) == _lib.CNL_E_UNSUPPORTED
+
+
 NECKS = {
     "simple_deconv": {"name": "simple", "upsample_type": "conv_transpose", "deconv_kernel": 3},        # configs/test_config.yaml
     "simple_deconv4_separable": {"name": "simple", "upsample_type": "conv_transpose", "deconv_kernel": 4, "conv_type": "separable"},
@@ -186,20 +220,35 @@ NECKS = {
     "fpn_deformable": {"name": "fpn", "upsample_type": "nearest", "conv_type": "deformable"},                       # DCNv2 (mask)
     "simple_deformable_v1_bilinear": {"name": "simple", "upsample_type": "bilinear", "conv_type": "deformable", "version": 1},
     "simple_deformable_nearest": {"name": "simple", "upsample_type": "nearest", "conv_type": "deformable"},
+    # IDA / BiFPN (docs/implementation.md:42-43): defined on the reference's Fuse node, params.IDANeck / params.BiFPNNeck
+    "ida_nearest": {"name": "ida"},
+    "ida_bilinear_weighted": {"name": "ida", "upsample_type": "bilinear", "weighted_fusion": True},
+    "ida_deconv_separable": {"name": "ida", "upsample_type": "conv_transpose", "conv_type": "separable"},
+    "bifpn_nearest": {"name": "bifpn", "num_channels": 64, "num_layers": 2},
+    "bifpn_weighted_3layers": {"name": "bifpn", "num_channels": 32, "num_layers": 3, "weighted_fusion": True},
+    "bifpn_bilinear_separable_weighted": {"name": "bifpn", "num_channels": 64, "num_layers": 2, "upsample_type": "bilinear", "conv_type": "separable",
+                                          "weighted_fusion": True},
+    "bifpn_deconv_1layer": {"name": "bifpn", "num_channels": 96, "num_layers": 1, "upsample_type": "conv_transpose"},
 }
 
 
 @pytest.mark.parametrize("name", sorted(NECKS))
 def test_model_with_neck_option_matches_cpu_oracle(name):
-    neck = dict(NECKS[name], upsample_channels=[256, 128, 64])
-    ups = neck["upsample_type"]
+    neck = dict(NECKS[name])
+    if neck["name"] in ("simple", "fpn"):
+        neck["upsample_channels"] = [256, 128, 64]
+    ups = neck.get("upsample_type", "nearest")
+    new = neck["name"] in ("ida", "bifpn")
     torch.manual_seed(0)
     model = cl.build_centernet({"task": "detection", "backbone": {"name": "resnet34", "pretrained": False}, "neck": neck,
                                 "output_heads": {"heatmap": {"num_classes": 5, "init_bias": -2.19}, "box_2d": {"init_bias": 10}}})
     sd = ref_cpu.synth_state_dict(model.state_dict(), seed=1, calib_shape=(2, 3, 128, 128), upsample_type=ups)
     if "weighted" in name:
         assert any(k.endswith(".weights") for k in sd)
-        sd["neck.fuse.1.weights"][0] = -0.3                     # relu(weights): this level ignores its skip input
+        first = sorted(k for k in sd if k.endswith(".weights"))[1]
+        sd[first][0] = -0.3                                     # relu(weights): this node ignores its first input
+        for i, k in enumerate(sorted(k for k in sd if k.endswith(".weights"))[2:]):
+            sd[k] = torch.rand(sd[k].shape, generator=torch.Generator().manual_seed(i)) + 0.25
     model.load_state_dict(sd)
     model = model.cuda()
     x = recipes.images(4321, (2, 3, 96, 128))
@@ -210,6 +259,16 @@ def test_model_with_neck_option_matches_cpu_oracle(name):
         assert tuple(enc[k].shape) == tuple(r.shape) == (2, r.shape[1], 24, 32)
         torch.testing.assert_close(enc[k].cpu(), r, rtol=TOL, atol=TOL)
     what = [L.what for L in next(iter(model._engine.plans.values())).launches]
+    if new:
+        nodes = {"ida": 6, "bifpn": 3 * neck.get("num_layers", 3) + 3 * (neck.get("num_layers", 3) - 1)}[neck["name"]]
+        assert sum(w.startswith("neck.") and ".output_conv" in w and not w.endswith(".dw") for w in what) == nodes
+        if name == "ida_nearest":                               # project -> upsample -> sum inside one 1x1 conv per node
+            assert sum("project+up+sum" in w for w in what) == 6 and not any(".sum (" in w for w in what)
+        if name == "bifpn_nearest":
+            assert sum("max-pool down" in w for w in what) == 3
+        if ups == "conv_transpose":
+            assert sum(".resize (conv_transpose)" in w for w in what) == (6 if neck["name"] == "ida" else 3)
+        return
     if ups == "conv_transpose":
         assert sum("conv_transpose" in w for w in what) == 3
     if ups == "bilinear":

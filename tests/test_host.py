@@ -94,7 +94,7 @@ def test_reference_yaml_files_build(name):
 
 def test_out_of_scope_options_raise():
     base = {"backbone": {"name": "resnet34"}, "neck": {"name": "fpn"}, "output_heads": {"heatmap": {"num_classes": 3}, "box_2d": {}}}
-    for bad in ({"backbone": {"name": "mobilenet_v2"}}, {"neck": {"name": "bifpn"}}, {"neck": {"name": "fpn", "conv_type": "dilated"}},
+    for bad in ({"backbone": {"name": "mobilenet_v2"}}, {"neck": {"name": "nas_fpn"}}, {"neck": {"name": "fpn", "conv_type": "dilated"}},
                 {"neck": {"name": "simple", "upsample_type": "conv_transpose", "deconv_kernel": 7}}):
         cfg = dict(base, **bad)
         with pytest.raises(ValueError):
@@ -102,7 +102,7 @@ def test_out_of_scope_options_raise():
 
 
 # ----------------------------------------------------------------------------- model contract
-@pytest.mark.parametrize("neck", ["simple", "fpn"])
+@pytest.mark.parametrize("neck", ["simple", "fpn", "ida", "bifpn"])
 def test_model_attributes_contract(neck):
     m = cl.CenterNet({"name": "resnet34"}, {"name": neck}, {"heatmap": {"num_classes": 20}, "box_2d": {}}, "detection")
     assert isinstance(m.output_stride, int) and m.output_stride == 4 and m.stride == 4       # tests/test_models.py:64

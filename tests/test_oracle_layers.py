@@ -80,7 +80,8 @@ def test_config_surface_neck_options():
     assert "neck.fuse.0.weights" in sd and "neck.fuse.2.output_conv.3.weight" in sd and sd["neck.fuse.1.output_conv.0.weight"].shape == (128, 1, 3, 3)
     for bad in ({"name": "fpn", "conv_type": "dilated"}, {"name": "simple", "upsample_type": "cubic"},
                 {"name": "fpn", "conv_type": "deformable", "mask_activation": "Hardsigmoid"}, {"name": "fpn", "conv_type": "deformable", "version": 3},
-                {"name": "simple", "upsample_type": "conv_transpose", "deconv_kernel": 5}, {"name": "bifpn"}):
+                {"name": "simple", "upsample_type": "conv_transpose", "deconv_kernel": 5}, {"name": "panet"},
+                {"name": "bifpn", "num_layers": 0}, {"name": "bifpn", "num_channels": 30}, {"name": "ida", "upsample_type": "cubic"}):
         with pytest.raises(ValueError):
             cl.build_centernet(_cfg(bad))
     # the CPU oracle runs every option (shape contract of tests/test_necks.py:27-28,44-45: stride 32 -> 4, C = upsample_channels[-1])
@@ -90,6 +91,51 @@ def test_config_surface_neck_options():
         x = torch.rand(1, 3, 64, 96)
         out, feats, nk = ref_cpu.forward(m.state_dict(), x, return_intermediates=True, upsample_type=ups)
         assert tuple(nk.shape) == (1, 64, 16, 24) and tuple(out["heatmap"].shape) == (1, 3, 16, 24)
+
+
+def test_fuse_down_and_three_inputs_match_reference_fuse():
+    """The node types BiFPN's bottom-up path is made of — resize="down" (always MaxPool2d(2, 2): the `downsample=` argument never reaches
+    make_downsample, layers.py:118/:156) and three inputs — against outputs of the reference's own Fuse (oracle/make_golden_fuse_down.py);
+    and the product's FuseNode takes the reference module's state_dict verbatim."""
+    g = dict(np.load(os.path.join(os.path.dirname(GOLDEN), "layers_fuse_down.npz")))
+    assert len(g["cases"]) == 5
+    for name in [str(c) for c in g["cases"]]:
+        sd = {"f." + k: v for k, v in _sd(g, f"{name}.sd.", "").items()}
+        xs = [torch.from_numpy(g[f"{name}.in{j}"]) for j in range(int(g[f"{name}.n_in"]))]
+        y = ref_cpu.fuse_forward_n(sd, "f.", xs, str(g[f"{name}.resize"]))
+        np.testing.assert_array_equal(y.numpy(), g[f"{name}.out"])
+        in_ch = [int(x.shape[1]) for x in xs]
+        node = P.FuseNode(in_ch, int(g[f"{name}.out"].shape[1]), str(g[f"{name}.resize"]), weighted_fusion="f.weights" in sd,
+                          conv_type="separable" if "f.output_conv.3.weight" in sd else "normal")
+        node.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+
+
+def test_ida_and_bifpn_necks_surface():
+    """neck.name = ida | bifpn (README.md:70, docs/implementation.md:42-43 of the reference; the classes themselves are missing there):
+    shape contract of the reference's neck tests (stride 32 -> 4), key layout, what the CPU oracle computes."""
+    for neck, n_out, keys in (({"name": "ida"}, 64, ("neck.stages.0.2.project.1.weight", "neck.stages.2.0.output_conv.1.running_var")),
+                              ({"name": "bifpn", "num_channels": 32, "num_layers": 2, "weighted_fusion": True}, 32,
+                               ("neck.bifpn.0.td.2.project.1.weight", "neck.bifpn.0.bu.0.weights", "neck.bifpn.0.bu.2.output_conv.0.weight",
+                                "neck.bifpn.1.td.0.weights")),
+                              ({"name": "ida", "upsample_type": "conv_transpose", "conv_type": "separable"}, 64, ("neck.stages.1.1.resize.0.weight",))):
+        m = cl.build_centernet(_cfg(neck))
+        sd = m.state_dict()
+        assert all(k in sd for k in keys), [k for k in keys if k not in sd]
+        assert m.output_stride == 4 and m.neck.out_channels == n_out
+        out, feats, nk = ref_cpu.forward(sd, torch.rand(1, 3, 64, 96), return_intermediates=True, upsample_type=neck.get("upsample_type", "nearest"))
+        assert tuple(nk.shape) == (1, n_out, 16, 24) and tuple(out["box_2d"].shape) == (1, 4, 16, 24)
+    sd = cl.build_centernet(_cfg({"name": "bifpn", "num_layers": 2})).state_dict()
+    assert "neck.bifpn.1.bu.0.output_conv.0.weight" not in sd          # the last layer's bottom-up nodes feed nothing
+    assert sd["neck.bifpn.0.bu.2.project.0.weight"].shape == (64, 512, 1, 1) and "neck.bifpn.1.td.2.project.0.weight" not in sd
+    # IDA == nested Fuse calls written out by hand on one stage
+    m = cl.build_centernet(_cfg({"name": "ida"}))
+    sd = m.state_dict()
+    feats = ref_cpu.backbone_features(sd, torch.rand(1, 3, 64, 64))
+    lv = list(feats[1:])
+    s0 = [ref_cpu.fuse_forward_n(sd, f"neck.stages.0.{i}.", [lv[i], lv[i + 1]]) for i in range(3)]
+    s1 = [ref_cpu.fuse_forward_n(sd, f"neck.stages.1.{i}.", [s0[i], s0[i + 1]]) for i in range(2)]
+    want = ref_cpu.fuse_forward_n(sd, "neck.stages.2.0.", [s1[0], s1[1]])
+    torch.testing.assert_close(ref_cpu.neck_forward(sd, feats), want, rtol=0, atol=0)
 
 
 def test_deformable_conv_params_and_oracle():
