@@ -293,7 +293,7 @@ def cpu_baseline(model, config, tracking, k, H, W, gpu_decode_p50_ms, budget_s=7
     def one(x):
         o = ref_cpu.forward(sd, x, sigmoid=True)
         t0 = time.perf_counter()
-        decode_ref.decode_detections(o["heatmap"].numpy(), o["box_2d"].numpy(), k, 3, reid=o["reid"].numpy() if tracking else None)
+        decode_ref.decode_detections_torch(o["heatmap"], o["box_2d"], k, 3, reid=o["reid"] if tracking else None)
         return time.perf_counter() - t0
 
     def leg(n, h, w, budget):
@@ -334,9 +334,9 @@ def cpu_baseline(model, config, tracking, k, H, W, gpu_decode_p50_ms, budget_s=7
     cn = leg(8, H, W, budget_s * 0.7)
     return {"value": cn["images_per_s"], "unit": "images/s", "cores": cn["threads"], "kind": "port",
             "os_cpu_count": cores, "cpu_model": cpu_model,
-            "sample": f"oracle/ref_cpu.forward + decode_ref.decode_detections (same weights) on 8x3x{H}x{W}, 2 warm-ups + {cn['timed_passes']} timed passes, median; "
+            "sample": f"oracle/ref_cpu.forward + decode_ref.decode_detections_torch (same weights) on 8x3x{H}x{W}, 2 warm-ups + {cn['timed_passes']} timed passes, median; "
                       f"torch {torch.__version__} CPU fp32, {cn['threads']} threads{', channels_last' if cn['channels_last'] else ''} "
-                      f"(the best of the probed thread counts / layouts: bench_config_N8.probes_images_per_s); decode = the numpy oracle",
+                      f"(the best of the probed thread counts / layouts: bench_config_N8.probes_images_per_s); decode = the reference's torch op sequence on CPU",
             "bench_config_N8": cn, "C0_1x3x512x512": c0,
             "decode_p50_ms": {"cpu_N8": cn["decode_p50_ms"], "cpu_N1_C0": c0["decode_p50_ms"], "gpu_full_batch": gpu_decode_p50_ms}}
 

@@ -102,6 +102,38 @@ def decode_detections(heat, box_offsets, num_detections=100, nms_kernel=3, norma
     return out
 
 
+def decode_detections_torch(heat, box_offsets, num_detections=100, nms_kernel=3, normalize_boxes=False, box_multiplier=1.0, stride=4,
+                            reid=None):
+    """The same decode with the reference's own torch op sequence on CPU tensors (centernet.py:243-304: max_pool2d == heat mask,
+    torch.max over classes, torch.topk, torch.gather; fairmot.py:63-73) — the multi-threaded form a CPU user of the reference runs.
+    bench.py's cpu_baseline times THIS (the numpy functions above are single-threaded restatements kept for bit-exact checking);
+    tests/test_oracle_golden.py checks both agree after canonicalize().  Torch's topk breaks score ties in an unspecified order."""
+    import torch
+    import torch.nn.functional as F
+    N, _, H, W = heat.shape
+    pad = (nms_kernel - 1) // 2
+    m = F.max_pool2d(heat, nms_kernel, stride=1, padding=pad)
+    h = heat * (m == heat)
+    score, label = torch.max(h, dim=1)
+    scores, indices = torch.topk(score.view(N, -1), num_detections)
+    labels = torch.gather(label.view(N, -1), 1, indices)
+    cx = (indices % W) + 0.5
+    cy = torch.div(indices, W, rounding_mode="floor") + 0.5
+    g = torch.gather(box_offsets.reshape(N, 4, -1), 2, indices.unsqueeze(1).expand(N, 4, num_detections)).swapaxes(1, 2)
+    g = (g * box_multiplier).clamp_min(0)
+    boxes = torch.stack([cx - g[..., 0], cy - g[..., 1], cx + g[..., 2], cy + g[..., 3]], dim=-1)
+    if normalize_boxes:
+        boxes[..., [0, 2]] /= W
+        boxes[..., [1, 3]] /= H
+    else:
+        boxes = boxes * stride
+    out = {"boxes": boxes, "scores": scores, "labels": labels, "indices": indices}
+    if reid is not None:
+        E = reid.shape[1]
+        out["embeddings"] = torch.gather(reid.reshape(N, E, -1), 2, indices.unsqueeze(1).expand(N, E, num_detections)).swapaxes(1, 2)
+    return out
+
+
 def canonicalize(scores, indices, *others):
     """Re-order each image's detections into (score desc, index asc).  Only permutes inside groups of
     equal score, so it is the identity on tie-free outputs."""

@@ -85,6 +85,25 @@ def test_canonicalize_is_identity_on_tie_free():
     assert np.array_equal(i, o["indices"]) and np.array_equal(l, o["labels"])
 
 
+def test_torch_decode_used_by_the_cpu_baseline_agrees_with_the_numpy_oracle():
+    """bench.py's cpu_baseline times decode_detections_torch (the reference's torch op sequence, multi-threaded); it must be the same
+    function as the numpy oracle up to tie order."""
+    g = torch.Generator().manual_seed(5)
+    heat = torch.sigmoid(torch.randn(3, 7, 24, 40, generator=g) * 2)
+    box = torch.rand(3, 4, 24, 40, generator=g) * 9 - 0.5
+    reid = torch.randn(3, 16, 24, 40, generator=g)
+    a = decode_ref.decode_detections(heat.numpy(), box.numpy(), 50, 3, reid=reid.numpy())
+    b = decode_ref.decode_detections_torch(heat, box, 50, 3, reid=reid)
+    ca = decode_ref.canonicalize(a["scores"], a["indices"], a["boxes"], a["labels"], a["embeddings"])
+    cb = decode_ref.canonicalize(b["scores"].numpy(), b["indices"].numpy(), b["boxes"].numpy(), b["labels"].numpy(), b["embeddings"].numpy())
+    for x, y in zip(ca, cb):
+        np.testing.assert_array_equal(x, y)
+    c = decode_ref.decode_detections_torch(heat, box, 50, 3, normalize_boxes=True)
+    d = decode_ref.decode_detections(heat.numpy(), box.numpy(), 50, 3, normalize_boxes=True)
+    np.testing.assert_allclose(decode_ref.canonicalize(c["scores"].numpy(), c["indices"].numpy(), c["boxes"].numpy())[2],
+                               decode_ref.canonicalize(d["scores"], d["indices"], d["boxes"])[2], rtol=1e-6, atol=1e-7)
+
+
 def test_pack_unpack_roundtrip():
     h, b, r = [t.numpy() for t in recipes.decode_inputs(3, (2, 5, 16, 24), 8)]
     o = decode_ref.decode_detections(h, b, 30, reid=r)
