@@ -54,9 +54,12 @@ HBM_PEAK_GBPS = 8000.0            # same guide: HBM3E spec peak (6.29 TB/s measu
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 [gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md §HBM]
 # + WRITE_SIZE, mean over the kernel's launches of one step).  From committed profiles — NOT measured by this run.
 PROFILED_TRAFFIC = {
-    ("simple", 32, 512, 512, "winograd_f16x2"): (484.3e6, "profiles/r01_pmc_traffic_final9.txt (29 winograd5 launches of a C1 step)"),
-    ("simple", 32, 512, 512, "winograd_f32"): (328.9e6, "profiles/r01_pmc_traffic_final9.txt"),
+    ("simple", 32, 512, 512, "winograd_f16x2"): (484.2e6, "profiles/r02_pmc_traffic_c1_default.txt (29 winograd5 launches of a C1 step; r01: 484.3)"),
+    ("simple", 32, 512, 512, "winograd_f32"): (305.9e6, "profiles/r02_pmc_traffic_c1_default.txt"),
 }
+# decode stage 1 / stage 2 at C1 (same profile): HBM MB per launch and rocprofv3 average duration
+PROFILED_DECODE = {("simple", 32, 512, 512): {"peaks_cminor_kernel": {"traffic_MB": 209.3, "avg_us": 52.2}, "topk_kernel": {"traffic_MB": 3.1, "avg_us": 24.7},
+                                             "source": "profiles/r02_pmc_traffic_c1_default.txt, profiles/r02_kernel_stats_c1_default.csv — not measured by this run"}}
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 KIND_NAMES = {"winograd_f4": "cnl_wino8::winograd8_kernel (Winograd F(4x4,3x3); fp32 operands scaled per image by a power of two and split into 2 fp16 pieces, "
                              "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
@@ -228,7 +231,7 @@ def p50_ms(fn, reps=30, warm=3):
     return lat[len(lat) // 2]
 
 
-def decode_block(model, x, tracking, k):
+def decode_block(model, x, tracking, k, config=None):
     with torch.no_grad():
         out = model(x)
         logits = model.get_encoded_outputs(x)
@@ -242,6 +245,7 @@ def decode_block(model, x, tracking, k):
     gbps = must / (p_wo * 1e-3) / 1e9
     return {"p50_ms_without_sigmoid": round(p_wo, 4), "p50_ms_with_separate_sigmoid_pass": round(p_w, 4),
             "must_move_bytes": must, "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4),
+            "kernels_profiled": PROFILED_DECODE.get((config, N, x.shape[2], x.shape[3])),
             "note": "without = the path (sigmoid is the heatmap out_conv's epilogue); with = torch.sigmoid(logits) + decode, what a caller "
                     "holding logits pays; HIP events around gather_detection2d on the forward's own outputs, median of 30"}
 
@@ -432,7 +436,7 @@ def main():
         with torch.no_grad():
             rows, plan = conv_kernel_profile(model, x)
         roof, stack = roofline_block(rows, args.config, B, H, W)
-        dec = decode_block(model, x, tracking, args.k)
+        dec = decode_block(model, x, tracking, args.k, args.config)
         eng = model._engine
         result = {
             "metric": "images/sec @512x512 ResNet34 CenterNet forward + gather_detection2d",
