@@ -292,6 +292,12 @@ class PackedWeights:
         return False
 
 
+class BufferTooLarge(ValueError):
+    """A plan buffer would cross the kernels' 32-bit buffer addressing (< 4 GiB per tensor): the engine retries with a smaller sub-batch."""
+
+
+ADDRESS_LIMIT = 0xF0000000 - (1 << 24)
+
 _VBASE = 1 << 60        # virtual addresses of plan buffers while the plan is being built (far above any device pointer)
 
 
@@ -496,6 +502,8 @@ class Plan:
 
     # -- helpers --
     def _buf(self, n, h, w, c):
+        if n * h * w * c * 4 > ADDRESS_LIMIT:
+            raise BufferTooLarge(f"activation [{n},{h},{w},{c}] fp32 exceeds the kernels' 4 GiB buffer addressing")
         t = _VBuf((n, h, w, c), self._vnext)
         self._vnext += t.nbytes + 4096
         self.buffers.append(t)
@@ -848,12 +856,15 @@ class Engine:
     def __init__(self, model):
         self.model = model
         self.weights = None
-        self.plans = {}
+        self.plans = OrderedDict()                     # least recently used first
+        self._sub_override = {}                        # (H, W) -> largest sub-batch found to fit after a BufferTooLarge retry
+        self.max_plans = 8                             # each plan owns an activation arena (GBs at large batches): bound what is kept
         self.options = KernelOptions()
 
     def invalidate(self):
         self.weights = None
         self.plans.clear()
+        self._sub_override.clear()
 
     def set_options(self, **kw):
         """Replace kernel options (KernelOptions fields); plans are keyed by them, so nothing else needs invalidating."""
@@ -890,16 +901,23 @@ class Engine:
             self.weights_device = dev
             self.plans.clear()
         chunk = self.sub_batch(N, H, W)
-        if N > chunk:
-            # the kernels address each tensor through 32-bit buffer offsets (< 4 GiB per tensor): run contiguous, equally sized
-            # sub-batches (images are independent; results are byte-identical to one big batch) and concatenate
-            parts = [self._run(x[i:i + chunk], sigmoid, H, W, norm) for i in range(0, N, chunk)]
-            return OrderedDict((k, torch.cat([p[k] for p in parts], dim=0)) for k in parts[0])
-        return self._run(x, sigmoid, H, W, norm)
+        while True:
+            try:
+                if N > chunk:
+                    # the kernels address each tensor through 32-bit buffer offsets (< 4 GiB per tensor): run contiguous, equally sized
+                    # sub-batches (images are independent; results are byte-identical to one big batch) and concatenate
+                    parts = [self._run(x[i:i + chunk], sigmoid, H, W, norm) for i in range(0, N, chunk)]
+                    return OrderedDict((k, torch.cat([p[k] for p in parts], dim=0)) for k in parts[0])
+                return self._run(x, sigmoid, H, W, norm)
+            except BufferTooLarge:
+                # max_batch() prices the backbone / head tensors; a neck option can hold something wider (deformable columns): split further
+                if chunk == 1:
+                    raise
+                self._sub_override[(H, W)] = chunk = -(-N // (-(-N // chunk) + 1))
 
     def sub_batch(self, N, H, W):
         """Images per launch plan: N when it fits the addressing limit, else N split into the fewest equal parts that do."""
-        limit = self.max_batch(H, W)
+        limit = min(self.max_batch(H, W), self._sub_override.get((H, W), 1 << 30))
         parts = -(-N // limit)
         return -(-N // parts)
 
@@ -908,7 +926,7 @@ class Engine:
         widest = max(64, sum(b[0].cout for b in self.weights.head_blocks.values() if b) if self.weights.fused_first is not None else 0,
                      max((l.cout for b in self.weights.head_blocks.values() for l in b), default=64))
         per_image = max((H // 2) * (W // 2) * 64, (H // 4) * (W // 4) * widest) * 4
-        return max(1, (0xF0000000 - (1 << 24)) // per_image)
+        return max(1, ADDRESS_LIMIT // per_image)
 
     def _run(self, x, sigmoid, H, W, norm):
         dev = x.device
@@ -920,6 +938,10 @@ class Engine:
             with torch.cuda.device(dev):
                 plan = Plan(self.weights, N, H, W, dev, bool(sigmoid), self.options)
             self.plans[key] = plan
+            while len(self.plans) > max(1, self.max_plans):
+                self.plans.popitem(last=False)         # drop the least recently used plan (and its arena)
+        else:
+            self.plans.move_to_end(key)
         with torch.cuda.device(dev):
             return plan.run(x, norm)
 

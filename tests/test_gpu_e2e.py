@@ -325,6 +325,33 @@ def test_large_batch_is_split_below_the_4gib_addressing_limit(monkeypatch):
         assert torch.equal(full[k], split[k])
 
 
+def test_buffer_over_the_addressing_limit_retries_with_a_smaller_sub_batch_and_plans_are_bounded(monkeypatch):
+    """A plan buffer max_batch() did not price (a neck option's wider tensor) must not be addressed past 4 GiB: Plan raises
+    BufferTooLarge, the engine splits further and the bytes stay those of the one-batch run.  The plan cache is an LRU of max_plans."""
+    from centernet_lightning_amd import engine as E
+    model, _ = build("resnet34_simple.yaml")
+    x = recipes.images(6, (4, 3, 64, 64)).cuda()
+    full = model.get_encoded_outputs(x)
+    eng = model._engine
+    # the widest tensor of a 2-image plan at 64x64: [2, 16, 16, 512] fp32 = 1 MiB; allow a little less than the 4-image one needs
+    monkeypatch.setattr(E, "ADDRESS_LIMIT", 4 * 16 * 16 * 512 * 4 - 1)
+    monkeypatch.setattr(type(eng), "max_batch", lambda self, H, W: 64)           # the a-priori estimate sees nothing wrong
+    eng.plans.clear()
+    split = model.get_encoded_outputs(x)
+    assert eng._sub_override[(64, 64)] == 2 and all(k[0] == 2 for k in eng.plans)
+    for k in full:
+        assert torch.equal(full[k], split[k])
+    monkeypatch.setattr(E, "ADDRESS_LIMIT", 16)
+    with pytest.raises(E.BufferTooLarge):
+        model.get_encoded_outputs(x[:1])
+    monkeypatch.undo()
+    eng.invalidate()
+    eng.max_plans = 2
+    for n in (1, 2, 3, 1):
+        model.get_encoded_outputs(x[:n])
+    assert [k[0] for k in eng.plans] == [3, 1]                   # least recently used first; N = 2 was evicted
+
+
 def test_preprocess_uint8_bit_exact_and_feeds_forward():
     """uint8 HWC -> normalised fp32 (cnl_normalize_u8_nhwc_f32) is bit-exact against the numpy restatement of A.Normalize, and
     the channels_last result goes through forward() like a contiguous NCHW tensor of the same values."""
