@@ -58,8 +58,8 @@ PROFILED_TRAFFIC = {
     ("simple", 32, 512, 512, "winograd_f32"): (305.9e6, "profiles/r02_pmc_traffic_c1_default.txt"),
 }
 # decode stage 1 / stage 2 at C1 (same profile): HBM MB per launch and rocprofv3 average duration
-PROFILED_DECODE = {("simple", 32, 512, 512): {"peaks_cminor_kernel": {"traffic_MB": 209.3, "avg_us": 52.2}, "topk_kernel": {"traffic_MB": 3.1, "avg_us": 24.7},
-                                             "source": "profiles/r02_pmc_traffic_c1_default.txt, profiles/r02_kernel_stats_c1_default.csv — not measured by this run"}}
+PROFILED_DECODE = {("simple", 32, 512, 512): {"peaks_c8_kernel": {"avg_us": 35.5}, "topk_kernel": {"avg_us": 11.3},
+                                             "source": "profiles/r02_decode_variants.txt (rocprofv3 --kernel-trace --stats of tools/decode_bench.py) — not measured by this run"}}
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 KIND_NAMES = {"winograd_f4": "cnl_wino8::winograd8_kernel (Winograd F(4x4,3x3); fp32 operands scaled per image by a power of two and split into 2 fp16 pieces, "
                              "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
@@ -231,23 +231,45 @@ def p50_ms(fn, reps=30, warm=3):
     return lat[len(lat) // 2]
 
 
+def gpu_ms_back_to_back(fn, calls=50, rounds=5):
+    """GPU time per call: `calls` calls enqueued without a host sync between HIP events (the host runs ahead, as inside a step), best round."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(calls):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / calls)
+    return best
+
+
 def decode_block(model, x, tracking, k, config=None):
     with torch.no_grad():
         out = model(x)
         logits = model.get_encoded_outputs(x)
         gather = model.gather_tracking2d if tracking else model.gather_detection2d
         p_wo = p50_ms(lambda: gather(out, num_detections=k))
+        g_wo = gpu_ms_back_to_back(lambda: gather(out, num_detections=k))
         rest = tuple(out[1:])
         p_w = p50_ms(lambda: gather((torch.sigmoid(logits["heatmap"]),) + rest, num_detections=k))
     N, C, h, w = out[0].shape
     E = out[2].shape[1] if tracking else 0
     must = N * (4 * C * h * w + k * (16 + 4 * E) + k * (4 + 8 + 8 + 16 + 4 * E))      # SURVEY.md §8d: heatmap once + k gathers + outputs
-    gbps = must / (p_wo * 1e-3) / 1e9
-    return {"p50_ms_without_sigmoid": round(p_wo, 4), "p50_ms_with_separate_sigmoid_pass": round(p_w, 4),
+    gbps = must / (g_wo * 1e-3) / 1e9
+    return {"gpu_ms": round(g_wo, 4), "p50_ms_without_sigmoid": round(p_wo, 4), "p50_ms_with_separate_sigmoid_pass": round(p_w, 4),
             "must_move_bytes": must, "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4),
+            "GBps_single_call": round(must / (p_wo * 1e-3) / 1e9, 1),
             "kernels_profiled": PROFILED_DECODE.get((config, N, x.shape[2], x.shape[3])),
-            "note": "without = the path (sigmoid is the heatmap out_conv's epilogue); with = torch.sigmoid(logits) + decode, what a caller "
-                    "holding logits pays; HIP events around gather_detection2d on the forward's own outputs, median of 30"}
+            "note": "gpu_ms = GPU time of one decode (both kernels): 50 calls enqueued back to back between HIP events, as inside a step where the "
+                    "host runs ahead — GBps / frac_of_8TBps use it; p50 = one call at a time from Python with the GPU idle before it (HIP events "
+                    "around gather_detection2d on the forward's own outputs, median of 30): it adds the host's ~25 us of argument set-up and "
+                    "launch latency.  without = the path (sigmoid is the heatmap out_conv's epilogue); with = torch.sigmoid(logits) + decode, "
+                    "what a caller holding logits pays"}
 
 
 def feature_errors(config, x2, algo):
@@ -456,7 +478,7 @@ def main():
             "roofline": roof,
             "conv_stack": stack,
             "decode": dec,
-            "decode_p50_ms": dec["p50_ms_without_sigmoid"],
+            "decode_p50_ms": dec["p50_ms_without_sigmoid"], "decode_gpu_ms": dec["gpu_ms"],
             "activation_arena_MB": {"with_liveness_reuse": round(plan.arena_bytes / 1e6, 1), "every_buffer_separate": round(plan.bytes_without_reuse / 1e6, 1),
                                     "sub_batch": eng.sub_batch(B, H, W)},
         }

@@ -12,12 +12,13 @@
 //     16-byte coalesced loads, cross-channel-group reduce through LDS in class order;
 //   - any other strides (NCHW tensors from reference-style callers): thread = pixel column, loop
 //     over classes, lanes along x.
-// Stage 2 (topk_kernel): one workgroup per image.  Radix select (4 x 8-bit digits, LDS histograms) of the
-//   k-th largest score key; ordered compaction (keys above the threshold + the lowest-index ties);
-//   bitonic sort of <= 1024 (key, ~index) pairs in LDS -> (score desc, index asc), the canonical
-//   order the oracle defines where torch.topk leaves ties unspecified; then the label / ltrb box /
-//   embedding gathers and the box decode for the k winners only (the reference transforms the whole
-//   4xHxW map first, centernet.py:282-286).
+// Stage 2 (topk_kernel): one workgroup per image.  The scores are read ONCE (keys kept in LDS).  A pruning bound — the minimum over
+//   the 16 waves of the ceil(k/16)-th largest per-thread maximum — has at least k elements at or above it, so only the elements >= it
+//   (typically 1.5-3 k of H*W) are compacted in index order and sorted: bitonic on (key, ~index) pairs, wave shuffles below distance 64,
+//   LDS above -> (score desc, index asc), the canonical order the oracle defines where torch.topk leaves ties unspecified.  When more
+//   than 1024 elements pass the bound (plateaus / ties en masse) the exact k-th key comes from a radix select (12 / 10 / 10-bit digits,
+//   LDS histograms) instead.  Then the label / ltrb box / embedding gathers and the box decode for the k winners only (the reference
+//   transforms the whole 4xHxW map first, centernet.py:282-286).
 #include "cnl_common.h"
 
 #pragma clang fp contract(off)   // one rounding per op, like ATen: box decode must be bit-exact
@@ -156,6 +157,138 @@ __global__ __launch_bounds__(256) void peaks_cminor_kernel(const PeakArgs a) {
     }
 }
 
+// ---- stage 1, channel-minor layout with C % 8 == 0 (the 80-class heads): thread = (run of 4 pixels, 8 channels) ----
+// A thread loads the 4 + 2P pixels its run needs per row as 2 x 16 bytes each (a pixel's C floats are contiguous: the 10 lanes of a pixel
+// read 320 contiguous bytes), so every input vector is loaded 1.5 x (P = 1) instead of 3 x, and a block spans 128 pixels of a row (no
+// column halo at W = 128).  The maximum / first arg-max over the channel groups is an LDS atomic max of (score key, ~class) pairs —
+// 8 bytes per output pixel instead of a [pixel][group] array, no second reduction pass.
+struct Peak8Args {
+    PeakArgs p;
+    int CG8, RUNS, TW;       // channel groups of 8 per pixel, pixel runs per block, block width in pixels (RUNS * 4)
+};
+
+__device__ __forceinline__ unsigned score_key_fwd(float f) {
+    unsigned u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float score_key_inv(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// Block = 160 threads = 16 runs x 10 channel groups at C = 80 (64 pixels wide); strips of R = 16 rows: measured best at 32 x 128 x 128 x 80
+// (back-to-back decode, us: R 8 / 12 / 16 / 24 / 32 = 52 / 62 / 45 / 57 / 68; 80 / 160 / 320 threads = 46.7 / 45.0 / 46.0;
+// profiles/r02_decode_variants.txt); R = 4 when 16-row strips would leave most CUs without a block (small batches).
+constexpr int PK8_THREADS = 160;
+
+template <int P, int PK8_R>
+__global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q) {
+    const PeakArgs& a = q.p;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);       // [PK8_R][TW]
+    int b = (int)cnl::xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = b % a.tiles_x; b /= a.tiles_x;
+    const int by = b % a.strips;
+    const int n = b / a.strips;
+    const int tid = threadIdx.x;
+    const int run = tid / q.CG8, g = tid - run * q.CG8;
+    const int x0 = bx * q.TW + run * 4;
+    const int y0 = by * PK8_R;
+    const bool active = run < q.RUNS && x0 < a.W;
+    const float NINF = -__builtin_inff();
+    for (int i = tid; i < PK8_R * q.TW; i += PK8_THREADS) red[i] = 0ull;
+    __syncthreads();
+
+    if (active) {
+        const float* base = a.heat + (long)n * a.sn + (long)g * 8;
+        float hm[2 * P + 1][4][8];    // horizontal maxima of the last 2P+1 rows
+        float ct[P + 1][4][8];        // centre values of the last P+1 rows
+#pragma unroll
+        for (int i = 0; i < 2 * P + 1; ++i)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int v = 0; v < 8; ++v) hm[i][p][v] = NINF;
+#pragma unroll
+        for (int i = 0; i < P + 1; ++i)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int v = 0; v < 8; ++v) ct[i][p][v] = NINF;
+        const int y_end = min(y0 + PK8_R, a.H);
+        for (int yy = y0 - P; yy < y_end + P; ++yy) {
+#pragma unroll
+            for (int i = 0; i < 2 * P; ++i)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) hm[i][p][v] = hm[i + 1][p][v];
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) ct[i][p][v] = ct[i + 1][p][v];
+            float t[4 + 2 * P][8];
+            const bool row_ok = (unsigned)yy < (unsigned)a.H;
+            const float* row = base + (long)yy * a.sh;
+#pragma unroll
+            for (int j = 0; j < 4 + 2 * P; ++j) {
+                const int xx = x0 - P + j;
+                if (row_ok && (unsigned)xx < (unsigned)a.W) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (long)xx * a.sw);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (long)xx * a.sw + 4);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { t[j][v] = lo[v]; t[j][4 + v] = hi[v]; }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) t[j][v] = NINF;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    float h = t[p][v];
+#pragma unroll
+                    for (int d = 1; d <= 2 * P; ++d) h = fmaxf(h, t[p + d][v]);
+                    hm[2 * P][p][v] = h;
+                    ct[P][p][v] = t[p + P][v];
+                }
+            const int yo = yy - P;                    // row whose (2P+1)-window is now complete
+            if (yo >= y0) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float bv = 0.f;
+                    int bc = 0;
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        float m = hm[0][p][v];
+#pragma unroll
+                        for (int i = 1; i < 2 * P + 1; ++i) m = fmaxf(m, hm[i][p][v]);
+                        const float cv = ct[0][p][v];
+                        const float val = cv * (cv == m ? 1.0f : 0.0f);      // heatmap * nms_mask
+                        if (v == 0 || val > bv) { bv = val; bc = g * 8 + v; }
+                    }
+                    if (x0 + p < a.W)            // larger key wins; equal keys: the smaller class (torch.max(dim=1) keeps the first)
+                        atomicMax(&red[(yo - y0) * q.TW + run * 4 + p],
+                                  ((unsigned long long)score_key_fwd(bv) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)bc));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < PK8_R * q.TW; t += PK8_THREADS) {
+        const int r = t / q.TW, p = t - r * q.TW;
+        const int xo = bx * q.TW + p, yo = y0 + r;
+        if (xo >= a.W || yo >= a.H) continue;
+        const unsigned long long c = red[t];
+        const long o = (long)n * a.H * a.W + (long)yo * a.W + xo;
+        a.ws_score[o] = score_key_inv((unsigned)(c >> 32));
+        a.ws_label[o] = (int)(0xFFFFFFFFu - (unsigned)(c & 0xFFFFFFFFull));
+    }
+}
+
 // ---- stage 1, generic strides (lanes along x, loop over classes) ----
 template <int P, int R>
 __global__ __launch_bounds__(256) void peaks_generic_kernel(const PeakArgs a) {
@@ -268,6 +401,12 @@ __device__ __forceinline__ unsigned score_key(float f) {
 }
 
 constexpr int TK_THREADS = 1024;
+#ifdef TK_TIMING
+__device__ unsigned long long tk_stamps[64 * 16];
+#define TK_STAMP(slot_) do { if (tid == 0 && blockIdx.x < 64) tk_stamps[blockIdx.x * 16 + (slot_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TK_STAMP(slot_) do {} while (0)
+#endif
 
 // wave-level helpers (64-wide wavefront)
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
@@ -279,12 +418,37 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
     return v;
 }
 
+// Descending bitonic sort of cand[0 .. S) (S a power of two <= TK_THREADS), one element per thread: exchanges at distances below 64 are
+// wave shuffles, only the distances >= 64 go through LDS (S = 256: 36 steps, 3 of them with barriers).  Every thread of the block calls it.
+__device__ __forceinline__ void block_sort_desc(unsigned long long* cand, int S, int tid) {
+    unsigned long long e = tid < S ? cand[tid] : 0ull;
+    for (int size = 2; size <= S; size <<= 1) {
+        for (int st = size >> 1; st > 0; st >>= 1) {
+            unsigned long long p;
+            if (st >= 64) {
+                __syncthreads();                       // the previous exchange's readers are done
+                if (tid < S) cand[tid] = e;
+                __syncthreads();
+                p = tid < S ? cand[tid ^ st] : 0ull;
+            } else {
+                if ((tid & ~63) >= S) continue;        // a wave with no element: nothing to exchange (it still joins the barriers above)
+                p = __shfl_xor(e, st);
+            }
+            const bool take_max = ((tid & st) == 0) == ((tid & size) == 0);
+            e = take_max ? (e > p ? e : p) : (e < p ? e : p);
+        }
+    }
+    __syncthreads();
+    if (tid < S) cand[tid] = e;
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     extern __shared__ unsigned lds_keys[];          // [HW] when a.keys_in_lds
     __shared__ unsigned hist[4096];
     __shared__ unsigned wave_tot[TK_THREADS / 64];
     __shared__ unsigned long long cand[1024];
-    __shared__ unsigned sh_prefix, sh_need;
+    __shared__ unsigned sh_prefix, sh_need, sh_count;
 
     const int n = blockIdx.x;
     const int tid = threadIdx.x;
@@ -292,6 +456,131 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     const float* sc = a.ws_score + (long)n * a.HW;
     const int KCH = (a.HW + TK_THREADS - 1) / TK_THREADS, KST = KCH | 1;      // indices per thread, LDS row pitch (odd)
 
+    // --- phase A: the keys go to LDS (when they fit: the only pass over memory) and every thread keeps the maximum of the keys it read.
+    // PRUNING BOUND: the m-th largest of a wave's 64 thread maxima, m = ceil(k / 16), has m elements at or above it; the minimum of that
+    // over the 16 waves, T_lo, therefore has >= 16 m >= k elements at or above it, so T_lo <= the k-th largest key and every winner (and
+    // every tie at the k-th key) is among the elements >= T_lo — typically 1.5-3 k of them instead of H*W.
+    TK_STAMP(0);
+    constexpr int FAST_CAP = 512;                            // candidates the rank step takes (O(n^2 / threads)); more -> radix select
+    unsigned long long* win = reinterpret_cast<unsigned long long*>(hist);      // [k] winners of the fast path (hist is unused there)
+    for (int i = tid; i < FAST_CAP + 8; i += TK_THREADS) cand[i] = 0ull;        // zero padding: never greater than a candidate
+    if (tid == 0) sh_count = 0u;
+    unsigned tmax = 0u;
+    const bool kch_pow2 = (KCH & (KCH - 1)) == 0;            // then i / KCH, i % KCH are a shift and a mask (KCH = 16 at 128 x 128)
+    const int kch_sh = 31 - __builtin_clz((unsigned)KCH);
+    for (int i = tid; i < a.HW; i += 8 * TK_THREADS) {       // eight independent loads in flight per thread, then the bookkeeping
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = i + j * TK_THREADS < a.HW ? sc[i + j * TK_THREADS] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ii = i + j * TK_THREADS;
+            if (ii < a.HW) {
+                const unsigned key = score_key(v[j]);
+                if (a.keys_in_lds) {
+                    const int own = kch_pow2 ? (ii >> kch_sh) : ii / KCH;
+                    lds_keys[own * KST + (ii - own * KCH)] = key;
+                }
+                tmax = tmax > key ? tmax : key;
+            }
+        }
+    }
+    {
+        // wave bitonic sort of the 64 thread maxima, descending.  Exchange distances 1 / 2: DPP quad permutes (one VALU instruction),
+        // 4 / 8 / 16: ds_swizzle xor masks, 32: one bpermute.
+        unsigned v = tmax;
+#define TK_EXCH(st_) ((st_) == 1 ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false)                        \
+                    : (st_) == 2 ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false)                        \
+                    : (st_) == 4 ? (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (4 << 10))                                \
+                    : (st_) == 8 ? (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (8 << 10))                                \
+                    : (st_) == 16 ? (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (16 << 10))                              \
+                    : (unsigned)__shfl_xor((int)v, 32))
+#pragma unroll
+        for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+            for (int st = size >> 1; st > 0; st >>= 1) {
+                const unsigned pv = TK_EXCH(st);
+                const bool take_max = ((lane & st) == 0) == ((lane & size) == 0);
+                v = take_max ? (v > pv ? v : pv) : (v < pv ? v : pv);
+            }
+        }
+#undef TK_EXCH
+        const unsigned vm = __shfl(v, (a.k + TK_THREADS / 64 - 1) / (TK_THREADS / 64) - 1);
+        if (lane == 0) wave_tot[wave] = vm;
+    }
+    __syncthreads();                                         // + every key is in LDS, cand is zero, the counter is reset
+    TK_STAMP(1);
+    unsigned Tlo = wave_tot[0];
+#pragma unroll
+    for (int w = 1; w < TK_THREADS / 64; ++w) Tlo = Tlo < wave_tot[w] ? Tlo : wave_tot[w];
+    bool fast = false;
+    {
+        // compaction of the elements >= T_lo into cand[] — in ANY order: the winners are placed by rank of the (key, ~index) pair below.
+        // Thread t owns the contiguous index range [t*KCH, (t+1)*KCH); one LDS atomic per wave and round reserves the wave's slots.
+        const int j0 = tid * KCH, j1 = min(j0 + KCH, a.HW);
+        if (a.keys_in_lds && KCH <= 64) {
+            unsigned long long qual = 0ull;                  // bit c: the thread's c-th element passes the bound
+            for (int c0 = 0; c0 < KCH; c0 += 8) {            // eight independent LDS reads at a time
+                unsigned kk[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kk[j] = (c0 + j < KCH && j0 + c0 + j < a.HW) ? lds_keys[tid * KST + c0 + j] : 0u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (c0 + j < KCH && j0 + c0 + j < a.HW && kk[j] >= Tlo) qual |= 1ull << (c0 + j);
+            }
+            for (;;) {                                       // most threads own no candidate at all: 1-3 rounds per wave
+                const bool has = qual != 0ull;
+                const unsigned long long bal = __ballot(has);
+                if (bal == 0ull) break;
+                const int leader = __builtin_ctzll(bal);
+                unsigned base = 0u;
+                if (lane == leader) base = atomicAdd(&sh_count, (unsigned)__builtin_popcountll(bal));
+                base = (unsigned)__shfl((int)base, leader);
+                if (has) {
+                    const int c = __builtin_ctzll(qual);
+                    qual &= qual - 1;
+                    const unsigned pos = base + (unsigned)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                    if (pos < (unsigned)FAST_CAP)
+                        cand[pos] = ((unsigned long long)lds_keys[tid * KST + c] << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(j0 + c));
+                }
+            }
+        } else {                                             // maps beyond the LDS budget: plain per-element reservation
+            for (int i = j0; i < j1; ++i) {
+                const unsigned key = a.keys_in_lds ? lds_keys[tid * KST + (i - j0)] : score_key(sc[i]);
+                if (key >= Tlo) {
+                    const unsigned pos = atomicAdd(&sh_count, 1u);
+                    if (pos < (unsigned)FAST_CAP) cand[pos] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned total = sh_count;
+        TK_STAMP(2);
+#ifdef TK_TIMING
+        if (tid == 0 && blockIdx.x < 64) tk_stamps[blockIdx.x * 16 + 8] = total;
+#endif
+        if (total <= (unsigned)FAST_CAP) {                   // else: ties / plateaus en masse -> radix select below
+            fast = true;
+            // rank of a candidate = how many candidates are greater ((key, ~index) pairs are distinct): the k winners land in canonical
+            // order (score desc, index asc) without a sort.  All lanes read the same 16 bytes (two candidates): LDS broadcasts.
+            if (tid < (int)total) {
+                const unsigned long long mine = cand[tid];
+                unsigned rank = 0;
+                for (unsigned j = 0; j < total; j += 8) {
+                    unsigned long long o[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = cand[j + q];           // zero beyond total (the array is padded)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rank += o[q] > mine ? 1u : 0u;
+                }
+                if (rank < (unsigned)a.k) win[rank] = mine;
+            }
+            __syncthreads();
+            TK_STAMP(3);
+            TK_STAMP(4);
+        }
+    }
+    if (!fast) {
     // --- radix select: key T of the k-th largest element, digits of 12 / 10 / 10 bits from the top.  (A 12-bit first digit
     // spreads sigmoid scores, which share 1-2 exponents, over 16x more bins than an 8-bit one: far less LDS-atomic contention.) ---
     unsigned prefix = 0, mask = 0, need = (unsigned)a.k;
@@ -303,7 +592,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         const int per = nbins / TK_THREADS;               // bins per thread in the scan: 4 or 1
         for (int i = tid; i < nbins; i += TK_THREADS) hist[i] = 0;
         __syncthreads();
-        if (a.keys_in_lds && pass > 0) {
+        if (a.keys_in_lds) {
             // keys live in LDS as [thread][KST] (thread t owns indices t*KCH .. t*KCH+KCH-1; the odd row pitch KST keeps both this
             // loop and the ordered compaction below free of bank conflicts)
             for (int j = 0; j < KCH; ++j) {
@@ -312,9 +601,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (unsigned)(nbins - 1)], 1u);
             }
         } else {
-            for (int i = tid; i < a.HW; i += TK_THREADS) {          // coalesced: the only pass over memory when the keys fit in LDS
+            for (int i = tid; i < a.HW; i += TK_THREADS) {          // maps too large for LDS: every pass streams the scores (L2-resident)
                 const unsigned key = score_key(sc[i]);
-                if (a.keys_in_lds) lds_keys[(i / KCH) * KST + (i % KCH)] = key;
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (unsigned)(nbins - 1)], 1u);
             }
         }
@@ -413,51 +701,13 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     }
     __syncthreads();
 
-    // --- sort descending by (key, ~index) ---
-    if (a.KP <= 128) {
-        // one wave, two elements per lane (indices lane and lane + 64), exchanges by shuffle: no barriers
-        if (wave == 0) {
-            unsigned long long e0 = lane < a.KP ? cand[lane] : 0ull;
-            unsigned long long e1 = lane + 64 < a.KP ? cand[lane + 64] : 0ull;
-            for (int size = 2; size <= 128; size <<= 1) {
-                for (int st = size >> 1; st > 0; st >>= 1) {
-                    if (st == 64) {
-                        // partner of index lane is lane + 64: same lane; direction of the final merge is descending
-                        if (e0 < e1) { const unsigned long long t = e0; e0 = e1; e1 = t; }
-                    } else {
-                        const unsigned long long p0 = __shfl_xor(e0, st), p1 = __shfl_xor(e1, st);
-                        const bool lower = (lane & st) == 0;                   // this lane holds the lower index of the pair
-                        const bool desc0 = (lane & size) == 0;                 // block direction for index lane
-                        const bool desc1 = ((lane + 64) & size) == 0;          // ... and for index lane + 64
-                        const bool take_max0 = lower == desc0, take_max1 = lower == desc1;
-                        e0 = take_max0 ? (e0 > p0 ? e0 : p0) : (e0 < p0 ? e0 : p0);
-                        e1 = take_max1 ? (e1 > p1 ? e1 : p1) : (e1 < p1 ? e1 : p1);
-                    }
-                }
-            }
-            cand[lane] = e0;
-            cand[lane + 64] = e1;
-        }
-        __syncthreads();
-    } else {
-        for (int size = 2; size <= a.KP; size <<= 1) {
-            for (int st = size >> 1; st > 0; st >>= 1) {
-                if (tid < a.KP) {
-                    const int j = tid ^ st;
-                    if (j > tid) {
-                        const unsigned long long x = cand[tid], y = cand[j];
-                        const bool desc = (tid & size) == 0;
-                        if (desc ? (x < y) : (x > y)) { cand[tid] = y; cand[j] = x; }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-    }
+    block_sort_desc(cand, a.KP, tid);                        // descending by (key, ~index)
+    }   // !fast
 
+    TK_STAMP(5);
     // --- gathers + box decode for the k winners ---
     if (tid < a.k) {
-        const unsigned long long comp = cand[tid];
+        const unsigned long long comp = (fast ? win : cand)[tid];
         const int idx = (int)(0xFFFFFFFFu - (unsigned)(comp & 0xFFFFFFFFull));
         const long o = (long)n * a.k + tid;
         a.scores[o] = sc[idx];
@@ -471,13 +721,14 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         // embeddings: k*E elements, E-contiguous per detection (one coalesced row when reid is NHWC)
         for (int t = tid; t < a.k * a.E; t += TK_THREADS) {
             const int d = t / a.E, e = t - d * a.E;
-            const unsigned long long comp = cand[d];
+            const unsigned long long comp = (fast ? win : cand)[d];
             const int idx = (int)(0xFFFFFFFFu - (unsigned)(comp & 0xFFFFFFFFull));
             const int yi = idx / a.W, xi = idx - yi * a.W;
             a.emb[((long)n * a.k + d) * a.E + e] =
                 a.reid[(long)n * a.rsn + (long)e * a.rsc + (long)yi * a.rsh + (long)xi * a.rsw];
         }
     }
+    TK_STAMP(6);
 }
 
 // ---- standalone gathers at caller-supplied indices (heads[name].gather_at_indices) ----
@@ -521,6 +772,12 @@ int launch_cminor(const PeakArgs& a, int P, size_t lds, unsigned blocks, hipStre
 }  // namespace cnl_decode
 using namespace cnl_decode;
 
+#ifdef TK_TIMING
+extern "C" int cnl_debug_topk_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cnl_decode::tk_stamps), sizeof(unsigned long long) * 64 * 16) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" size_t cnl_decode_workspace_bytes(int32_t N, int32_t H, int32_t W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     return (size_t)N * H * W * 8 + 256;
@@ -562,7 +819,31 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
         };
         vec = ok(4) ? 4 : (ok(2) ? 2 : 1);
     }
-    if (cminor && p->C / vec <= 256) {
+    if (cminor && vec == 4 && p->C % 8 == 0 && p->C / 8 <= PK8_THREADS && P <= 2 && p->W >= 8) {
+        Peak8Args q;
+        q.CG8 = p->C / 8;
+        q.RUNS = PK8_THREADS / q.CG8;
+        const int runs_w = (p->W + 3) / 4;
+        if (q.RUNS > runs_w) q.RUNS = runs_w;
+        q.TW = q.RUNS * 4;
+        a.tiles_x = (p->W + q.TW - 1) / q.TW;
+        int R8 = 16;
+        if ((long long)p->N * a.tiles_x * ((p->H + 15) / 16) < 256) R8 = 4;      // few images: more, shorter strips (results are identical)
+        a.strips = (p->H + R8 - 1) / R8;
+        a.CG = q.CG8; a.PXB = q.TW; a.R = R8;
+        q.p = a;
+        const long long blocks = (long long)p->N * a.tiles_x * a.strips;
+        CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_decode_f32: grid too large");
+        const size_t lds = (size_t)R8 * q.TW * 8;
+#define PK8_LAUNCH(P_, R_) hipLaunchKernelGGL((peaks_c8_kernel<P_, R_>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q)
+        if (R8 == 16) {
+            if (P == 0) PK8_LAUNCH(0, 16); else if (P == 1) PK8_LAUNCH(1, 16); else PK8_LAUNCH(2, 16);
+        } else {
+            if (P == 0) PK8_LAUNCH(0, 4); else if (P == 1) PK8_LAUNCH(1, 4); else PK8_LAUNCH(2, 4);
+        }
+#undef PK8_LAUNCH
+        rc = cnl::check_launch("peaks_c8_kernel");
+    } else if (cminor && p->C / vec <= 256) {
         a.CG = p->C / vec;
         a.PXB = 256 / a.CG;
         if (a.PXB > p->W) a.PXB = p->W;

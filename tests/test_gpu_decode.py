@@ -178,5 +178,23 @@ def test_collate_through_rccl_single_rank():
         assert g is not dets
         for key in dets:
             assert torch.equal(g[key], dets[key]), key
+        # the pipelined form: persistent slots, gather on the side stream behind an event, result one step behind submit
+        c = cl.Collator(depth=2, force=True)
+        batches = []
+        for i in range(5):
+            o = hip_decode.decode(*[t.cuda() for t in recipes.decode_inputs(10 + i, (3, 2, 16, 24), 8)], 25, 3)
+            batches.append({"bboxes": o["boxes"], "scores": o["scores"], "labels": o["labels"], "embeddings": o["embeddings"]})
+        pending, got = None, []
+        for d in batches:
+            h = c.submit(d)
+            if pending is not None:
+                got.append({k: v.clone() for k, v in c.result(pending).items()})
+            pending = h
+        got.append(c.result(pending))
+        torch.cuda.synchronize()
+        assert len(next(iter(c._slots.values()))) == 2 and len(c._slots) == 1          # two slots, allocated once
+        for d, g in zip(batches, got):
+            for key in d:
+                assert torch.equal(g[key], d[key]), key
     finally:
         dist.destroy_process_group()
