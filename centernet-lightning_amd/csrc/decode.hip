@@ -468,12 +468,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     unsigned tmax = 0u;
     const bool kch_pow2 = (KCH & (KCH - 1)) == 0;            // then i / KCH, i % KCH are a shift and a mask (KCH = 16 at 128 x 128)
     const int kch_sh = 31 - __builtin_clz((unsigned)KCH);
-    for (int i = tid; i < a.HW; i += 8 * TK_THREADS) {       // eight independent loads in flight per thread, then the bookkeeping
-        float v[8];
+    for (int i = tid; i < a.HW; i += 16 * TK_THREADS) {      // sixteen independent loads in flight per thread, then the bookkeeping
+        float v[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = i + j * TK_THREADS < a.HW ? sc[i + j * TK_THREADS] : 0.f;
+        for (int j = 0; j < 16; ++j) v[j] = i + j * TK_THREADS < a.HW ? sc[i + j * TK_THREADS] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 16; ++j) {
             const int ii = i + j * TK_THREADS;
             if (ii < a.HW) {
                 const unsigned key = score_key(v[j]);
@@ -563,17 +563,24 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
             fast = true;
             // rank of a candidate = how many candidates are greater ((key, ~index) pairs are distinct): the k winners land in canonical
             // order (score desc, index asc) without a sort.  All lanes read the same 16 bytes (two candidates): LDS broadcasts.
-            if (tid < (int)total) {
-                const unsigned long long mine = cand[tid];
+            // 2 .. 8 neighbouring lanes share a candidate (1024 threads, at most 512 candidates) and scan interleaved slices of the array.
+            int psh = 1;
+            while (psh < 3 && (total << (psh + 1)) <= (unsigned)TK_THREADS) ++psh;
+            const int c = tid >> psh, part = tid & ((1 << psh) - 1);
+            {
+                const unsigned long long mine = c < (int)total ? cand[c] : ~0ull;
                 unsigned rank = 0;
-                for (unsigned j = 0; j < total; j += 8) {
+                for (unsigned j = (unsigned)part * 8u; j < total; j += 8u << psh) {
                     unsigned long long o[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) o[q] = cand[j + q];           // zero beyond total (the array is padded)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) rank += o[q] > mine ? 1u : 0u;
                 }
-                if (rank < (unsigned)a.k) win[rank] = mine;
+                rank += (unsigned)__shfl_xor((int)rank, 1);
+                if (psh > 1) rank += (unsigned)__shfl_xor((int)rank, 2);
+                if (psh > 2) rank += (unsigned)__shfl_xor((int)rank, 4);
+                if (part == 0 && c < (int)total && rank < (unsigned)a.k) win[rank] = mine;
             }
             __syncthreads();
             TK_STAMP(3);
