@@ -267,8 +267,8 @@ def decode_block(model, x, tracking, k, config=None):
             "kernels_profiled": PROFILED_DECODE.get((config, N, x.shape[2], x.shape[3])),
             "note": "gpu_ms = GPU time of one decode (both kernels): 50 calls enqueued back to back between HIP events, as inside a step where the "
                     "host runs ahead — GBps / frac_of_8TBps use it; p50 = one call at a time from Python with the GPU idle before it (HIP events "
-                    "around gather_detection2d on the forward's own outputs, median of 30): it adds the host's ~25 us of argument set-up and "
-                    "launch latency.  without = the path (sigmoid is the heatmap out_conv's epilogue); with = torch.sigmoid(logits) + decode, "
+                    "around gather_detection2d on the forward's own outputs, median of 30): it adds the host's argument set-up and launch "
+                    "latency before the first kernel starts (~8 us).  without = the path (sigmoid is the heatmap out_conv's epilogue); with = torch.sigmoid(logits) + decode, "
                     "what a caller holding logits pays"}
 
 
@@ -330,7 +330,7 @@ def cpu_baseline(model, config, tracking, k, H, W, gpu_decode_p50_ms, budget_s=7
         one(x0)                                                                 # global warm-up (oneDNN primitive caches, allocator)
         probes = []
         t_start = time.perf_counter()
-        for threads in sorted({max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, min(32, cores)), max(1, min(16, cores))}):    # fewest first: on many-core hosts oneDNN scales negatively here
+        for threads in sorted({max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, min(48, cores)), max(1, min(32, cores)), max(1, min(24, cores)), max(1, min(16, cores)), max(1, min(8, cores))}):    # fewest first: on many-core hosts oneDNN scales negatively here
             for cl_ in (False, True):
                 if probes and time.perf_counter() - t_start > budget * 0.5:
                     break

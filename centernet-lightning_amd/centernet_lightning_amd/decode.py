@@ -45,14 +45,22 @@ def decode(heatmap, box_2d, reid=None, num_detections=100, nms_kernel=3, normali
         if reid.shape[0] != N or tuple(reid.shape[2:]) != (H, W):
             raise ValueError(f"reid shape {tuple(reid.shape)} does not match heatmap {tuple(heatmap.shape)}")
         E = reid.shape[1]
-    with torch.cuda.device(dev):
-        scores = torch.empty((N, k), device=dev, dtype=torch.float32)
-        indices = torch.empty((N, k), device=dev, dtype=torch.int64)
-        labels = torch.empty((N, k), device=dev, dtype=torch.int64)
-        boxes = torch.empty((N, k, 4), device=dev, dtype=torch.float32)
-        emb = torch.empty((N, k, E), device=dev, dtype=torch.float32) if E else None
-        ws_bytes = lib.cnl_decode_workspace_bytes(N, H, W)
-        ws = torch.empty((max(ws_bytes, 16),), device=dev, dtype=torch.uint8)
+    # ONE allocation for the outputs and the workspace, carved up AFTER the launch: the host-side tensor bookkeeping then overlaps the
+    # kernels instead of delaying them (single-call latency: 84 -> 62 us at C1 came from the kernels, the rest is this ordering)
+    ws_bytes = max(int(lib.cnl_decode_workspace_bytes(N, H, W)), 16)
+    al = lambda n: (n + 255) & ~255
+    o_idx, o_lab = 0, al(N * k * 8)
+    o_box = o_lab + al(N * k * 8)
+    o_sc = o_box + al(N * k * 16)
+    o_emb = o_sc + al(N * k * 4)
+    o_ws = o_emb + al(N * k * E * 4)
+    switch = torch.cuda.current_device() != dev.index
+    if switch:
+        prev = torch.cuda.current_device()
+        torch.cuda.set_device(dev)
+    try:
+        buf = torch.empty((o_ws + ws_bytes,), device=dev, dtype=torch.uint8)
+        base = buf.data_ptr()
         p = DecodeParams()
         p.heat = heatmap.data_ptr()
         p.heat_sn, p.heat_sc, p.heat_sh, p.heat_sw = heatmap.stride()
@@ -61,17 +69,22 @@ def decode(heatmap, box_2d, reid=None, num_detections=100, nms_kernel=3, normali
         if E:
             p.reid = reid.data_ptr()
             p.reid_sn, p.reid_sc, p.reid_sh, p.reid_sw = reid.stride()
-            p.emb = emb.data_ptr()
+            p.emb = base + o_emb
         p.N, p.C, p.H, p.W, p.E = N, C, H, W, E
         p.k, p.nms_kernel = k, int(nms_kernel)
         p.normalize_boxes, p.box_log = int(bool(normalize_boxes)), int(bool(box_log))
         p.box_multiplier, p.stride = float(box_multiplier), float(stride)
-        p.scores, p.indices, p.labels, p.boxes = scores.data_ptr(), indices.data_ptr(), labels.data_ptr(), boxes.data_ptr()
-        p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
+        p.scores, p.indices, p.labels, p.boxes = base + o_sc, base + o_idx, base + o_lab, base + o_box
+        p.workspace, p.workspace_bytes = base + o_ws, ws_bytes
         _lib.check(lib.cnl_decode_f32(ctypes.byref(p), _stream(dev)), "cnl_decode_f32")
-    out = {"scores": scores, "indices": indices, "labels": labels, "boxes": boxes}
+    finally:
+        if switch:
+            torch.cuda.set_device(prev)
+    view = lambda off, nbytes, dtype, shape: buf[off:off + nbytes].view(dtype).view(shape)
+    out = {"scores": view(o_sc, N * k * 4, torch.float32, (N, k)), "indices": view(o_idx, N * k * 8, torch.int64, (N, k)),
+           "labels": view(o_lab, N * k * 8, torch.int64, (N, k)), "boxes": view(o_box, N * k * 16, torch.float32, (N, k, 4))}
     if E:
-        out["embeddings"] = emb
+        out["embeddings"] = view(o_emb, N * k * E * 4, torch.float32, (N, k, E))
     return out
 
 
