@@ -14,6 +14,7 @@ Fusions relative to the reference's op-per-layer graph (results identical up to 
 """
 import bisect
 import ctypes
+import threading
 from collections import OrderedDict
 from dataclasses import dataclass
 
@@ -856,6 +857,8 @@ class Engine:
     def __init__(self, model):
         self.model = model
         self.weights = None
+        self._lock = threading.RLock()                 # host-side enqueue of one forward at a time: a plan's per-call state (patched
+                                                       # output pointers, LRU order) is not re-entrant, and threads share the default stream
         self.plans = OrderedDict()                     # least recently used first
         self._sub_override = {}                        # (H, W) -> largest sub-batch found to fit after a BufferTooLarge retry
         self.max_plans = 8                             # each plan owns an activation arena (GBs at large batches): bound what is kept
@@ -895,6 +898,10 @@ class Engine:
         return self._dispatch(x, sigmoid, N, H, W, None)
 
     def _dispatch(self, x, sigmoid, N, H, W, norm):
+        with self._lock:
+            return self._dispatch_locked(x, sigmoid, N, H, W, norm)
+
+    def _dispatch_locked(self, x, sigmoid, N, H, W, norm):
         dev = x.device
         if self.weights is None or self.weights_device != dev or self.weights.stale():
             self.weights = PackedWeights(self.model, dev)

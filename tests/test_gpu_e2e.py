@@ -248,6 +248,33 @@ def test_two_streams_do_not_share_plan_state():
     assert len({key[-1] for key in model._engine.plans}) == 3          # default stream + two side streams
 
 
+def test_forward_from_two_threads_on_the_default_stream():
+    """Serving code calls model(x) from several Python threads, all on the default stream: the engine serialises the host-side enqueue
+    (a plan patches its output pointers per call), so every thread gets the bytes of a single-threaded call."""
+    import threading
+    model, _ = build("resnet34_simple.yaml")
+    xs = [recipes.images(40 + i, (2, 3, 96, 96)).cuda() for i in range(4)]
+    want = [{k: v.clone() for k, v in model.get_encoded_outputs(x).items()} for x in xs]
+    got, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            for _ in range(10):
+                o = model.get_encoded_outputs(xs[i])
+            got[i] = o
+        except Exception as e:                                   # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(4):
+        for k in want[i]:
+            assert torch.equal(got[i][k], want[i][k]), (i, k)
+
+
 def test_in_place_weight_edit_is_noticed_without_refresh():
     """model.backbone.load_state_dict(...) / in-place edits after the first forward must not run on stale packed weights."""
     model, sd = build("resnet34_simple.yaml")
