@@ -74,6 +74,35 @@ def test_decode_random_vs_oracle(shape, k, nms, emb):
         _check(o, ref)
 
 
+def _sweep_cases():
+    """Edge shapes of the C % 8 == 0 stage-1 kernel (runs of 4 pixels, 64-pixel blocks, 16- / 4-row strips) and of stage 2's pruning bound
+    (k from 1 to H*W, maps smaller than a workgroup, more than 16 keys per thread), seeded."""
+    rng = np.random.default_rng(2024)
+    cases = []
+    for W in (8, 9, 13, 63, 64, 65, 130):
+        for H in (1, 3, 16, 17, 33):
+            C = int(rng.choice([8, 16, 40, 80, 88]))
+            N = int(rng.choice([1, 2, 3]))
+            nms = int(rng.choice([1, 3, 5]))
+            k = int(rng.integers(1, min(H * W, 400) + 1))
+            cases.append((N, C, H, W, k, nms))
+    cases += [(40, 8, 48, 20, 33, 3), (20, 16, 70, 64, 1024, 3), (1, 80, 152, 272, 1000, 3), (2, 8, 4, 8, 32, 7)]
+    return cases
+
+
+@pytest.mark.parametrize("case", _sweep_cases(), ids=lambda c: "N{}C{}_{}x{}_k{}_nms{}".format(*c))
+def test_decode_shape_sweep_vs_oracle(case):
+    N, C, H, W, k, nms = case
+    ins = recipes.decode_inputs(N * 7 + C + H * 3 + W + k, (N, C, H, W), 0)
+    heat = ins[0]
+    if (H + W) % 3 == 0:                                 # a third of the cases: quantised scores -> ties across the k boundary and plateaus
+        heat = (heat * 16).floor() / 16
+    ref = decode_ref.decode_detections(heat.numpy(), ins[1].numpy(), k, nms)
+    _check(_np(hip_decode.decode(_layouts(heat)[1], _layouts(ins[1])[1], None, k, nms)), ref)       # NHWC storage: the channel-minor kernels
+    if C * H * W <= 40000:
+        _check(_np(hip_decode.decode(_layouts(heat)[0], _layouts(ins[1])[0], None, k, nms)), ref)   # contiguous NCHW: the generic kernel
+
+
 def test_decode_quantised_scores_many_ties():
     """Scores on a coarse grid produce large tie groups everywhere, including across the k boundary."""
     g = torch.Generator().manual_seed(3)
