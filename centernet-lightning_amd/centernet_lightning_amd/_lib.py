@@ -21,7 +21,7 @@ CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_F4, CNL_ALGO_FORCE = 0, 1, 2,
 CNL_WINO_F32, CNL_WINO_F16X2, CNL_WINO_F16X2_F4 = 2, 5, 8
 
 CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4
-ABI_VERSION = 5          # CNL_ABI_VERSION of include/centernet_gfx950.h
+ABI_VERSION = 6          # CNL_ABI_VERSION of include/centernet_gfx950.h
 
 
 class ConvParams(Structure):
@@ -29,7 +29,8 @@ class ConvParams(Structure):
                 ("N", c_int32), ("H_in", c_int32), ("W_in", c_int32), ("Cin", c_int32), ("Cout", c_int32),
                 ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
                 ("ldx", c_int32), ("ldy", c_int32), ("ldr", c_int32), ("flags", c_uint32),
-                ("x_absmax", c_void_p), ("y_absmax", c_void_p), ("w_absmax", c_void_p), ("algo", c_uint32)]
+                ("x_absmax", c_void_p), ("y_absmax", c_void_p), ("w_absmax", c_void_p), ("algo", c_uint32),
+                ("splitk", c_int32), ("splitk_scratch", c_void_p), ("splitk_scratch_bytes", c_size_t)]
 
 
 class DeconvParams(Structure):
@@ -67,6 +68,7 @@ _SIGNATURES = {
     "cnl_deconv2x_nhwc_f32": (ctypes.c_int, [POINTER(DeconvParams), c_void_p]),
     "cnl_deconv_phase_geometry": (ctypes.c_int, [c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
     "cnl_deconv_weight_floats": (c_size_t, [c_int32, c_int32, c_int32]),
+    "cnl_conv2d_splitk_scratch_bytes": (c_size_t, [POINTER(ConvParams)]),
     "cnl_fuse_sum_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                              c_int32, c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int32, c_void_p]),
     "cnl_upsample2x_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,

@@ -41,13 +41,18 @@ class KernelOptions:
       absmax_handover  per-image max |y| handed from producer to consumer launches (else each fp16-split Winograd launch makes
                        its own pass and the direct convs stay on the fp32 matrix cores)
       stem_fused_pool  the 3x3/2 max-pool inside the stem kernel
-      reuse_buffers    activation buffers share one arena by liveness; False keeps every intermediate (tests read them)"""
+      reuse_buffers    activation buffers share one arena by liveness; False keeps every intermediate (tests read them)
+      split_small      latency mode for small batches (default off): launches whose output is too small to fill the chip (one image: the
+                       16x16 .. 64x64 maps) run as direct convs with the reduction split over several workgroups per output tile and a
+                       fixed-order reduce (cnl_conv_params.splitk).  The choice then depends on the batch size, so results are no longer
+                       bit-identical between a shard and the full batch (they stay within the fp32-grade error bars)."""
     algo: str = "auto"
     winograd: bool = True
     up2: bool = True
     absmax_handover: bool = True
     stem_fused_pool: bool = True
     reuse_buffers: bool = True
+    split_small: bool = False
 
     @property
     def algo_id(self):
@@ -363,7 +368,7 @@ class Plan:
 
         def pointers(L):
             if isinstance(L.args, (ConvParams, DeconvParams)):
-                return [(L.args, f) for f in ("x", "y", "residual")]
+                return [(L.args, f) for f in (("x", "y", "residual", "splitk_scratch") if isinstance(L.args, ConvParams) else ("x", "y", "residual"))]
             if isinstance(L.args, list):
                 return [(L.args, i) for i in range(len(L.args))]
             return []
@@ -529,6 +534,15 @@ class Plan:
         _lib.check(self.lib.cnl_conv2d_out_hw(ctypes.byref(p), ctypes.byref(ho), ctypes.byref(wo)), what)
         flops = 2 * self.N * ho.value * wo.value * layer.cout * layer.kh * layer.kw * layer.cin   # direct-conv (algorithmic) flops
         fn = self.lib.cnl_conv2d_nhwc_f32
+        split = self._split_slices(layer, flags, ho.value, wo.value)
+        if split > 1:
+            # small grid: direct conv, reduction split over `split` workgroups per output tile + fixed-order reduce
+            p.splitk = split
+            scratch = self._buf(split, self.N * ho.value, wo.value, layer.cout)
+            p.splitk_scratch = scratch.data_ptr()
+            p.splitk_scratch_bytes = scratch.nbytes
+            self.launches.append(_Launch(fn, p, what + f" [split x{split}]", flops, keep=(x, y, residual, layer, scratch)))
+            return p, ho.value, wo.value
         if self.options.winograd and layer.u is not None and not (flags & (CNL_UPSAMPLE_OUT_ADD | CNL_SIGMOID)) and (4 * x_off) % 16 == 0:
             p.w = layer.u.data_ptr()
             fn = self.lib.cnl_conv3x3_winograd_f32
@@ -543,6 +557,21 @@ class Plan:
             what = what.replace(" [winograd]", "") + " [sub-pixel phases]"
         self.launches.append(_Launch(fn, p, what, flops, keep=(x, y, residual, layer)))
         return p, ho.value, wo.value
+
+    def _split_slices(self, layer, flags, ho, wo):
+        """KernelOptions.split_small: slices of the reduction for a launch with at most 32 output tiles of 64 x 128 (an eighth of the CUs).  Only
+        where the channel loop is long enough to pay for the second launch (Cin >= 256; their inputs' maxima are always handed over)."""
+        if not self.options.split_small or self.algo == CNL_ALGO_F32 or not self.options.absmax_handover:
+            return 0
+        if flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD) or layer.kh != layer.kw or layer.kh not in (1, 3) or layer.cin < 256 or layer.cin % 32:
+            return 0
+        tiles = -(-(self.N * ho * wo) // 64) * -(-layer.cout // 128)
+        kt = layer.kh * layer.kw * layer.cin // 32
+        if tiles > 64 or kt < 8:            # measured at N = 1 (profiles/r02_split_small.txt): a split launch costs ~25-35 us whatever its
+                                            # size; the unsplit Winograd launch it replaces ~2.7 us per 16 channels -> Cin >= 256 only
+            return 0
+        s_ = min(kt // 3, max(1, 512 // tiles), 64)       # two 64 x 128 workgroups are co-resident per CU; >= 3 chunks per slice
+        return s_ if s_ >= 2 else 0
 
     def _sep(self, layer, x, xh, xw, ldx, y, ldy, what):
         """Separable conv (layers.py:56-69): depthwise 3x3 + BN + ReLU6 -> pointwise 1x1 + BN + ReLU6."""

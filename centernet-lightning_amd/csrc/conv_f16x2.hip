@@ -66,7 +66,7 @@ __device__ __forceinline__ float pow2_scale(float mx) {
 // KS: compile-time square kernel size (1, 2 or 3).  SUB: the launch is one sub-pixel phase of a conv on the nearest-2x upsampled input
 // (cnl_conv3x3_up2_nhwc_f32): row m = (n, oy, ox) is stored at pixel (2 oy + sub_dy, 2 ox + sub_dx) of the 2x output grid; pad (rows)
 // and pad_x (columns) differ between phases.  No CNL_UPSAMPLE_IN gather, no CNL_UPSAMPLE_OUT_ADD epilogue (those stay on conv_mfma.hip).
-template <int WM, int WN, int TM, int TN, int KS, bool SUB>
+template <int WM, int WN, int TM, int TN, int KS, bool SUB, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     using C = Cfg<WM, WN, TM, TN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -80,7 +80,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int hi = lane >> 5;
 
-    const unsigned tile = cnl::xcd_remap(blockIdx.x, (unsigned)a.tiles);
+    unsigned tile = cnl::xcd_remap(blockIdx.x, (unsigned)a.tiles);
+    int slice = 0;
+    if constexpr (SPLIT) { slice = (int)(tile % (unsigned)a.ksplit); tile /= (unsigned)a.ksplit; }
+    const int kt0 = SPLIT ? slice * a.kt_per : 0;                                   // this workgroup's chunks: [kt0, kt0 + KTs)
+    const int KTs = SPLIT ? min(a.kt_per, a.KT - kt0) : a.KT;
     const int n_tile = tile % a.tiles_n;
     const int m_tile = tile / a.tiles_n;
     const int m0 = m_tile * C::BM;
@@ -143,8 +147,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
             C5_TAP(tap, ky, kx);                        \
         }                                               \
     } while (0)
-    C5_TAP(0, 0, 0);
-    C5_ISSUE(0, 0, 0);                       // first chunk in flight before anything else
+    if constexpr (SPLIT) {
+        tap = kt0 / a.CC; cc = kt0 - tap * a.CC; ky = tap / KS; kx = tap - ky * KS;
+    }
+    C5_TAP(tap, ky, kx);
+    C5_ISSUE(0, cc * 32, kt0 * 32);          // first chunk in flight before anything else
 
     // ---- scales: one per row of the tile (its image's), one for the weights ----
     const float Sw = SUB ? *a.wscale : pow2_scale(*a.wmax);       // SUB: the weights were split when they were packed
@@ -214,27 +221,27 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     __syncthreads();                                    // ... and everyone's, and the scale tables are written
 #pragma unroll
     for (int i = 0; i < TM; ++i) sA[i] = sScl[(wm * TM + i) * 32 + (lane & 31)];
-    if (a.KT > 1) {
+    if (KTs > 1) {
         C5_ADVANCE();
-        C5_ISSUE(1, cc * 32, 32);
+        C5_ISSUE(1, cc * 32, (kt0 + 1) * 32);
     }
     C5_READ(smem, 0);
     // One K chunk = two 16-channel groups.  The barrier of chunk kt sits between its two MFMA groups and guarantees (a) every wave
     // has finished reading chunk kt's stage (group 1's fragments are in registers) -> it may be refilled with chunk kt+2, (b) every
     // wave's DMA of chunk kt+1 has landed -> it may be read.
-    for (int kt = 0; kt < a.KT; ++kt) {
+    for (int kt = 0; kt < KTs; ++kt) {
         const char* sS = smem + (kt & 1) * C::STAGE_BYTES;
         const char* sN = smem + ((kt + 1) & 1) * C::STAGE_BYTES;
         C5_SPLIT();
         C5_READ(sS, 1);
         C5_MFMA();
         C5_SPLIT();
-        if (kt + 1 < a.KT) {
+        if (kt + 1 < KTs) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kt + 2 < a.KT) {
+            if (kt + 2 < KTs) {
                 C5_ADVANCE();
-                C5_ISSUE(kt & 1, cc * 32, (kt + 2) * 32);
+                C5_ISSUE(kt & 1, cc * 32, (kt0 + kt + 2) * 32);
             }
             C5_READ(sN, 0);
         }
@@ -247,6 +254,26 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
 #undef C5_SPLIT
 #undef C5_MFMA
 
+    if constexpr (SPLIT) {
+        // partial sums of this slice, scaled back, to part[slice][m][col]: the epilogue proper runs in splitk_reduce_kernel
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rl = (wm * TM + i) * 32 + 4 * hi;
+                const int mb = m0 + rl;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    const bool ok = col < a.Cout && mb + ro < a.M;
+                    buf_store(acc[i][j][r] * sInv[rl + ro], a.part, a.part_bytes,
+                              ok ? (unsigned)((((long long)slice * a.M + mb + ro) * a.Cout + col) * 4) : OOB, 0u);
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: row scale back, + bias (+ residual) -> clamp -> (sigmoid) -> NHWC store; max |y| per image ----
     const float lo = (a.flags & (CNL_RELU | CNL_RELU6)) ? 0.f : -__builtin_inff();
     const float hi6 = (a.flags & CNL_RELU6) ? 6.f : __builtin_inff();
@@ -318,6 +345,81 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     }
 }
 
+// y[m][col] = act(sum_s part[s][m][col] + bias[col] (+ residual)) in slice order; max |y| per image.  Thread = (row, 4 columns).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
+    const int C4 = (a.Cout + 3) / 4;
+    const long total = (long)a.M * C4;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    float omax = 0.f;
+    int img = -1;
+    if (t < total) {
+        const int m = (int)(t / C4), col = (int)(t - (long)m * C4) * 4;
+        img = (int)fast_div((unsigned)m, a.mg_hw, a.sh_hw);
+        const bool vec = col + 4 <= a.Cout && (a.Cout & 3) == 0;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const long sstride = (long)a.M * a.Cout;
+        const float* p0 = a.part + (long)m * a.Cout + col;
+        if (vec) {
+            for (int s0 = 0; s0 < a.ksplit; s0 += 8) {           // eight independent loads in flight, added in slice order
+                f32x4 q[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    q[j] = s0 + j < a.ksplit ? *reinterpret_cast<const f32x4*>(p0 + (s0 + j) * sstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += q[j][i];
+            }
+        } else {
+            for (int s = 0; s < a.ksplit; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (col + i < a.Cout) v[i] += p0[s * sstride + i];
+        }
+        const float lo = (a.flags & (CNL_RELU | CNL_RELU6)) ? 0.f : -__builtin_inff();
+        const float hi6 = (a.flags & CNL_RELU6) ? 6.f : __builtin_inff();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (col + i >= a.Cout) continue;
+            float o = v[i] + a.bias[col + i];
+            if (a.res) o += a.res[(long)m * a.ldr + col + i];
+            o = fminf(fmaxf(o, lo), hi6);
+            if (a.flags & CNL_SIGMOID) o = 1.0f / (1.0f + expf(-o));
+            a.y[(long)m * a.ldy + col + i] = o;
+            omax = fmaxf(omax, fabsf(o));
+        }
+    }
+    if (a.ymax) {
+        const int img0 = __shfl(img, 0, 64);
+        const bool same = __all(img == img0 || img < 0);
+        if (same) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
+            if ((threadIdx.x & 63) == 0 && img0 >= 0 && omax > 0.f) atomicMax(a.ymax + img0, __float_as_uint(omax));
+        } else if (img >= 0 && omax > 0.f) {
+            atomicMax(a.ymax + img, __float_as_uint(omax));
+        }
+    }
+}
+
+template <int KS>
+static int launch_split5(const ConvArgs& in, hipStream_t stream) {
+    using C = Cfg<2, 2, 1, 2>;                          // 64 x 128 tiles: the grids this path exists for are small
+    ConvArgs a = in;
+    const int tiles_m = (a.M + C::BM - 1) / C::BM;
+    a.tiles_n = (a.Cout + C::BN - 1) / C::BN;
+    a.tiles = tiles_m * a.tiles_n * a.ksplit;
+    static cnl::DeviceOnce once;
+    int rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&conv_f16x2_kernel<2, 2, 1, 2, KS, false, true>), 160 * 1024);
+    if (rc != CNL_OK) return rc;
+    hipLaunchKernelGGL((conv_f16x2_kernel<2, 2, 1, 2, KS, false, true>), dim3(a.tiles), dim3(C::THREADS), C::LDS_BYTES + C::BM * 16, stream, a);
+    rc = cnl::check_launch("conv_f16x2_kernel (split)");
+    if (rc != CNL_OK) return rc;
+    const long total = (long)a.M * ((a.Cout + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    return cnl::check_launch("splitk_reduce_kernel");
+}
+
 template <int WM, int WN, int TM, int TN, int KS, bool SUB>
 static int launch_one5(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<WM, WN, TM, TN>;
@@ -348,10 +450,12 @@ bool f16x2_eligible(const ConvArgs& a) {
     const long long min_out_1x1 = a.algo == CNL_ALGO_FORCE + 5 ? 0 : (1ll << 20);
     if (a.algo == CNL_ALGO_F32 || !a.xmax || (a.flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD))) return false;
     if (a.flags & CNL_I_SUBPIXEL) return a.KH == 2 && a.KW == 2 && !a.res && a.wscale;       // the phases of cnl_conv3x3_up2_nhwc_f32
-    return a.wmax && a.KH == a.KW && (a.KH == 1 || a.KH == 3) && a.pad == a.pad_x && (a.KH == 3 || (long long)a.Ho * a.Wo * a.Cout >= min_out_1x1);
+    return a.wmax && a.KH == a.KW && (a.KH == 1 || a.KH == 3) && a.pad == a.pad_x &&
+           (a.KH == 3 || a.ksplit > 1 || (long long)a.Ho * a.Wo * a.Cout >= min_out_1x1);      // a split 1x1 is latency-bound on its K loop: the short chunks win
 }
 
 int f16x2_launch(const ConvArgs& a, hipStream_t s) {
+    if (a.ksplit > 1 && !(a.flags & CNL_I_SUBPIXEL)) return a.KH == 3 ? launch_split5<3>(a, s) : launch_split5<1>(a, s);
     // Tile choice: BN follows Cout; shrink BM when the grid would not fill 256 CUs x 2 workgroups (as conv_mfma.hip).
     if (a.Cout <= 32) return launch_cfg5<4, 1, 2, 1>(a, s);         // 256 x 32
     if (a.Cout <= 64) return launch_cfg5<4, 1, 2, 2>(a, s);         // 256 x 64

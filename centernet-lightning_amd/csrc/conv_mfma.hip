@@ -437,7 +437,21 @@ static int finish_and_launch(ConvArgs& a, bool out4x, const char* who, hipStream
 #ifdef CNL_TRACE
     if (const char* e = getenv("CNL_TRACE_PTR")) a.trace = (long long*)strtoull(e, nullptr, 0);
 #endif
-    if (f16x2_eligible(a)) return f16x2_launch(a, s);               // conv_f16x2.hip: the caller handed over max |x|, max |w|
+    if (f16x2_eligible(a)) {                                         // conv_f16x2.hip: the caller handed over max |x|, max |w|
+        if (a.ksplit > 1) {                  // split reduction: needs >= 2 chunks per slice and an unscattered output
+            const int per = (a.KT + a.ksplit - 1) / a.ksplit;
+            const unsigned long long pb = (unsigned long long)a.ksplit * (unsigned long long)M * a.Cout * 4ull;
+            if (per >= 2 && !out4x && !(a.flags & CNL_UPSAMPLE_IN) && pb < lim) {
+                a.kt_per = per;
+                a.ksplit = (a.KT + per - 1) / per;                   // no empty slice
+                a.part_bytes = (unsigned)((unsigned long long)a.ksplit * (unsigned long long)M * a.Cout * 4ull);
+            } else {
+                a.ksplit = 0;
+            }
+        }
+        return f16x2_launch(a, s);
+    }
+    a.ksplit = 0;
     // Tile choice: BN follows Cout; shrink BM when the grid would not fill 256 CUs x 2 workgroups.
     if (a.Cout <= 32) return launch_cfg<4, 1, 2, 1>(a, s);          // 256 x 32
     if (a.Cout <= 64) return launch_cfg<4, 1, 2, 2>(a, s);          // 256 x 64
@@ -456,11 +470,19 @@ extern "C" int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32
     return CNL_OK;
 }
 
+extern "C" size_t cnl_conv2d_splitk_scratch_bytes(const cnl_conv_params* p) {
+    if (!p || p->splitk <= 1) return 0;
+    int32_t ho = 0, wo = 0;
+    if (cnl_conv2d_out_hw(p, &ho, &wo) != CNL_OK || ho <= 0 || wo <= 0) return 0;
+    return (size_t)p->splitk * (size_t)p->N * (size_t)ho * (size_t)wo * (size_t)p->Cout * 4;
+}
+
 extern "C" int cnl_conv2d_kernel(const cnl_conv_params* p) {
     CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv2d_kernel: null params");
     ConvArgs a;
     a.KH = p->KH; a.KW = p->KW; a.pad = a.pad_x = p->pad; a.flags = p->flags; a.Cout = p->Cout;
     a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.wscale = nullptr; a.res = p->residual; a.algo = p->algo;
+    a.ksplit = p->splitk > 1 ? p->splitk : 0;
     int32_t ho = 0, wo = 0;
     const int rc = cnl_conv2d_out_hw(p, &ho, &wo);
     if (rc != CNL_OK) return rc;
@@ -499,6 +521,13 @@ extern "C" int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream) {
     a.HL = p->H_in * up; a.WL = p->W_in * up;
     a.Ho = (a.HL + 2 * p->pad - p->KH) / p->stride + 1;
     a.Wo = (a.WL + 2 * p->pad - p->KW) / p->stride + 1;
+    if (p->splitk > 1) {
+        CNL_REQUIRE(p->splitk <= 256, CNL_E_BAD_ARG, "cnl_conv2d_nhwc_f32: splitk=%d (at most 256 slices)", p->splitk);
+        CNL_REQUIRE(p->splitk_scratch && ((uintptr_t)p->splitk_scratch & 15) == 0 && p->splitk_scratch_bytes >= cnl_conv2d_splitk_scratch_bytes(p),
+                    CNL_E_WORKSPACE, "cnl_conv2d_nhwc_f32: splitk_scratch missing, unaligned or smaller than cnl_conv2d_splitk_scratch_bytes()");
+        a.ksplit = p->splitk;
+        a.part = p->splitk_scratch;
+    }
     return finish_and_launch(a, up_out, "cnl_conv2d_nhwc_f32", (hipStream_t)stream);
 }
 

@@ -90,8 +90,8 @@ constexpr int BN = 64;
 constexpr int NPOS = 36, NP = 2;
 constexpr int PH = 4 * TY + 2, PW = 4 * TX + 2;           // 18 x 34 patch
 constexpr int PP = 35;                                    // slots per (row, quad) line of the LDS image [py][quad][PP][4 floats]
-constexpr int P_USED = PH * 4 * PP;                       // 2520 16-byte slots
-constexpr int P_SLOTS = 2560;                             // 10 x 256
+constexpr int P_SLOTS = 2560;                             // 10 x 256 (PH * 4 * PP = 2520 used)
+static_assert(PH * 4 * PP <= P_SLOTS, "patch image exceeds its LDS buffer");
 constexpr int P_BYTES = P_SLOTS * 16;                     // 40960 per buffer
 constexpr int VPIECE = T * 32;                            // 1024: one (position, piece) plane [32 tiles][16 ci fp16]
 constexpr int V_BYTES = NPOS * NP * VPIECE;               // 73728

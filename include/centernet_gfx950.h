@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 5   /* 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 6   /* 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -108,9 +108,19 @@ typedef struct cnl_conv_params {
      * the fp32 matrix-core kernel, 2-3x faster) and honour y_absmax; without them the fp32 matrix-core kernel runs.             */
     const float* w_absmax;
     uint32_t algo;          /* CNL_ALGO_* (0 = CNL_ALGO_AUTO)                                                                       */
+    /* cnl_conv2d_nhwc_f32 only, optional (0 / NULL = off): split the reduction (KH*KW*Cin) over `splitk` workgroups per output tile —
+     * for launches whose output is too small to fill the chip (one image, 16x16 .. 32x32 maps): slice s writes its partial sums to
+     * splitk_scratch[s][N*Ho*Wo][Cout] (cnl_conv2d_splitk_scratch_bytes()), a second kernel adds the slices IN SLICE ORDER (deterministic)
+     * and applies bias / residual / activation / y_absmax.  Honoured where the fp16-split kernel runs (x_absmax and w_absmax given,
+     * 1x1 or 3x3, no CNL_UPSAMPLE_*); elsewhere the launch runs unsplit.  The result depends on `splitk` (summation grouping), so a
+     * caller that needs shard == full batch bit for bit must choose it from the layer shape alone.                                  */
+    int32_t splitk;
+    float* splitk_scratch;
+    size_t splitk_scratch_bytes;
 } cnl_conv_params;
 
 int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream);
+size_t cnl_conv2d_splitk_scratch_bytes(const cnl_conv_params* p);   /* for p->splitk slices; 0 when splitk <= 1 */
 
 /* Which kernel cnl_conv2d_nhwc_f32 takes for *p (a function of the hints, kernel size and flags only — never of the batch). */
 #define CNL_CONV_F32 2     /* fp32 matrix cores (csrc/conv_mfma.hip); ignores y_absmax                                    */

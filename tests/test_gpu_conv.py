@@ -20,7 +20,7 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0, x_off=0, hints=False, algo=CNL_ALGO_AUTO):
+def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0, x_off=0, hints=False, algo=CNL_ALGO_AUTO, splitk=0):
     """x_nchw: CPU tensor. Returns NCHW CPU output of cnl_conv2d_nhwc_f32.  hints: hand over max |x| per image (from
     cnl_absmax_per_image_f32) and max |w|, which selects the fp16-split kernel where it applies; then returns (out, kernel, y_absmax)."""
     lib = _lib.load()
@@ -54,6 +54,13 @@ def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0
         wm = wd.abs().max().reshape(1).contiguous()
         ym = torch.zeros(N, device="cuda")
         p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), wm.data_ptr(), ym.data_ptr()
+    if splitk:
+        p.splitk = splitk
+        nbytes = lib.cnl_conv2d_splitk_scratch_bytes(ctypes.byref(p))
+        assert nbytes == splitk * N * ho.value * wo.value * Cout * 4
+        scratch = torch.full((nbytes // 4 + 4,), float("nan"), device="cuda")
+        assert lib.cnl_conv2d_nhwc_f32(ctypes.byref(p), _stream()) == _lib.CNL_E_WORKSPACE       # scratch missing
+        p.splitk_scratch, p.splitk_scratch_bytes = scratch.data_ptr(), nbytes
     _lib.check(lib.cnl_conv2d_nhwc_f32(ctypes.byref(p), _stream()), "conv")
     torch.cuda.synchronize()
     if hints:
@@ -102,6 +109,31 @@ CASES = [
     (2, 512, 2, 2, 256, 1, 1, CNL_UPSAMPLE_OUT_ADD, True),
     (2, 64, 40, 40, 256, 3, 1, CNL_RELU, False),           # > 512 tiles -> 128x128 config, many K chunks
 ]
+
+
+
+@pytest.mark.parametrize("case", [(1, 512, 16, 16, 512, 3, 1, 16, True), (1, 256, 32, 32, 256, 3, 1, 9, False), (2, 256, 17, 9, 96, 3, 2, 4, True),
+                                  (1, 512, 16, 16, 256, 1, 1, 4, False), (3, 128, 8, 8, 130, 3, 1, 7, True), (1, 128, 12, 12, 64, 3, 1, 64, False)],
+                         ids=lambda c: "N{}c{}_{}x{}_o{}k{}s{}_split{}r{}".format(*[int(v) for v in c]))
+def test_split_reduction_matches_cpu_and_unsplit(case):
+    """cnl_conv_params.splitk (small grids: the reduction of an output tile split over several workgroups, partial sums added in slice
+    order by splitk_reduce_kernel): the path's 1e-4 tolerance against conv2d on the CPU, fp32-grade agreement with the unsplit launch,
+    bias / residual / ReLU / max |y| hand-over applied once by the reduce, deterministic; without the hints the launch runs unsplit."""
+    N, Cin, H, W, Cout, K, stride, split, use_res = case
+    x, w, b = mk(N, Cin, H, W, Cout, K, seed=Cin + Cout + split)
+    ho, wo = (H + 2 * ((K - 1) // 2) - K) // stride + 1, (W + 2 * ((K - 1) // 2) - K) // stride + 1
+    res = torch.randn(N, Cout, ho, wo, generator=torch.Generator().manual_seed(3)) if use_res else None
+    want = ref_conv(x, w, b, stride=stride, flags=CNL_RELU, residual=res)
+    y0, k0, m0 = run_conv(x, w, b, stride=stride, flags=CNL_RELU, residual=res, hints=True)
+    y1, k1, m1 = run_conv(x, w, b, stride=stride, flags=CNL_RELU, residual=res, hints=True, splitk=split)
+    y2, _, _ = run_conv(x, w, b, stride=stride, flags=CNL_RELU, residual=res, hints=True, splitk=split)
+    assert k1 == 5 and k0 == (5 if K == 3 else 2)            # a small 1x1 takes the fp16-split kernel only when it is split
+    torch.testing.assert_close(y1, want, rtol=RTOL, atol=ATOL)
+    assert float((y1 - y0).abs().max()) <= 4e-6 * float(want.abs().max())              # fp32-grade: other summation grouping / kernel
+    assert torch.equal(y1, y2)                                                          # slice order is fixed
+    assert torch.equal(m1, y1.abs().amax(dim=(1, 2, 3)))
+    y3 = run_conv(x, w, b, stride=stride, flags=CNL_RELU, residual=res, splitk=split)   # no hints -> fp32 matrix cores, unsplit
+    torch.testing.assert_close(y3, want, rtol=RTOL, atol=ATOL)
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "N{}c{}_{}x{}_o{}k{}s{}f{}r{}".format(*[int(v) for v in c]))

@@ -275,6 +275,31 @@ def test_forward_from_two_threads_on_the_default_stream():
             assert torch.equal(got[i][k], want[i][k]), (i, k)
 
 
+@pytest.mark.parametrize("cfg,shape", [("resnet34_simple.yaml", (1, 3, 512, 512)), ("resnet34_fpn.yaml", (2, 3, 256, 256)),
+                                       ("tracking_resnet34_fpn.yaml", (1, 3, 224, 416))])
+def test_split_small_latency_mode_matches_oracle(cfg, shape):
+    """KernelOptions(split_small=True): the small maps of a small batch run as split-reduction direct convs.  Same parity bars as the
+    default plan: outputs within 1e-4 of the CPU oracle, features fp32-grade against float64; and the split launches are really there."""
+    model, sd = build(cfg, split_small=True, reuse_buffers=False)
+    x = recipes.images(77, shape)
+    ref = ref_cpu.forward(sd, x, sigmoid=False)
+    enc = model.get_encoded_outputs(x.cuda())
+    for name, r in ref.items():
+        torch.testing.assert_close(enc[name].cpu(), r, rtol=TOL, atol=TOL)
+    plan = model._engine.plan_for(x.cuda(), sigmoid=False)
+    what = [L.what for L in plan.launches]
+    assert sum("[split x" in w for w in what) >= 5, what
+    assert not any("[split x" in w for w in what if w.startswith("heads.") and "out_conv" not in w and shape[2] >= 512)
+    _, _, neck64, heads64 = ref_cpu.forward_float64(sd, x, sigmoid=False, return_intermediates="heads")
+    nb, _, _, nc, nup = plan.neck_out
+    neck = plan.tensor(nb)[..., :nc].permute(0, 3, 1, 2).cpu()
+    if nup:
+        neck = torch.nn.functional.interpolate(neck, scale_factor=2, mode="nearest")
+    assert float((neck.double() - neck64).abs().max() / neck64.abs().max()) <= 5e-5
+    # a batch large enough to fill the chip takes the default kernels under the same option
+    model.get_encoded_outputs(recipes.images(78, (16,) + tuple(shape[1:])).cuda()) if shape[2] <= 256 else None
+
+
 def test_in_place_weight_edit_is_noticed_without_refresh():
     """model.backbone.load_state_dict(...) / in-place edits after the first forward must not run on stale packed weights."""
     model, sd = build("resnet34_simple.yaml")

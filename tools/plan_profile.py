@@ -19,8 +19,9 @@ def main():
     ap.add_argument("--size", type=int, nargs=2, default=[512, 512])
     ap.add_argument("--algo", default="auto")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--split-small", action="store_true")
     a = ap.parse_args()
-    model = bench.build_model(a.config, algo=a.algo)
+    model = bench.build_model(a.config, algo=a.algo, split_small=a.split_small)
     x = torch.rand(a.batch, 3, *a.size, device="cuda")
     rows, plan = bench.conv_kernel_profile(model, x, reps=a.reps)
     tot = sum(r[2] for r in rows)
