@@ -507,6 +507,21 @@ def main():
                         del m2
                     except Exception as e:      # reported, never fatal: `value` above is the measurement
                         result["variants"][algo] = {"error": repr(e)}
+            if not args.no_also:
+                # one image (BASELINE C0 shape when the bench runs C1): forward + decode, back to back, default plan and latency mode
+                try:
+                    lat = {}
+                    for name, opts in (("default", {}), ("split_small", {"split_small": True})):
+                        m3 = build_model(args.config, **opts)
+                        x1 = x[:1]
+                        gather3 = m3.gather_tracking2d if tracking else m3.gather_detection2d
+                        with torch.no_grad():
+                            lat[name] = round(gpu_ms_back_to_back(lambda: gather3(m3(x1), num_detections=args.k), calls=30, rounds=3), 4)
+                        del m3
+                    result["latency_ms_N1"] = dict(lat, note=f"1 x 3 x {H} x {W}, forward + decode, 30 calls back to back; split_small = KernelOptions(split_small=True) "
+                                                             "(reduction of the small-grid convs split over workgroups; off by default)")
+                except Exception as e:
+                    result["latency_ms_N1"] = {"error": repr(e)}
             if not args.no_also and args.config == "simple" and (B, H, W) == (32, 512, 512):
                 result["also"] = []
                 for cfg, b_, h_, w_, k_ in (("fpn", 64, 512, 512, 100), ("tracking", 32, 608, 1088, 100)):
