@@ -1,6 +1,7 @@
 """PCIe-inclusive rate of the path when frames arrive as HOST uint8 buffers (the boundary itself takes device tensors):
-pinned uint8 HWC frames -> H2D -> cnl_normalize_u8_nhwc_f32 -> forward -> gather_detection2d, C1 shape (32 x 512 x 512).
-Reported: images/s with the copy serialised on the compute stream, and with the next batch's copy on a second stream."""
+pinned uint8 HWC frames -> H2D -> CenterNet.forward_uint8 (A.Normalize inside the stem kernel: no fp32 image in HBM) -> gather_detection2d,
+C1 shape (32 x 512 x 512); `--hd`: 1080 x 1920 frames, resized on the device to 512 x 512 (cnl_resize_bilinear_u8, cv2 INTER_LINEAR rule) first.
+Reported: images/s with the frames resident, with the copy serialised on the compute stream, and with the next batch's copy on a second stream."""
 import os
 import sys
 import time
@@ -13,15 +14,15 @@ sys.path.insert(0, os.path.join(ROOT, "centernet-lightning_amd"))
 import bench  # noqa: E402
 import centernet_lightning_amd as cl  # noqa: E402
 
-B, H, W, STEPS = 32, 512, 512, 20
+HD = "--hd" in sys.argv
+B, H, W, STEPS = 32, (1080 if HD else 512), (1920 if HD else 512), 20
 torch.manual_seed(0)
 model = bench.synthetic_weights_(cl.build_centernet(os.path.join(ROOT, "centernet-lightning_amd", "configs", "resnet34_simple.yaml"))).cuda()
 host = [torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
 
 
 def step_dev(u8):
-    x = model.preprocess_uint8(u8)
-    return model.gather_detection2d(model(x))
+    return model.gather_detection2d(model.forward_uint8(u8, resize=(512, 512)) if HD else model.forward_uint8(u8))
 
 
 with torch.no_grad():
