@@ -58,7 +58,7 @@ PROFILED_TRAFFIC = {
     ("simple", 32, 512, 512, "winograd_f32"): (305.9e6, "profiles/r02_pmc_traffic_c1_default.txt"),
 }
 # decode stage 1 / stage 2 at C1 (same profile): HBM MB per launch and rocprofv3 average duration
-PROFILED_DECODE = {("simple", 32, 512, 512): {"peaks_c8_kernel": {"traffic_MB": 190.5, "avg_us": 35.5}, "topk_kernel": {"traffic_MB": 3.1, "avg_us": 11.3},
+PROFILED_DECODE = {("simple", 32, 512, 512): {"peaks_c8_kernel": {"traffic_MB": 172.1, "avg_us": 34.6}, "topk_kernel": {"traffic_MB": 3.1, "avg_us": 11.3},
                                              "source": "profiles/r02_pmc_traffic_c1_default.txt, profiles/r02_kernel_stats_c1_default.csv, profiles/r02_decode_variants.txt — not measured by this run"}}
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 KIND_NAMES = {"winograd_f4": "cnl_wino8::winograd8_kernel (Winograd F(4x4,3x3); fp32 operands scaled per image by a power of two and split into 2 fp16 pieces, "

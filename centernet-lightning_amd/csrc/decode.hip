@@ -216,7 +216,13 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
 #pragma unroll
                 for (int v = 0; v < 8; ++v) ct[i][p][v] = NINF;
         const int y_end = min(y0 + PK8_R, a.H);
-        for (int yy = y0 - P; yy < y_end + P; ++yy) {
+        // Even strips walk down, odd strips walk up: two neighbouring strips then read the two rows they share (each other's halo) at the
+        // same moment — the start for one pair of neighbours, the end for the other — and the second read hits L2 instead of fetching the
+        // row again (the ring is symmetric in the row order).
+        const int dir = (by & 1) ? -1 : 1;
+        const int rows = y_end - y0 + 2 * P;
+        for (int step = 0; step < rows; ++step) {
+            const int yy = dir > 0 ? y0 - P + step : y_end + P - 1 - step;
 #pragma unroll
             for (int i = 0; i < 2 * P; ++i)
 #pragma unroll
@@ -255,8 +261,8 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
                     hm[2 * P][p][v] = h;
                     ct[P][p][v] = t[p + P][v];
                 }
-            const int yo = yy - P;                    // row whose (2P+1)-window is now complete
-            if (yo >= y0) {
+            const int yo = yy - dir * P;              // row whose (2P+1)-window is now complete
+            if (step >= 2 * P) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     float bv = 0.f;
