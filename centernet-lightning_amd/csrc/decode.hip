@@ -471,10 +471,30 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     unsigned long long* win = reinterpret_cast<unsigned long long*>(hist);      // [k] winners of the fast path (hist is unused there)
     for (int i = tid; i < FAST_CAP + 8; i += TK_THREADS) cand[i] = 0ull;        // zero padding: never greater than a candidate
     if (tid == 0) sh_count = 0u;
+    TK_STAMP(11);
     unsigned tmax = 0u;
-    const bool kch_pow2 = (KCH & (KCH - 1)) == 0;            // then i / KCH, i % KCH are a shift and a mask (KCH = 16 at 128 x 128)
+    // Maps of at most 16 x 1024 pixels (128 x 128): the thread's 16 keys (indices tid + 1024 j) simply stay in registers — no LDS copy, no
+    // index arithmetic; the fallback re-reads the scores from memory.  Larger maps: keys in LDS ([owner thread][odd pitch]) when they fit.
+    const bool in_regs = KCH <= 16;
+    const bool klds = a.keys_in_lds && !in_regs;
+    unsigned kreg[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) kreg[j] = 0u;
+    if (in_regs) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = tid + j * TK_THREADS < a.HW ? sc[tid + j * TK_THREADS] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (tid + j * TK_THREADS < a.HW) {
+                kreg[j] = score_key(v[j]);
+                tmax = tmax > kreg[j] ? tmax : kreg[j];
+            }
+        }
+    }
+    const bool kch_pow2 = (KCH & (KCH - 1)) == 0;            // then i / KCH, i % KCH are a shift and a mask
     const int kch_sh = 31 - __builtin_clz((unsigned)KCH);
-    for (int i = tid; i < a.HW; i += 16 * TK_THREADS) {      // sixteen independent loads in flight per thread, then the bookkeeping
+    for (int i = tid; !in_regs && i < a.HW; i += 16 * TK_THREADS) {      // sixteen independent loads in flight per thread, then the bookkeeping
         float v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = i + j * TK_THREADS < a.HW ? sc[i + j * TK_THREADS] : 0.f;
@@ -483,7 +503,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
             const int ii = i + j * TK_THREADS;
             if (ii < a.HW) {
                 const unsigned key = score_key(v[j]);
-                if (a.keys_in_lds) {
+                if (klds) {
                     const int own = kch_pow2 ? (ii >> kch_sh) : ii / KCH;
                     lds_keys[own * KST + (ii - own * KCH)] = key;
                 }
@@ -494,6 +514,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     {
         // wave bitonic sort of the 64 thread maxima, descending.  Exchange distances 1 / 2: DPP quad permutes (one VALU instruction),
         // 4 / 8 / 16: ds_swizzle xor masks, 32: one bpermute.
+        TK_STAMP(9);
         unsigned v = tmax;
 #define TK_EXCH(st_) ((st_) == 1 ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false)                        \
                     : (st_) == 2 ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false)                        \
@@ -513,6 +534,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
 #undef TK_EXCH
         const unsigned vm = __shfl(v, (a.k + TK_THREADS / 64 - 1) / (TK_THREADS / 64) - 1);
         if (lane == 0) wave_tot[wave] = vm;
+        TK_STAMP(10);
     }
     __syncthreads();                                         // + every key is in LDS, cand is zero, the counter is reset
     TK_STAMP(1);
@@ -524,9 +546,14 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         // compaction of the elements >= T_lo into cand[] — in ANY order: the winners are placed by rank of the (key, ~index) pair below.
         // Thread t owns the contiguous index range [t*KCH, (t+1)*KCH); one LDS atomic per wave and round reserves the wave's slots.
         const int j0 = tid * KCH, j1 = min(j0 + KCH, a.HW);
-        if (a.keys_in_lds && KCH <= 64) {
+        if (in_regs || (klds && KCH <= 64)) {
             unsigned long long qual = 0ull;                  // bit c: the thread's c-th element passes the bound
-            for (int c0 = 0; c0 < KCH; c0 += 8) {            // eight independent LDS reads at a time
+            if (in_regs) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (tid + j * TK_THREADS < a.HW && kreg[j] >= Tlo) qual |= 1ull << j;
+            }
+            for (int c0 = 0; !in_regs && c0 < KCH; c0 += 8) {            // eight independent LDS reads at a time
                 unsigned kk[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) kk[j] = (c0 + j < KCH && j0 + c0 + j < a.HW) ? lds_keys[tid * KST + c0 + j] : 0u;
@@ -546,13 +573,22 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                     const int c = __builtin_ctzll(qual);
                     qual &= qual - 1;
                     const unsigned pos = base + (unsigned)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
-                    if (pos < (unsigned)FAST_CAP)
-                        cand[pos] = ((unsigned long long)lds_keys[tid * KST + c] << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(j0 + c));
+                    unsigned key, idx;
+                    if (in_regs) {
+                        key = kreg[0];
+#pragma unroll
+                        for (int j = 1; j < 16; ++j) key = c == j ? kreg[j] : key;
+                        idx = (unsigned)(tid + c * TK_THREADS);
+                    } else {
+                        key = lds_keys[tid * KST + c];
+                        idx = (unsigned)(j0 + c);
+                    }
+                    if (pos < (unsigned)FAST_CAP) cand[pos] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - idx);
                 }
             }
         } else {                                             // maps beyond the LDS budget: plain per-element reservation
             for (int i = j0; i < j1; ++i) {
-                const unsigned key = a.keys_in_lds ? lds_keys[tid * KST + (i - j0)] : score_key(sc[i]);
+                const unsigned key = klds ? lds_keys[tid * KST + (i - j0)] : score_key(sc[i]);
                 if (key >= Tlo) {
                     const unsigned pos = atomicAdd(&sh_count, 1u);
                     if (pos < (unsigned)FAST_CAP) cand[pos] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
@@ -605,7 +641,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         const int per = nbins / TK_THREADS;               // bins per thread in the scan: 4 or 1
         for (int i = tid; i < nbins; i += TK_THREADS) hist[i] = 0;
         __syncthreads();
-        if (a.keys_in_lds) {
+        if (klds) {
             // keys live in LDS as [thread][KST] (thread t owns indices t*KCH .. t*KCH+KCH-1; the odd row pitch KST keeps both this
             // loop and the ordered compaction below free of bank conflicts)
             for (int j = 0; j < KCH; ++j) {
@@ -664,7 +700,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     const int i0 = tid * CH, i1 = min(i0 + CH, a.HW);
     unsigned cnt = 0;
     for (int i = i0; i < i1; ++i) {
-        const unsigned key = a.keys_in_lds ? lds_keys[tid * KST + (i - i0)] : score_key(sc[i]);
+        const unsigned key = klds ? lds_keys[tid * KST + (i - i0)] : score_key(sc[i]);
         cnt += key > T ? 0x10000u : 0u;
         cnt += key == T ? 1u : 0u;
     }
@@ -703,7 +739,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     for (int i = tid; i < a.KP; i += TK_THREADS) cand[i] = 0ull;   // padding sorts last
     __syncthreads();
     for (int i = i0; i < i1; ++i) {
-        const unsigned key = a.keys_in_lds ? lds_keys[tid * KST + (i - i0)] : score_key(sc[i]);
+        const unsigned key = klds ? lds_keys[tid * KST + (i - i0)] : score_key(sc[i]);
         const unsigned long long comp = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
         if (key > T) {
             cand[pos_gt++] = comp;
