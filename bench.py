@@ -401,6 +401,8 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the f2 / f32 legs")
     ap.add_argument("--no-also", action="store_true", help="skip the short C2 / C4 lines")
     ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--collate-probe", action="store_true", help="N=1 only: also time the steps with the RCCL all-gather of the detections forced "
+                    "through a world-size-1 process group (side stream, one step behind) — the N>1 data path on the one GPU a box has")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer conv table to stderr")
     args = ap.parse_args()
 
@@ -507,6 +509,30 @@ def main():
                         del m2
                     except Exception as e:      # reported, never fatal: `value` above is the measurement
                         result["variants"][algo] = {"error": repr(e)}
+            if args.collate_probe:
+                try:
+                    import socket
+                    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+                    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+                    forced = cl.Collator(force=True)
+                    el_f = timed(model, x, tracking, args.k, args.warmup, args.steps, forced, sync)
+                    el_0 = timed(model, x, tracking, args.k, args.warmup, args.steps, cl.Collator(), sync)
+                    with torch.no_grad():
+                        o = model(x)
+                        dets = model.gather_tracking2d(o, num_detections=args.k) if tracking else model.gather_detection2d(o, num_detections=args.k)
+                        cts = []
+                        for _ in range(10):
+                            sync(); t0 = time.perf_counter()
+                            forced.result(forced.submit(dets)); sync()
+                            cts.append(time.perf_counter() - t0)
+                    cts.sort()
+                    result["collate_probe"] = {"ms_per_step_with_forced_rccl_gather": round(el_f / args.steps * 1e3, 3), "ms_per_step_without": round(el_0 / args.steps * 1e3, 3),
+                                               "collate_ms_synchronous": round(cts[len(cts) // 2] * 1e3, 4),
+                                               "note": "world-size-1 nccl (= RCCL) group, Collator(force=True): pack kernel -> all_gather_into_tensor on the side stream "
+                                                       "behind an event -> unpack one step later; the same code path N > 1 ranks take, minus the wire"}
+                    dist.destroy_process_group()
+                except Exception as e:
+                    result["collate_probe"] = {"error": repr(e)}
             if not args.no_also:
                 # one image (BASELINE C0 shape when the bench runs C1): forward + decode, back to back, default plan and latency mode
                 try:
@@ -542,10 +568,17 @@ def main():
                     result["accuracy"] = {"error": repr(e)}
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(model, args.config, tracking, args.k, H, W, dec["p50_ms_without_sigmoid"])
-        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes out last: RCCL writes a version banner through C stdio, which a pipe would otherwise deliver after Python's line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
