@@ -872,6 +872,7 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
         Peak8Args q;
         q.CG8 = p->C / 8;
         q.RUNS = PK8_THREADS / q.CG8;
+        if (q.RUNS > 32) q.RUNS = 32;                      // blocks at most 128 pixels wide: R x TW x 8 bytes of LDS stays small for any C
         const int runs_w = (p->W + 3) / 4;
         if (q.RUNS > runs_w) q.RUNS = runs_w;
         q.TW = q.RUNS * 4;

@@ -86,7 +86,7 @@ def _sweep_cases():
             nms = int(rng.choice([1, 3, 5]))
             k = int(rng.integers(1, min(H * W, 400) + 1))
             cases.append((N, C, H, W, k, nms))
-    cases += [(40, 8, 48, 20, 33, 3), (20, 16, 70, 64, 1024, 3), (1, 80, 152, 272, 1000, 3), (2, 8, 4, 8, 32, 7)]
+    cases += [(40, 8, 48, 20, 33, 3), (20, 16, 70, 64, 1024, 3), (1, 80, 152, 272, 1000, 3), (2, 8, 4, 8, 32, 7), (1, 8, 6, 1500, 200, 3), (2, 16, 3, 700, 64, 5)]
     return cases
 
 
