@@ -805,7 +805,11 @@ class Plan:
         # ---- heads ----
         self.head_features = {}
         first = {}
-        if Wt.fused_first is not None:
+        # the first blocks of all heads run as ONE launch writing one wide buffer — unless 32 images of that buffer (BASELINE's batch per
+        # GPU) would cross the kernels' 4 GiB addressing (C4: 32 x 152 x 272 x 768 floats = 4.06 GB): then they run per head, which costs
+        # two more launches and nothing else (a Winograd work item is one cout block either way) and lets such a batch stay in ONE plan
+        # instead of two sub-batches.  Decided per IMAGE, never by N: a shard and the full batch take the same launches.
+        if Wt.fused_first is not None and 32 * oh_ * ow_ * Wt.fused_first.cout * 4 <= ADDRESS_LIMIT:
             tot = Wt.fused_first.cout
             fb = self._buf(N, oh_, ow_, tot)
             self._conv(Wt.fused_first, neck, nh, nw, nc, fb, tot, CNL_RELU | neck_up, what="heads.*.block_1 (fused)")
@@ -959,8 +963,8 @@ class Engine:
 
     def max_batch(self, H, W):
         """Largest batch whose biggest activation tensor stays below the 4 GiB buffer-addressing limit of the kernels."""
-        widest = max(64, sum(b[0].cout for b in self.weights.head_blocks.values() if b) if self.weights.fused_first is not None else 0,
-                     max((l.cout for b in self.weights.head_blocks.values() for l in b), default=64))
+        widest = max(64, max((l.cout for b in self.weights.head_blocks.values() for l in b), default=64))      # (the fused first head
+                                                                                                          # blocks fall back to per-head launches)
         per_image = max((H // 2) * (W // 2) * 64, (H // 4) * (W // 4) * widest) * 4
         return max(1, ADDRESS_LIMIT // per_image)
 
