@@ -476,6 +476,8 @@ class Plan:
             return k == 5
 
         slot_of, pairs, passes, reports = {}, [], [], set()       # reports: launches that run an fp16-split kernel
+        shared = []                                               # launches that take the slot of their group's explicit pass
+        own_pass = {}                                             # input buffer -> fp16-split Winograd launches without a reporting producer
         for L in self.launches:         # plan order: a direct conv only reports max |y| if it got its own hint
             if not isinstance(L.args, ConvParams):
                 continue
@@ -490,15 +492,24 @@ class Plan:
                 pairs.append((P, L, slot_of.setdefault(id(P), len(slot_of))))
                 reports.add(id(L))
             elif is_wino5:
-                reports.add(id(L))      # makes its own pass over the input
+                reports.add(id(L))      # makes its own pass over the input ...
+                if id(x) not in unsafe and len(ws) <= 1:
+                    own_pass.setdefault((id(x), L.args.x, L.args.Cin, L.args.ldx), []).append(L)      # ... unless several launches read the same tensor (below)
             elif L.args.KH == 3:
                 passes.append((L, slot_of.setdefault(id(L), len(slot_of))))
                 reports.add(id(L))
+        # a tensor read by several such launches (the per-head first blocks behind an fp32-kernel neck layer): ONE explicit pass, shared
+        for group in own_pass.values():
+            if len(group) >= 2:
+                passes.append((group[0], slot_of.setdefault(("shared", id(group[0].keep[0])), len(slot_of))))
+                shared.extend(group[1:])
         # one float per (tensor, image): an image's scale must not depend on its batch neighbours
         self.absmax = torch.zeros((max(len(slot_of), 1), self.N), device=self.device, dtype=torch.float32) if slot_of else None
         for P, L, i in pairs:
             P.args.y_absmax = self.absmax.data_ptr() + 4 * i * self.N
             L.args.x_absmax = self.absmax.data_ptr() + 4 * i * self.N
+        for L in shared:
+            L.args.x_absmax = self.absmax.data_ptr() + 4 * slot_of[("shared", id(L.keep[0]))] * self.N
         for L, i in passes:
             a = L.args
             L.args.x_absmax = self.absmax.data_ptr() + 4 * i * self.N

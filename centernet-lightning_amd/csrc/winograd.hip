@@ -128,7 +128,7 @@ static int wino_choice(const cnl_conv_params* p) {
         return v;
     }
     if (p->algo == CNL_ALGO_F32 || p->Cin % 16) return 2;
-    if (items_per_image >= 8 && (p->Cin >= 128 || p->Cout >= 512)) {
+    if (items_per_image >= 8 && (p->Cin >= 128 || p->Cout >= 256)) {      // (Cin 64 -> 256 / 512 / 768: the first head blocks, per head or fused)
         const long long area = (long long)H * W;
         if (p->algo == CNL_ALGO_F4 && p->Cin >= 256 && area >= 64 * 64 && cnl_wino8_eligible(p)) {
             // F(4x4): 32x16-pixel items.  Measured against kernel 5 / 6 on one box (profiles/r02_winograd8_variants.txt): 0.89-0.93 of

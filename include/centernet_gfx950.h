@@ -157,7 +157,7 @@ int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);
  * (BN-folded) weights; flags: CNL_RELU only (upsample / sigmoid variants stay on cnl_conv2d_nhwc_f32). Cin % 8 == 0.
  *
  * Several multiplier arrays serve this entry point, chosen from the layer SHAPE and p->algo (never the batch size): the fp32 matrix
- * core (csrc/winograd2.hip), or — where the channel loop is long (Cin >= 128 or Cout >= 512, Cin % 16 == 0) — the fp16 matrix core
+ * core (csrc/winograd2.hip), or — where the channel loop is long (Cin >= 128 or Cout >= 256, Cin % 16 == 0) — the fp16 matrix core
  * fed with a two-way fp16 split of both fp32 operands under a per-image power-of-two scale (three cross terms, fp32
  * accumulation: csrc/winograd5.hip, winograd6.hip; measured error at or below the fp32 matrix core's, half-precision rate = 16x), as
  * F(2x2,3x3) or, under CNL_ALGO_F4 on large maps that 32x16-pixel work items tile well, F(4x4,3x3) (csrc/winograd8.hip).
