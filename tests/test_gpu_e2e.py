@@ -496,3 +496,27 @@ def test_torchscript_export_traces_saves_and_replays_bit_equal(tmp_path):
     assert r.returncode == 0 and "fresh-process replay ok" in r.stdout, r.stderr[-2000:]
     with pytest.raises(NotImplementedError):
         cl.export_onnx(model, "x.onnx")
+
+
+def test_bench_contract_one_json_line():
+    """bench.py's driver contract on a tiny workload: the LAST stdout line is the one JSON object, with the contract's keys, the `roofline`
+    block measured in the run and `cpu_baseline` absent only because this invocation switches it off."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "2", "--height", "128",
+                          "--width", "128", "--no-cpu-baseline", "--no-variants", "--no-accuracy"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    d = json.loads(lines[-1])
+    assert sum(ln.lstrip().startswith("{") for ln in lines) == 1
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "decode", "decode_p50_ms", "decode_gpu_ms", "latency_ms_N1"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "images/s" and d["value"] > 0 and abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3e-3)) < 0.02 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("mfma", "hbm") and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["decode"]["gpu_ms"] > 0 and set(d["latency_ms_N1"]) >= {"default", "split_small"}
