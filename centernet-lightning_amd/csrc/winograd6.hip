@@ -49,6 +49,8 @@ struct Args {
     unsigned x_bytes, u_bytes, y_bytes, r_bytes;
     unsigned flags;
     int order;                        // work-item order (see W6_SETUP)
+    int SW;                           // STACK: W + 2 = image pitch of the virtual row of images
+    unsigned mg_sw, sh_sw;            // STACK: magic division by SW (n < 2^31)
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -152,6 +154,25 @@ __device__ __forceinline__ void xop(Xf& s, const int set, const int P, const int
     }
 }
 
+// n / d for n < 2^31 with host-computed (magic, shift); shift == 0xFF encodes d == 1
+__device__ __forceinline__ unsigned fast_div6(unsigned n, unsigned magic, unsigned shift) { return shift == 0xFFu ? n : (__umulhi(n, magic) >> shift); }
+__device__ __forceinline__ float pow2_scale_v(float mx4) {        // the power of two S with mx4 S in [2^13, 2^14); 1 for 0 / Inf / NaN
+    float S = 1.f;
+    if (mx4 > 0.f && mx4 < __builtin_inff()) {
+        int e;
+        (void)__builtin_frexpf(mx4, &e);
+        e = 14 - e;
+        S = __builtin_ldexpf(1.f, e < -100 ? -100 : (e > 100 ? 100 : e));
+    }
+    return S;
+}
+
+// STACK: the N images of the launch lie SIDE BY SIDE in one virtual row, W + 2 columns apart (two zero columns between neighbours — the
+// zero padding both of them need), and the 16-pixel blocks tile that row: a 34-wide map then costs 36 columns per image instead of 48.
+// A work item may span two images, so the image (and with it the per-image scale, the addresses and the max |y| slot) is a property of
+// the tile column / patch slot instead of the item; every tile is still computed from its own 4x4 patch in the same order, so the
+// results are bit-identical to the plain layout's.  Tiles inside a gap read both neighbours and are never stored.
+template <bool STACK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void winograd6_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sV = smem;                                  // [4 waves][4 positions][3 pieces][64 tiles][16 ci] bf16
@@ -192,6 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float omax = 0.f;          // running max |y| of this lane's stores of the current item
 
     int n, y0, x0, n0;
+    int ne_n = 0;              // STACK: image of this thread's epilogue tile column, for the item set up last
     unsigned p_off[3], u_voff;
     float bias_n[4];           // bias of the item set up last (the next one, from the epilogue's prefetch on)
 #define W6_SETUP(item_)                                                                                          \
@@ -212,22 +234,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int s_ = i * 256 + tid;              /* 16-byte slot of the patch image: (py*4 + quad)*PWP + px */ \
             const int rowq_ = s_ / PWP, pxx_ = s_ - rowq_ * PWP;                                                 \
             const int py_ = rowq_ >> 2, q_ = rowq_ & 3;                                                          \
-            const int iy_ = y0 - 1 + py_, ix_ = x0 - 1 + pxx_;                                                   \
-            const bool ok_ = py_ < PH && pxx_ < PW && (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W; \
+            const int iy_ = y0 - 1 + py_;                                                                        \
+            int ix_ = x0 - 1 + pxx_, ni_ = n;                                                                    \
+            bool okx_ = (unsigned)ix_ < (unsigned)a.W;                                                           \
+            if constexpr (STACK) {                  /* virtual column -> (image, column); gap columns read zeros */ \
+                ni_ = ix_ >= 0 ? (int)fast_div6((unsigned)ix_, a.mg_sw, a.sh_sw) : 0;                            \
+                const int vx_ = ix_;                                                                             \
+                ix_ = vx_ - ni_ * a.SW;                                                                          \
+                okx_ = vx_ >= 0 && ni_ < a.N && ix_ < a.W;                                                       \
+            }                                                                                                    \
+            const bool ok_ = py_ < PH && pxx_ < PW && (unsigned)iy_ < (unsigned)a.H && okx_;                     \
             const int sy_ = up ? (iy_ >> 1) : iy_, sx_ = up ? (ix_ >> 1) : ix_;   /* nearest-2x upsample folded in */ \
-            p_off[i] = ok_ ? (unsigned)((((n * a.Hs + sy_) * a.Ws + sx_) * a.ldx + q_ * 4) * 4) : OOB;           \
+            p_off[i] = ok_ ? (unsigned)((((ni_ * a.Hs + sy_) * a.Ws + sx_) * a.ldx + q_ * 4) * 4) : OOB;         \
         }                                                                                                        \
         /* this lane's B fragments: cout row n0 + (lane & 31) (+ 32 for the second group), channel half hi */    \
         u_voff = (unsigned)((n0 + (lane & 31)) * 32 + hi * 16);                                                  \
-        {                                                                                                        \
-            const float mx4_ = 4.f * a.xmax[n];                                                                  \
-            S = 1.f;                                                                                             \
-            if (mx4_ > 0.f && mx4_ < __builtin_inff()) {                                                         \
-                int e_;                                                                                          \
-                (void)__builtin_frexpf(mx4_, &e_);            /* 2^(e-1) <= mx4 < 2^e */                         \
-                e_ = 14 - e_;                                                                                    \
-                S = __builtin_ldexpf(1.f, e_ < -100 ? -100 : (e_ > 100 ? 100 : e_));                             \
-            }                                                                                                    \
+        if constexpr (STACK) {                                                                                   \
+            /* the transform lane's tile column and the epilogue thread's tile column each have their own image */ \
+            const int nt_ = min((int)fast_div6((unsigned)(x0 + 2 * t_tx), a.mg_sw, a.sh_sw), a.N - 1);           \
+            S = pow2_scale_v(4.f * a.xmax[nt_]);                                                                 \
+            ne_n = (int)fast_div6((unsigned)(x0 + 2 * ((tid >> 5) & 7)), a.mg_sw, a.sh_sw);                      \
+            inv_n = 1.f / (pow2_scale_v(4.f * a.xmax[min(ne_n, a.N - 1)]) * Su);                                 \
+        } else {                                                                                                 \
+            S = pow2_scale_v(4.f * a.xmax[n]);                                                                   \
             inv_n = 1.f / (S * Su);                                                                              \
         }                                                                                                        \
         /* bias of this thread's two epilogue columns: requested now, used after the chunk loop */               \
@@ -386,8 +415,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // four rows meet through LDS, one PAIR of cout groups per pass ([4 i][2 c][2 cout groups][32 tiles][32 co] = the 64 KB region) ----
         float* sQ = reinterpret_cast<float*>(smem);
         const int co = tid & 31;
-        const int en = n, ey0 = y0, ex0 = x0, en0 = n0;        // this item's coordinates (the setup below moves on to the next)
-        const bool full = (y0 + 8 <= a.H) && (x0 + 16 <= a.W) && (n0 + BN <= a.Cout);
+        const int en = STACK ? ne_n : n, ey0 = y0, en0 = n0;   // this item's coordinates (the setup below moves on to the next)
+        const int ex0 = STACK ? x0 - ne_n * a.SW : x0;         // STACK: this thread's tile column in its own image's coordinates
+        const bool full = !STACK && (y0 + 8 <= a.H) && (x0 + 16 <= a.W) && (n0 + BN <= a.Cout);
+        const bool img_ok = !STACK || ne_n < a.N;
         const float bv[4] = {bias_n[0], bias_n[1], bias_n[2], bias_n[3]};
         const float inv = inv_n;
         const unsigned next = item + gridDim.x;
@@ -413,7 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                         for (int dx = 0; dx < 2; ++dx) {
-                            ok[g][it][dy][dx] = full || (col_ok && oy + dy < a.H && ox + dx < a.W);
+                            ok[g][it][dy][dx] = full || (img_ok && col_ok && oy + dy < a.H && ox + dx < a.W);
                             rv[g][it][dy][dx] = 0.f;
                         }
                     r_voffs[g][it] = r_voff;
@@ -474,9 +505,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         if (a.ymax) {          // max |y| of this item into its image's slot: one atomic per wave and item (no return value awaited)
+            if constexpr (STACK) {     // a half wave = one tile column = one image
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
-            if (lane == 0 && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
+                for (int o = 16; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
+                if ((lane & 31) == 0 && img_ok && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
+            } else {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
+                if (lane == 0 && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
+            }
             omax = 0.f;
         }
         if (!more) break;
@@ -533,7 +570,18 @@ int cnl_wino6_launch(const cnl_conv_params* p, const void* u5, float* scal, void
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
     a.CC = p->Cin / 16;
     a.nb = (p->Cout + BN - 1) / BN; a.bx = (a.W + 15) / 16; a.by = (a.H + 7) / 8;
-    const long long blocks = (long long)p->N * a.by * a.bx * a.nb;
+    // images side by side (STACK, see the kernel): where the 16-pixel blocks pad the map's width by more than the two gap columns cost
+    a.SW = a.W + 2; a.mg_sw = 0; a.sh_sw = 0xFFu;
+    const long long bx_stack = ((long long)p->N * a.SW + 15) / 16;
+    const bool stack = upf == 1 && (a.W & 1) == 0 && p->N >= 2 && (long long)p->N * a.SW < (1ll << 30) && bx_stack * 100 <= (long long)p->N * a.bx * 92;
+    if (stack) {
+        unsigned sft = 0;
+        while ((1ull << sft) < (unsigned)a.SW) ++sft;               // ceil(log2 SW); SW >= 4
+        a.mg_sw = (unsigned)(((1ull << (31 + sft)) / (unsigned)a.SW) + 1);
+        a.sh_sw = sft - 1;
+        a.bx = (int)bx_stack;
+    }
+    const long long blocks = (long long)(stack ? 1 : p->N) * a.by * a.bx * a.nb;
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: grid too large");
     a.blocks = (int)blocks;
     const unsigned long long xb = (((unsigned long long)p->N * p->H_in * p->W_in - 1) * p->ldx + p->Cin) * 4ull;
@@ -553,10 +601,13 @@ int cnl_wino6_launch(const cnl_conv_params* p, const void* u5, float* scal, void
 #endif          // pairs of cout blocks fastest (profiles/r01_winograd_variants.txt)
     static cnl::DeviceOnce once;
     int n_cu = 0;                          // persistent workgroups: one per CU, walking the work items with stride gridDim.x
-    int rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd6_kernel), LDS_BYTES, &n_cu);
+    static cnl::DeviceOnce once_stack;
+    int rc = stack ? cnl::kernel_setup(once_stack, reinterpret_cast<const void*>(&winograd6_kernel<true>), LDS_BYTES, &n_cu)
+                   : cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd6_kernel<false>), LDS_BYTES, &n_cu);
     if (rc != CNL_OK) return rc;
     if (!p->x_absmax && (rc = cnl_wino5_own_absmax(p, scal, stream)) != CNL_OK) return rc;      // winograd5.hip
     const unsigned grid = (unsigned)(blocks < (long long)n_cu ? blocks : (long long)n_cu);
-    hipLaunchKernelGGL(winograd6_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    if (stack) hipLaunchKernelGGL(winograd6_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(winograd6_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return cnl::check_launch("winograd6_kernel");
 }

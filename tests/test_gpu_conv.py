@@ -428,7 +428,7 @@ def test_maxpool_matches_cpu_bit_exact(shape):
 
 
 # ----------------------------------------------------------------------------- Winograd F(2x2,3x3) path
-def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None, algo=CNL_ALGO_AUTO, lib=None, want=None):
+def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None, algo=CNL_ALGO_AUTO, lib=None, want=None, ymax=False):
     """`want`: assert that the dispatcher reports this kernel class (2 fp32 / 5 fp16-split F(2x2) / 8 fp16-split F(4x4))."""
     lib = lib or _lib.load()
     N, Cin, Hs, Ws = x_nchw.shape
@@ -450,10 +450,16 @@ def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None, algo=CNL_ALGO_AUT
     if residual is not None:
         rd = residual.permute(0, 2, 3, 1).contiguous().cuda()
         p.residual, p.ldr = rd.data_ptr(), Cout
+    if ymax:                                                   # also hand the input's maxima over and collect the output's
+        xm = x_nchw.abs().amax(dim=(1, 2, 3)).cuda()
+        ym = torch.zeros(N, device="cuda")
+        p.x_absmax, p.y_absmax = xm.data_ptr(), ym.data_ptr()
     if want is not None:
         assert lib.cnl_conv3x3_winograd_kernel(ctypes.byref(p)) == want
     _lib.check(lib.cnl_conv3x3_winograd_f32(ctypes.byref(p), _stream()), "winograd")
     torch.cuda.synchronize()
+    if ymax:
+        return y.cpu().permute(0, 3, 1, 2), ym.cpu()
     return y.cpu().permute(0, 3, 1, 2)
 
 
@@ -535,6 +541,28 @@ def test_winograd_is_batch_invariant_across_magnitudes():
         for i in range(3):
             assert torch.equal(full[i:i + 1], run_winograd(x[i:i + 1], w, b, CNL_RELU, algo=algo)), (algo, i)
         torch.testing.assert_close(full, ref_conv(x, w, b, 1, CNL_RELU), rtol=RTOL, atol=ATOL * 300)
+
+
+@pytest.mark.parametrize("shape", [(5, 19, 34), (4, 38, 68), (7, 9, 20), (3, 8, 8), (2, 5, 40)], ids=lambda t: "N{}_{}x{}".format(*t))
+def test_winograd6_images_side_by_side_is_bit_identical_to_one_image_at_a_time(shape):
+    """winograd6_kernel<STACK>: where 16-pixel blocks pad a map's width by more than two gap columns cost, the images of a launch are laid
+    side by side (W + 2 apart) and the blocks tile that virtual row — work items then span two images.  Every tile is still computed from
+    its own patch, with its own image's scale: the batch gives bit for bit what each image gives alone (the plain layout), residual,
+    ReLU, cout tail and the per-image max |y| hand-over included; images of very different magnitude."""
+    N, H, W = shape
+    g = torch.Generator().manual_seed(N * 100 + W)
+    mags = torch.tensor([1.0, 1e-3, 300.0, 0.05, 7.0, 1e-6, 40.0])[:N].view(N, 1, 1, 1)
+    x = torch.randn(N, 128, H, W, generator=g).clamp_min(0) * mags
+    w = torch.randn(256, 128, 3, 3, generator=g) * (2.0 / (128 * 9)) ** 0.5
+    b = torch.randn(256, generator=g)
+    res = torch.randn(N, 256, H, W, generator=g) * mags
+    full = run_winograd(x, w, b, CNL_RELU, residual=res, algo=CNL_ALGO_FORCE + 6, want=5)
+    hinted, ym = run_winograd(x, w, b, CNL_RELU, residual=res, algo=CNL_ALGO_FORCE + 6, ymax=True)
+    assert torch.equal(hinted, full) and torch.equal(ym, full.abs().amax(dim=(1, 2, 3)))
+    for i in range(N):
+        one = run_winograd(x[i:i + 1], w, b, CNL_RELU, residual=res[i:i + 1], algo=CNL_ALGO_FORCE + 6)
+        assert torch.equal(full[i:i + 1], one), i
+    torch.testing.assert_close(full, ref_conv(x, w, b, 1, CNL_RELU, res), rtol=RTOL, atol=ATOL * 300)
 
 
 F4_CASES = [
