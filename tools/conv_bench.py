@@ -17,6 +17,8 @@ SHAPES = {
     "head256": (32, 128, 128, 256, 256, 3, 1, CNL_RELU, False),
     "headfirst": (32, 64, 64, 64, 512, 3, 1, CNL_RELU | CNL_UPSAMPLE_IN, False),
     "layer1": (32, 128, 128, 64, 64, 3, 1, CNL_RELU, False),
+    "fpnfirst": (32, 128, 128, 64, 512, 3, 1, CNL_RELU, False),
+    "c4first": (16, 152, 272, 64, 256, 3, 1, CNL_RELU, False),
     "layer1res": (32, 128, 128, 64, 64, 3, 1, CNL_RELU, True),
     "layer2": (32, 64, 64, 128, 128, 3, 1, CNL_RELU, True),
     "layer2n64": (64, 64, 64, 128, 128, 3, 1, CNL_RELU, True),
