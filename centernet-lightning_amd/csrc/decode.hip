@@ -453,7 +453,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     extern __shared__ unsigned lds_keys[];          // [HW] when a.keys_in_lds
     __shared__ unsigned hist[4096];
     __shared__ unsigned wave_tot[TK_THREADS / 64];
-    __shared__ unsigned long long cand[1024];
+    __shared__ unsigned long long cand[1024 + 8];
     __shared__ unsigned sh_prefix, sh_need, sh_count;
 
     const int n = blockIdx.x;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     // over the 16 waves, T_lo, therefore has >= 16 m >= k elements at or above it, so T_lo <= the k-th largest key and every winner (and
     // every tie at the k-th key) is among the elements >= T_lo — typically 1.5-3 k of them instead of H*W.
     TK_STAMP(0);
-    constexpr int FAST_CAP = 512;                            // candidates the rank step takes (O(n^2 / threads)); more -> radix select
+    constexpr int FAST_CAP = 1024;                           // candidates the rank step takes (O(n^2 / threads)); more -> radix select
     unsigned long long* win = reinterpret_cast<unsigned long long*>(hist);      // [k] winners of the fast path (hist is unused there)
     for (int i = tid; i < FAST_CAP + 8; i += TK_THREADS) cand[i] = 0ull;        // zero padding: never greater than a candidate
     if (tid == 0) sh_count = 0u;
@@ -546,20 +546,22 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         // compaction of the elements >= T_lo into cand[] — in ANY order: the winners are placed by rank of the (key, ~index) pair below.
         // Thread t owns the contiguous index range [t*KCH, (t+1)*KCH); one LDS atomic per wave and round reserves the wave's slots.
         const int j0 = tid * KCH, j1 = min(j0 + KCH, a.HW);
-        if (in_regs || (klds && KCH <= 64)) {
+        const bool strided = !in_regs && KCH <= 64;          // up to 64 x 1024 pixels: thread t takes indices t + 1024 c again (coalesced; the
+                                                             // scores are L2-resident by now) — the compaction needs no index order
+        if (in_regs || strided) {
             unsigned long long qual = 0ull;                  // bit c: the thread's c-th element passes the bound
             if (in_regs) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
                     if (tid + j * TK_THREADS < a.HW && kreg[j] >= Tlo) qual |= 1ull << j;
             }
-            for (int c0 = 0; !in_regs && c0 < KCH; c0 += 8) {            // eight independent LDS reads at a time
-                unsigned kk[8];
+            for (int c0 = 0; strided && c0 < KCH; c0 += 8) {             // eight independent loads at a time
+                float vv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) kk[j] = (c0 + j < KCH && j0 + c0 + j < a.HW) ? lds_keys[tid * KST + c0 + j] : 0u;
+                for (int j = 0; j < 8; ++j) vv[j] = tid + (c0 + j) * TK_THREADS < a.HW ? sc[tid + (c0 + j) * TK_THREADS] : 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (c0 + j < KCH && j0 + c0 + j < a.HW && kk[j] >= Tlo) qual |= 1ull << (c0 + j);
+                    if (tid + (c0 + j) * TK_THREADS < a.HW && score_key(vv[j]) >= Tlo) qual |= 1ull << (c0 + j);
             }
             for (;;) {                                       // most threads own no candidate at all: 1-3 rounds per wave
                 const bool has = qual != 0ull;
@@ -580,8 +582,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                         for (int j = 1; j < 16; ++j) key = c == j ? kreg[j] : key;
                         idx = (unsigned)(tid + c * TK_THREADS);
                     } else {
-                        key = lds_keys[tid * KST + c];
-                        idx = (unsigned)(j0 + c);
+                        idx = (unsigned)(tid + c * TK_THREADS);
+                        key = score_key(sc[idx]);
                     }
                     if (pos < (unsigned)FAST_CAP) cand[pos] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - idx);
                 }
@@ -605,8 +607,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
             fast = true;
             // rank of a candidate = how many candidates are greater ((key, ~index) pairs are distinct): the k winners land in canonical
             // order (score desc, index asc) without a sort.  All lanes read the same 16 bytes (two candidates): LDS broadcasts.
-            // 2 .. 8 neighbouring lanes share a candidate (1024 threads, at most 512 candidates) and scan interleaved slices of the array.
-            int psh = 1;
+            // 1 .. 8 neighbouring lanes share a candidate (1024 threads, at most 1024 candidates) and scan interleaved slices of the array.
+            int psh = 0;
             while (psh < 3 && (total << (psh + 1)) <= (unsigned)TK_THREADS) ++psh;
             const int c = tid >> psh, part = tid & ((1 << psh) - 1);
             {
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) rank += o[q] > mine ? 1u : 0u;
                 }
-                rank += (unsigned)__shfl_xor((int)rank, 1);
+                if (psh > 0) rank += (unsigned)__shfl_xor((int)rank, 1);
                 if (psh > 1) rank += (unsigned)__shfl_xor((int)rank, 2);
                 if (psh > 2) rank += (unsigned)__shfl_xor((int)rank, 4);
                 if (part == 0 && c < (int)total && rank < (unsigned)a.k) win[rank] = mine;
