@@ -225,9 +225,11 @@ class Tracker:
         det = self.model.gather_tracking2d(heatmap, box_2d, reid, nms_kernel=nms_kernel, num_detections=num_detections,
                                            normalize_bbox=True)
         # boxes / labels / scores of the batch go to the host in one copy (they are reported per track); embeddings stay in HBM
-        host_boxes = det["bboxes"].cpu().numpy()
-        host_labels = det["labels"].cpu().numpy()
-        host_scores = det["scores"].cpu().numpy()
+        nb, kk = det["scores"].shape
+        packed = torch.cat([det["bboxes"].reshape(nb, kk, 4), det["scores"].reshape(nb, kk, 1), det["labels"].reshape(nb, kk, 1).to(torch.float32)],
+                           dim=2).cpu().numpy()                      # one copy, one sync (class ids < 2^24 are exact in fp32)
+        host_boxes, host_scores = np.ascontiguousarray(packed[..., :4]), np.ascontiguousarray(packed[..., 4])
+        host_labels = packed[..., 5].astype(np.int64)
         out = {"bboxes": [], "track_ids": []}
         for i in range(images.shape[0]):
             self._update_device(det["bboxes"][i], det["scores"][i], det["embeddings"][i], host_boxes[i], host_labels[i], host_scores[i], **kwargs)
@@ -247,7 +249,15 @@ class Tracker:
         dev = self.device
         to_dev = lambda a: torch.as_tensor(a).to(device=dev, dtype=torch.float32).contiguous()
         host = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-        self._update_device(to_dev(bboxes), to_dev(scores), to_dev(embeddings), host(bboxes), host(labels), host(scores), **kwargs)
+        if all(isinstance(a, torch.Tensor) and a.is_cuda for a in (bboxes, labels, scores)) and bboxes.dim() == 2:
+            # device inputs: ONE device -> host copy (and one sync) for the three small arrays the host-side life cycle reads
+            k = scores.shape[0]
+            packed = torch.cat([bboxes.reshape(k, 4).float(), scores.reshape(k, 1).float(), labels.reshape(k, 1).to(torch.float32)], dim=1).cpu().numpy()
+            h_box, h_score = np.ascontiguousarray(packed[:, :4]), np.ascontiguousarray(packed[:, 4])
+            h_label = packed[:, 5].astype(np.int64)          # class ids are far below 2^24: exact in fp32
+        else:
+            h_box, h_label, h_score = host(bboxes), host(labels), host(scores)
+        self._update_device(to_dev(bboxes), to_dev(scores), to_dev(embeddings), h_box, h_label, h_score, **kwargs)
 
     # ------------------------------------------------------------------ one frame
     def _update_device(self, d_box, d_score, d_emb, h_box, h_label, h_score, **kwargs):
