@@ -389,8 +389,8 @@ def short_line(config, B, H, W, k, steps=5, warmup=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="simple")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--height", type=int, default=512)
@@ -499,7 +499,7 @@ def main():
                         continue
                     try:
                         m2 = build_model(args.config, algo=algo)
-                        st = max(args.steps // 2, 3)
+                        st = min(max(args.steps // 2, 3), 20)
                         el = timed(m2, x, tracking, args.k, min(args.warmup, 3), st, cl.Collator(), sync)
                         with torch.no_grad():
                             r2, _ = conv_kernel_profile(m2, x, reps=2)
