@@ -61,6 +61,11 @@ size_t cnl_wino8_scalar_floats();
 int cnl_wino8_transform_weights(const float* w_ohwi, void* u8, float* scal, int Cin, int Cout, void* stream);
 bool cnl_wino8_eligible(const cnl_conv_params* p);
 int cnl_wino8_launch(const cnl_conv_params* p, const void* u8, const float* scal, const float* xmax, void* stream);
+size_t cnl_wino9_weight_bytes(int Cin, int Cout);                                  // winograd9.hip
+size_t cnl_wino9_scalar_floats(int Cin, int Cout);
+int cnl_wino9_transform_weights(const float* w_ohwi, void* u9, float* isu, int Cin, int Cout, void* stream);
+bool cnl_wino9_eligible(const cnl_conv_params* p);
+int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream);
 #ifdef CNL_EXPERIMENTS
 int cnl_wino1_launch(const cnl_conv_params* p, void* stream);                       // experiments/winograd1.hip
 size_t cnl_wino3_weight_bytes(int Cin, int Cout);                                  // experiments/winograd3.hip
@@ -79,7 +84,7 @@ static size_t wino_f32_floats(int Cin, int Cout) {
     return (size_t)(Cin / 8) * 16 * CoutP * 8;
 }
 struct WeightLayout {
-    size_t u3, u5, s5, u8, s8, total;     // float offsets
+    size_t u3, u5, s5, u8, s8, u9, s9, total;     // float offsets
     WeightLayout(int Cin, int Cout) {
         const bool split = Cin % 16 == 0;
         u3 = wino_f32_floats(Cin, Cout);
@@ -87,7 +92,9 @@ struct WeightLayout {
         s5 = u5 + cnl_wino5_weight_bytes(Cin, Cout) / 4;
         u8 = s5 + (split ? cnl_wino5_scalar_floats() : 0);
         s8 = u8 + cnl_wino8_weight_bytes(Cin, Cout) / 4;
-        total = s8 + (split ? cnl_wino8_scalar_floats() : 0);
+        u9 = s8 + (split ? cnl_wino8_scalar_floats() : 0);
+        s9 = u9 + cnl_wino9_weight_bytes(Cin, Cout) / 4;
+        total = s9 + cnl_wino9_scalar_floats(Cin, Cout);
     }
 };
 
@@ -112,7 +119,9 @@ extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u,
 #endif
     rc = cnl_wino5_transform_weights(w_ohwi, u, L.u3, u + L.u5, u + L.s5, Cin, Cout, stream);
     if (rc != CNL_OK) return rc;
-    return cnl_wino8_transform_weights(w_ohwi, u + L.u8, u + L.s8, Cin, Cout, stream);
+    rc = cnl_wino8_transform_weights(w_ohwi, u + L.u8, u + L.s8, Cin, Cout, stream);
+    if (rc != CNL_OK || Cin % 32) return rc;
+    return cnl_wino9_transform_weights(w_ohwi, u + L.u9, u + L.s9, Cin, Cout, stream);
 }
 
 // which kernel a layer takes (see the file header); CNL_ALGO_FORCE + v pins variant v wherever it can run at all
@@ -124,6 +133,7 @@ static int wino_choice(const cnl_conv_params* p) {
         const int v = (int)p->algo - CNL_ALGO_FORCE;
         if (v <= 2 || p->Cin % 16) return v == 1 ? 1 : 2;
         if (v == 8 && !cnl_wino8_eligible(p)) return 5;
+        if (v == 9 && !cnl_wino9_eligible(p)) return 5;
         if (v == 6 && p->Cout % 128) return 5;
         return v;
     }
@@ -150,7 +160,7 @@ extern "C" int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p) {
     CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: null params");
     CNL_REQUIRE(p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: non-positive dimension");
     const int c = wino_choice(p);
-    return c == 8 ? CNL_WINO_F16X2_F4 : (c == 5 || c == 6 || c == 7) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
+    return c == 8 ? CNL_WINO_F16X2_F4 : (c == 5 || c == 6 || c == 7 || c == 9) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
 }
 
 extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) {
@@ -166,14 +176,14 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 "cnl_conv3x3_winograd_f32: Cin %% 8 != 0 or bad pixel stride");
     CNL_REQUIRE(((uintptr_t)p->x & 15) == 0 && ((uintptr_t)p->w & 15) == 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unaligned x / u");
     CNL_REQUIRE(!p->residual || p->ldr >= p->Cout, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: ldr < Cout");
-    CNL_REQUIRE(p->algo <= CNL_ALGO_F4 || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 8), CNL_E_BAD_ARG,
+    CNL_REQUIRE(p->algo <= CNL_ALGO_F4 || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 9), CNL_E_BAD_ARG,
                 "cnl_conv3x3_winograd_f32: unknown algo %u", p->algo);
     const int choice = wino_choice(p);
     const WeightLayout L(p->Cin, p->Cout);
     float* u = const_cast<float*>(p->w);
-    if (choice == 8 || choice == 5 || choice == 6 || choice == 7) {
+    if (choice == 8 || choice == 5 || choice == 6 || choice == 7 || choice == 9) {
         float* s5 = u + L.s5;
-        if (choice == 8) {
+        if (choice == 8 || choice == 9) {
             // the per-image maxima: handed over by the producer, else one pass over the input (stream-ordered, scratch = the F(2x2)
             // scalars of this layer: one launch at a time per layer and stream, see the header)
             const float* xmax = p->x_absmax;
@@ -182,6 +192,7 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 if (rc != CNL_OK) return rc;
                 xmax = s5 + 16;
             }
+            if (choice == 9) return cnl_wino9_launch(p, u + L.u9, u + L.s9, xmax, stream);
             return cnl_wino8_launch(p, u + L.u8, u + L.s8, xmax, stream);
         }
 #ifdef CNL_EXPERIMENTS
