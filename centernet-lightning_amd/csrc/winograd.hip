@@ -148,6 +148,11 @@ static int wino_choice(const cnl_conv_params* p) {
             const long long pad8 = (long long)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32);
             if (pad8 * 100 <= area * 115) return 8;
         }
+        // row-Winograd (winograd9.hip): 8-row x 64-pixel x 64-cout work items, long channel loops on maps they tile with little padding
+        if (p->Cin >= 128 && p->Cin % 64 == 0 && !p->residual && cnl_wino9_eligible(p)) {
+            const long long pad9 = (long long)((H + 7) / 8 * 8) * ((W + 63) / 64 * 64);
+            if (pad9 * 100 <= area * 110) return 9;
+        }
         // the 8x16-pixel x 128-cout work items of winograd6.hip: where the channel loop is short and the couts many, and on maps
         // that 16-row blocks pad more than 8-row blocks (19x34, 38x68, 152x272 of 608x1088 frames: -1 .. -4 %)
         const long long pad16 = (long long)((H + 15) / 16 * 16) * ((W + 15) / 16 * 16), pad8 = (long long)((H + 7) / 8 * 8) * ((W + 15) / 16 * 16);

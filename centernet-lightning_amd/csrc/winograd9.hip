@@ -26,6 +26,9 @@
 #ifndef W9_NT_Y
 #define W9_NT_Y 2     /* cache policy (aux) of the output stores: nt (see winograd5.hip) */
 #endif
+#ifndef W9_EXP
+#define W9_EXP 0      /* timing builds (WRONG results), bit mask: 1 no weight loads in the loop, 2 no patch reads, 4 no transform / split, 8 no patch DMA, 16 no barrier, 32 no MFMA, 64 no epilogue */
+#endif
 namespace cnl_wino9 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -51,7 +54,15 @@ struct Args {
     int blocks;
     unsigned x_bytes, u_bytes, y_bytes, r_bytes, b_bytes;
     unsigned flags;
+#ifdef W9_TRACE
+    unsigned long long* trace;        // timing build: [item][16] s_memtime stamps of block 0 / wave 0
+#endif
 };
+#ifdef W9_TRACE
+#define W9_STAMP(i_) do { if (blockIdx.x == 0 && tid == 0 && tr_item < 64) a.trace[tr_item * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W9_STAMP(i_) do {} while (0)
+#endif
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr int R = 8;                        // output rows per work item
@@ -65,16 +76,28 @@ constexpr int ROW_BYTES = ROW_SLOTS * 16;   // 4224
 constexpr int P_SLOTS = 2688;               // PR * ROW_SLOTS = 2640 used; 42 wave-instructions of 64 slots
 constexpr int P_BYTES = P_SLOTS * 16;       // 43008 per buffer (two buffers)
 constexpr int X_BYTES = 65536;              // epilogue exchange: [4 blocks][4 positions][4 quads][64 lanes] x 16 B
-constexpr int LDS_BYTES = 2 * P_BYTES + X_BYTES;     // 151552: one workgroup per CU (the accumulators allow no more)
+constexpr int T_OFF = 2 * P_BYTES + X_BYTES;         // 151552: this thread's 11 patch-DMA source offsets of the current item, [11][256] u32
+constexpr int T_BYTES = 11 * 256 * 4;                // (in registers they cost 11 VGPRs across the main loop: the allocator then spills)
+constexpr int LDS_BYTES = T_OFF + T_BYTES;           // 162816 of 163840: one workgroup per CU (the accumulators allow no more)
 constexpr int NSLICE = 144;                 // MFMAs per wave and chunk
 constexpr int JOB_SLICES = 14;              // one V fragment (28 VALU operations) is produced beside 14 MFMAs
 constexpr int JOB0 = 2;                     // job j runs in slices [JOB0 + 14 j, JOB0 + 14 j + 14)
 constexpr int BARRIER_SLICE = 98;           // before job 7 (the first to read the next patch)
 
-__device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* lds_dst, unsigned voffset, unsigned soffset) {
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 0, 0);
+// Patch DMA (global -> LDS, 16 bytes per lane, lane-linear at lds_addr) as INLINE ASSEMBLY: hipcc orders every later ds_read behind a
+// pending LDS-DMA it knows of (no alias information between the two patch buffers / the exchange region: "s_waitcnt vmcnt(n)" before
+// each read, i.e. the DMA of the chunk after next would have to land within half a chunk), and counts it into the waits of the weight
+// fragments.  Hidden from the compiler, the DMAs are ordered by this kernel's own vmcnt(0) + barrier once per chunk.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    return i32x4{(int)__builtin_amdgcn_readfirstlane((unsigned)p), (int)(__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) & 0xFFFFu),
+                 (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000};
 }
+__device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+}
+#define W9_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)      /* vmcnt(0), known to the compiler's wait-count pass */
 __device__ __forceinline__ u32x4 buf_load16(const void* base, unsigned bytes, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
     return (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
@@ -108,6 +131,19 @@ __device__ __forceinline__ float split_res_hi(float v, float S, unsigned pk) {
 }
 __device__ __forceinline__ f32x4 lds_f4(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
 #define W9_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// after a barrier the four waves run the same instruction stream in lockstep and reach every VMEM instruction (patch DMA, weight
+// fragment load) together: the CU's one address unit serialises them and the last wave waits for three others.  A per-wave skew of
+// W9_SKEW_NOPS x 16 cycles spreads them out (the MFMA pipes are per SIMD, nothing else is shared per slice).
+#ifndef W9_SKEW_NOPS
+#define W9_SKEW_NOPS 0
+#endif
+#define W9_SKEW(w_)                                                                                   \
+    do {                                                                                              \
+        if (W9_SKEW_NOPS) {                                                                           \
+            _Pragma("unroll") for (int q_ = 1; q_ < 4; ++q_)                                          \
+                if ((w_) >= q_) { _Pragma("unroll") for (int z_ = 0; z_ < W9_SKEW_NOPS; ++z_) asm volatile("s_nop 15"); } \
+        }                                                                                             \
+    } while (0)
 
 // ---- the static schedule of a chunk -----------------------------------------------------------------------------------------
 // MFMA slices are ordered by INPUT row r = 0..9 (patch row; output row yo = r - ky): rows 0 / 9 feed one output row (6 MFMAs),
@@ -130,10 +166,12 @@ struct State {
     f32x16 acc[R][2];        // [output row][cout half]: D[cout][tile]
     u32x4 fb[2][3][2][2];    // weight fragments (A operand): [chunk parity][ky][cout half][piece]
     u32x4 vf[4][2];          // V fragments (B operand): [(10 chunk + row) % 4][piece]
-    f32x4 raw[2][4];         // patch reads of a job: [job parity][pixel a quad 0, a quad 1, pixel b quad 0, b quad 1]
-    float v[8], rr[8];       // transform / residual temporaries of the running job
-    unsigned p_off[11];      // this thread's patch DMA source offsets
+    f32x4 raw[4];            // patch reads of a job: pixel a quad 0, a quad 1, pixel b quad 0, b quad 1 (consumed by operations 0..7, refilled for the next job right after)
+    float v[8];              // transform temporaries of the running job (V, then its residual in place)
+    const char* tb;          // this thread's column of the DMA-offset table in LDS
     unsigned u_voff;
+    i32x4 xrsrc;             // buffer descriptor of x (SGPRs)
+    unsigned lds0;           // LDS address of smem
     const char* pa[2];       // LDS address of this lane's pixel a / b in patch buffer 0 / 1
     const char* pb[2];
     float sg, S;
@@ -141,26 +179,26 @@ struct State {
 
 // VALU operation o (0..27) of the job that builds V fragment `buf` from raw set `set`
 template <int O>
-__device__ __forceinline__ void vop(State& st, const int set, const int buf) {
+__device__ __forceinline__ void vop(State& st, const int buf) {
     if constexpr (O < 8) {
-        st.v[O] = __builtin_fmaf(st.raw[set][2 + (O >> 2)][O & 3], st.sg, st.raw[set][O >> 2][O & 3]);
+        st.v[O] = __builtin_fmaf(st.raw[2 + (O >> 2)][O & 3], st.sg, st.raw[O >> 2][O & 3]);
     } else if constexpr (O < 12) {
         st.vf[buf][0][O - 8] = split_hi_lo(st.v[2 * (O - 8)], st.S);
     } else if constexpr (O < 16) {
         st.vf[buf][0][O - 12] = split_hi_hi(st.vf[buf][0][O - 12], st.v[2 * (O - 12) + 1], st.S);
     } else if constexpr (O < 24) {
         constexpr int e = O - 16;
-        st.rr[e] = (e & 1) ? split_res_hi(st.v[e], st.S, st.vf[buf][0][e >> 1]) : split_res_lo(st.v[e], st.S, st.vf[buf][0][e >> 1]);
+        st.v[e] = (e & 1) ? split_res_hi(st.v[e], st.S, st.vf[buf][0][e >> 1]) : split_res_lo(st.v[e], st.S, st.vf[buf][0][e >> 1]);
     } else {
         constexpr int j = O - 24;
-        st.vf[buf][1][j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(st.rr[2 * j], st.rr[2 * j + 1]));
+        st.vf[buf][1][j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(st.v[2 * j], st.v[2 * j + 1]));
     }
 }
 // LDS read i (0..3) of patch row `row` of buffer `pbuf` into raw set `set`
 template <int I>
-__device__ __forceinline__ void rread(State& st, const int set, const int pbuf, const int row) {
+__device__ __forceinline__ void rread(State& st, const int pbuf, const int row) {
     const char* p = (I < 2 ? st.pa[pbuf] : st.pb[pbuf]) + row * ROW_BYTES + (I & 1) * (QUAD_SLOTS * 16);
-    st.raw[set][I] = lds_f4(p);
+    st.raw[I] = lds_f4(p);
 }
 
 template <int PAR>
@@ -182,36 +220,40 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, ch
     constexpr int nbh = idx & 1;
     constexpr int ku = term == 1 ? 1 : 0, kv = term == 0 ? 1 : 0;
     constexpr int vbuf = (r + 2 * PAR) & 3;
-    if constexpr (S == BARRIER_SLICE && !LAST) {
+    if constexpr (S == BARRIER_SLICE && !LAST && !(W9_EXP & 16)) {
         // every wave's DMAs of the next patch have landed, every wave is done reading this one
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W9_VMCNT0();
         W9_BARRIER();
+        W9_SKEW(wave);
         __builtin_amdgcn_sched_barrier(0);
     }
-    st.acc[r - ky][nbh] = mfma16(st.fb[PAR][ky][nbh][ku], st.vf[vbuf][kv], st.acc[r - ky][nbh]);
+    if constexpr (!(W9_EXP & 32)) st.acc[r - ky][nbh] = mfma16(st.fb[PAR][ky][nbh][ku], st.vf[vbuf][kv], st.acc[r - ky][nbh]);
     // ---- V production: job j builds the fragment of row j + 2 of this chunk (j < 8) or of row j - 8 of the next chunk ----
     if constexpr (S >= JOB0 && S < JOB0 + 10 * JOB_SLICES) {
         constexpr int j = (S - JOB0) / JOB_SLICES, k = (S - JOB0) % JOB_SLICES;
         if constexpr (!(LAST && j >= 8)) {
             constexpr int buf = j < 8 ? ((j + 2 + 2 * PAR) & 3) : ((j - 8 + 2 * (PAR ^ 1)) & 3);
-            vop<2 * k>(st, j & 1, buf);
-            vop<2 * k + 1>(st, j & 1, buf);
+            if constexpr (!(W9_EXP & 4)) {
+                vop<2 * k>(st, buf);
+                vop<2 * k + 1>(st, buf);
+            }
             // raw reads of the next job (j + 1): rows 3..9 of this patch, then rows 0, 1, 2 of the next
-            if constexpr (k >= 1 && k <= 4 && !(LAST && j >= 7)) {
+            if constexpr (k >= 4 && k <= 7 && !(LAST && j >= 7) && !(W9_EXP & 2)) {
                 constexpr int jn = j + 1;
                 constexpr int nrow = jn < 8 ? jn + 2 : jn - 8;
                 constexpr int npb = jn < 8 ? PAR : (PAR ^ 1);
-                rread<k - 1>(st, jn & 1, npb, nrow);
+                rread<k - 4>(st, npb, nrow);
             }
         }
     }
     // ---- weight fragments of the next chunk ----
-    if constexpr (!LAST && S >= 6 && S < 6 + 72 && (S - 6) % 6 == 0) load_b<PAR ^ 1>(st, a, cn + 1, (S - 6) / 6, u_plane, u_wave);
+    if constexpr (!LAST && S >= 6 && S < 6 + 72 && (S - 6) % 6 == 0 && !(W9_EXP & 1)) load_b<PAR ^ 1>(st, a, cn + 1, (S - 6) / 6, u_plane, u_wave);
     // ---- patch of the chunk after next into this chunk's buffer (dead after the barrier) ----
-    if constexpr (!LAST && S >= 100 && S <= 120 && (S - 100) % 2 == 0) {
+    if constexpr (!LAST && S >= 100 && S <= 120 && (S - 100) % 2 == 0 && !(W9_EXP & 8)) {
         constexpr int i = (S - 100) / 2;
         if (cn + 2 < a.CC && (i < 10 || wave < 2))
-            dma16(a.x, a.x_bytes, smem + PAR * P_BYTES + (i * 256 + wave * 64) * 16, st.p_off[i], (unsigned)((cn + 2) * 64));
+            dma16(st.xrsrc, st.lds0 + (unsigned)(PAR * P_BYTES + (i * 256 + wave * 64) * 16), *reinterpret_cast<const unsigned*>(st.tb + i * 1024),
+                  (unsigned)((cn + 2) * 64));
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -228,10 +270,11 @@ __device__ __forceinline__ void chunk(State& st, const Args& a, const int cn, ch
     chunk_impl<PAR, LAST>(st, a, cn, smem, wave, u_plane, u_wave, std::make_integer_sequence<int, NSLICE>{});
 }
 template <int... O>
-__device__ __forceinline__ void job_all(State& st, const int set, const int buf, std::integer_sequence<int, O...>) {
-    (vop<O>(st, set, buf), ...);
+__device__ __forceinline__ void job_all(State& st, const int buf, std::integer_sequence<int, O...>) {
+    (vop<O>(st, buf), ...);
 }
 
+template <bool RES>      // RES: the launch adds a residual (32 more registers live through the epilogue passes)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void winograd9_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem + 2 * P_BYTES;      // dedicated exchange region; passes 1 use the (idle) patch area instead
@@ -245,6 +288,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned u_wave = (unsigned)wave * 6u * u_plane;
 
     State st;
+    st.xrsrc = make_rsrc(a.x, a.x_bytes);
+    st.lds0 = (unsigned)(unsigned long)(lds_void*)smem;
+    st.tb = smem + T_OFF + tid * 4;
     // V_p = d[offa] + sg d[offb] over the four pixels 2t-1 .. 2t+2 of a tile:  p = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
     const int offa = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int offb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
@@ -262,53 +308,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float omax = 0.f;
 
     int n, y0, x0, n0;
-#define W9_SETUP(item_)                                                                                          \
+#define W9_IMAGE_OF(item_) ((int)(__builtin_amdgcn_readfirstlane(cnl::xcd_remap((item_), (unsigned)a.blocks)) / (unsigned)(a.nb * a.bx * a.by)))
+#define W9_SETUP(item_, xmax_)                                                                                   \
     do {                                                                                                         \
-        unsigned b_ = cnl::xcd_remap((item_), (unsigned)a.blocks);                                               \
+        unsigned b_ = __builtin_amdgcn_readfirstlane(cnl::xcd_remap((item_), (unsigned)a.blocks));               \
         const int nbi_ = b_ % a.nb; b_ /= a.nb;                                                                  \
         const int bxi_ = b_ % a.bx; b_ /= a.bx;                                                                  \
         const int byi_ = b_ % a.by; n = b_ / a.by;                                                               \
         y0 = byi_ * R; x0 = bxi_ * (2 * TW); n0 = nbi_ * BN;                                                     \
+        int tid_ = tid;                                                                                          \
+        asm volatile("" : "+v"(tid_));      /* keeps the slot decode INSIDE the item loop: hoisted, its 30-odd per-thread invariants live across the main loop and spill */ \
         _Pragma("unroll") for (int i = 0; i < 11; ++i) {                                                         \
-            const int s_ = i * 256 + tid;               /* slot: ((row * 4 + quad) * 2 + parity) * 33 + idx */   \
+            const int s_ = i * 256 + tid_;              /* slot: ((row * 4 + quad) * 2 + parity) * 33 + idx */   \
             const int row_ = s_ / ROW_SLOTS, rem_ = s_ - row_ * ROW_SLOTS;                                       \
             const int q_ = rem_ / QUAD_SLOTS, rem2_ = rem_ - q_ * QUAD_SLOTS;                                    \
             const int par_ = rem2_ / PXH, idx_ = rem2_ - par_ * PXH;                                             \
             const int iy_ = y0 - 1 + row_, ix_ = x0 - 1 + 2 * idx_ + par_;                                       \
             const bool ok_ = row_ < PR && (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W;        \
             const int sy_ = up ? (iy_ >> 1) : iy_, sx_ = up ? (ix_ >> 1) : ix_;                                  \
-            st.p_off[i] = ok_ ? (unsigned)((((n * a.Hs + sy_) * a.Ws + sx_) * a.ldx + q_ * 4) * 4) : OOB;        \
+            *reinterpret_cast<unsigned*>(const_cast<char*>(st.tb) + i * 1024) =                                  \
+                ok_ ? (unsigned)((((n * a.Hs + sy_) * a.Ws + sx_) * a.ldx + q_ * 4) * 4) : OOB;                  \
         }                                                                                                        \
-        st.u_voff = (unsigned)((n0 + t) * 32 + h * 16);                                                          \
+        st.u_voff = (unsigned)((n0 + (tid_ & 31)) * 32 + ((tid_ >> 5) & 1) * 16);                                \
         {                                                                                                        \
-            const float mx2_ = 2.f * a.xmax[n];           /* |V| <= 2 max |x| */                                 \
-            float S_ = 1.f;                                                                                      \
+            const float mx2_ = 2.f * (xmax_);             /* |V| <= 2 max |x| */                                 \
+            int es_ = 0;                                                                                         \
             if (mx2_ > 0.f && mx2_ < __builtin_inff()) {                                                         \
                 int e_;                                                                                          \
                 (void)__builtin_frexpf(mx2_, &e_);            /* 2^(e-1) <= mx2 < 2^e */                         \
                 e_ = 14 - e_;                                                                                    \
-                S_ = __builtin_ldexpf(1.f, e_ < -100 ? -100 : (e_ > 100 ? 100 : e_));                            \
+                es_ = e_ < -100 ? -100 : (e_ > 100 ? 100 : e_);                                                  \
             }                                                                                                    \
-            st.S = S_;                                                                                           \
-            inv_n = 1.f / S_;                                                                                    \
+            st.S = __builtin_ldexpf(1.f, es_);                                                                   \
+            inv_n = __builtin_ldexpf(1.f, -es_);                                                                 \
         }                                                                                                        \
     } while (0)
 #define W9_ISSUE_P(cc_)                                                                                          \
     do {                                                                                                         \
-        char* d_ = smem + ((cc_) & 1) * P_BYTES;                                                                 \
+        const unsigned d_ = st.lds0 + (unsigned)(((cc_) & 1) * P_BYTES);                                         \
         _Pragma("unroll") for (int i = 0; i < 10; ++i)                                                           \
-            dma16(a.x, a.x_bytes, d_ + (i * 256 + wave * 64) * 16, st.p_off[i], (unsigned)((cc_) * 64));         \
-        if (wave < 2) dma16(a.x, a.x_bytes, d_ + (2560 + wave * 64) * 16, st.p_off[10], (unsigned)((cc_) * 64)); \
+            dma16(st.xrsrc, d_ + (unsigned)((i * 256 + wave * 64) * 16), *reinterpret_cast<const unsigned*>(st.tb + i * 1024), (unsigned)((cc_) * 64)); \
+        if (wave < 2) dma16(st.xrsrc, d_ + (unsigned)((2560 + wave * 64) * 16), *reinterpret_cast<const unsigned*>(st.tb + 10240), (unsigned)((cc_) * 64)); \
     } while (0)
 #define W9_LOAD_B0()                                                                                             \
     _Pragma("unroll") for (int i = 0; i < 12; ++i) load_b<0>(st, a, 0, i, u_plane, u_wave)
 
     unsigned item = blockIdx.x;
-    W9_SETUP(item);
+#ifdef W9_TRACE
+    int tr_item = 0;
+#endif
+    W9_STAMP(0);
+    W9_SETUP(item, a.xmax[W9_IMAGE_OF(item)]);
     W9_ISSUE_P(0);
     W9_ISSUE_P(1);
     W9_LOAD_B0();
     while (true) {
+        W9_STAMP(1);
 #pragma unroll
         for (int yo = 0; yo < R; ++yo)
 #pragma unroll
@@ -316,21 +371,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int e = 0; e < 16; ++e) st.acc[yo][g][e] = 0.f;
         // patches 0 / 1 and the weight fragments of chunk 0 landed (this wave's parts) ... and everybody's
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W9_STAMP(2);
+        W9_VMCNT0();
+        W9_STAMP(3);
         W9_BARRIER();
+        W9_SKEW(wave);
+        W9_STAMP(4);
         // fragments of rows 0 and 1 of chunk 0 (not overlapped with MFMAs), raw reads of row 2 for job 0
-        rread<0>(st, 0, 0, 0); rread<1>(st, 0, 0, 0); rread<2>(st, 0, 0, 0); rread<3>(st, 0, 0, 0);
-        rread<0>(st, 1, 0, 1); rread<1>(st, 1, 0, 1); rread<2>(st, 1, 0, 1); rread<3>(st, 1, 0, 1);
-        job_all(st, 0, 0, std::make_integer_sequence<int, 28>{});
-        rread<0>(st, 0, 0, 2); rread<1>(st, 0, 0, 2); rread<2>(st, 0, 0, 2); rread<3>(st, 0, 0, 2);
-        job_all(st, 1, 1, std::make_integer_sequence<int, 28>{});
+        rread<0>(st, 0, 0); rread<1>(st, 0, 0); rread<2>(st, 0, 0); rread<3>(st, 0, 0);
+        job_all(st, 0, std::make_integer_sequence<int, 28>{});
+        rread<0>(st, 0, 1); rread<1>(st, 0, 1); rread<2>(st, 0, 1); rread<3>(st, 0, 1);
+        job_all(st, 1, std::make_integer_sequence<int, 28>{});
+        rread<0>(st, 0, 2); rread<1>(st, 0, 2); rread<2>(st, 0, 2); rread<3>(st, 0, 2);
+        W9_STAMP(5);
 
         for (int cn = 0; cn < a.CC - 2; cn += 2) {
             chunk<0, false>(st, a, cn, smem, wave, u_plane, u_wave);
             chunk<1, false>(st, a, cn + 1, smem, wave, u_plane, u_wave);
         }
-        chunk<0, false>(st, a, a.CC - 2, smem, wave, u_plane, u_wave);
+        chunk<0, false>(st, a, a.CC - 2, smem, wave, u_plane, u_wave);     // (a mid-loop exit instead of this second copy sends the register allocator into 700 spills)
         chunk<1, true>(st, a, a.CC - 1, smem, wave, u_plane, u_wave);
+        W9_STAMP(6);
 
         // ---- epilogue: out0 = Y0 + Y1 + Y2, out1 = Y1 - Y2 - Y3; the four positions (waves) meet through LDS.  Pass k: output rows
         // 2k, 2k+1 x two cout halves = 4 blocks; every wave writes its 4 blocks, wave w finishes block w = (row 2k + (w >> 1), half w & 1)
@@ -339,6 +400,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float inv = inv_n;
         const unsigned next = item + gridDim.x;
         const bool more = next < (unsigned)a.blocks;
+        const float xmax_next = more ? a.xmax[W9_IMAGE_OF(next)] : 0.f;     // requested now, used by the prefetch in pass 2
         const int cbase = n0 + (wave & 1) * 32 + 4 * h;             // + 8 q: this thread's cout quads
         f32x4 bq[4], iq[4];
 #pragma unroll
@@ -349,7 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             iq[q] = s_ * inv;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = (W9_EXP & 64) ? 3 : 0; k < 4; ++k) {
             char* X = (k == 1) ? smem : sX;
             const int oy = ey0 + 2 * k + (wave >> 1);
             const int ox = ex0 + 2 * t;
@@ -365,13 +427,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int px = 0; px < 2; ++px) {
                     rv[px][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (a.res) {
+                    if constexpr (RES) {
                         const unsigned rvo = (pix * (unsigned)a.ldr + (unsigned)(cbase + 8 * q)) * 4u;
                         rv[px][q] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, (okc[q] && ox + px < a.W) ? rvo : OOB,
                                                                          (unsigned)(px * a.ldr * 4)));
                     }
                 }
             }
+            W9_STAMP(7 + 2 * k);
             if (k == 3) W9_BARRIER();                  // pass 2's readers are done with sX
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy)
@@ -384,12 +447,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             f32x4{A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};
                     }
             W9_BARRIER();
+            W9_STAMP(8 + 2 * k);
             if (k == 2 && more) {                      // everyone is past pass 1's reads: the patch area and the fragment registers are idle
-                W9_SETUP(next);
+                W9_SETUP(next, xmax_next);
                 W9_ISSUE_P(0);
                 W9_ISSUE_P(1);
-                W9_LOAD_B0();
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 Y[4];
@@ -409,13 +473,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 buf_store16(o0, a.y, a.y_bytes, ok0 ? yv[q] : OOB, 0);
                 buf_store16(o1, a.y, a.y_bytes, ok1 ? yv[q] : OOB, (unsigned)(a.ldy * 4));
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (more) { W9_LOAD_B0(); }
         if (a.ymax) {          // max |y| of this item into its image's slot: one atomic per wave and item
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
             if (lane == 0 && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
             omax = 0.f;
         }
+        W9_STAMP(15);
+#ifdef W9_TRACE
+        ++tr_item;
+#endif
         if (!more) break;
         item = next;
     }
@@ -496,6 +566,10 @@ int cnl_wino9_transform_weights(const float* w_ohwi, void* u9, float* isu, int C
     return cnl::check_launch("weights9_kernel");
 }
 
+#ifdef W9_TRACE
+static unsigned long long* g_w9_trace = nullptr;
+extern "C" void cnl_w9_set_trace(void* p) { g_w9_trace = (unsigned long long*)p; }
+#endif
 // can this kernel run the layer at all?  (shape / alignment only)
 bool cnl_wino9_eligible(const cnl_conv_params* p) {
     return p->Cin % 32 == 0 && p->Cin >= 32 && p->Cout % 4 == 0 && p->ldy % 4 == 0 && ((uintptr_t)p->y & 15) == 0 &&
@@ -526,11 +600,17 @@ int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu,
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb; a.b_bytes = (unsigned)p->Cout * 4u;
     a.flags = p->flags;
+#ifdef W9_TRACE
+    a.trace = g_w9_trace;
+#endif
     static cnl::DeviceOnce once;
     int n_cu = 0;                          // persistent workgroups: one per CU, walking the work items with stride gridDim.x
-    int rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd9_kernel), LDS_BYTES, &n_cu);
+    static cnl::DeviceOnce once_res;
+    int rc = p->residual ? cnl::kernel_setup(once_res, reinterpret_cast<const void*>(&winograd9_kernel<true>), LDS_BYTES, &n_cu)
+                         : cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd9_kernel<false>), LDS_BYTES, &n_cu);
     if (rc != CNL_OK) return rc;
     const unsigned grid = (unsigned)(blocks < (long long)n_cu ? blocks : (long long)n_cu);
-    hipLaunchKernelGGL(winograd9_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    if (p->residual) hipLaunchKernelGGL(winograd9_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(winograd9_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return cnl::check_launch("winograd9_kernel");
 }

@@ -15,6 +15,8 @@ from centernet_lightning_amd._lib import CNL_RELU, CNL_SIGMOID, CNL_UPSAMPLE_IN,
 # name: (N, H, W, Cin, Cout, k, stride, flags, residual)
 SHAPES = {
     "head256": (32, 128, 128, 256, 256, 3, 1, CNL_RELU, False),
+    "head128": (32, 128, 128, 128, 256, 3, 1, CNL_RELU, False),
+    "head512": (32, 128, 128, 512, 256, 3, 1, CNL_RELU, False),
     "headfirst": (32, 64, 64, 64, 512, 3, 1, CNL_RELU | CNL_UPSAMPLE_IN, False),
     "layer1": (32, 128, 128, 64, 64, 3, 1, CNL_RELU, False),
     "fpnfirst": (32, 128, 128, 64, 512, 3, 1, CNL_RELU, False),
