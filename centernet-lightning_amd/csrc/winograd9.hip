@@ -11,11 +11,19 @@
 //   * V of an INPUT row serves the three output rows around it, and V_p = d_a +- d_b is one add: 2.25 V elements per output pixel
 //     and channel instead of 4, 3.5 instead of 4.5 VALU operations each;
 //   * the lane that transforms + splits a V fragment is the lane that feeds it to the MFMA (B operand: column = tile, k = 8
-//     channels): V never goes through LDS.  Per 16-channel chunk a wave issues 144 MFMAs beside 280 VALU, 40 ds_read_b128, 12
-//     weight-fragment loads and 10.5 patch DMAs — 2.4 other issues per MFMA where winograd5 has 7.8;
+//     channels): V never goes through LDS.  Per 16-channel chunk a wave issues 144 MFMAs beside 280 VALU, 40 ds_read_b128, 23
+//     global loads (12 weight fragments, 10.5 patch pieces) and 10.5 ds_write_b128 — 2.5 other issues per MFMA where winograd5
+//     has 7.8;
 //   * rounding error below 2-D F(2x2)'s (the transform adds two numbers, not four).
 // Wave p of the 4-wave workgroup owns transform position p for the whole work item (each V_p is produced exactly once per CU, each
 // weight fragment is loaded by exactly one wave); the four positions meet through LDS in the epilogue.
+// The input patch of a chunk (10 rows x 66 pixels x 16 channels) travels global -> registers (issued early in the chunk before the
+// one it is for: a plain buffer load costs the wave a few cycles) -> LDS (ds_write_b128 right after the chunk's barrier).  The
+// LDS-DMA form (buffer_load ... lds) of the first version cost ~130 cycles of issue per 1 KB piece — 23 % of the chunk loop
+// (timing builds: 6 200 -> 4 800 cycles per chunk without it, against 4 608 of pure MFMA issue).
+// Weight fragments are single-buffered: the MFMAs of a chunk run kernel row by kernel row inside an input row (ky-major), so the
+// ky = 0 / 1 / 2 fragments die at slices 114 / 126 / 144 of 144 and are reloaded for the next chunk 24-30 slices before their
+// first use (L2 hits).
 // Weights: U_p[ky] = (G g[ky])_p, scaled PER OUTPUT CHANNEL by a power of two (max |U S_u[co]| in [2^12, 2^13)) and split into two
 // fp16 pieces, [ci/16][p][ky][piece][CoutP][16 ci]; the epilogue multiplies by 1/(S_v S_u[co]).
 #include "cnl_common.h"
@@ -26,16 +34,12 @@
 #ifndef W9_NT_Y
 #define W9_NT_Y 2     /* cache policy (aux) of the output stores: nt (see winograd5.hip) */
 #endif
-#ifndef W9_EXP
-#define W9_EXP 0      /* timing builds (WRONG results), bit mask: 1 no weight loads in the loop, 2 no patch reads, 4 no transform / split, 8 no patch DMA, 16 no barrier, 32 no MFMA, 64 no epilogue */
-#endif
 namespace cnl_wino9 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) void lds_void;
 
 struct Args {
     const float* x;
@@ -55,7 +59,7 @@ struct Args {
     unsigned x_bytes, u_bytes, y_bytes, r_bytes, b_bytes;
     unsigned flags;
 #ifdef W9_TRACE
-    unsigned long long* trace;        // timing build: [item][16] s_memtime stamps of block 0 / wave 0
+    unsigned long long* trace;        // timing build: [item][16] s_memtime stamps of block 0 / thread 0
 #endif
 };
 #ifdef W9_TRACE
@@ -73,31 +77,16 @@ constexpr int PXH = TW + 1;                 // 33 pixels per parity plane of a p
 constexpr int QUAD_SLOTS = 2 * PXH;         // 66 16-byte slots per (row, channel quad): [parity][33]
 constexpr int ROW_SLOTS = 4 * QUAD_SLOTS;   // 264 per patch row: [quad][parity][33]
 constexpr int ROW_BYTES = ROW_SLOTS * 16;   // 4224
-constexpr int P_SLOTS = 2688;               // PR * ROW_SLOTS = 2640 used; 42 wave-instructions of 64 slots
+constexpr int P_SLOTS = 2688;               // PR * ROW_SLOTS = 2640 used (+ 48 slots that absorb the idle lanes of the last staging piece)
 constexpr int P_BYTES = P_SLOTS * 16;       // 43008 per buffer (two buffers)
 constexpr int X_BYTES = 65536;              // epilogue exchange: [4 blocks][4 positions][4 quads][64 lanes] x 16 B
-constexpr int T_OFF = 2 * P_BYTES + X_BYTES;         // 151552: this thread's 11 patch-DMA source offsets of the current item, [11][256] u32
-constexpr int T_BYTES = 11 * 256 * 4;                // (in registers they cost 11 VGPRs across the main loop: the allocator then spills)
-constexpr int LDS_BYTES = T_OFF + T_BYTES;           // 162816 of 163840: one workgroup per CU (the accumulators allow no more)
+constexpr int LDS_BYTES = 2 * P_BYTES + X_BYTES;     // 151552: one workgroup per CU (the accumulators allow no more)
 constexpr int NSLICE = 144;                 // MFMAs per wave and chunk
 constexpr int JOB_SLICES = 14;              // one V fragment (28 VALU operations) is produced beside 14 MFMAs
 constexpr int JOB0 = 2;                     // job j runs in slices [JOB0 + 14 j, JOB0 + 14 j + 14)
 constexpr int BARRIER_SLICE = 98;           // before job 7 (the first to read the next patch)
+constexpr int NSTG = 11;                    // staging pieces per thread and patch: 10 x (row i, pixel tid / 4, quad tid % 4) + the two last pixel columns
 
-// Patch DMA (global -> LDS, 16 bytes per lane, lane-linear at lds_addr) as INLINE ASSEMBLY: hipcc orders every later ds_read behind a
-// pending LDS-DMA it knows of (no alias information between the two patch buffers / the exchange region: "s_waitcnt vmcnt(n)" before
-// each read, i.e. the DMA of the chunk after next would have to land within half a chunk), and counts it into the waits of the weight
-// fragments.  Hidden from the compiler, the DMAs are ordered by this kernel's own vmcnt(0) + barrier once per chunk.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
-    const unsigned long long p = (unsigned long long)base;
-    return i32x4{(int)__builtin_amdgcn_readfirstlane((unsigned)p), (int)(__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) & 0xFFFFu),
-                 (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000};
-}
-__device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
-}
-#define W9_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)      /* vmcnt(0), known to the compiler's wait-count pass */
 __device__ __forceinline__ u32x4 buf_load16(const void* base, unsigned bytes, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
     return (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
@@ -131,53 +120,33 @@ __device__ __forceinline__ float split_res_hi(float v, float S, unsigned pk) {
 }
 __device__ __forceinline__ f32x4 lds_f4(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
 #define W9_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// after a barrier the four waves run the same instruction stream in lockstep and reach every VMEM instruction (patch DMA, weight
-// fragment load) together: the CU's one address unit serialises them and the last wave waits for three others.  A per-wave skew of
-// W9_SKEW_NOPS x 16 cycles spreads them out (the MFMA pipes are per SIMD, nothing else is shared per slice).
-#ifndef W9_SKEW_NOPS
-#define W9_SKEW_NOPS 0
-#endif
-#define W9_SKEW(w_)                                                                                   \
-    do {                                                                                              \
-        if (W9_SKEW_NOPS) {                                                                           \
-            _Pragma("unroll") for (int q_ = 1; q_ < 4; ++q_)                                          \
-                if ((w_) >= q_) { _Pragma("unroll") for (int z_ = 0; z_ < W9_SKEW_NOPS; ++z_) asm volatile("s_nop 15"); } \
-        }                                                                                             \
-    } while (0)
 
 // ---- the static schedule of a chunk -----------------------------------------------------------------------------------------
-// MFMA slices are ordered by INPUT row r = 0..9 (patch row; output row yo = r - ky): rows 0 / 9 feed one output row (6 MFMAs),
-// rows 1 / 8 two (12), the others three (18).  Inside a row: term (hi lo', lo hi', hi hi'), then ky, then the cout half.
-constexpr int row_start(int r) {
-    int s = 0;
-    for (int i = 0; i < r; ++i) s += 6 * ((i < 2 ? i : 2) - (i - 7 > 0 ? i - 7 : 0) + 1);
-    return s;
-}
-constexpr int slice_row(int s) {
-    int r = 0;
-    while (r < PR - 1 && s >= row_start(r + 1)) ++r;
-    return r;
-}
-constexpr int ky_min(int r) { return r - 7 > 0 ? r - 7 : 0; }
-constexpr int ky_max(int r) { return r < 2 ? r : 2; }
-static_assert(row_start(PR) == NSLICE, "144 MFMAs per chunk");
+// 24 segments of 6 MFMAs (3 terms x 2 cout halves), each one (input row r, kernel row ky) -> output row r - ky.  Rows in order,
+// ky-major inside a row; the tail interleaves rows 7-9 so that the ky = 0 fragments die at slice 114 and the ky = 1 fragments at 126.
+constexpr int SEG_ROW[24] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 6, 6, 6, 7, 7, 8, 7, 8, 9};
+constexpr int SEG_KY[24] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 1, 2, 2, 2};
+constexpr int KY0_DEAD = 114, KY1_DEAD = 126;      // first slices after the last use of the ky = 0 / ky = 1 weight fragments
 
 struct State {
     f32x16 acc[R][2];        // [output row][cout half]: D[cout][tile]
-    u32x4 fb[2][3][2][2];    // weight fragments (A operand): [chunk parity][ky][cout half][piece]
+    u32x4 fb[3][2][2];       // weight fragments (A operand): [ky][cout half][piece], single-buffered
     u32x4 vf[4][2];          // V fragments (B operand): [(10 chunk + row) % 4][piece]
     f32x4 raw[4];            // patch reads of a job: pixel a quad 0, a quad 1, pixel b quad 0, b quad 1 (consumed by operations 0..7, refilled for the next job right after)
     float v[8];              // transform temporaries of the running job (V, then its residual in place)
-    const char* tb;          // this thread's column of the DMA-offset table in LDS
+    u32x4 stg[NSTG];         // patch pieces on their way global -> LDS
+    unsigned vcol, vext;     // source offsets: column part of pieces 0..9 (the row is a scalar offset), full offset of piece 10
     unsigned u_voff;
-    i32x4 xrsrc;             // buffer descriptor of x (SGPRs)
-    unsigned lds0;           // LDS address of smem
+    unsigned img_base, row_pitch;   // scalars: byte offset of image n, bytes per stored input row
+    int y0m1;                       // y0 - 1: first patch row
     const char* pa[2];       // LDS address of this lane's pixel a / b in patch buffer 0 / 1
     const char* pb[2];
+    char* wb;                // LDS write address of piece 0 in buffer 0 (piece i: + i rows), and of piece 10
+    char* wext;
     float sg, S;
 };
 
-// VALU operation o (0..27) of the job that builds V fragment `buf` from raw set `set`
+// VALU operation o (0..27) of the job that builds V fragment `buf`
 template <int O>
 __device__ __forceinline__ void vop(State& st, const int buf) {
     if constexpr (O < 8) {
@@ -194,51 +163,74 @@ __device__ __forceinline__ void vop(State& st, const int buf) {
         st.vf[buf][1][j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(st.v[2 * j], st.v[2 * j + 1]));
     }
 }
-// LDS read i (0..3) of patch row `row` of buffer `pbuf` into raw set `set`
+// LDS read i (0..3) of patch row `row` of buffer `pbuf`
 template <int I>
 __device__ __forceinline__ void rread(State& st, const int pbuf, const int row) {
     const char* p = (I < 2 ? st.pa[pbuf] : st.pb[pbuf]) + row * ROW_BYTES + (I & 1) * (QUAD_SLOTS * 16);
     st.raw[I] = lds_f4(p);
 }
-
-template <int PAR>
+// weight fragment i (cout half i >> 1, piece i & 1) of kernel row KY of chunk cc: global -> registers
+template <int KY>
 __device__ __forceinline__ void load_b(State& st, const Args& a, const int cc, const int i, const unsigned u_plane, const unsigned u_wave) {
-    const int ky = i >> 2, nbh = (i >> 1) & 1, piece = i & 1;
-    const unsigned so = (unsigned)cc * (24u * u_plane) + u_wave + (unsigned)(ky * 2 + piece) * u_plane + (unsigned)nbh * 1024u;
-    st.fb[PAR][ky][nbh][piece] = buf_load16(a.u9, a.u_bytes, st.u_voff, so);
+    const int nbh = i >> 1, piece = i & 1;
+    const unsigned so = (unsigned)cc * (24u * u_plane) + u_wave + (unsigned)(KY * 2 + piece) * u_plane + (unsigned)nbh * 1024u;
+    st.fb[KY][nbh][piece] = buf_load16(a.u9, a.u_bytes, st.u_voff, so);
+}
+// patch piece I of chunk cc: global -> staging register (rows outside the image: zeros, the conv's padding)
+template <int I>
+__device__ __forceinline__ void pload(State& st, u32x4 (&stg)[NSTG], const Args& a, const int cc, const bool up, const int wave) {
+    if constexpr (I < 10) {
+        // always issued (a branch around the load makes hipcc's wait counts conservative: vmcnt(0) at the next weight-fragment use);
+        // a row outside the image reads out of range -> zeros
+        const int iy = st.y0m1 + I;
+        const bool ok = (unsigned)iy < (unsigned)a.H;
+        const int sy = ok ? (up ? (iy >> 1) : iy) : 0;
+        stg[I] = buf_load16(a.x, a.x_bytes, ok ? st.vcol : OOB, st.img_base + (unsigned)sy * st.row_pitch + (unsigned)cc * 64u);
+    } else {
+        stg[10] = buf_load16(a.x, a.x_bytes, st.vext, st.img_base + (unsigned)cc * 64u);      // (threads >= 80: out of range -> zeros)
+    }
+}
+// ... staging register -> patch buffer `pbuf`
+template <int I>
+__device__ __forceinline__ void pwrite(State& st, const u32x4 (&stg)[NSTG], const int pbuf, const int wave) {
+    if constexpr (I < 10) {
+        *reinterpret_cast<u32x4*>(st.wb + pbuf * P_BYTES + I * ROW_BYTES) = stg[I];
+    } else {
+        *reinterpret_cast<u32x4*>(st.wext + pbuf * P_BYTES) = stg[10];                           // (threads >= 80: into the slack slots)
+    }
+}
+template <int... I>
+__device__ __forceinline__ void pload_all(State& st, u32x4 (&stg)[NSTG], const Args& a, const int cc, const bool up, const int wave, std::integer_sequence<int, I...>) {
+    (pload<I>(st, stg, a, cc, up, wave), ...);
+}
+template <int... I>
+__device__ __forceinline__ void pwrite_all(State& st, const u32x4 (&stg)[NSTG], const int pbuf, const int wave, std::integer_sequence<int, I...>) {
+    (pwrite<I>(st, stg, pbuf, wave), ...);
 }
 
 // One slice: MFMA S of the chunk with parity PAR, and what is issued beside it.
 template <int S, int PAR, bool LAST>
-__device__ __forceinline__ void slice(State& st, const Args& a, const int cn, char* smem, const int wave, const unsigned u_plane,
-                                      const unsigned u_wave) {
-    constexpr int r = slice_row(S);
-    constexpr int idx = S - row_start(r);
-    constexpr int nky = ky_max(r) - ky_min(r) + 1;
-    constexpr int term = idx / (2 * nky);
-    constexpr int ky = ky_min(r) + (idx % (2 * nky)) / 2;
-    constexpr int nbh = idx & 1;
-    constexpr int ku = term == 1 ? 1 : 0, kv = term == 0 ? 1 : 0;
+__device__ __forceinline__ void slice(State& st, const Args& a, const int cn, const int wave, const bool up, const unsigned u_plane, const unsigned u_wave) {
+    constexpr int seg = S / 6;
+    constexpr int r = SEG_ROW[seg], ky = SEG_KY[seg];
+    constexpr int term = (S % 6) / 2, nbh = S & 1;
+    constexpr int ku = term == 1 ? 1 : 0, kv = term == 0 ? 1 : 0;         // terms: hi lo', lo hi', hi hi'
     constexpr int vbuf = (r + 2 * PAR) & 3;
-    if constexpr (S == BARRIER_SLICE && !LAST && !(W9_EXP & 16)) {
-        // every wave's DMAs of the next patch have landed, every wave is done reading this one
-        W9_VMCNT0();
+    if constexpr (S == BARRIER_SLICE && !LAST) {
+        // every wave is done reading this chunk's patch, and the next chunk's (written a chunk ago) is complete
         W9_BARRIER();
-        W9_SKEW(wave);
         __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (!(W9_EXP & 32)) st.acc[r - ky][nbh] = mfma16(st.fb[PAR][ky][nbh][ku], st.vf[vbuf][kv], st.acc[r - ky][nbh]);
+    st.acc[r - ky][nbh] = mfma16(st.fb[ky][nbh][ku], st.vf[vbuf][kv], st.acc[r - ky][nbh]);
     // ---- V production: job j builds the fragment of row j + 2 of this chunk (j < 8) or of row j - 8 of the next chunk ----
     if constexpr (S >= JOB0 && S < JOB0 + 10 * JOB_SLICES) {
         constexpr int j = (S - JOB0) / JOB_SLICES, k = (S - JOB0) % JOB_SLICES;
         if constexpr (!(LAST && j >= 8)) {
             constexpr int buf = j < 8 ? ((j + 2 + 2 * PAR) & 3) : ((j - 8 + 2 * (PAR ^ 1)) & 3);
-            if constexpr (!(W9_EXP & 4)) {
-                vop<2 * k>(st, buf);
-                vop<2 * k + 1>(st, buf);
-            }
+            vop<2 * k>(st, buf);
+            vop<2 * k + 1>(st, buf);
             // raw reads of the next job (j + 1): rows 3..9 of this patch, then rows 0, 1, 2 of the next
-            if constexpr (k >= 4 && k <= 7 && !(LAST && j >= 7) && !(W9_EXP & 2)) {
+            if constexpr (k >= 4 && k <= 7 && !(LAST && j >= 7)) {
                 constexpr int jn = j + 1;
                 constexpr int nrow = jn < 8 ? jn + 2 : jn - 8;
                 constexpr int npb = jn < 8 ? PAR : (PAR ^ 1);
@@ -246,28 +238,29 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, ch
             }
         }
     }
-    // ---- weight fragments of the next chunk ----
-    if constexpr (!LAST && S >= 6 && S < 6 + 72 && (S - 6) % 6 == 0 && !(W9_EXP & 1)) load_b<PAR ^ 1>(st, a, cn + 1, (S - 6) / 6, u_plane, u_wave);
-    // ---- patch of the chunk after next into this chunk's buffer (dead after the barrier) ----
-    if constexpr (!LAST && S >= 100 && S <= 120 && (S - 100) % 2 == 0 && !(W9_EXP & 8)) {
-        constexpr int i = (S - 100) / 2;
-        if (cn + 2 < a.CC && (i < 10 || wave < 2))
-            dma16(st.xrsrc, st.lds0 + (unsigned)(PAR * P_BYTES + (i * 256 + wave * 64) * 16), *reinterpret_cast<const unsigned*>(st.tb + i * 1024),
-                  (unsigned)((cn + 2) * 64));
+    // ---- weight fragments: kernel row 2 of THIS chunk (first used at slice 30), rows 0 / 1 of the next once this chunk is done with them ----
+    if constexpr (S < 4) load_b<2>(st, a, cn, S, u_plane, u_wave);
+    if constexpr (!LAST && S >= KY0_DEAD && S < KY0_DEAD + 8 && (S - KY0_DEAD) % 2 == 0) load_b<0>(st, a, cn + 1, (S - KY0_DEAD) / 2, u_plane, u_wave);
+    if constexpr (!LAST && S >= KY1_DEAD && S < KY1_DEAD + 8 && (S - KY1_DEAD) % 2 == 0) load_b<1>(st, a, cn + 1, (S - KY1_DEAD) / 2, u_plane, u_wave);
+    // ---- patch of the chunk after next: global -> registers early, registers -> this chunk's buffer (dead after the barrier) ----
+    if constexpr (!LAST && S >= 4 && S <= 44 && (S - 4) % 4 == 0) {
+        pload<(S - 4) / 4>(st, st.stg, a, cn + 2, up, wave);      // (unconditional: past the last chunk it fetches out-of-range zeros / a neighbour's channels into a dead buffer)
+    }
+    if constexpr (!LAST && S >= 99 && S <= 119 && (S - 99) % 2 == 0) {
+        pwrite<(S - 99) / 2>(st, st.stg, PAR, wave);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int PAR, bool LAST, int... S>
-__device__ __forceinline__ void chunk_impl(State& st, const Args& a, const int cn, char* smem, const int wave, const unsigned u_plane,
+__device__ __forceinline__ void chunk_impl(State& st, const Args& a, const int cn, const int wave, const bool up, const unsigned u_plane,
                                            const unsigned u_wave, std::integer_sequence<int, S...>) {
     __builtin_amdgcn_sched_barrier(0);
-    (slice<S, PAR, LAST>(st, a, cn, smem, wave, u_plane, u_wave), ...);
+    (slice<S, PAR, LAST>(st, a, cn, wave, up, u_plane, u_wave), ...);
 }
 template <int PAR, bool LAST>
-__device__ __forceinline__ void chunk(State& st, const Args& a, const int cn, char* smem, const int wave, const unsigned u_plane,
-                                      const unsigned u_wave) {
-    chunk_impl<PAR, LAST>(st, a, cn, smem, wave, u_plane, u_wave, std::make_integer_sequence<int, NSLICE>{});
+__device__ __forceinline__ void chunk(State& st, const Args& a, const int cn, const int wave, const bool up, const unsigned u_plane, const unsigned u_wave) {
+    chunk_impl<PAR, LAST>(st, a, cn, wave, up, u_plane, u_wave, std::make_integer_sequence<int, NSLICE>{});
 }
 template <int... O>
 __device__ __forceinline__ void job_all(State& st, const int buf, std::integer_sequence<int, O...>) {
@@ -277,7 +270,7 @@ __device__ __forceinline__ void job_all(State& st, const int buf, std::integer_s
 template <bool RES>      // RES: the launch adds a residual (32 more registers live through the epilogue passes)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void winograd9_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sX = smem + 2 * P_BYTES;      // dedicated exchange region; passes 1 use the (idle) patch area instead
+    char* sX = smem + 2 * P_BYTES;      // dedicated exchange region; pass 1 uses the (idle) patch area instead
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -286,11 +279,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool up = a.flags & CNL_UPSAMPLE_IN;
     const unsigned u_plane = (unsigned)(a.CoutP * 32);               // bytes per (chunk, position, ky, piece) plane of U
     const unsigned u_wave = (unsigned)wave * 6u * u_plane;
+    typedef std::make_integer_sequence<int, NSTG> AllPieces;
 
     State st;
-    st.xrsrc = make_rsrc(a.x, a.x_bytes);
-    st.lds0 = (unsigned)(unsigned long)(lds_void*)smem;
-    st.tb = smem + T_OFF + tid * 4;
+    st.row_pitch = (unsigned)(a.Ws * a.ldx * 4);
     // V_p = d[offa] + sg d[offb] over the four pixels 2t-1 .. 2t+2 of a tile:  p = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
     const int offa = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int offb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
@@ -302,6 +294,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int sb = (2 * h) * QUAD_SLOTS + (offb & 1) * PXH + t + (offb >> 1);
         st.pa[0] = smem + sa * 16; st.pa[1] = smem + P_BYTES + sa * 16;
         st.pb[0] = smem + sb * 16; st.pb[1] = smem + P_BYTES + sb * 16;
+    }
+    // staging pieces: piece i < 10 = (patch row i, column tid / 4, channel quad tid % 4): 64 bytes per pixel from 4 lanes; piece 10 =
+    // the columns 64, 65 of all ten rows (threads 0..79).  8 consecutive lanes (2 pixels x 4 quads) of a ds_write_b128 hit all 32 banks.
+    {
+        const int q = tid & 3, c = tid >> 2;
+        st.wb = smem + (q * QUAD_SLOTS + (c & 1) * PXH + (c >> 1)) * 16;
+        const int er = tid >> 3, ec = 64 + ((tid >> 2) & 1);
+        st.wext = tid < 80 ? smem + (er * ROW_SLOTS + q * QUAD_SLOTS + (ec & 1) * PXH + (ec >> 1)) * 16 : smem + (PR * ROW_SLOTS + (tid & 31)) * 16;
     }
     const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
     float inv_n = 1.f;
@@ -316,18 +316,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int bxi_ = b_ % a.bx; b_ /= a.bx;                                                                  \
         const int byi_ = b_ % a.by; n = b_ / a.by;                                                               \
         y0 = byi_ * R; x0 = bxi_ * (2 * TW); n0 = nbi_ * BN;                                                     \
+        st.y0m1 = y0 - 1;                                                                                        \
+        st.img_base = (unsigned)(n * a.Hs) * st.row_pitch;                                                       \
         int tid_ = tid;                                                                                          \
-        asm volatile("" : "+v"(tid_));      /* keeps the slot decode INSIDE the item loop: hoisted, its 30-odd per-thread invariants live across the main loop and spill */ \
-        _Pragma("unroll") for (int i = 0; i < 11; ++i) {                                                         \
-            const int s_ = i * 256 + tid_;              /* slot: ((row * 4 + quad) * 2 + parity) * 33 + idx */   \
-            const int row_ = s_ / ROW_SLOTS, rem_ = s_ - row_ * ROW_SLOTS;                                       \
-            const int q_ = rem_ / QUAD_SLOTS, rem2_ = rem_ - q_ * QUAD_SLOTS;                                    \
-            const int par_ = rem2_ / PXH, idx_ = rem2_ - par_ * PXH;                                             \
-            const int iy_ = y0 - 1 + row_, ix_ = x0 - 1 + 2 * idx_ + par_;                                       \
-            const bool ok_ = row_ < PR && (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W;        \
-            const int sy_ = up ? (iy_ >> 1) : iy_, sx_ = up ? (ix_ >> 1) : ix_;                                  \
-            *reinterpret_cast<unsigned*>(const_cast<char*>(st.tb) + i * 1024) =                                  \
-                ok_ ? (unsigned)((((n * a.Hs + sy_) * a.Ws + sx_) * a.ldx + q_ * 4) * 4) : OOB;                  \
+        asm volatile("" : "+v"(tid_));      /* keeps the per-thread decode inside the item loop (hoisted, its values live across the main loop) */ \
+        {                                                                                                        \
+            const int q_ = tid_ & 3, ix_ = x0 - 1 + (tid_ >> 2);                                                 \
+            const int sx_ = up ? (ix_ >> 1) : ix_;                                                               \
+            st.vcol = (unsigned)ix_ < (unsigned)a.W ? (unsigned)((sx_ * a.ldx + q_ * 4) * 4) : OOB;              \
+            const int er_ = tid_ >> 3, ex_ = x0 + 63 + ((tid_ >> 2) & 1), ey_ = y0 - 1 + er_;                    \
+            const bool ok_ = tid_ < 80 && (unsigned)ey_ < (unsigned)a.H && (unsigned)ex_ < (unsigned)a.W;        \
+            const int esy_ = up ? (ey_ >> 1) : ey_, esx_ = up ? (ex_ >> 1) : ex_;                                \
+            st.vext = ok_ ? (unsigned)(((esy_ * a.Ws + esx_) * a.ldx + q_ * 4) * 4) : OOB;                       \
         }                                                                                                        \
         st.u_voff = (unsigned)((n0 + (tid_ & 31)) * 32 + ((tid_ >> 5) & 1) * 16);                                \
         {                                                                                                        \
@@ -343,15 +343,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             inv_n = __builtin_ldexpf(1.f, -es_);                                                                 \
         }                                                                                                        \
     } while (0)
-#define W9_ISSUE_P(cc_)                                                                                          \
+#define W9_LOAD_B01()                                                                                            \
     do {                                                                                                         \
-        const unsigned d_ = st.lds0 + (unsigned)(((cc_) & 1) * P_BYTES);                                         \
-        _Pragma("unroll") for (int i = 0; i < 10; ++i)                                                           \
-            dma16(st.xrsrc, d_ + (unsigned)((i * 256 + wave * 64) * 16), *reinterpret_cast<const unsigned*>(st.tb + i * 1024), (unsigned)((cc_) * 64)); \
-        if (wave < 2) dma16(st.xrsrc, d_ + (unsigned)((2560 + wave * 64) * 16), *reinterpret_cast<const unsigned*>(st.tb + 10240), (unsigned)((cc_) * 64)); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) load_b<0>(st, a, 0, i, u_plane, u_wave);                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) load_b<1>(st, a, 0, i, u_plane, u_wave);                   \
     } while (0)
-#define W9_LOAD_B0()                                                                                             \
-    _Pragma("unroll") for (int i = 0; i < 12; ++i) load_b<0>(st, a, 0, i, u_plane, u_wave)
 
     unsigned item = blockIdx.x;
 #ifdef W9_TRACE
@@ -359,9 +355,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
     W9_STAMP(0);
     W9_SETUP(item, a.xmax[W9_IMAGE_OF(item)]);
-    W9_ISSUE_P(0);
-    W9_ISSUE_P(1);
-    W9_LOAD_B0();
+    u32x4 stg1[NSTG];                   // patch 1 of the item set up last (patch 0 waits in st.stg)
+    pload_all(st, st.stg, a, 0, up, wave, AllPieces{});
+    pload_all(st, stg1, a, 1, up, wave, AllPieces{});
+    W9_LOAD_B01();
     while (true) {
         W9_STAMP(1);
 #pragma unroll
@@ -370,13 +367,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) st.acc[yo][g][e] = 0.f;
-        // patches 0 / 1 and the weight fragments of chunk 0 landed (this wave's parts) ... and everybody's
-        W9_STAMP(2);
-        W9_VMCNT0();
-        W9_STAMP(3);
+        // patches 0 / 1 of this item: registers -> LDS (everybody is past the previous item's last exchange pass: barrier below pass 3)
+        pwrite_all(st, st.stg, 0, wave, AllPieces{});
+        pwrite_all(st, stg1, 1, wave, AllPieces{});
         W9_BARRIER();
-        W9_SKEW(wave);
-        W9_STAMP(4);
         // fragments of rows 0 and 1 of chunk 0 (not overlapped with MFMAs), raw reads of row 2 for job 0
         rread<0>(st, 0, 0); rread<1>(st, 0, 0); rread<2>(st, 0, 0); rread<3>(st, 0, 0);
         job_all(st, 0, std::make_integer_sequence<int, 28>{});
@@ -386,22 +380,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W9_STAMP(5);
 
         for (int cn = 0; cn < a.CC - 2; cn += 2) {
-            chunk<0, false>(st, a, cn, smem, wave, u_plane, u_wave);
-            chunk<1, false>(st, a, cn + 1, smem, wave, u_plane, u_wave);
+            chunk<0, false>(st, a, cn, wave, up, u_plane, u_wave);
+            chunk<1, false>(st, a, cn + 1, wave, up, u_plane, u_wave);
         }
-        chunk<0, false>(st, a, a.CC - 2, smem, wave, u_plane, u_wave);     // (a mid-loop exit instead of this second copy sends the register allocator into 700 spills)
-        chunk<1, true>(st, a, a.CC - 1, smem, wave, u_plane, u_wave);
+        chunk<0, false>(st, a, a.CC - 2, wave, up, u_plane, u_wave);     // (a mid-loop exit instead of this second copy sends the register allocator into 700 spills)
+        chunk<1, true>(st, a, a.CC - 1, wave, up, u_plane, u_wave);
         W9_STAMP(6);
 
         // ---- epilogue: out0 = Y0 + Y1 + Y2, out1 = Y1 - Y2 - Y3; the four positions (waves) meet through LDS.  Pass k: output rows
         // 2k, 2k+1 x two cout halves = 4 blocks; every wave writes its 4 blocks, wave w finishes block w = (row 2k + (w >> 1), half w & 1)
         // for all four positions: thread = (tile, 4 couts) x 4 cout quads, 16-byte stores ----
         const int en = n, ey0 = y0, ex0 = x0;
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));        // the epilogue's per-lane constants are re-derived here (hoisted, they live across the chunk loop and spill)
+        const int t_e = lane_e & 31, h_e = lane_e >> 5;
         const float inv = inv_n;
         const unsigned next = item + gridDim.x;
         const bool more = next < (unsigned)a.blocks;
         const float xmax_next = more ? a.xmax[W9_IMAGE_OF(next)] : 0.f;     // requested now, used by the prefetch in pass 2
-        const int cbase = n0 + (wave & 1) * 32 + 4 * h;             // + 8 q: this thread's cout quads
+        const int cbase = n0 + (wave & 1) * 32 + 4 * h_e;             // + 8 q: this thread's cout quads
         f32x4 bq[4], iq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -411,10 +408,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             iq[q] = s_ * inv;
         }
 #pragma unroll
-        for (int k = (W9_EXP & 64) ? 3 : 0; k < 4; ++k) {
+        for (int k = 0; k < 4; ++k) {
             char* X = (k == 1) ? smem : sX;
             const int oy = ey0 + 2 * k + (wave >> 1);
-            const int ox = ex0 + 2 * t;
+            const int ox = ex0 + 2 * t_e;
             const bool row_ok = oy < a.H;
             const unsigned pix = (unsigned)((en * a.H + oy) * a.W + ox);
             unsigned yv[4];
@@ -443,29 +440,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const f32x16& A = st.acc[2 * k + yy][g];
-                        *reinterpret_cast<f32x4*>(X + ((((yy * 2 + g) * 4 + wave) * 4 + q) * 64 + lane) * 16) =
+                        *reinterpret_cast<f32x4*>(X + ((((yy * 2 + g) * 4 + wave) * 4 + q) * 64 + lane_e) * 16) =
                             f32x4{A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};
                     }
             W9_BARRIER();
             W9_STAMP(8 + 2 * k);
-            if (k == 2 && more) {                      // everyone is past pass 1's reads: the patch area and the fragment registers are idle
+            if (k == 2 && more) {                      // the staging and fragment registers are idle: request the next item's first two patches
                 W9_SETUP(next, xmax_next);
-                W9_ISSUE_P(0);
-                W9_ISSUE_P(1);
+                pload_all(st, st.stg, a, 0, up, wave, AllPieces{});
+                pload_all(st, stg1, a, 1, up, wave, AllPieces{});
+            } else if (k == 2) {                       // (no loop-carried staging values: they would stay live through the chunk loop)
+#pragma unroll
+                for (int i = 0; i < NSTG; ++i) { st.stg[i] = u32x4{0u, 0u, 0u, 0u}; stg1[i] = u32x4{0u, 0u, 0u, 0u}; }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 Y[4];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) Y[p] = lds_f4(X + (((wave * 4 + p) * 4 + q) * 64 + lane) * 16);
+                for (int p = 0; p < 4; ++p) Y[p] = lds_f4(X + (((wave * 4 + p) * 4 + q) * 64 + lane_e) * 16);
                 f32x4 o0, o1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float ya = (Y[0][e] + Y[1][e] + Y[2][e]) * iq[q][e];
                     const float yb = (Y[1][e] - Y[2][e] - Y[3][e]) * iq[q][e];
-                    o0[e] = fmaxf(ya + bq[q][e] + rv[0][q][e], lo);
-                    o1[e] = fmaxf(yb + bq[q][e] + rv[1][q][e], lo);
+                    if constexpr (RES) {
+                        o0[e] = fmaxf(ya + bq[q][e] + rv[0][q][e], lo);
+                        o1[e] = fmaxf(yb + bq[q][e] + rv[1][q][e], lo);
+                    } else {
+                        o0[e] = fmaxf(ya + bq[q][e], lo);
+                        o1[e] = fmaxf(yb + bq[q][e], lo);
+                    }
                 }
                 const bool ok0 = okc[q] && ox < a.W, ok1 = okc[q] && ox + 1 < a.W;
                 if (ok0) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o0[0]), fabsf(o0[1])), fmaxf(fabsf(o0[2]), fabsf(o0[3]))));
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) { W9_LOAD_B0(); }
+        if (more) { W9_LOAD_B01(); }
         if (a.ymax) {          // max |y| of this item into its image's slot: one atomic per wave and item
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
@@ -488,10 +493,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
         if (!more) break;
         item = next;
+        W9_BARRIER();          // everybody is done with the exchange regions before the patch buffers are refilled
     }
 #undef W9_SETUP
-#undef W9_ISSUE_P
-#undef W9_LOAD_B0
+#undef W9_LOAD_B01
 }
 
 // fp32 OHWI 3x3 weights -> U_p[ky] = (G g[ky])_p per (co, ci), scaled per OUTPUT CHANNEL by S_u[co] = 2^(13 - e) (max |U[co]| = m 2^e)
