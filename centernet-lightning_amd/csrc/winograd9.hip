@@ -31,6 +31,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef W9_STAGGER
+#define W9_STAGGER 1  /* scale of the start-up stagger (0 = off) */
+#endif
 #ifndef W9_NT_Y
 #define W9_NT_Y 2     /* cache policy (aux) of the output stores: nt (see winograd5.hip) */
 #endif
@@ -58,6 +61,7 @@ struct Args {
     int blocks;
     unsigned x_bytes, u_bytes, y_bytes, r_bytes, b_bytes;
     unsigned flags;
+    unsigned stagger;                 // start-up delay step: workgroup b waits ((37 b) mod 256) * stagger / 256 cycles before its first item
 #ifdef W9_TRACE
     unsigned long long* trace;        // timing build: [item][16] s_memtime stamps of block 0 / thread 0
 #endif
@@ -85,7 +89,7 @@ constexpr int NSLICE = 144;                 // MFMAs per wave and chunk
 constexpr int JOB_SLICES = 14;              // one V fragment (28 VALU operations) is produced beside 14 MFMAs
 constexpr int JOB0 = 2;                     // job j runs in slices [JOB0 + 14 j, JOB0 + 14 j + 14)
 constexpr int BARRIER_SLICE = 98;           // before job 7 (the first to read the next patch)
-constexpr int NSTG = 11;                    // staging pieces per thread and patch: 10 x (row i, pixel tid / 4, quad tid % 4) + the two last pixel columns
+constexpr int NSTG = 6;                     // staging registers per thread: a patch (10 pieces (row i, pixel tid / 4, quad tid % 4) + 1 for the two last pixel columns) travels in two halves
 
 __device__ __forceinline__ u32x4 buf_load16(const void* base, unsigned bytes, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
@@ -128,6 +132,13 @@ constexpr int SEG_ROW[24] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 6, 6, 
 constexpr int SEG_KY[24] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 1, 2, 2, 2};
 constexpr int KY0_DEAD = 114, KY1_DEAD = 126;      // first slices after the last use of the ky = 0 / ky = 1 weight fragments
 
+struct Item {               // per-work-item addressing state (two live: the item being multiplied and the one after it)
+    unsigned vcol, vext;     // source offsets: column part of pieces 0..9 (the row is a scalar offset), full offset of piece 10
+    unsigned u_voff;         // this lane's row of the weight planes
+    unsigned img_base;       // scalar: byte offset of image n
+    int y0m1;                // scalar: y0 - 1, first patch row
+    float S;                 // power-of-two scale of V for this item's image
+};
 struct State {
     f32x16 acc[R][2];        // [output row][cout half]: D[cout][tile]
     u32x4 fb[3][2][2];       // weight fragments (A operand): [ky][cout half][piece], single-buffered
@@ -135,29 +146,27 @@ struct State {
     f32x4 raw[4];            // patch reads of a job: pixel a quad 0, a quad 1, pixel b quad 0, b quad 1 (consumed by operations 0..7, refilled for the next job right after)
     float v[8];              // transform temporaries of the running job (V, then its residual in place)
     u32x4 stg[NSTG];         // patch pieces on their way global -> LDS
-    unsigned vcol, vext;     // source offsets: column part of pieces 0..9 (the row is a scalar offset), full offset of piece 10
-    unsigned u_voff;
-    unsigned img_base, row_pitch;   // scalars: byte offset of image n, bytes per stored input row
-    int y0m1;                       // y0 - 1: first patch row
+    Item cur, nxt;
+    unsigned row_pitch;      // scalar: bytes per stored input row
     const char* pa[2];       // LDS address of this lane's pixel a / b in patch buffer 0 / 1
     const char* pb[2];
     char* wb;                // LDS write address of piece 0 in buffer 0 (piece i: + i rows), and of piece 10
     char* wext;
-    float sg, S;
+    float sg;
 };
 
-// VALU operation o (0..27) of the job that builds V fragment `buf`
+// VALU operation o (0..27) of the job that builds V fragment `buf` (S: the scale of the image the fragment belongs to)
 template <int O>
-__device__ __forceinline__ void vop(State& st, const int buf) {
+__device__ __forceinline__ void vop(State& st, const int buf, const float S) {
     if constexpr (O < 8) {
         st.v[O] = __builtin_fmaf(st.raw[2 + (O >> 2)][O & 3], st.sg, st.raw[O >> 2][O & 3]);
     } else if constexpr (O < 12) {
-        st.vf[buf][0][O - 8] = split_hi_lo(st.v[2 * (O - 8)], st.S);
+        st.vf[buf][0][O - 8] = split_hi_lo(st.v[2 * (O - 8)], S);
     } else if constexpr (O < 16) {
-        st.vf[buf][0][O - 12] = split_hi_hi(st.vf[buf][0][O - 12], st.v[2 * (O - 12) + 1], st.S);
+        st.vf[buf][0][O - 12] = split_hi_hi(st.vf[buf][0][O - 12], st.v[2 * (O - 12) + 1], S);
     } else if constexpr (O < 24) {
         constexpr int e = O - 16;
-        st.v[e] = (e & 1) ? split_res_hi(st.v[e], st.S, st.vf[buf][0][e >> 1]) : split_res_lo(st.v[e], st.S, st.vf[buf][0][e >> 1]);
+        st.v[e] = (e & 1) ? split_res_hi(st.v[e], S, st.vf[buf][0][e >> 1]) : split_res_lo(st.v[e], S, st.vf[buf][0][e >> 1]);
     } else {
         constexpr int j = O - 24;
         st.vf[buf][1][j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(st.v[2 * j], st.v[2 * j + 1]));
@@ -171,52 +180,54 @@ __device__ __forceinline__ void rread(State& st, const int pbuf, const int row) 
 }
 // weight fragment i (cout half i >> 1, piece i & 1) of kernel row KY of chunk cc: global -> registers
 template <int KY>
-__device__ __forceinline__ void load_b(State& st, const Args& a, const int cc, const int i, const unsigned u_plane, const unsigned u_wave) {
+__device__ __forceinline__ void load_b(State& st, const Args& a, const unsigned u_voff, const int cc, const int i, const unsigned u_plane, const unsigned u_wave) {
     const int nbh = i >> 1, piece = i & 1;
     const unsigned so = (unsigned)cc * (24u * u_plane) + u_wave + (unsigned)(KY * 2 + piece) * u_plane + (unsigned)nbh * 1024u;
-    st.fb[KY][nbh][piece] = buf_load16(a.u9, a.u_bytes, st.u_voff, so);
+    st.fb[KY][nbh][piece] = buf_load16(a.u9, a.u_bytes, u_voff, so);
 }
-// patch piece I of chunk cc: global -> staging register (rows outside the image: zeros, the conv's padding)
-template <int I>
-__device__ __forceinline__ void pload(State& st, u32x4 (&stg)[NSTG], const Args& a, const int cc, const bool up, const int wave) {
-    if constexpr (I < 10) {
-        // always issued (a branch around the load makes hipcc's wait counts conservative: vmcnt(0) at the next weight-fragment use);
-        // a row outside the image reads out of range -> zeros
-        const int iy = st.y0m1 + I;
-        const bool ok = (unsigned)iy < (unsigned)a.H;
+// The patch of a chunk travels global -> staging registers -> LDS in two halves that share the registers: half A = rows 0..4 + the
+// piece with the two last pixel columns of all rows (stg[5]), half B = rows 5..9.  Piece I of half HALF of chunk cc of item `it`:
+// always issued (a branch around the load makes hipcc's wait counts conservative: vmcnt(0) at the next weight-fragment use); a row
+// outside the image reads out of range -> zeros, the convolution's padding.
+template <int HALF, int I>
+__device__ __forceinline__ void pload(State& st, const Item& it, const Args& a, const int cc, const bool up) {
+    if constexpr (I < 5) {
+        const int iy = __builtin_amdgcn_readfirstlane(it.y0m1) + 5 * HALF + I;     // (uniform by construction; the copies cur = nxt hide it from the
+        const bool ok = (unsigned)iy < (unsigned)a.H;                               //  compiler, which then wraps every load in a waterfall loop)
         const int sy = ok ? (up ? (iy >> 1) : iy) : 0;
-        stg[I] = buf_load16(a.x, a.x_bytes, ok ? st.vcol : OOB, st.img_base + (unsigned)sy * st.row_pitch + (unsigned)cc * 64u);
+        const unsigned so = __builtin_amdgcn_readfirstlane(it.img_base + (unsigned)sy * st.row_pitch + (unsigned)cc * 64u);
+        st.stg[I] = buf_load16(a.x, a.x_bytes, ok ? it.vcol : OOB, so);
     } else {
-        stg[10] = buf_load16(a.x, a.x_bytes, st.vext, st.img_base + (unsigned)cc * 64u);      // (threads >= 80: out of range -> zeros)
+        static_assert(HALF == 0, "the column piece belongs to half A");
+        st.stg[5] = buf_load16(a.x, a.x_bytes, it.vext, __builtin_amdgcn_readfirstlane(it.img_base + (unsigned)cc * 64u));   // (threads >= 80: out of range -> zeros)
     }
 }
 // ... staging register -> patch buffer `pbuf`
-template <int I>
-__device__ __forceinline__ void pwrite(State& st, const u32x4 (&stg)[NSTG], const int pbuf, const int wave) {
-    if constexpr (I < 10) {
-        *reinterpret_cast<u32x4*>(st.wb + pbuf * P_BYTES + I * ROW_BYTES) = stg[I];
-    } else {
-        *reinterpret_cast<u32x4*>(st.wext + pbuf * P_BYTES) = stg[10];                           // (threads >= 80: into the slack slots)
-    }
+template <int HALF, int I>
+__device__ __forceinline__ void pwrite(State& st, const int pbuf) {
+    if constexpr (I < 5) *reinterpret_cast<u32x4*>(st.wb + pbuf * P_BYTES + (5 * HALF + I) * ROW_BYTES) = st.stg[I];
+    else *reinterpret_cast<u32x4*>(st.wext + pbuf * P_BYTES) = st.stg[5];                        // (threads >= 80: into the slack slots)
 }
-template <int... I>
-__device__ __forceinline__ void pload_all(State& st, u32x4 (&stg)[NSTG], const Args& a, const int cc, const bool up, const int wave, std::integer_sequence<int, I...>) {
-    (pload<I>(st, stg, a, cc, up, wave), ...);
+template <int HALF, int... I>
+__device__ __forceinline__ void pload_all(State& st, const Item& it, const Args& a, const int cc, const bool up, std::integer_sequence<int, I...>) {
+    (pload<HALF, I>(st, it, a, cc, up), ...);
 }
-template <int... I>
-__device__ __forceinline__ void pwrite_all(State& st, const u32x4 (&stg)[NSTG], const int pbuf, const int wave, std::integer_sequence<int, I...>) {
-    (pwrite<I>(st, stg, pbuf, wave), ...);
+template <int HALF, int... I>
+__device__ __forceinline__ void pwrite_all(State& st, const int pbuf, std::integer_sequence<int, I...>) {
+    (pwrite<HALF, I>(st, pbuf), ...);
 }
 
-// One slice: MFMA S of the chunk with parity PAR, and what is issued beside it.
-template <int S, int PAR, bool LAST>
-__device__ __forceinline__ void slice(State& st, const Args& a, const int cn, const int wave, const bool up, const unsigned u_plane, const unsigned u_wave) {
+// One slice: MFMA S of the chunk with parity PAR, and what is issued beside it.  The chunk stream runs on across work items:
+// MODE 0 = a chunk with two more chunks of its item behind it, 1 = the item's last but one (the patch it requests is chunk 0 of the
+// NEXT item), 2 = the item's last (requests chunk 1 of the next item, loads the weights and builds the first two V rows of its chunk 0).
+template <int S, int PAR, int MODE>
+__device__ __forceinline__ void slice(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave) {
     constexpr int seg = S / 6;
     constexpr int r = SEG_ROW[seg], ky = SEG_KY[seg];
     constexpr int term = (S % 6) / 2, nbh = S & 1;
     constexpr int ku = term == 1 ? 1 : 0, kv = term == 0 ? 1 : 0;         // terms: hi lo', lo hi', hi hi'
     constexpr int vbuf = (r + 2 * PAR) & 3;
-    if constexpr (S == BARRIER_SLICE && !LAST) {
+    if constexpr (S == BARRIER_SLICE) {
         // every wave is done reading this chunk's patch, and the next chunk's (written a chunk ago) is complete
         W9_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
@@ -225,52 +236,59 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
     // ---- V production: job j builds the fragment of row j + 2 of this chunk (j < 8) or of row j - 8 of the next chunk ----
     if constexpr (S >= JOB0 && S < JOB0 + 10 * JOB_SLICES) {
         constexpr int j = (S - JOB0) / JOB_SLICES, k = (S - JOB0) % JOB_SLICES;
-        if constexpr (!(LAST && j >= 8)) {
-            constexpr int buf = j < 8 ? ((j + 2 + 2 * PAR) & 3) : ((j - 8 + 2 * (PAR ^ 1)) & 3);
-            vop<2 * k>(st, buf);
-            vop<2 * k + 1>(st, buf);
-            // raw reads of the next job (j + 1): rows 3..9 of this patch, then rows 0, 1, 2 of the next
-            if constexpr (k >= 4 && k <= 7 && !(LAST && j >= 7)) {
-                constexpr int jn = j + 1;
-                constexpr int nrow = jn < 8 ? jn + 2 : jn - 8;
-                constexpr int npb = jn < 8 ? PAR : (PAR ^ 1);
-                rread<k - 4>(st, npb, nrow);
-            }
+        constexpr int buf = j < 8 ? ((j + 2 + 2 * PAR) & 3) : ((j - 8 + 2 * (PAR ^ 1)) & 3);
+        const float Sj = (MODE == 2 && j >= 8) ? st.nxt.S : st.cur.S;
+        vop<2 * k>(st, buf, Sj);
+        vop<2 * k + 1>(st, buf, Sj);
+        // raw reads of the next job (j + 1): rows 3..9 of this patch, then rows 0, 1, 2 of the next
+        if constexpr (k >= 4 && k <= 7) {
+            constexpr int jn = j + 1;
+            constexpr int nrow = jn < 8 ? jn + 2 : jn - 8;
+            constexpr int npb = jn < 8 ? PAR : (PAR ^ 1);
+            rread<k - 4>(st, npb, nrow);
         }
     }
     // ---- weight fragments: kernel row 2 of THIS chunk (first used at slice 30), rows 0 / 1 of the next once this chunk is done with them ----
-    if constexpr (S < 4) load_b<2>(st, a, cn, S, u_plane, u_wave);
-    if constexpr (!LAST && S >= KY0_DEAD && S < KY0_DEAD + 8 && (S - KY0_DEAD) % 2 == 0) load_b<0>(st, a, cn + 1, (S - KY0_DEAD) / 2, u_plane, u_wave);
-    if constexpr (!LAST && S >= KY1_DEAD && S < KY1_DEAD + 8 && (S - KY1_DEAD) % 2 == 0) load_b<1>(st, a, cn + 1, (S - KY1_DEAD) / 2, u_plane, u_wave);
-    // ---- patch of the chunk after next: global -> registers early, registers -> this chunk's buffer (dead after the barrier) ----
-    if constexpr (!LAST && S >= 4 && S <= 44 && (S - 4) % 4 == 0) {
-        pload<(S - 4) / 4>(st, st.stg, a, cn + 2, up, wave);      // (unconditional: past the last chunk it fetches out-of-range zeros / a neighbour's channels into a dead buffer)
+    if constexpr (S < 4) load_b<2>(st, a, st.cur.u_voff, cn, S, u_plane, u_wave);
+    if constexpr (S >= KY0_DEAD && S < KY0_DEAD + 8 && (S - KY0_DEAD) % 2 == 0)
+        load_b<0>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - KY0_DEAD) / 2, u_plane, u_wave);
+    if constexpr (S >= KY1_DEAD && S < KY1_DEAD + 8 && (S - KY1_DEAD) % 2 == 0)
+        load_b<1>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - KY1_DEAD) / 2, u_plane, u_wave);
+    // ---- patch of the chunk after next (of the next item in MODE 1 / 2), in two halves through the same staging registers:
+    //   slices 28..36   half B of the NEXT chunk's patch (requested a chunk ago) -> the other buffer, rows 5..9 (first read a chunk from now)
+    //   slices 38..58   request half A        99..109  half A -> this chunk's buffer (dead after the barrier)        111..127  request half B
+    if constexpr (S >= 28 && S <= 36 && (S - 28) % 2 == 0) pwrite<1, (S - 28) / 2>(st, PAR ^ 1);
+    if constexpr (S >= 38 && S <= 58 && (S - 38) % 4 == 0) {
+        if constexpr (MODE == 0) pload<0, (S - 38) / 4>(st, st.cur, a, cn + 2, up);
+        else pload<0, (S - 38) / 4>(st, st.nxt, a, MODE - 1, up);
     }
-    if constexpr (!LAST && S >= 99 && S <= 119 && (S - 99) % 2 == 0) {
-        pwrite<(S - 99) / 2>(st, st.stg, PAR, wave);
+    if constexpr (S >= 99 && S <= 109 && (S - 99) % 2 == 0) pwrite<0, (S - 99) / 2>(st, PAR);
+    if constexpr (S >= 111 && S <= 127 && (S - 111) % 4 == 0) {
+        if constexpr (MODE == 0) pload<1, (S - 111) / 4>(st, st.cur, a, cn + 2, up);
+        else pload<1, (S - 111) / 4>(st, st.nxt, a, MODE - 1, up);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int PAR, bool LAST, int... S>
-__device__ __forceinline__ void chunk_impl(State& st, const Args& a, const int cn, const int wave, const bool up, const unsigned u_plane,
-                                           const unsigned u_wave, std::integer_sequence<int, S...>) {
+template <int PAR, int MODE, int... S>
+__device__ __forceinline__ void chunk_impl(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave,
+                                           std::integer_sequence<int, S...>) {
     __builtin_amdgcn_sched_barrier(0);
-    (slice<S, PAR, LAST>(st, a, cn, wave, up, u_plane, u_wave), ...);
+    (slice<S, PAR, MODE>(st, a, cn, up, u_plane, u_wave), ...);
 }
-template <int PAR, bool LAST>
-__device__ __forceinline__ void chunk(State& st, const Args& a, const int cn, const int wave, const bool up, const unsigned u_plane, const unsigned u_wave) {
-    chunk_impl<PAR, LAST>(st, a, cn, wave, up, u_plane, u_wave, std::make_integer_sequence<int, NSLICE>{});
+template <int PAR, int MODE>
+__device__ __forceinline__ void chunk(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave) {
+    chunk_impl<PAR, MODE>(st, a, cn, up, u_plane, u_wave, std::make_integer_sequence<int, NSLICE>{});
 }
 template <int... O>
-__device__ __forceinline__ void job_all(State& st, const int buf, std::integer_sequence<int, O...>) {
-    (vop<O>(st, buf), ...);
+__device__ __forceinline__ void job_all(State& st, const int buf, const float S, std::integer_sequence<int, O...>) {
+    (vop<O>(st, buf, S), ...);
 }
 
-template <bool RES>      // RES: the launch adds a residual (32 more registers live through the epilogue passes)
+template <bool RES>      // RES: the launch adds a residual
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void winograd9_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sX = smem + 2 * P_BYTES;      // dedicated exchange region; pass 1 uses the (idle) patch area instead
+    char* sX = smem + 2 * P_BYTES;      // exchange region of the epilogue: two halves of 32 KB
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -279,7 +297,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool up = a.flags & CNL_UPSAMPLE_IN;
     const unsigned u_plane = (unsigned)(a.CoutP * 32);               // bytes per (chunk, position, ky, piece) plane of U
     const unsigned u_wave = (unsigned)wave * 6u * u_plane;
-    typedef std::make_integer_sequence<int, NSTG> AllPieces;
+    typedef std::make_integer_sequence<int, 6> HalfA;      // rows 0..4 + the column piece
+    typedef std::make_integer_sequence<int, 5> HalfB;      // rows 5..9
 
     State st;
     st.row_pitch = (unsigned)(a.Ws * a.ldx * 4);
@@ -304,49 +323,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         st.wext = tid < 80 ? smem + (er * ROW_SLOTS + q * QUAD_SLOTS + (ec & 1) * PXH + (ec >> 1)) * 16 : smem + (PR * ROW_SLOTS + (tid & 31)) * 16;
     }
     const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
-    float inv_n = 1.f;
     float omax = 0.f;
 
-    int n, y0, x0, n0;
-#define W9_IMAGE_OF(item_) ((int)(__builtin_amdgcn_readfirstlane(cnl::xcd_remap((item_), (unsigned)a.blocks)) / (unsigned)(a.nb * a.bx * a.by)))
-#define W9_SETUP(item_, xmax_)                                                                                   \
+    // coordinates of a work item (scalars) and the per-thread addressing that follows from them
+    struct Coord { int n, y0, x0, n0; };
+#define W9_COORD(c_, item_)                                                                                      \
     do {                                                                                                         \
         unsigned b_ = __builtin_amdgcn_readfirstlane(cnl::xcd_remap((item_), (unsigned)a.blocks));               \
         const int nbi_ = b_ % a.nb; b_ /= a.nb;                                                                  \
         const int bxi_ = b_ % a.bx; b_ /= a.bx;                                                                  \
-        const int byi_ = b_ % a.by; n = b_ / a.by;                                                               \
-        y0 = byi_ * R; x0 = bxi_ * (2 * TW); n0 = nbi_ * BN;                                                     \
-        st.y0m1 = y0 - 1;                                                                                        \
-        st.img_base = (unsigned)(n * a.Hs) * st.row_pitch;                                                       \
+        const int byi_ = b_ % a.by;                                                                              \
+        (c_).n = b_ / a.by; (c_).y0 = byi_ * R; (c_).x0 = bxi_ * (2 * TW); (c_).n0 = nbi_ * BN;                  \
+    } while (0)
+#define W9_ITEM(it_, c_)                                                                                         \
+    do {                                                                                                         \
+        (it_).y0m1 = (c_).y0 - 1;                                                                                \
+        (it_).img_base = (unsigned)((c_).n * a.Hs) * st.row_pitch;                                               \
         int tid_ = tid;                                                                                          \
         asm volatile("" : "+v"(tid_));      /* keeps the per-thread decode inside the item loop (hoisted, its values live across the main loop) */ \
-        {                                                                                                        \
-            const int q_ = tid_ & 3, ix_ = x0 - 1 + (tid_ >> 2);                                                 \
-            const int sx_ = up ? (ix_ >> 1) : ix_;                                                               \
-            st.vcol = (unsigned)ix_ < (unsigned)a.W ? (unsigned)((sx_ * a.ldx + q_ * 4) * 4) : OOB;              \
-            const int er_ = tid_ >> 3, ex_ = x0 + 63 + ((tid_ >> 2) & 1), ey_ = y0 - 1 + er_;                    \
-            const bool ok_ = tid_ < 80 && (unsigned)ey_ < (unsigned)a.H && (unsigned)ex_ < (unsigned)a.W;        \
-            const int esy_ = up ? (ey_ >> 1) : ey_, esx_ = up ? (ex_ >> 1) : ex_;                                \
-            st.vext = ok_ ? (unsigned)(((esy_ * a.Ws + esx_) * a.ldx + q_ * 4) * 4) : OOB;                       \
-        }                                                                                                        \
-        st.u_voff = (unsigned)((n0 + (tid_ & 31)) * 32 + ((tid_ >> 5) & 1) * 16);                                \
-        {                                                                                                        \
-            const float mx2_ = 2.f * (xmax_);             /* |V| <= 2 max |x| */                                 \
-            int es_ = 0;                                                                                         \
-            if (mx2_ > 0.f && mx2_ < __builtin_inff()) {                                                         \
-                int e_;                                                                                          \
-                (void)__builtin_frexpf(mx2_, &e_);            /* 2^(e-1) <= mx2 < 2^e */                         \
-                e_ = 14 - e_;                                                                                    \
-                es_ = e_ < -100 ? -100 : (e_ > 100 ? 100 : e_);                                                  \
-            }                                                                                                    \
-            st.S = __builtin_ldexpf(1.f, es_);                                                                   \
-            inv_n = __builtin_ldexpf(1.f, -es_);                                                                 \
-        }                                                                                                        \
+        const int q_ = tid_ & 3, ix_ = (c_).x0 - 1 + (tid_ >> 2);                                                \
+        const int sx_ = up ? (ix_ >> 1) : ix_;                                                                   \
+        (it_).vcol = (unsigned)ix_ < (unsigned)a.W ? (unsigned)((sx_ * a.ldx + q_ * 4) * 4) : OOB;               \
+        const int er_ = tid_ >> 3, ex_ = (c_).x0 + 63 + ((tid_ >> 2) & 1), ey_ = (c_).y0 - 1 + er_;              \
+        const bool ok_ = tid_ < 80 && (unsigned)ey_ < (unsigned)a.H && (unsigned)ex_ < (unsigned)a.W;            \
+        const int esy_ = up ? (ey_ >> 1) : ey_, esx_ = up ? (ex_ >> 1) : ex_;                                    \
+        (it_).vext = ok_ ? (unsigned)(((esy_ * a.Ws + esx_) * a.ldx + q_ * 4) * 4) : OOB;                        \
+        (it_).u_voff = (unsigned)(((c_).n0 + (tid_ & 31)) * 32 + ((tid_ >> 5) & 1) * 16);                        \
     } while (0)
-#define W9_LOAD_B01()                                                                                            \
+    // power-of-two scale of V from the image's maximum: |V| <= 2 max |x|, 2 max |x| S in [2^13, 2^14); es_ = log2 S
+#define W9_SCALE_EXP(es_, xmax_)                                                                                 \
     do {                                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) load_b<0>(st, a, 0, i, u_plane, u_wave);                   \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) load_b<1>(st, a, 0, i, u_plane, u_wave);                   \
+        const float mx2_ = 2.f * (xmax_);                                                                        \
+        (es_) = 0;                                                                                               \
+        if (mx2_ > 0.f && mx2_ < __builtin_inff()) {                                                             \
+            int e_;                                                                                              \
+            (void)__builtin_frexpf(mx2_, &e_);            /* 2^(e-1) <= mx2 < 2^e */                             \
+            e_ = 14 - e_;                                                                                        \
+            (es_) = e_ < -100 ? -100 : (e_ > 100 ? 100 : e_);                                                    \
+        }                                                                                                        \
     } while (0)
 
     unsigned item = blockIdx.x;
@@ -354,137 +368,169 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int tr_item = 0;
 #endif
     W9_STAMP(0);
-    W9_SETUP(item, a.xmax[W9_IMAGE_OF(item)]);
-    u32x4 stg1[NSTG];                   // patch 1 of the item set up last (patch 0 waits in st.stg)
-    pload_all(st, st.stg, a, 0, up, wave, AllPieces{});
-    pload_all(st, stg1, a, 1, up, wave, AllPieces{});
-    W9_LOAD_B01();
+    // Work items all take the same time, so without this every CU of the chip reaches its epilogue — 128 KB of output stores — in the
+    // same few microseconds: a 32 MB write burst every item period, during which the store queues fill and the epilogue passes take
+    // 3-10x their time (s_memtime traces).  A one-off start-up delay spreads the workgroups' phases over `stagger` cycles.
+    if (a.stagger) {
+        const unsigned wait_ = (((blockIdx.x * 37u) & 255u) * a.stagger) >> 8;
+        for (unsigned w_ = 0; w_ < wait_; w_ += 1024) __builtin_amdgcn_s_sleep(16);
+    }
+    Coord cc_cur, cc_nxt;
+    int es_cur;
+    W9_COORD(cc_cur, item);
+    W9_ITEM(st.cur, cc_cur);
+    W9_SCALE_EXP(es_cur, a.xmax[cc_cur.n]);
+    st.cur.S = __builtin_ldexpf(1.f, es_cur);
+    // the first item's prologue (afterwards the chunk stream itself fetches ahead): patches 0 / 1, weights and first V rows of chunk 0
+    {   // all four half-patches are requested before the first is written (the fragment registers are still free: one memory latency, not four)
+        u32x4 keep[3][NSTG];
+        pload_all<0>(st, st.cur, a, 0, up, HalfA{});
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) keep[0][i] = st.stg[i];
+        pload_all<1>(st, st.cur, a, 0, up, HalfB{});
+#pragma unroll
+        for (int i = 0; i < 5; ++i) keep[1][i] = st.stg[i];
+        pload_all<0>(st, st.cur, a, 1, up, HalfA{});
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) keep[2][i] = st.stg[i];
+        pload_all<1>(st, st.cur, a, 1, up, HalfB{});       // (half B of patch 1 stays in the staging registers: chunk 0 writes it at slice 28)
+        u32x4 last[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) last[i] = st.stg[i];
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) st.stg[i] = keep[0][i];
+        pwrite_all<0>(st, 0, HalfA{});
+#pragma unroll
+        for (int i = 0; i < 5; ++i) st.stg[i] = keep[1][i];
+        pwrite_all<1>(st, 0, HalfB{});
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) st.stg[i] = keep[2][i];
+        pwrite_all<0>(st, 1, HalfA{});
+#pragma unroll
+        for (int i = 0; i < 5; ++i) st.stg[i] = last[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_b<0>(st, a, st.cur.u_voff, 0, i, u_plane, u_wave);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_b<1>(st, a, st.cur.u_voff, 0, i, u_plane, u_wave);
+    W9_BARRIER();
+    rread<0>(st, 0, 0); rread<1>(st, 0, 0); rread<2>(st, 0, 0); rread<3>(st, 0, 0);
+    job_all(st, 0, st.cur.S, std::make_integer_sequence<int, 28>{});
+    rread<0>(st, 0, 1); rread<1>(st, 0, 1); rread<2>(st, 0, 1); rread<3>(st, 0, 1);
+    job_all(st, 1, st.cur.S, std::make_integer_sequence<int, 28>{});
+    rread<0>(st, 0, 2); rread<1>(st, 0, 2); rread<2>(st, 0, 2); rread<3>(st, 0, 2);
     while (true) {
         W9_STAMP(1);
+        // the item after this one (the last item of a workgroup names itself: its fetch-ahead then re-reads valid memory into dead buffers)
+        const unsigned next = item + gridDim.x;
+        const bool more = next < (unsigned)a.blocks;
+        W9_COORD(cc_nxt, more ? next : item);
+        W9_ITEM(st.nxt, cc_nxt);
+        const float xmax_next = a.xmax[cc_nxt.n];             // requested now, used behind the chunk loop
 #pragma unroll
         for (int yo = 0; yo < R; ++yo)
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) st.acc[yo][g][e] = 0.f;
-        // patches 0 / 1 of this item: registers -> LDS (everybody is past the previous item's last exchange pass: barrier below pass 3)
-        pwrite_all(st, st.stg, 0, wave, AllPieces{});
-        pwrite_all(st, stg1, 1, wave, AllPieces{});
-        W9_BARRIER();
-        // fragments of rows 0 and 1 of chunk 0 (not overlapped with MFMAs), raw reads of row 2 for job 0
-        rread<0>(st, 0, 0); rread<1>(st, 0, 0); rread<2>(st, 0, 0); rread<3>(st, 0, 0);
-        job_all(st, 0, std::make_integer_sequence<int, 28>{});
-        rread<0>(st, 0, 1); rread<1>(st, 0, 1); rread<2>(st, 0, 1); rread<3>(st, 0, 1);
-        job_all(st, 1, std::make_integer_sequence<int, 28>{});
-        rread<0>(st, 0, 2); rread<1>(st, 0, 2); rread<2>(st, 0, 2); rread<3>(st, 0, 2);
         W9_STAMP(5);
 
         for (int cn = 0; cn < a.CC - 2; cn += 2) {
-            chunk<0, false>(st, a, cn, wave, up, u_plane, u_wave);
-            chunk<1, false>(st, a, cn + 1, wave, up, u_plane, u_wave);
+            chunk<0, 0>(st, a, cn, up, u_plane, u_wave);
+            chunk<1, 0>(st, a, cn + 1, up, u_plane, u_wave);
         }
-        chunk<0, false>(st, a, a.CC - 2, wave, up, u_plane, u_wave);     // (a mid-loop exit instead of this second copy sends the register allocator into 700 spills)
-        chunk<1, true>(st, a, a.CC - 1, wave, up, u_plane, u_wave);
+        int es_nxt;
+        W9_SCALE_EXP(es_nxt, xmax_next);
+        st.nxt.S = __builtin_ldexpf(1.f, es_nxt);
+        chunk<0, 1>(st, a, a.CC - 2, up, u_plane, u_wave);
+        chunk<1, 2>(st, a, a.CC - 1, up, u_plane, u_wave);
         W9_STAMP(6);
 
-        // ---- epilogue: out0 = Y0 + Y1 + Y2, out1 = Y1 - Y2 - Y3; the four positions (waves) meet through LDS.  Pass k: output rows
-        // 2k, 2k+1 x two cout halves = 4 blocks; every wave writes its 4 blocks, wave w finishes block w = (row 2k + (w >> 1), half w & 1)
-        // for all four positions: thread = (tile, 4 couts) x 4 cout quads, 16-byte stores ----
-        const int en = n, ey0 = y0, ex0 = x0;
+        // ---- epilogue: out0 = Y0 + Y1 + Y2, out1 = Y1 - Y2 - Y3; the four positions (waves) meet through LDS.  Pass j = output row j:
+        // every wave writes its two blocks (cout halves) of that row into one half of the exchange region (32 KB, the halves alternate: one
+        // barrier per pass) as [cout half][position][tile][16-byte piece = 4 couts], pieces XOR-swizzled by the tile (conflict-free both ways);
+        // wave w finishes cout half w & 1 of tiles 16 (w >> 1) .. + 15 for all four positions with thread = (tile, piece): the 8 lanes of a
+        // tile store one full 128-byte line (32 couts) of each of its two pixels.  (A first version stored 16 bytes per lane with the lanes
+        // along the tiles — 64 quarter lines per instruction: the epilogue passes queued behind their own stores, 3-20 K cycles each.)
+        // (The patch buffers already hold the next item's first two patches.) ----
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));        // the epilogue's per-lane constants are re-derived here (hoisted, they live across the chunk loop and spill)
         const int t_e = lane_e & 31, h_e = lane_e >> 5;
-        const float inv = inv_n;
-        const unsigned next = item + gridDim.x;
-        const bool more = next < (unsigned)a.blocks;
-        const float xmax_next = more ? a.xmax[W9_IMAGE_OF(next)] : 0.f;     // requested now, used by the prefetch in pass 2
-        const int cbase = n0 + (wave & 1) * 32 + 4 * h_e;             // + 8 q: this thread's cout quads
-        f32x4 bq[4], iq[4];
+        const float inv = __builtin_ldexpf(1.f, -es_cur);
+        const int g_e = wave & 1;
+        const int piece_e = lane_e & 7;
+        const int cout_e = cc_cur.n0 + g_e * 32 + piece_e * 4;            // this thread's four couts
+        const bool cok_e = cout_e < a.Cout;
+        const f32x4 bq = __builtin_bit_cast(f32x4, buf_load16(a.bias, a.b_bytes, cok_e ? (unsigned)cout_e * 4u : OOB, 0));
+        const f32x4 iq = *reinterpret_cast<const f32x4*>(a.isu + cout_e) * inv;
+        // writer: lane (h, t) holds piece 2 q + h of tile t;  reader, iteration i: tile 16 (w >> 1) + 8 i + lane / 8, piece lane % 8
+        const int wslot0 = t_e * 8, wsw = t_e & 7;
+        int rtile[2], rslot[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = cbase + 8 * q;
-            bq[q] = __builtin_bit_cast(f32x4, buf_load16(a.bias, a.b_bytes, c < a.Cout ? (unsigned)c * 4u : OOB, 0));
-            const f32x4 s_ = *reinterpret_cast<const f32x4*>(a.isu + c);
-            iq[q] = s_ * inv;
+        for (int i = 0; i < 2; ++i) {
+            rtile[i] = 16 * (wave >> 1) + 8 * i + (lane_e >> 3);
+            rslot[i] = rtile[i] * 8 + (piece_e ^ (rtile[i] & 7));
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            char* X = (k == 1) ? smem : sX;
-            const int oy = ey0 + 2 * k + (wave >> 1);
-            const int ox = ex0 + 2 * t_e;
-            const bool row_ok = oy < a.H;
-            const unsigned pix = (unsigned)((en * a.H + oy) * a.W + ox);
-            unsigned yv[4];
-            bool okc[4];
-            f32x4 rv[2][4];
+        for (int j = 0; j < R; ++j) {
+            char* X = sX + (j & 1) * (X_BYTES / 2);
+            const int oy = cc_cur.y0 + j;
+            const bool row_ok = oy < a.H && cok_e;
+            unsigned yv[2];
+            bool ok[2][2];
+            f32x4 rv[2][2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                okc[q] = row_ok && (cbase + 8 * q) < a.Cout;
-                yv[q] = (pix * (unsigned)a.ldy + (unsigned)(cbase + 8 * q)) * 4u;
+            for (int i = 0; i < 2; ++i) {
+                const int ox = cc_cur.x0 + 2 * rtile[i];
+                const unsigned pix = (unsigned)((cc_cur.n * a.H + oy) * a.W + ox);
+                yv[i] = (pix * (unsigned)a.ldy + (unsigned)cout_e) * 4u;
+                ok[i][0] = row_ok && ox < a.W; ok[i][1] = row_ok && ox + 1 < a.W;
+                if constexpr (RES) {
+                    const unsigned rvo = (pix * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
 #pragma unroll
-                for (int px = 0; px < 2; ++px) {
-                    rv[px][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if constexpr (RES) {
-                        const unsigned rvo = (pix * (unsigned)a.ldr + (unsigned)(cbase + 8 * q)) * 4u;
-                        rv[px][q] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, (okc[q] && ox + px < a.W) ? rvo : OOB,
-                                                                         (unsigned)(px * a.ldr * 4)));
-                    }
+                    for (int px = 0; px < 2; ++px)
+                        rv[i][px] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, ok[i][px] ? rvo : OOB, (unsigned)(px * a.ldr * 4)));
                 }
             }
-            W9_STAMP(7 + 2 * k);
-            if (k == 3) W9_BARRIER();                  // pass 2's readers are done with sX
+            W9_STAMP(7 + (j & 7));
 #pragma unroll
-            for (int yy = 0; yy < 2; ++yy)
+            for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x16& A = st.acc[2 * k + yy][g];
-                        *reinterpret_cast<f32x4*>(X + ((((yy * 2 + g) * 4 + wave) * 4 + q) * 64 + lane_e) * 16) =
-                            f32x4{A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const f32x16& A = st.acc[j][g];
+                    *reinterpret_cast<f32x4*>(X + ((g * 4 + wave) * 256 + wslot0 + ((2 * q + h_e) ^ wsw)) * 16) = f32x4{A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};
+                }
             W9_BARRIER();
-            W9_STAMP(8 + 2 * k);
-            if (k == 2 && more) {                      // the staging and fragment registers are idle: request the next item's first two patches
-                W9_SETUP(next, xmax_next);
-                pload_all(st, st.stg, a, 0, up, wave, AllPieces{});
-                pload_all(st, stg1, a, 1, up, wave, AllPieces{});
-            } else if (k == 2) {                       // (no loop-carried staging values: they would stay live through the chunk loop)
-#pragma unroll
-                for (int i = 0; i < NSTG; ++i) { st.stg[i] = u32x4{0u, 0u, 0u, 0u}; stg1[i] = u32x4{0u, 0u, 0u, 0u}; }
-            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int i = 0; i < 2; ++i) {
                 f32x4 Y[4];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) Y[p] = lds_f4(X + (((wave * 4 + p) * 4 + q) * 64 + lane_e) * 16);
+                for (int p = 0; p < 4; ++p) Y[p] = lds_f4(X + ((g_e * 4 + p) * 256 + rslot[i]) * 16);
                 f32x4 o0, o1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float ya = (Y[0][e] + Y[1][e] + Y[2][e]) * iq[q][e];
-                    const float yb = (Y[1][e] - Y[2][e] - Y[3][e]) * iq[q][e];
+                    const float ya = (Y[0][e] + Y[1][e] + Y[2][e]) * iq[e];
+                    const float yb = (Y[1][e] - Y[2][e] - Y[3][e]) * iq[e];
                     if constexpr (RES) {
-                        o0[e] = fmaxf(ya + bq[q][e] + rv[0][q][e], lo);
-                        o1[e] = fmaxf(yb + bq[q][e] + rv[1][q][e], lo);
+                        o0[e] = fmaxf(ya + bq[e] + rv[i][0][e], lo);
+                        o1[e] = fmaxf(yb + bq[e] + rv[i][1][e], lo);
                     } else {
-                        o0[e] = fmaxf(ya + bq[q][e], lo);
-                        o1[e] = fmaxf(yb + bq[q][e], lo);
+                        o0[e] = fmaxf(ya + bq[e], lo);
+                        o1[e] = fmaxf(yb + bq[e], lo);
                     }
                 }
-                const bool ok0 = okc[q] && ox < a.W, ok1 = okc[q] && ox + 1 < a.W;
-                if (ok0) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o0[0]), fabsf(o0[1])), fmaxf(fabsf(o0[2]), fabsf(o0[3]))));
-                if (ok1) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o1[0]), fabsf(o1[1])), fmaxf(fabsf(o1[2]), fabsf(o1[3]))));
-                buf_store16(o0, a.y, a.y_bytes, ok0 ? yv[q] : OOB, 0);
-                buf_store16(o1, a.y, a.y_bytes, ok1 ? yv[q] : OOB, (unsigned)(a.ldy * 4));
+                if (ok[i][0]) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o0[0]), fabsf(o0[1])), fmaxf(fabsf(o0[2]), fabsf(o0[3]))));
+                if (ok[i][1]) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o1[0]), fabsf(o1[1])), fmaxf(fabsf(o1[2]), fabsf(o1[3]))));
+                buf_store16(o0, a.y, a.y_bytes, ok[i][0] ? yv[i] : OOB, 0);
+                buf_store16(o1, a.y, a.y_bytes, ok[i][1] ? yv[i] : OOB, (unsigned)(a.ldy * 4));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) { W9_LOAD_B01(); }
         if (a.ymax) {          // max |y| of this item into its image's slot: one atomic per wave and item
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
-            if (lane == 0 && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
+            if (lane_e == 0 && omax > 0.f) atomicMax(a.ymax + cc_cur.n, __float_as_uint(omax));
             omax = 0.f;
         }
         W9_STAMP(15);
@@ -493,10 +539,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
         if (!more) break;
         item = next;
-        W9_BARRIER();          // everybody is done with the exchange regions before the patch buffers are refilled
+        cc_cur = cc_nxt;
+        es_cur = es_nxt;
+        st.cur = st.nxt;
     }
-#undef W9_SETUP
-#undef W9_LOAD_B01
+#undef W9_COORD
+#undef W9_ITEM
+#undef W9_SCALE_EXP
 }
 
 // fp32 OHWI 3x3 weights -> U_p[ky] = (G g[ky])_p per (co, ci), scaled per OUTPUT CHANNEL by S_u[co] = 2^(13 - e) (max |U[co]| = m 2^e)
@@ -605,6 +654,11 @@ int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu,
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb; a.b_bytes = (unsigned)p->Cout * 4u;
     a.flags = p->flags;
+    {   // ~12 % of a workgroup's estimated run time, at most one epilogue-burst period (32 K cycles)
+        const long long per_wg = (blocks + 255) / 256 * ((long long)a.CC * 5000 + 12000);
+        const long long st = per_wg / 8;
+        a.stagger = W9_STAGGER ? (unsigned)(st > 32768 ? 32768 : st) * W9_STAGGER : 0u;
+    }
 #ifdef W9_TRACE
     a.trace = g_w9_trace;
 #endif

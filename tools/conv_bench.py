@@ -23,6 +23,8 @@ SHAPES = {
     "c4first": (16, 152, 272, 64, 256, 3, 1, CNL_RELU, False),
     "layer1res": (32, 128, 128, 64, 64, 3, 1, CNL_RELU, True),
     "layer2": (32, 64, 64, 128, 128, 3, 1, CNL_RELU, True),
+    "l1nr": (32, 128, 128, 64, 64, 3, 1, CNL_RELU, False),
+    "l2nr": (32, 64, 64, 128, 128, 3, 1, CNL_RELU, False),
     "layer2n64": (64, 64, 64, 128, 128, 3, 1, CNL_RELU, True),
     "layer2n8": (8, 64, 64, 128, 128, 3, 1, CNL_RELU, True),
     "layer3": (32, 32, 32, 256, 256, 3, 1, CNL_RELU, True),
