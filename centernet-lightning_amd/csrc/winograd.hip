@@ -138,6 +138,13 @@ static int wino_choice(const cnl_conv_params* p) {
         return v;
     }
     if (p->algo == CNL_ALGO_F32 || p->Cin % 16) return 2;
+    // row-Winograd (winograd9.hip): 8-row x 64-pixel x 64-cout work items.  Measured against kernels 2 / 5 / 6 on every 3x3 shape of the
+    // three configurations (profiles/r03_winograd9_variants.txt): 0.5-0.8x their time wherever its blocks pad the map by less than ~1.5x
+    // (maps at least ~44 pixels wide), channel loops from 32 up, with or without residual / folded upsample
+    if (p->algo != CNL_ALGO_F4 && cnl_wino9_eligible(p)) {
+        const long long pad9 = (long long)((H + 7) / 8 * 8) * ((W + 63) / 64 * 64);
+        if (pad9 * 100 <= (long long)H * W * 150) return 9;
+    }
     if (items_per_image >= 8 && (p->Cin >= 128 || p->Cout >= 256)) {      // (Cin 64 -> 256 / 512 / 768: the first head blocks, per head or fused)
         const long long area = (long long)H * W;
         if (p->algo == CNL_ALGO_F4 && p->Cin >= 256 && area >= 64 * 64 && cnl_wino8_eligible(p)) {
@@ -147,11 +154,6 @@ static int wino_choice(const cnl_conv_params* p) {
             // where the padding of the map to 32x16-pixel items stays below 15 %
             const long long pad8 = (long long)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32);
             if (pad8 * 100 <= area * 115) return 8;
-        }
-        // row-Winograd (winograd9.hip): 8-row x 64-pixel x 64-cout work items, long channel loops on maps they tile with little padding
-        if (p->Cin >= 128 && p->Cin % 64 == 0 && !p->residual && cnl_wino9_eligible(p)) {
-            const long long pad9 = (long long)((H + 7) / 8 * 8) * ((W + 63) / 64 * 64);
-            if (pad9 * 100 <= area * 110) return 9;
         }
         // the 8x16-pixel x 128-cout work items of winograd6.hip: where the channel loop is short and the couts many, and on maps
         // that 16-row blocks pad more than 8-row blocks (19x34, 38x68, 152x272 of 608x1088 frames: -1 .. -4 %)

@@ -521,7 +521,7 @@ def test_winograd_split_kernels_exact_on_small_integers():
     x = torch.randint(-3, 4, (1, 256, 32, 32), generator=g).float()
     w = torch.randint(-2, 3, (128, 256, 3, 3), generator=g).float() * 4
     b = torch.randint(-5, 6, (128,), generator=g).float()
-    for v in (5, 6):
+    for v in (5, 6, 9):
         assert torch.equal(run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + v, want=5), ref_conv(x, w, b, 1, 0)), v
     assert torch.equal(run_winograd(x, w, b, 0, algo=CNL_ALGO_F2, want=5), ref_conv(x, w, b, 1, 0))
     out = run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + 8, want=8)               # F(4x4): integers up to ~4e3, error << 0.5
@@ -536,7 +536,7 @@ def test_winograd_is_batch_invariant_across_magnitudes():
     x = torch.randn(3, 256, 32, 32, generator=g).clamp_min(0) * torch.tensor([1.0, 1e-3, 300.0]).view(3, 1, 1, 1)
     w = torch.randn(128, 256, 3, 3, generator=g) * (2.0 / (256 * 9)) ** 0.5
     b = torch.randn(128, generator=g)
-    for algo, want in ((CNL_ALGO_FORCE + 8, 8), (CNL_ALGO_F2, 5), (CNL_ALGO_F32, 2)):
+    for algo, want in ((CNL_ALGO_FORCE + 8, 8), (CNL_ALGO_FORCE + 9, 5), (CNL_ALGO_FORCE + 5, 5), (CNL_ALGO_F2, 5), (CNL_ALGO_F32, 2)):
         full = run_winograd(x, w, b, CNL_RELU, algo=algo, want=want)
         for i in range(3):
             assert torch.equal(full[i:i + 1], run_winograd(x[i:i + 1], w, b, CNL_RELU, algo=algo)), (algo, i)
@@ -675,7 +675,7 @@ def test_winograd_split_kernels_error_not_above_fp32_mfma():
         b = torch.zeros(256)
         ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
         err = {}
-        for v in (2, 5, 6, 8) + ((3, 7) if exp is not None else ()):
+        for v in (2, 5, 6, 8, 9) + ((3, 7) if exp is not None else ()):
             out = run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + v, lib=exp if v in (3, 7) else None)
             assert torch.isfinite(out).all(), (case, v)
             err[v] = (out.double() - ref).abs().max().item()
@@ -686,6 +686,90 @@ def test_winograd_split_kernels_error_not_above_fp32_mfma():
             assert err[v] <= 1.25 * err[2] + 1e-7 * scale, (case, v, err, scale)
         assert err[8] <= 4e-6 * scale and err[8] <= 8 * err[2] + 1e-7 * scale, (case, err, scale)
         assert err[2] < 2e-5 * scale, (case, err, scale)
+
+
+W9_CASES = [
+    # N, Cin, H, W, Cout, flags, residual — winograd9.hip (row-Winograd): 8-row x 64-pixel x 64-cout work items
+    (1, 32, 8, 64, 64, 0, False),                       # one work item, two chunks (the shortest channel loop)
+    (1, 32, 8, 64, 64, CNL_RELU, True),
+    (2, 64, 16, 128, 64, CNL_RELU, False),              # two blocks across, two down, layer1 channels
+    (1, 256, 32, 32, 256, CNL_RELU, True),              # half-empty blocks, four cout blocks, residual
+    (2, 64, 19, 34, 96, CNL_RELU, True),                # ragged rows / columns / couts (96 -> 128)
+    (1, 128, 40, 24, 128, 0, True),
+    (3, 32, 5, 7, 4, 0, False),                         # Cout = 4: one cout quad of one block
+    (1, 64, 9, 130, 72, CNL_RELU, False),               # three blocks across, the last two pixels wide
+    (2, 32, 6, 10, 64, CNL_RELU | CNL_UPSAMPLE_IN, False),
+    (1, 512, 16, 16, 512, CNL_RELU, True),              # 32 chunks
+    (5, 64, 24, 72, 64, CNL_RELU, False),               # several items per workgroup never happen at this size; several images do
+]
+
+
+@pytest.mark.parametrize("case", W9_CASES, ids=lambda c: "N{}c{}_{}x{}_o{}f{}r{}".format(*[int(v) for v in c]))
+def test_winograd9_matches_cpu_and_reports_absmax(case):
+    """winograd9.hip forced on shapes that exercise its edges: the path's 1e-4 bar against conv2d on the CPU, error against float64 at or
+    below the fp32 matrix-core kernel's (+ 1e-7 of the layer maximum), max |y| per image handed over exactly."""
+    N, Cin, H, W, Cout, flags, use_res = case
+    x, w, b = mk(N, Cin, H, W, Cout, 3, seed=Cin + Cout + H + W)
+    up = 2 if flags & CNL_UPSAMPLE_IN else 1
+    res = torch.randn(N, Cout, H * up, W * up, generator=torch.Generator().manual_seed(6)) if use_res else None
+    ref = ref_conv(x, w, b, 1, flags, res)
+    out, ym = run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 9, want=5, ymax=True)
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out, ref, rtol=RTOL, atol=ATOL)
+    assert torch.equal(ym, out.abs().amax(dim=(1, 2, 3)))
+    ref64 = ref_conv(x.double(), w.double(), b.double(), 1, flags, res.double() if use_res else None)
+    e9 = (out.double() - ref64).abs().max().item()
+    e2 = (run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 2).double() - ref64).abs().max().item()
+    assert e9 <= 1.25 * e2 + 1e-7 * ref64.abs().max().item(), (e9, e2)
+
+
+def test_winograd9_many_items_per_workgroup_is_bit_identical_to_one_image_at_a_time():
+    """More work items than CUs (the chunk stream then runs on from one item into the next: patches, weights and the first V rows of
+    item i + 1 are fetched inside the last two chunks of item i): the batch must give bit for bit what each image gives alone, with
+    images of very different magnitude side by side (the scale changes between consecutive items of a workgroup)."""
+    g = torch.Generator().manual_seed(21)
+    N = 12
+    x = torch.randn(N, 64, 64, 128, generator=g).clamp_min(0) * torch.pow(10.0, torch.randint(-3, 3, (N, 1, 1, 1), generator=g).float())
+    w = torch.randn(128, 64, 3, 3, generator=g) * (2.0 / (64 * 9)) ** 0.5
+    b = torch.randn(128, generator=g)
+    res = torch.randn(N, 128, 64, 128, generator=g)
+    full, ym = run_winograd(x, w, b, CNL_RELU, res, algo=CNL_ALGO_FORCE + 9, want=5, ymax=True)      # 12 * 8 * 2 * 2 = 384 items on 256 CUs
+    torch.testing.assert_close(full, ref_conv(x, w, b, 1, CNL_RELU, res), rtol=RTOL, atol=ATOL * 100)
+    for i in (0, 3, 7, 11):
+        assert torch.equal(full[i:i + 1], run_winograd(x[i:i + 1], w, b, CNL_RELU, res[i:i + 1], algo=CNL_ALGO_FORCE + 9)), i
+    assert torch.equal(ym, full.abs().amax(dim=(1, 2, 3)))
+
+
+def test_split_kernels_on_trained_checkpoint_like_weights():
+    """weights as a trained checkpoint with BatchNorm folded has them — per-output-channel scales over four decades
+    (10^U(-3, 1)), 5 % dead channels (all-zero filters), inputs in the range of a normalised image (negative values) — must not cost the
+    fp16-split kernels accuracy: error against float64 PER OUTPUT CHANNEL, relative to that channel's largest output, at or below
+    1.25x the fp32 matrix-core kernel's.  (winograd5/6 scale the weights per tensor: a channel 10^-3 of the largest keeps 22 - 10 bits
+    in the first piece, the second piece restores them; winograd9 scales per output channel.)"""
+    g = torch.Generator().manual_seed(31)
+    Cin, Cout = 256, 256
+    x = torch.randn(1, Cin, 32, 64, generator=g) * 1.2 - 0.3
+    scale = torch.pow(10.0, torch.rand(Cout, generator=g) * 4 - 3)
+    scale[torch.randperm(Cout, generator=g)[:Cout // 20]] = 0.0
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5 * scale.view(-1, 1, 1, 1)
+    b = torch.randn(Cout, generator=g) * scale
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    cmax = ref.abs().amax(dim=(0, 2, 3))
+    live = cmax > 0
+    err = {}
+    for v in (2, 5, 6, 9):
+        out = run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + v)
+        assert torch.isfinite(out).all(), v
+        d = out.double() - ref
+        e = d.abs().amax(dim=(0, 2, 3))
+        assert float(e[~live].max()) == 0.0 if (~live).any() else True, v          # dead channels give exact zeros
+        err[v] = (e[live] / cmax[live], d.pow(2).mean(dim=(0, 2, 3)).sqrt()[live] / cmax[live])
+    for v in (5, 6, 9):
+        # per channel: rms error within 1.25x the fp32 matrix core's; the MAXIMUM over a channel's 2048 outputs is a noisy statistic -> 2x
+        worst_rms = float((err[v][1] / (1.25 * err[2][1] + 2e-8)).max())
+        worst_max = float((err[v][0] / (2.0 * err[2][0] + 1e-7)).max())
+        assert worst_rms <= 1.0 and worst_max <= 1.0, (v, worst_rms, worst_max, float(err[v][0].max()), float(err[2][0].max()))
+        assert float(err[v][0].max()) <= 1.25 * float(err[2][0].max()) + 1e-7, (v, float(err[v][0].max()), float(err[2][0].max()))
 
 
 def test_winograd_dispatch_is_a_function_of_shape_and_algo_only():
@@ -706,5 +790,7 @@ def test_winograd_dispatch_is_a_function_of_shape_and_algo_only():
         assert kind(N, 256, 128, 128, 256, CNL_ALGO_F32) == 2
         assert kind(N, 256, 32, 32, 256, CNL_ALGO_F4) == 5              # layer3: F(2x2) even when F(4x4) is allowed
         assert kind(N, 128, 64, 64, 128, CNL_ALGO_AUTO) == 5            # layer2
-        assert kind(N, 64, 128, 128, 64, CNL_ALGO_AUTO) == 2            # layer1: fp32 matrix cores
+        assert kind(N, 64, 128, 128, 64, CNL_ALGO_AUTO) == 5            # layer1: row-Winograd on the fp16 matrix cores (round 3)
+        assert kind(N, 64, 16, 16, 64, CNL_ALGO_AUTO) == 2              # short channel loop on a map its 64-pixel blocks would pad 4x: fp32 matrix cores
+        assert kind(N, 64, 128, 128, 64, CNL_ALGO_F32) == 2
         assert kind(N, 24, 128, 128, 64, CNL_ALGO_AUTO) == 2            # Cin % 16 != 0
