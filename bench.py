@@ -64,11 +64,15 @@ CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracki
 KIND_NAMES = {"winograd_f4": "cnl_wino8::winograd8_kernel (Winograd F(4x4,3x3); fp32 operands scaled per image by a power of two and split into 2 fp16 pieces, "
                              "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
               "winograd_f16x2": "cnl_wino5::winograd5_kernel / cnl_wino6::winograd6_kernel (Winograd F(2x2,3x3); the same split arithmetic)",
+              "winograd_row_f16x2": "cnl_wino9::winograd9_kernel (1-D Winograd F(2,3) along x, the three kernel rows in the reduction: 6 of the direct conv's 9 multiplies "
+                                    "per output; fp32 operands scaled per image / per output channel by a power of two and split into 2 fp16 pieces, "
+                                    "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
               "winograd_f32": "cnl_wino2::winograd2_kernel (Winograd F(2x2,3x3), fp32 v_mfma_f32_32x32x2_f32)",
               "direct_f16x2": "cnl_conv::conv_f16x2_kernel (direct implicit GEMM, fp16 matrix cores, scaled two-way split)",
               "direct": "cnl_conv::conv_mfma_kernel (direct implicit GEMM, fp32 v_mfma_f32_32x32x2_f32)"}
 # executed matrix flops / direct-conv flops, and the peak they run against
 EXEC = {"winograd_f4": (36.0 / 144.0 * 3.0, F16_MFMA_PEAK_TFLOPS), "winograd_f16x2": (16.0 / 36.0 * 3.0, F16_MFMA_PEAK_TFLOPS),
+        "winograd_row_f16x2": (6.0 / 9.0 * 3.0, F16_MFMA_PEAK_TFLOPS),
         "winograd_f32": (16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS), "direct_f16x2": (3.0, F16_MFMA_PEAK_TFLOPS), "direct": (1.0, FP32_MFMA_PEAK_TFLOPS)}
 
 
@@ -168,7 +172,7 @@ def conv_kernel_profile(model, x, reps=3):
             return "direct_f16x2" if lib.cnl_conv3x3_up2_kernel(ctypes.byref(L.args)) == 5 else "direct"
         if L.fn is not lib.cnl_conv3x3_winograd_f32:
             return "direct_f16x2" if lib.cnl_conv2d_kernel(ctypes.byref(L.args)) == 5 else "direct"
-        return {5: "winograd_f16x2", 8: "winograd_f4"}.get(lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)), "winograd_f32")
+        return {5: "winograd_f16x2", 6: "winograd_f16x2", 8: "winograd_f4", 9: "winograd_row_f16x2"}.get(lib.cnl_conv3x3_winograd_variant(ctypes.byref(L.args)), "winograd_f32")
 
     rows = []
     for i, L in enumerate(convs):

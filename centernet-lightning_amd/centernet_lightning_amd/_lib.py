@@ -57,6 +57,7 @@ _SIGNATURES = {
     "cnl_conv2d_out_hw": (ctypes.c_int, [POINTER(ConvParams), POINTER(c_int32), POINTER(c_int32)]),
     "cnl_conv3x3_winograd_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
     "cnl_conv3x3_winograd_kernel": (ctypes.c_int, [POINTER(ConvParams)]),
+    "cnl_conv3x3_winograd_variant": (ctypes.c_int, [POINTER(ConvParams)]),
     "cnl_conv2d_kernel": (ctypes.c_int, [POINTER(ConvParams)]),
     "cnl_up2_weight_floats": (c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "cnl_up2_pack_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int32, ctypes.c_int32, c_void_p]),

@@ -492,24 +492,26 @@ class Plan:
                 pairs.append((P, L, slot_of.setdefault(id(P), len(slot_of))))
                 reports.add(id(L))
             elif is_wino5:
-                reports.add(id(L))      # makes its own pass over the input ...
-                if id(x) not in unsafe and len(ws) <= 1:
-                    own_pass.setdefault((id(x), L.args.x, L.args.Cin, L.args.ldx), []).append(L)      # ... unless several launches read the same tensor (below)
+                # no reporting producer: an explicit cnl_absmax_per_image_f32 pass into a slot of THIS plan's absmax tensor (the library's own
+                # pass parks the maxima in scratch inside the shared weight buffer: two streams running one model would race on it — ADVICE r2).
+                # Launches reading the same single-writer tensor share one pass; a tensor with several writers gets a pass per reader
+                reports.add(id(L))
+                key = (id(x), L.args.x, L.args.Cin, L.args.ldx) if (id(x) not in unsafe and len(ws) <= 1) else ("solo", id(L))
+                own_pass.setdefault(key, []).append(L)
             elif L.args.KH == 3:
                 passes.append((L, slot_of.setdefault(id(L), len(slot_of))))
                 reports.add(id(L))
         # a tensor read by several such launches (the per-head first blocks behind an fp32-kernel neck layer): ONE explicit pass, shared
-        for group in own_pass.values():
-            if len(group) >= 2:
-                passes.append((group[0], slot_of.setdefault(("shared", id(group[0].keep[0])), len(slot_of))))
-                shared.extend(group[1:])
+        for key, group in own_pass.items():
+            passes.append((group[0], slot_of.setdefault(("shared", key), len(slot_of))))
+            shared.extend((L, key) for L in group[1:])
         # one float per (tensor, image): an image's scale must not depend on its batch neighbours
         self.absmax = torch.zeros((max(len(slot_of), 1), self.N), device=self.device, dtype=torch.float32) if slot_of else None
         for P, L, i in pairs:
             P.args.y_absmax = self.absmax.data_ptr() + 4 * i * self.N
             L.args.x_absmax = self.absmax.data_ptr() + 4 * i * self.N
-        for L in shared:
-            L.args.x_absmax = self.absmax.data_ptr() + 4 * slot_of[("shared", id(L.keep[0]))] * self.N
+        for L, key in shared:
+            L.args.x_absmax = self.absmax.data_ptr() + 4 * slot_of[("shared", key)] * self.N
         for L, i in passes:
             a = L.args
             L.args.x_absmax = self.absmax.data_ptr() + 4 * i * self.N
@@ -558,8 +560,13 @@ class Plan:
             p.w = layer.u.data_ptr()
             fn = self.lib.cnl_conv3x3_winograd_f32
             what += " [winograd]"
+        rowwino = False
+        if fn is self.lib.cnl_conv3x3_winograd_f32 and self.algo not in (CNL_ALGO_F32, CNL_ALGO_F4) and layer.cin % 32 == 0 and layer.cout % 4 == 0:
+            # the dispatcher's rule for winograd9.hip (8-row x 64-pixel work items pad the map by < 1.5x): it folds the upsample into its
+            # patch gather and beats the sub-pixel phases below (C1: 8.93 -> 8.82 ms per forward)
+            rowwino = -(-ho.value // 8) * 8 * -(-wo.value // 64) * 64 * 100 <= ho.value * wo.value * 150
         if (self.options.up2 and (flags & CNL_UPSAMPLE_IN) and not (flags & ~(CNL_RELU | CNL_UPSAMPLE_IN)) and residual is None
-                and layer.wants_up2()):
+                and layer.wants_up2() and not rowwino):
             # short channel loop, many couts, conv on the nearest-2x upsampled input (the fused first head blocks behind the simple
             # neck): four 2x2 sub-pixel phase convs on the low-resolution input (fp16-split direct kernel) beat Winograd there
             p.w = layer.up2().data_ptr()
@@ -964,7 +971,11 @@ class Engine:
                 # max_batch() prices the backbone / head tensors; a neck option can hold something wider (deformable columns): split further
                 if chunk == 1:
                     raise
-                self._sub_override[(H, W)] = chunk = -(-N // (-(-N // chunk) + 1))
+                # one more part — and strictly fewer images per part (ceil(N / (parts + 1)) stops shrinking once chunk <= ~sqrt(N):
+                # N = 9, chunk = 3 -> 3, an endless rebuild of the same plan)
+                smaller = min(chunk - 1, -(-N // (-(-N // chunk) + 1)))
+                assert 1 <= smaller < chunk
+                self._sub_override[(H, W)] = chunk = smaller
 
     def sub_batch(self, N, H, W):
         """Images per launch plan: N when it fits the addressing limit, else N split into the fewest equal parts that do."""

@@ -138,23 +138,24 @@ static int wino_choice(const cnl_conv_params* p) {
         return v;
     }
     if (p->algo == CNL_ALGO_F32 || p->Cin % 16) return 2;
+    const long long area = (long long)H * W;
+    if (p->algo == CNL_ALGO_F4 && items_per_image >= 8 && p->Cin >= 256 && area >= 64 * 64 && cnl_wino8_eligible(p)) {
+        // F(4x4): 32x16-pixel items.  Measured against kernel 5 / 6 on one box (profiles/r02_winograd8_variants.txt): 0.89-0.93 of
+        // their time on the 256 -> 256 head blocks at 128x128, 0.93-0.97 at 152x272, no gain on the backbone's 32x32 / 64x64 maps
+        // (few items per CU: the per-item prologue / epilogue weigh more) — taken only for the long channel loops on large maps,
+        // where the padding of the map to 32x16-pixel items stays below 15 %.  (An opt-in class: since round 3 the default's
+        // row-Winograd kernel is faster on these layers at a quarter of the rounding error.)
+        const long long pad8 = (long long)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32);
+        if (pad8 * 100 <= area * 115) return 8;
+    }
     // row-Winograd (winograd9.hip): 8-row x 64-pixel x 64-cout work items.  Measured against kernels 2 / 5 / 6 on every 3x3 shape of the
     // three configurations (profiles/r03_winograd9_variants.txt): 0.5-0.8x their time wherever its blocks pad the map by less than ~1.5x
     // (maps at least ~44 pixels wide), channel loops from 32 up, with or without residual / folded upsample
-    if (p->algo != CNL_ALGO_F4 && cnl_wino9_eligible(p)) {
+    if (cnl_wino9_eligible(p)) {
         const long long pad9 = (long long)((H + 7) / 8 * 8) * ((W + 63) / 64 * 64);
-        if (pad9 * 100 <= (long long)H * W * 150) return 9;
+        if (pad9 * 100 <= area * 150) return 9;
     }
     if (items_per_image >= 8 && (p->Cin >= 128 || p->Cout >= 256)) {      // (Cin 64 -> 256 / 512 / 768: the first head blocks, per head or fused)
-        const long long area = (long long)H * W;
-        if (p->algo == CNL_ALGO_F4 && p->Cin >= 256 && area >= 64 * 64 && cnl_wino8_eligible(p)) {
-            // F(4x4): 32x16-pixel items.  Measured against kernel 5 / 6 on one box (profiles/r02_winograd8_variants.txt): 0.89-0.93 of
-            // their time on the 256 -> 256 head blocks at 128x128, 0.93-0.97 at 152x272, no gain on the backbone's 32x32 / 64x64 maps
-            // (few items per CU: the per-item prologue / epilogue weigh more) — taken only for the long channel loops on large maps,
-            // where the padding of the map to 32x16-pixel items stays below 15 %
-            const long long pad8 = (long long)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32);
-            if (pad8 * 100 <= area * 115) return 8;
-        }
         // the 8x16-pixel x 128-cout work items of winograd6.hip: where the channel loop is short and the couts many, and on maps
         // that 16-row blocks pad more than 8-row blocks (19x34, 38x68, 152x272 of 608x1088 frames: -1 .. -4 %)
         const long long pad16 = (long long)((H + 15) / 16 * 16) * ((W + 15) / 16 * 16), pad8 = (long long)((H + 7) / 8 * 8) * ((W + 15) / 16 * 16);
@@ -168,6 +169,12 @@ extern "C" int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p) {
     CNL_REQUIRE(p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: non-positive dimension");
     const int c = wino_choice(p);
     return c == 8 ? CNL_WINO_F16X2_F4 : (c == 5 || c == 6 || c == 7 || c == 9) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
+}
+
+extern "C" int cnl_conv3x3_winograd_variant(const cnl_conv_params* p) {
+    CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_variant: null params");
+    CNL_REQUIRE(p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_variant: non-positive dimension");
+    return wino_choice(p);
 }
 
 extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) {

@@ -48,7 +48,7 @@ enum {
  *   CNL_ALGO_F4    AUTO, plus Winograd F(4x4,3x3) (csrc/winograd8.hip) on the long 3x3 layers over large maps: 0.56x the matrix work,
  *                  error ~1e-6 of the layer's largest output (~4x F(2x2)).  Opt-in: on MI355X it is bound by the same weight stream
  *                  from the L2 / Infinity Cache as the F(2x2) kernels and ends up within +-5 % of them.
- *   CNL_ALGO_FORCE + v  tests / A-B measurements: pin kernel variant v (2, 5, 6, 8; 1, 3, 4, 7 in `make experiments` builds) wherever
+ *   CNL_ALGO_FORCE + v  tests / A-B measurements: pin kernel variant v (2, 5, 6, 8, 9; 1, 3, 4, 7 in `make experiments` builds) wherever
  *                  it can run at all.
  */
 enum {
@@ -160,7 +160,10 @@ int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);
  * core (csrc/winograd2.hip), or — where the channel loop is long (Cin >= 128 or Cout >= 256, Cin % 16 == 0) — the fp16 matrix core
  * fed with a two-way fp16 split of both fp32 operands under a per-image power-of-two scale (three cross terms, fp32
  * accumulation: csrc/winograd5.hip, winograd6.hip; measured error at or below the fp32 matrix core's, half-precision rate = 16x), as
- * F(2x2,3x3) or, under CNL_ALGO_F4 on large maps that 32x16-pixel work items tile well, F(4x4,3x3) (csrc/winograd8.hip).
+ * F(2x2,3x3) or, under CNL_ALGO_F4 on large maps that 32x16-pixel work items tile well, F(4x4,3x3) (csrc/winograd8.hip).  Round 3: wherever
+ * 8-row x 64-pixel work items pad the map by less than 1.5x (Cin % 32 == 0, Cout % 4 == 0), the same split arithmetic runs as 1-D Winograd
+ * F(2,3) along x with the three kernel rows in the reduction (csrc/winograd9.hip: per-output-channel weight scales; 0.5-0.8x the time of the
+ * 2-D kernels, rounding error below theirs) — same class CNL_WINO_F16X2.
  * cnl_conv3x3_winograd_kernel reports which class a layer takes.  The fp16-split kernels without the x_absmax hint make their own
  * pass over the input and park the per-image maxima in the layer's weight buffer: such hint-less launches of ONE layer must not
  * run concurrently on two streams (launches that carry x_absmax — everything engine.py issues — have no hidden state).
@@ -171,6 +174,9 @@ int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);
 #define CNL_WINO_F16X2_F4 8
 int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream);
 int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p);            /* CNL_WINO_* for this layer shape, < 0: error code */
+int cnl_conv3x3_winograd_variant(const cnl_conv_params* p);           /* the kernel behind the class (reporting only): 2 winograd2, 5 / 6 winograd5 / 6
+                                                                         [F(2x2,3x3)], 8 winograd8 [F(4x4,3x3)], 9 winograd9 [F(2,3) along x, kernel rows
+                                                                         in the reduction: 2/3 of the direct conv's multiplies]; < 0: error code */
 size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout);        /* elements of the transformed weight buffer */
 int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream);
 
