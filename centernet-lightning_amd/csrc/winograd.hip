@@ -152,8 +152,11 @@ static int wino_choice(const cnl_conv_params* p) {
     // three configurations (profiles/r03_winograd9_variants.txt): 0.5-0.8x their time wherever its blocks pad the map by less than ~1.5x
     // (maps at least ~44 pixels wide), channel loops from 32 up, with or without residual / folded upsample
     if (cnl_wino9_eligible(p)) {
-        const long long pad9 = (long long)((H + 7) / 8 * 8) * ((W + 63) / 64 * 64);
-        if (pad9 * 100 <= area * 150) return 9;
+        // 32-pixel-wide maps: two images side by side in a block row (a function of the shape alone).  16-pixel-wide maps could take four
+        // (the kernel does it when forced), but there kernels 5 / 6 win: 512 -> 512 @16x16 85 vs 110 us, 512 -> 256 77 vs 98
+        const int side = (upf == 1 && W == 32) ? 2 : 1;
+        const long long pad9 = (long long)((H + 7) / 8 * 8) * ((W * side + 63) / 64 * 64);
+        if (pad9 * 100 <= area * side * 150) return 9;
     }
     if (items_per_image >= 8 && (p->Cin >= 128 || p->Cout >= 256)) {      // (Cin 64 -> 256 / 512 / 768: the first head blocks, per head or fused)
         // the 8x16-pixel x 128-cout work items of winograd6.hip: where the channel loop is short and the couts many, and on maps

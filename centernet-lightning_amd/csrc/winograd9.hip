@@ -58,6 +58,8 @@ struct Args {
     int ldx, ldy, ldr;
     int CC;                           // Cin / 16 (even)
     int nb, bx, by;                   // blocks along cout (64), x (64 px), y (8 rows)
+    int ipb, lw;                      // images side by side in one 64-pixel block row (W = 32: 2, W = 16: 4; else 1) and log2 W for them; N = groups of ipb images
+    int Nimg;                         // images of the launch (N = image groups)
     int blocks;
     unsigned x_bytes, u_bytes, y_bytes, r_bytes, b_bytes;
     unsigned flags;
@@ -302,10 +304,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     State st;
     st.row_pitch = (unsigned)(a.Ws * a.ldx * 4);
-    // V_p = d[offa] + sg d[offb] over the four pixels 2t-1 .. 2t+2 of a tile:  p = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
-    const int offa = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
-    const int offb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
-    st.sg = wave == 1 ? 1.f : -1.f;
+    // V_p = d[offa] + sg d[offb] over the four pixels 2t-1 .. 2t+2 of a tile:  p = 0: -(d0 - d2) (its weights are stored negated), 1: d1 + d2,
+    // 2: d2 - d1, 3: d1 - d3 — so that the two OUTER pixels d0 / d3 are always operand b.  With several images side by side in a block row
+    // (narrow maps) the outer pixel of an image's first / last tile belongs to the neighbour: there sg = 0, the convolution's zero padding.
+    const int offa = wave == 0 ? 2 : (wave == 2 ? 2 : 1);
+    const int offb = wave == 0 ? 0 : (wave == 3 ? 3 : (wave == 2 ? 1 : 2));
+    {
+        const int tpi = (a.ipb > 1) ? (1 << (a.lw - 1)) : 64;        // tiles per image in the block row
+        const int lt = t & (tpi - 1);
+        const bool outer_is_neighbour = (wave == 0 && lt == 0) || (wave == 3 && lt == tpi - 1);
+        st.sg = wave == 1 ? 1.f : (a.ipb > 1 && outer_is_neighbour ? 0.f : -1.f);
+    }
+    const int si_lane = (a.ipb > 1) ? ((2 * t) >> a.lw) : 0;         // this lane's sub-image (V production: its tile's image)
     // patch image [row][quad][parity][33 px] x 16 B: the lanes of a ds_read_b128 group (same h, 16 distinct t mod 16) read
     // consecutive slots of one plane — all 64 banks, no conflicts
     {
@@ -323,7 +333,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         st.wext = tid < 80 ? smem + (er * ROW_SLOTS + q * QUAD_SLOTS + (ec & 1) * PXH + (ec >> 1)) * 16 : smem + (PR * ROW_SLOTS + (tid & 31)) * 16;
     }
     const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
-    float omax = 0.f;
 
     // coordinates of a work item (scalars) and the per-thread addressing that follows from them
     struct Coord { int n, y0, x0, n0; };
@@ -338,18 +347,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W9_ITEM(it_, c_)                                                                                         \
     do {                                                                                                         \
         (it_).y0m1 = (c_).y0 - 1;                                                                                \
-        (it_).img_base = (unsigned)((c_).n * a.Hs) * st.row_pitch;                                               \
+        (it_).img_base = (unsigned)((c_).n * a.ipb * a.Hs) * st.row_pitch;                                       \
         int tid_ = tid;                                                                                          \
         asm volatile("" : "+v"(tid_));      /* keeps the per-thread decode inside the item loop (hoisted, its values live across the main loop) */ \
         const int q_ = tid_ & 3, ix_ = (c_).x0 - 1 + (tid_ >> 2);                                                \
-        const int sx_ = up ? (ix_ >> 1) : ix_;                                                                   \
-        (it_).vcol = (unsigned)ix_ < (unsigned)a.W ? (unsigned)((sx_ * a.ldx + q_ * 4) * 4) : OOB;               \
         const int er_ = tid_ >> 3, ex_ = (c_).x0 + 63 + ((tid_ >> 2) & 1), ey_ = (c_).y0 - 1 + er_;              \
-        const bool ok_ = tid_ < 80 && (unsigned)ey_ < (unsigned)a.H && (unsigned)ex_ < (unsigned)a.W;            \
-        const int esy_ = up ? (ey_ >> 1) : ey_, esx_ = up ? (ex_ >> 1) : ex_;                                    \
-        (it_).vext = ok_ ? (unsigned)(((esy_ * a.Ws + esx_) * a.ldx + q_ * 4) * 4) : OOB;                        \
+        if (a.ipb > 1) {   /* block row = ipb images of width 2^lw side by side (x0 = 0): column -> (sub-image, pixel) */ \
+            const int si_ = ix_ >> a.lw, px_ = ix_ & (a.W - 1);                                                  \
+            const bool okc_ = (unsigned)ix_ < 64u && (c_).n * a.ipb + si_ < a.Nimg;                              \
+            (it_).vcol = okc_ ? (unsigned)(((si_ * a.H * a.W + px_) * a.ldx + q_ * 4) * 4) : OOB;                \
+            const int esi_ = ex_ >> a.lw, epx_ = ex_ & (a.W - 1);                                                \
+            const bool oke_ = tid_ < 80 && (unsigned)ey_ < (unsigned)a.H && ex_ < 64 && (c_).n * a.ipb + esi_ < a.Nimg; \
+            (it_).vext = oke_ ? (unsigned)((((esi_ * a.H + ey_) * a.W + epx_) * a.ldx + q_ * 4) * 4) : OOB;      \
+        } else {                                                                                                 \
+            const int sx_ = up ? (ix_ >> 1) : ix_;                                                               \
+            (it_).vcol = (unsigned)ix_ < (unsigned)a.W ? (unsigned)((sx_ * a.ldx + q_ * 4) * 4) : OOB;           \
+            const bool ok_ = tid_ < 80 && (unsigned)ey_ < (unsigned)a.H && (unsigned)ex_ < (unsigned)a.W;        \
+            const int esy_ = up ? (ey_ >> 1) : ey_, esx_ = up ? (ex_ >> 1) : ex_;                                \
+            (it_).vext = ok_ ? (unsigned)(((esy_ * a.Ws + esx_) * a.ldx + q_ * 4) * 4) : OOB;                    \
+        }                                                                                                        \
         (it_).u_voff = (unsigned)(((c_).n0 + (tid_ & 31)) * 32 + ((tid_ >> 5) & 1) * 16);                        \
     } while (0)
+    // max |x| of the image a lane's tile (or an epilogue thread's tile) belongs to; images past the end of the batch: 0 -> scale 1
+#define W9_XMAX_OF(n_, si_) (((n_) * a.ipb + (si_)) < a.Nimg ? a.xmax[(n_) * a.ipb + (si_)] : 0.f)
     // power-of-two scale of V from the image's maximum: |V| <= 2 max |x|, 2 max |x| S in [2^13, 2^14); es_ = log2 S
 #define W9_SCALE_EXP(es_, xmax_)                                                                                 \
     do {                                                                                                         \
@@ -379,7 +399,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int es_cur;
     W9_COORD(cc_cur, item);
     W9_ITEM(st.cur, cc_cur);
-    W9_SCALE_EXP(es_cur, a.xmax[cc_cur.n]);
+    W9_SCALE_EXP(es_cur, W9_XMAX_OF(cc_cur.n, si_lane));
     st.cur.S = __builtin_ldexpf(1.f, es_cur);
     // the first item's prologue (afterwards the chunk stream itself fetches ahead): patches 0 / 1, weights and first V rows of chunk 0
     {   // all four half-patches are requested before the first is written (the fragment registers are still free: one memory latency, not four)
@@ -426,7 +446,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bool more = next < (unsigned)a.blocks;
         W9_COORD(cc_nxt, more ? next : item);
         W9_ITEM(st.nxt, cc_nxt);
-        const float xmax_next = a.xmax[cc_nxt.n];             // requested now, used behind the chunk loop
+        const float xmax_next = W9_XMAX_OF(cc_nxt.n, si_lane);  // requested now, used behind the chunk loop
 #pragma unroll
         for (int yo = 0; yo < R; ++yo)
 #pragma unroll
@@ -456,21 +476,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));        // the epilogue's per-lane constants are re-derived here (hoisted, they live across the chunk loop and spill)
         const int t_e = lane_e & 31, h_e = lane_e >> 5;
-        const float inv = __builtin_ldexpf(1.f, -es_cur);
         const int g_e = wave & 1;
         const int piece_e = lane_e & 7;
         const int cout_e = cc_cur.n0 + g_e * 32 + piece_e * 4;            // this thread's four couts
         const bool cok_e = cout_e < a.Cout;
         const f32x4 bq = __builtin_bit_cast(f32x4, buf_load16(a.bias, a.b_bytes, cok_e ? (unsigned)cout_e * 4u : OOB, 0));
-        const f32x4 iq = *reinterpret_cast<const f32x4*>(a.isu + cout_e) * inv;
+        const f32x4 isu_e = *reinterpret_cast<const f32x4*>(a.isu + cout_e);
         // writer: lane (h, t) holds piece 2 q + h of tile t;  reader, iteration i: tile 16 (w >> 1) + 8 i + lane / 8, piece lane % 8
         const int wslot0 = t_e * 8, wsw = t_e & 7;
-        int rtile[2], rslot[2];
+        int rtile[2], rslot[2], rimg[2], rpx[2];
+        f32x4 iq[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             rtile[i] = 16 * (wave >> 1) + 8 * i + (lane_e >> 3);
             rslot[i] = rtile[i] * 8 + (piece_e ^ (rtile[i] & 7));
+            // the image this tile belongs to (several side by side on narrow maps): its column there, its scale
+            const int si = a.ipb > 1 ? ((2 * rtile[i]) >> a.lw) : 0;
+            rimg[i] = cc_cur.n * a.ipb + si;
+            rpx[i] = a.ipb > 1 ? ((2 * rtile[i]) & (a.W - 1)) : cc_cur.x0 + 2 * rtile[i];
+            int es_i;
+            W9_SCALE_EXP(es_i, W9_XMAX_OF(cc_cur.n, si));
+            iq[i] = isu_e * __builtin_ldexpf(1.f, -es_i);
         }
+        float omax2[2] = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             char* X = sX + (j & 1) * (X_BYTES / 2);
@@ -481,10 +509,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             f32x4 rv[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int ox = cc_cur.x0 + 2 * rtile[i];
-                const unsigned pix = (unsigned)((cc_cur.n * a.H + oy) * a.W + ox);
+                const int ox = rpx[i];
+                const unsigned pix = (unsigned)((rimg[i] * a.H + oy) * a.W + ox);
                 yv[i] = (pix * (unsigned)a.ldy + (unsigned)cout_e) * 4u;
-                ok[i][0] = row_ok && ox < a.W; ok[i][1] = row_ok && ox + 1 < a.W;
+                ok[i][0] = row_ok && ox < a.W && rimg[i] < a.Nimg; ok[i][1] = row_ok && ox + 1 < a.W && rimg[i] < a.Nimg;
                 if constexpr (RES) {
                     const unsigned rvo = (pix * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
 #pragma unroll
@@ -510,8 +538,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 f32x4 o0, o1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float ya = (Y[0][e] + Y[1][e] + Y[2][e]) * iq[e];
-                    const float yb = (Y[1][e] - Y[2][e] - Y[3][e]) * iq[e];
+                    const float ya = (Y[0][e] + Y[1][e] + Y[2][e]) * iq[i][e];
+                    const float yb = (Y[1][e] - Y[2][e] - Y[3][e]) * iq[i][e];
                     if constexpr (RES) {
                         o0[e] = fmaxf(ya + bq[e] + rv[i][0][e], lo);
                         o1[e] = fmaxf(yb + bq[e] + rv[i][1][e], lo);
@@ -520,18 +548,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         o1[e] = fmaxf(yb + bq[e], lo);
                     }
                 }
-                if (ok[i][0]) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o0[0]), fabsf(o0[1])), fmaxf(fabsf(o0[2]), fabsf(o0[3]))));
-                if (ok[i][1]) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o1[0]), fabsf(o1[1])), fmaxf(fabsf(o1[2]), fabsf(o1[3]))));
+                if (ok[i][0]) omax2[i] = fmaxf(omax2[i], fmaxf(fmaxf(fabsf(o0[0]), fabsf(o0[1])), fmaxf(fabsf(o0[2]), fabsf(o0[3]))));
+                if (ok[i][1]) omax2[i] = fmaxf(omax2[i], fmaxf(fmaxf(fabsf(o1[0]), fabsf(o1[1])), fmaxf(fabsf(o1[2]), fabsf(o1[3]))));
                 buf_store16(o0, a.y, a.y_bytes, ok[i][0] ? yv[i] : OOB, 0);
                 buf_store16(o1, a.y, a.y_bytes, ok[i][1] ? yv[i] : OOB, (unsigned)(a.ldy * 4));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (a.ymax) {          // max |y| of this item into its image's slot: one atomic per wave and item
+        if (a.ymax) {          // max |y| of this item into its image's slot: the 8 tiles of an iteration lie in one image (tiles per image: 8, 16 or all)
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
-            if (lane_e == 0 && omax > 0.f) atomicMax(a.ymax + cc_cur.n, __float_as_uint(omax));
-            omax = 0.f;
+            for (int i = 0; i < 2; ++i) {
+                float m = omax2[i];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                const int img = __builtin_amdgcn_readfirstlane(rimg[i]);
+                if (lane_e == 0 && m > 0.f && img < a.Nimg) atomicMax(a.ymax + img, __float_as_uint(m));
+            }
         }
         W9_STAMP(15);
 #ifdef W9_TRACE
@@ -546,6 +578,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W9_COORD
 #undef W9_ITEM
 #undef W9_SCALE_EXP
+#undef W9_XMAX_OF
 }
 
 // fp32 OHWI 3x3 weights -> U_p[ky] = (G g[ky])_p per (co, ci), scaled per OUTPUT CHANNEL by S_u[co] = 2^(13 - e) (max |U[co]| = m 2^e)
@@ -586,7 +619,7 @@ __global__ __launch_bounds__(256) void weights9_kernel(const float* __restrict__
                 g0 = w[((long)co * 9 + ky * 3 + 0) * Cin + ci]; g1 = w[((long)co * 9 + ky * 3 + 1) * Cin + ci];
                 g2 = w[((long)co * 9 + ky * 3 + 2) * Cin + ci];
             }
-            const float uu[4] = {g0, 0.5f * (g0 + g1 + g2), 0.5f * (g0 - g1 + g2), g2};
+            const float uu[4] = {-g0, 0.5f * (g0 + g1 + g2), 0.5f * (g0 - g1 + g2), g2};      // position 0 negated: the kernel forms -(d0 - d2) there
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const float xs = uu[p] * Su;
@@ -637,12 +670,16 @@ int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu,
     a.x = p->x; a.u9 = u9; a.xmax = xmax; a.isu = isu; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
     a.bias = p->bias; a.res = p->residual; a.y = p->y;
     const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
-    a.N = p->N; a.Hs = p->H_in; a.Ws = p->W_in; a.H = p->H_in * upf; a.W = p->W_in * upf; a.Cin = p->Cin; a.Cout = p->Cout;
+    a.Nimg = p->N; a.Hs = p->H_in; a.Ws = p->W_in; a.H = p->H_in * upf; a.W = p->W_in * upf; a.Cin = p->Cin; a.Cout = p->Cout;
+    // narrow maps: 2 (W = 32) or 4 (W = 16) images side by side in one 64-pixel block row (no folded upsample there)
+    a.ipb = (upf == 1 && (a.W == 32 || a.W == 16)) ? 64 / a.W : 1;
+    a.lw = a.W == 32 ? 5 : 4;
+    a.N = (p->N + a.ipb - 1) / a.ipb;
     a.CoutP = (p->Cout + 63) / 64 * 64;
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
     a.CC = p->Cin / 16;
     a.nb = a.CoutP / BN; a.bx = (a.W + 2 * TW - 1) / (2 * TW); a.by = (a.H + R - 1) / R;
-    const long long blocks = (long long)p->N * a.by * a.bx * a.nb;
+    const long long blocks = (long long)a.N * a.by * a.bx * a.nb;
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: grid too large");
     a.blocks = (int)blocks;
     const unsigned long long xb = (((unsigned long long)p->N * p->H_in * p->W_in - 1) * p->ldx + p->Cin) * 4ull;

@@ -22,6 +22,10 @@ CASES = [  # N, Cin, H, W, Cout, flags, residual
     (1, 64, 9, 130, 72, CNL_RELU, False),
     (2, 32, 6, 10, 64, CNL_RELU | CNL_UPSAMPLE_IN, False),
     (1, 512, 16, 16, 512, CNL_RELU, True),
+    (5, 64, 32, 32, 64, CNL_RELU, True),
+    (3, 32, 9, 32, 96, 0, False),
+    (7, 64, 16, 16, 128, CNL_RELU, True),
+    (2, 32, 5, 16, 64, 0, False),
 ]
 bad = 0
 for (N, Cin, H, W, Cout, flags, use_res) in CASES:
@@ -45,6 +49,16 @@ w = torch.randint(-2, 3, (96, 64, 3, 3), generator=g).float() * 4
 b = torch.randint(-5, 6, (96,), generator=g).float()
 eq = torch.equal(run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + V), ref_conv(x, w, b, 1, 0))
 print("exact on integers:", eq)
+# batch invariance, images side by side
+g = torch.Generator().manual_seed(18)
+for (n_, w_) in ((5, 32), (6, 16)):
+    x = torch.randn(n_, 64, 16, w_, generator=g).clamp_min(0) * torch.pow(10.0, torch.randint(-3, 3, (n_, 1, 1, 1), generator=g).float())
+    w = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / (64 * 9)) ** 0.5
+    b = torch.randn(64, generator=g)
+    full = run_winograd(x, w, b, CNL_RELU, algo=CNL_ALGO_FORCE + V)
+    ok_ = all(torch.equal(full[i:i + 1], run_winograd(x[i:i + 1], w, b, CNL_RELU, algo=CNL_ALGO_FORCE + V)) for i in range(n_))
+    print("side by side W", w_, "batch invariant:", ok_)
+    bad += not ok_
 # batch invariance
 g = torch.Generator().manual_seed(17)
 x = torch.randn(3, 64, 24, 80, generator=g).clamp_min(0) * torch.tensor([1.0, 1e-3, 300.0]).view(3, 1, 1, 1)
