@@ -51,15 +51,21 @@ import centernet_lightning_amd as cl  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense fp16 / bf16 (v_mfma_f32_32x32x16_f16)
 HBM_PEAK_GBPS = 8000.0            # same guide: HBM3E spec peak (6.29 TB/s measured float4 copy)
-# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 [gfx950 reports half of a 16 B/lane stream, MI355X_MICROARCH.md §HBM]
-# + WRITE_SIZE, mean over the kernel's launches of one step).  From committed profiles — NOT measured by this run.
-PROFILED_TRAFFIC = {
-    ("simple", 32, 512, 512, "winograd_f16x2"): (484.2e6, "profiles/r02_pmc_traffic_c1_default.txt (29 winograd5 launches of a C1 step; r01: 484.3)"),
-    ("simple", 32, 512, 512, "winograd_f32"): (305.9e6, "profiles/r02_pmc_traffic_c1_default.txt"),
-}
-# decode stage 1 / stage 2 at C1 (same profile): HBM MB per launch and rocprofv3 average duration
-PROFILED_DECODE = {("simple", 32, 512, 512): {"peaks_c8_kernel": {"traffic_MB": 172.1, "avg_us": 34.6}, "topk_kernel": {"traffic_MB": 3.1, "avg_us": 11.3},
-                                             "source": "profiles/r02_pmc_traffic_c1_default.txt, profiles/r02_kernel_stats_c1_default.csv, profiles/r02_decode_variants.txt — not measured by this run"}}
+# rocprofv3 figures this line quotes but does not measure itself (HBM bytes per launch from the PMC passes: FETCH_SIZE x 2 + WRITE_SIZE, see
+# tools/rocpd_summary.py json; kernel-trace averages of the decode kernels): read from the committed profile JSON of the same command, so a
+# quoted number is byte-equal to a field of that file.  Written on the GPU box by tools/_trace/r03_profile.sh.
+PROFILE_JSON = {("simple", 32, 512, 512): "profiles/r03_profile_c1.json"}
+KIND_KERNEL = {"winograd_row_f16x2": "cnl_wino9::winograd9_kernel<false>", "winograd_f16x2": "cnl_wino5::winograd5_kernel",
+               "winograd_f32": "cnl_wino2::winograd2_kernel", "winograd_f4": "cnl_wino8::winograd8_kernel"}
+
+
+def profiled(config, B, H, W):
+    path = PROFILE_JSON.get((config, B, H, W))
+    if not path or not os.path.exists(os.path.join(ROOT, path)):
+        return None, path
+    return json.load(open(os.path.join(ROOT, path))), path
+
+
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 KIND_NAMES = {"winograd_f4": "cnl_wino8::winograd8_kernel (Winograd F(4x4,3x3); fp32 operands scaled per image by a power of two and split into 2 fp16 pieces, "
                              "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
@@ -196,7 +202,10 @@ def roofline_block(rows, config, B, H, W):
     n, ms, fl, nb = agg[dom]
     ratio, peak = EXEC[dom]
     exec_tf = fl * ratio / (ms * 1e-3) / 1e12
-    traffic = PROFILED_TRAFFIC.get((config, B, H, W, dom))
+    prof, prof_path = profiled(config, B, H, W)
+    pk = (prof or {}).get("kernels", {}).get(KIND_KERNEL.get(dom, ""), {})
+    traffic = (pk["hbm_MB_per_launch"] * 1e6, f"{prof_path} [kernels][{KIND_KERNEL[dom]}][hbm_MB_per_launch] over {pk.get('pmc_launches')} launches "
+               f"(all its launches of the profiled steps; rocprofv3 average duration there {pk.get('avg_us')} us)") if "hbm_MB_per_launch" in pk else None
     roof = {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": round(exec_tf, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(exec_tf / peak, 4),
             "achieved_counts": f"EXECUTED matrix-core flops = direct-conv flops x {ratio:.4f} (Winograd multiplies x split terms); the algorithmic rate is effective_tflops",
@@ -252,6 +261,17 @@ def gpu_ms_back_to_back(fn, calls=50, rounds=5):
     return best
 
 
+def decode_profiled(config, B, H, W):
+    prof, path = profiled(config, B, H, W)
+    if not prof:
+        return None
+    out = {"source": f"{path} — rocprofv3 kernel-trace / PMC of an earlier run of this command, not measured by this run"}
+    for name, k in prof["kernels"].items():
+        if name.startswith("cnl_decode::"):
+            out[name] = {f: k[f] for f in ("avg_us", "hbm_MB_per_launch", "calls") if f in k}
+    return out
+
+
 def decode_block(model, x, tracking, k, config=None):
     with torch.no_grad():
         out = model(x)
@@ -268,7 +288,7 @@ def decode_block(model, x, tracking, k, config=None):
     return {"gpu_ms": round(g_wo, 4), "p50_ms_without_sigmoid": round(p_wo, 4), "p50_ms_with_separate_sigmoid_pass": round(p_w, 4),
             "must_move_bytes": must, "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4),
             "GBps_single_call": round(must / (p_wo * 1e-3) / 1e9, 1),
-            "kernels_profiled": PROFILED_DECODE.get((config, N, x.shape[2], x.shape[3])),
+            "kernels_profiled": decode_profiled(config, N, x.shape[2], x.shape[3]),
             "note": "gpu_ms = GPU time of one decode (both kernels): 50 calls enqueued back to back between HIP events, as inside a step where the "
                     "host runs ahead — GBps / frac_of_8TBps use it; p50 = one call at a time from Python with the GPU idle before it (HIP events "
                     "around gather_detection2d on the forward's own outputs, median of 30): it adds the host's argument set-up and launch "

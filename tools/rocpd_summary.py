@@ -3,7 +3,12 @@
 
     python tools/rocpd_summary.py stats <dir-with-*_results.db>              -> per-kernel calls / total / average (us) / %
     python tools/rocpd_summary.py pmc <fetch-dir> <write-dir>                 -> per-kernel mean FETCH_SIZE / WRITE_SIZE per launch
+    python tools/rocpd_summary.py json <stats-dir> <fetch-dir> <write-dir> <out.json> [key=value ...]
+                                                                              -> the same numbers as ONE json (what bench.py quotes as
+                                                                                 roofline.traffic / decode.kernels_profiled: a quoted figure
+                                                                                 is then byte-equal to a field of a committed profiles/ file)
 """
+import json
 import glob
 import os
 import sqlite3
@@ -28,6 +33,26 @@ def stats(root):
         print(f'"{_short(name)}",{calls},{total * 1e3:.0f},{avg * 1e3:.0f},{pct:.2f}')
 
 
+def as_json(sroot, froot, wroot, out, meta):
+    """{"meta": {...}, "kernels": {short name: {calls, avg_us, total_us, pct, fetch_KiB, write_KiB, hbm_MB_per_launch}}};
+    hbm_MB_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / 1e6 — gfx950's FETCH_SIZE reports half of a 16 B/lane stream
+    (MI355X_MICROARCH.md, HBM section)."""
+    kern = {}
+    for name, calls, total, avg, pct in _db(sroot).execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+        kern[_short(name)] = {"calls": calls, "total_us": round(total, 1), "avg_us": round(avg, 2), "pct": round(pct, 2)}
+    for root in (froot, wroot):
+        for name, ctr, n, mean in _db(root).execute(
+                "select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"):
+            k = kern.setdefault(_short(name), {})
+            k[{"FETCH_SIZE": "fetch_KiB", "WRITE_SIZE": "write_KiB"}.get(ctr, ctr)] = round(mean, 1)
+            k["pmc_launches"] = n
+    for k in kern.values():
+        if "fetch_KiB" in k and "write_KiB" in k:
+            k["hbm_MB_per_launch"] = round((2 * k["fetch_KiB"] + k["write_KiB"]) * 1024 / 1e6, 1)
+    json.dump({"meta": meta, "kernels": kern}, open(out, "w"), indent=1, sort_keys=True)
+    print(f"wrote {out}: {len(kern)} kernels")
+
+
 def pmc(froot, wroot):
     acc = {}
     for root in (froot, wroot):
@@ -40,6 +65,9 @@ def pmc(froot, wroot):
         print(f"{k:70s} {max(f[0], w[0]):8d} {f[1]:15.1f} {w[1]:15.1f} {(2 * f[1] + w[1]) * 1024 / 1e6:34.1f}")
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "json":
+    as_json(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], dict(kv.split("=", 1) for kv in sys.argv[6:]))
+    sys.exit(0)
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
