@@ -86,14 +86,29 @@ class _Layer:
         self.pad = (self.kh - 1) // 2
         self.wmax = w_ohwi.abs().max().reshape(1).contiguous()      # cnl_conv_params.w_absmax (fp16-split direct kernel)
         self.u = None
+        self.u_has_f4 = False
         if self.kh == 3 and self.kw == 3 and stride == 1 and self.cin % 8 == 0 and w_ohwi.is_cuda:
-            lib = _lib.load()
-            n = lib.cnl_winograd_weight_floats(self.cin, self.cout)
-            with torch.cuda.device(w_ohwi.device):
-                self.u = torch.empty((n,), device=w_ohwi.device, dtype=torch.float32)
-                stream = ctypes.c_void_p(torch.cuda.current_stream(w_ohwi.device).cuda_stream)
-                _lib.check(lib.cnl_winograd_transform_weights_f32(w_ohwi.data_ptr(), self.u.data_ptr(), self.cin, self.cout, stream),
-                           "cnl_winograd_transform_weights_f32")
+            self._transform(f4=False)
+
+    def _transform(self, f4):
+        lib = _lib.load()
+        w = self.w
+        n = (lib.cnl_winograd_f4_weight_floats if f4 else lib.cnl_winograd_weight_floats)(self.cin, self.cout)
+        with torch.cuda.device(w.device):
+            self.u = torch.empty((n,), device=w.device, dtype=torch.float32)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
+            _lib.check(lib.cnl_winograd_transform_weights_f32(w.data_ptr(), self.u.data_ptr(), self.cin, self.cout, stream),
+                       "cnl_winograd_transform_weights_f32")
+            if f4:
+                _lib.check(lib.cnl_winograd_transform_weights_f4_f32(w.data_ptr(), self.u.data_ptr(), self.cin, self.cout, stream),
+                           "cnl_winograd_transform_weights_f4_f32")
+        self.u_has_f4 = f4
+
+    def ensure_f4(self):
+        """The F(4x4,3x3) copy of the weights (an opt-in arithmetic class: KernelOptions(algo="f4")) is built on the first plan that
+        launches this layer on winograd8 — not on every weight load (0.4 GB and 78 launches over a ResNet-34 CenterNet)."""
+        if self.u is not None and not self.u_has_f4:
+            self._transform(f4=True)
 
 
 def _layer_wants_up2(self):
@@ -560,6 +575,9 @@ class Plan:
             p.w = layer.u.data_ptr()
             fn = self.lib.cnl_conv3x3_winograd_f32
             what += " [winograd]"
+            if self.lib.cnl_conv3x3_winograd_kernel(ctypes.byref(p)) == CNL_WINO_F16X2_F4:
+                layer.ensure_f4()                       # lazily: only plans of the opt-in class pay for the F(4x4) weight copy
+                p.w = layer.u.data_ptr()
         rowwino = False
         if fn is self.lib.cnl_conv3x3_winograd_f32 and self.algo not in (CNL_ALGO_F32, CNL_ALGO_F4) and layer.cin % 32 == 0 and layer.cout % 4 == 0:
             # the dispatcher's rule for winograd9.hip (8-row x 64-pixel work items pad the map by < 1.5x): it folds the upsample into its

@@ -13,7 +13,7 @@
 //   8  winograd8.hip  F(4x4,3x3) with the same split: 0.56x the matrix work and split work per output, error ~4x kernel 5's
 //                     (~1e-6 of the layer maximum) — long channel loops on large maps its 32x16-pixel items tile well, CNL_ALGO_F4 only.
 // The 16x16-pixel-block fp32 kernel this file used to hold, the exact three-way bf16 split (winograd3/4) and the two-waves-per-SIMD
-// form of 5 (winograd7) are measured-and-superseded variants: experiments/ (`make experiments`, algo = CNL_ALGO_FORCE + variant).
+// form of 5 (winograd7) are measured-and-superseded variants: tools/experiments/ (`make -C csrc experiments`, algo = CNL_ALGO_FORCE + variant).
 #include "cnl_common.h"
 
 namespace cnl_wino {
@@ -67,40 +67,54 @@ int cnl_wino9_transform_weights(const float* w_ohwi, void* u9, float* isu, int C
 bool cnl_wino9_eligible(const cnl_conv_params* p);
 int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream);
 #ifdef CNL_EXPERIMENTS
-int cnl_wino1_launch(const cnl_conv_params* p, void* stream);                       // experiments/winograd1.hip
-size_t cnl_wino3_weight_bytes(int Cin, int Cout);                                  // experiments/winograd3.hip
+int cnl_wino1_launch(const cnl_conv_params* p, void* stream);                       // tools/experiments/winograd1.hip
+size_t cnl_wino3_weight_bytes(int Cin, int Cout);                                  // tools/experiments/winograd3.hip
 int cnl_wino3_transform_weights(const float* w_ohwi, void* u3, int Cin, int Cout, void* stream);
 int cnl_wino3_launch(const cnl_conv_params* p, const void* u3, void* stream);
-int cnl_wino4_launch(const cnl_conv_params* p, const void* u3, void* stream);        // experiments/winograd4.hip
-int cnl_wino7_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream);        // experiments/winograd7.hip
+int cnl_wino4_launch(const cnl_conv_params* p, const void* u3, void* stream);        // tools/experiments/winograd4.hip
+int cnl_wino7_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream);        // tools/experiments/winograd7.hip
 #else
 static size_t cnl_wino3_weight_bytes(int, int) { return 0; }
 #endif
 
 // Layout of the transformed-weight buffer (floats): [fp32 U = [ci/8][16][CoutP][8]] [experiment builds: bf16 x 3 pieces]
-// [fp16 x 2 pieces of F(2x2)] [its scalars] [fp16 x 2 pieces of F(4x4)] [its scalars]; the split copies exist for Cin % 16 == 0 only.
+// [fp16 x 2 pieces of F(2x2)] [its scalars] [fp16 x 2 pieces of the row-Winograd kernel] [its per-cout scales]
+// [optional tail: fp16 x 2 pieces of F(4x4)] [its scalars]; the split copies exist for Cin % 16 == 0 only.  The F(4x4) tail (0.4 GB over a
+// ResNet-34 CenterNet, 2 launches per layer) is produced by cnl_winograd_transform_weights_f4_f32 only: for callers that opt into CNL_ALGO_F4.
 static size_t wino_f32_floats(int Cin, int Cout) {
     const size_t CoutP = (size_t)((Cout + 63) / 64) * 64;
     return (size_t)(Cin / 8) * 16 * CoutP * 8;
 }
 struct WeightLayout {
-    size_t u3, u5, s5, u8, s8, u9, s9, total;     // float offsets
+    size_t u3, u5, s5, u9, s9, u8, s8, total, total_f4;     // float offsets
     WeightLayout(int Cin, int Cout) {
         const bool split = Cin % 16 == 0;
         u3 = wino_f32_floats(Cin, Cout);
         u5 = u3 + cnl_wino3_weight_bytes(Cin, Cout) / 4;
         s5 = u5 + cnl_wino5_weight_bytes(Cin, Cout) / 4;
-        u8 = s5 + (split ? cnl_wino5_scalar_floats() : 0);
-        s8 = u8 + cnl_wino8_weight_bytes(Cin, Cout) / 4;
-        u9 = s8 + (split ? cnl_wino8_scalar_floats() : 0);
+        u9 = s5 + (split ? cnl_wino5_scalar_floats() : 0);
         s9 = u9 + cnl_wino9_weight_bytes(Cin, Cout) / 4;
         total = s9 + cnl_wino9_scalar_floats(Cin, Cout);
+        u8 = total;
+        s8 = u8 + cnl_wino8_weight_bytes(Cin, Cout) / 4;
+        total_f4 = s8 + (split ? cnl_wino8_scalar_floats() : 0);
     }
 };
 
 extern "C" size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8) return 0;
     return WeightLayout(Cin, Cout).total;
+}
+extern "C" size_t cnl_winograd_f4_weight_floats(int32_t Cin, int32_t Cout) {
+    if (Cin <= 0 || Cout <= 0 || Cin % 8) return 0;
+    return WeightLayout(Cin, Cout).total_f4;
+}
+extern "C" int cnl_winograd_transform_weights_f4_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream) {
+    CNL_REQUIRE(w_ohwi && u, CNL_E_BAD_ARG, "cnl_winograd_transform_weights_f4_f32: null pointer");
+    CNL_REQUIRE(Cin > 0 && Cout > 0 && Cin % 8 == 0, CNL_E_UNSUPPORTED, "cnl_winograd_transform_weights_f4_f32: Cin %% 8 != 0");
+    if (Cin % 16) return CNL_OK;                       // no split kernels for this layer: nothing to add
+    const WeightLayout L(Cin, Cout);
+    return cnl_wino8_transform_weights(w_ohwi, u + L.u8, u + L.s8, Cin, Cout, stream);
 }
 
 extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream) {
@@ -119,7 +133,6 @@ extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u,
 #endif
     rc = cnl_wino5_transform_weights(w_ohwi, u, L.u3, u + L.u5, u + L.s5, Cin, Cout, stream);
     if (rc != CNL_OK) return rc;
-    rc = cnl_wino8_transform_weights(w_ohwi, u + L.u8, u + L.s8, Cin, Cout, stream);
     if (rc != CNL_OK || Cin % 32) return rc;
     return cnl_wino9_transform_weights(w_ohwi, u + L.u9, u + L.s9, Cin, Cout, stream);
 }

@@ -23,9 +23,6 @@
 #ifndef W5_NT_Y
 #define W5_NT_Y 2     /* cache policy (aux) of the output stores: nt — a layer's output is far larger than the L2 and would only evict the input patches and weights that ARE re-read (fused first head blocks -9 %) */
 #endif
-#ifndef W5_EXP
-#define W5_EXP 0     /* timing experiments (wrong results): 1 no B loads, 2 no A reads, 3 no patch reads, 4 no barrier in the loop */
-#endif
 namespace cnl_wino5 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -305,24 +302,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int pi = k / 6, ks = k % 6;                                                                    \
             if ((MID_) && k == 6) {                                                                              \
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   /* all but the newest 4 B loads: the patch DMA is older */ \
-                if (W5_EXP != 4) W5_BARRIER();                                                                   \
+                W5_BARRIER();                                                                   \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
             }                                                                                                    \
             W5_MFMA(j_, buf_, k);                                                                                \
             if (PA_) {                                                                                           \
-                if (k == 0 && W5_EXP != 1) W5_LOAD_B(cA_, jA_, (buf_) ^ 1, 1);                                                  \
-                if (k >= 2 && k < 6 && W5_EXP != 2) {                                                            \
+                if (k == 0) W5_LOAD_B(cA_, jA_, (buf_) ^ 1, 1);                                                  \
+                if (k >= 2 && k < 6) {                                                            \
                     const int g_ = (k - 2) >> 1, kk_ = (k - 2) & 1;                                              \
                     fa[(buf_) ^ 1][g_][kk_] = lds_u4(sV + fragA + ((jA_) * NP + kk_) * VPIECE + g_ * 1024);      \
                 }                                                                                                \
             }                                                                                                    \
-            if ((PB_) && k == 6 && W5_EXP != 1) W5_LOAD_B(cB_, jB_, buf_, 0);                                                   \
+            if ((PB_) && k == 6) W5_LOAD_B(cB_, jB_, buf_, 0);                                                   \
             if (JOBS_) {                                                                                         \
-                if (k < 6 && W5_EXP != 3) W5_X_READ1(1, pa, pb, P_, (it0_) + 1, k >> 1, k & 1);                                 \
+                if (k < 6) W5_X_READ1(1, pa, pb, P_, (it0_) + 1, k >> 1, k & 1);                                 \
                 _Pragma("unroll") for (int o_ = 0; o_ < 8; ++o_) xop(xf, pi, P_, ks * 8 + o_, sg, S, (it0_) + pi); \
                 if (ks == 5) { if (pi == 0) { W5_X_WRITE(P_, it0_); } else { W5_X_WRITE(P_, (it0_) + 1); } }     \
             }                                                                                                    \
-            if ((RDN_) && k >= 6 && W5_EXP != 3) W5_X_READ1(0, npa_, npb_, nP_, nIt_, (k - 6) >> 1, k & 1);                     \
+            if ((RDN_) && k >= 6) W5_X_READ1(0, npa_, npb_, nP_, nIt_, (k - 6) >> 1, k & 1);                     \
             if ((MID_) && k == 7) W5_ISSUE_P(dC_);                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
         }                                                                                                        \
@@ -653,11 +650,7 @@ int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.flags = p->flags;
-#ifdef W5_ORDER
-    a.order = W5_ORDER;                    // timing builds
-#else
     a.order = (a.nb & 1) ? 0 : 2;          
-#endif          // pairs of cout blocks fastest: measured best (profiles/r01_winograd_variants.txt)
     static cnl::DeviceOnce once;
     int n_cu = 0;                          // persistent workgroups: one per CU, walking the work items with stride gridDim.x
     int rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd5_kernel), LDS_BYTES, &n_cu);

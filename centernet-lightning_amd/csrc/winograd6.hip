@@ -594,11 +594,7 @@ int cnl_wino6_launch(const cnl_conv_params* p, const void* u5, float* scal, void
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb;
     a.flags = p->flags;
-#ifdef W5_ORDER
-    a.order = W5_ORDER;                    // timing builds
-#else
     a.order = (a.nb & 1) ? 0 : 2;          
-#endif          // pairs of cout blocks fastest (profiles/r01_winograd_variants.txt)
     static cnl::DeviceOnce once;
     int n_cu = 0;                          // persistent workgroups: one per CU, walking the work items with stride gridDim.x
     static cnl::DeviceOnce once_stack;

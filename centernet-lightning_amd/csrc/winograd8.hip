@@ -33,19 +33,9 @@
 #ifndef W8_NT_Y
 #define W8_NT_Y 2
 #endif
-#ifndef W8_EXP
-#define W8_EXP 0      /* timing builds (wrong results): 1 no B loads in the MFMA phase, 2 no input transform, 3 no MFMA phase, 4 no output stores, 5 no epilogue */
-#endif
 #ifndef W8_NT_X
 #define W8_NT_X 0     /* cache policy (aux) of the patch DMA loads: 2 = nt (streaming: do not displace the weights in L2) */
 #endif
-// Channel-chunk rotation: work item (tile, cout block) walks the channel chunks starting at a chunk that depends on its tile position,
-// so that the CUs of an XCD do not all ask for the same weight lines in the same chunk period.  The start is a function of the tile
-// position inside the image and the cout block only — an image's result never depends on its batch neighbours.
-#ifndef W8_ROTATE
-#define W8_ROTATE 0
-#endif
-#define W8_ROT(c_) (W8_ROTATE ? (((c_) + rot) >= a.CC ? ((c_) + rot - a.CC) : ((c_) + rot)) : (c_))
 #ifndef W8_ORDER
 #define W8_ORDER 2    /* work-item order: 0 cout block fastest, 1 cout block slowest inside an image, 2 pairs of cout blocks fastest */
 #endif
@@ -264,7 +254,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     float omax = 0.f;
     // ---- work-item state (set by W8_SETUP for the item about to run; the epilogue works on copies) ----
-    int n, y0, x0, n0, rot;
+    int n, y0, x0, n0;
     unsigned p_off[10], u_voff;
     float S, inv;
 #define W8_SETUP(item_)                                                                                          \
@@ -283,7 +273,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int pr_ = b_ % np_; n = b_ / np_; nbi_ = pr_ * 2 + lo_;                                        \
         }                                                                                                        \
         y0 = byi_ * (4 * TY); x0 = bxi_ * (4 * TX); n0 = nbi_ * BN;                                              \
-        rot = W8_ROTATE ? (bxi_ + 5 * byi_ + 3 * nbi_) % a.CC : 0;                                               \
         _Pragma("unroll") for (int i = 0; i < 10; ++i) {                                                         \
             const int s_ = i * 256 + tid;              /* 16-byte slot of the patch image: (py*4 + quad)*PP + px */ \
             const int rowq_ = s_ / PP, pxx_ = s_ - rowq_ * PP;                                                   \
@@ -311,13 +300,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if ((cc_) < a.CC) {                                                                                      \
             char* d_ = sP + ((cc_) & 1) * P_BYTES;                                                               \
             _Pragma("unroll") for (int i = 0; i < 10; ++i)                                                       \
-                dma16(a.x, a.x_bytes, d_ + (i * 256 + wave * 64) * 16, p_off[i], (unsigned)(W8_ROT(cc_) * 64));  \
+                dma16(a.x, a.x_bytes, d_ + (i * 256 + wave * 64) * 16, p_off[i], (unsigned)((cc_) * 64));  \
         }                                                                                                        \
     } while (0)
     // the four B fragments of position j_ of chunk cc_ into ring buffer (j_) % 3
 #define W8_LOAD_B(cc_, j_)                                                                                       \
     do {                                                                                                         \
-        const unsigned so_ = (unsigned)W8_ROT(cc_) * u_chunk + (unsigned)(9 * wave + (j_)) * u_pos;              \
+        const unsigned so_ = (unsigned)(cc_) * u_chunk + (unsigned)(9 * wave + (j_)) * u_pos;              \
         _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_)                                                         \
             _Pragma("unroll") for (int kk_ = 0; kk_ < NP; ++kk_)                                                 \
                 fb[(j_) % 3][g_][kk_] = buf_load16(a.u8, a.u_bytes, u_voff, so_ + (unsigned)g_ * 1024u + (unsigned)kk_ * u_piece); \
@@ -346,7 +335,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // patch cc landed (this wave's part): its DMAs were issued in the last slices of chunk cc-2's MFMA phase, before B loads
             // that have been consumed since
             W8_BARRIER();                               // everyone's part; and every wave is done with V of the previous chunk
-            if (W8_EXP != 2) {
+            {
                 const char* src = sP + (cc & 1) * P_BYTES + src0;
                 if (t_half == 0) transform_chunk<0>(src, sV + dstv, S);
                 else transform_chunk<1>(src, sV + dstv, S);
@@ -361,7 +350,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // itself — 147 KB per chunk and CU at the ~27 B/clk/CU the L2 -> CU path delivers, whatever the number of loads in flight
             // (all nine positions requested at once: slower) and whatever the work-item order (profiles/r02_winograd8_variants.txt).
             u32x4 fa[2][NP];
-            if (W8_EXP != 3) {
+            {
                 {
                     const char* va = sV + (9 * wave) * NP * VPIECE + fragA;
                     fa[0][0] = lds_u4(va);
@@ -375,11 +364,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         const int t = k >> 1, g = k & 1;   // terms hi lo', lo hi', hi hi'
                         if (j == 8) mfma16_vgpr(fa[j & 1][t == 1 ? 1 : 0], fb[j % 3][g][t == 0 ? 1 : 0], acc[j][g]);
                         else acc[j][g] = mfma16(fa[j & 1][t == 1 ? 1 : 0], fb[j % 3][g][t == 0 ? 1 : 0], acc[j][g]);
-                        if (k < 4 && W8_EXP != 1) {        // one B fragment of the position after next
+                        if (k < 4) {        // one B fragment of the position after next
                             const int jn = (j + 2) % 9;
                             const int cn = cc + (j + 2 >= 9 ? 1 : 0);
                             if (j + 2 < 9 || cn < a.CC) {
-                                const unsigned so_ = (unsigned)W8_ROT(cn) * u_chunk + (unsigned)(9 * wave + jn) * u_pos + (unsigned)(k >> 1) * 1024u + (unsigned)(k & 1) * u_piece;
+                                const unsigned so_ = (unsigned)cn * u_chunk + (unsigned)(9 * wave + jn) * u_pos + (unsigned)(k >> 1) * 1024u + (unsigned)(k & 1) * u_piece;
                                 fb[jn % 3][k >> 1][k & 1] = buf_load16(a.u8, a.u_bytes, u_voff, so_);
                             }
                         } else if (k >= 4 && j + 1 < 9) {  // one A fragment of the next position
@@ -405,7 +394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int e_cq = tid & 7, e_tile = tid >> 3;
         const int oy = ey0 + 4 * (e_tile >> 3), ox = ex0 + 4 * (e_tile & 7);
 #pragma unroll
-        for (int g = 0; g < (W8_EXP == 5 ? 0 : 2); ++g) {
+        for (int g = 0; g < 2; ++g) {
             W8_BARRIER();                               // V (g = 0) / the previous pass's exchange buffer is no longer read
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -477,7 +466,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         o[e] = fmaxf(yv[dy][e] * einv + bv[e] + rv[e], lo);
                         omax = fmaxf(omax, ok ? fabsf(o[e]) : 0.f);
                     }
-                    buf_store16(o, a.y, a.y_bytes, (ok && (W8_EXP != 4 || o[0] == 12345.f)) ? y_voff : OOB, so * (unsigned)a.ldy * 4u);
+                    buf_store16(o, a.y, a.y_bytes, ok ? y_voff : OOB, so * (unsigned)a.ldy * 4u);
                 }
             }
         }

@@ -31,9 +31,6 @@
 
 #pragma clang fp contract(off)
 
-#ifndef W9_STAGGER
-#define W9_STAGGER 1  /* scale of the start-up stagger (0 = off) */
-#endif
 #ifndef W9_NT_Y
 #define W9_NT_Y 2     /* cache policy (aux) of the output stores: nt (see winograd5.hip) */
 #endif
@@ -63,7 +60,6 @@ struct Args {
     int blocks;
     unsigned x_bytes, u_bytes, y_bytes, r_bytes, b_bytes;
     unsigned flags;
-    unsigned stagger;                 // start-up delay step: workgroup b waits ((37 b) mod 256) * stagger / 256 cycles before its first item
 #ifdef W9_TRACE
     unsigned long long* trace;        // timing build: [item][16] s_memtime stamps of block 0 / thread 0
 #endif
@@ -388,13 +384,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int tr_item = 0;
 #endif
     W9_STAMP(0);
-    // Work items all take the same time, so without this every CU of the chip reaches its epilogue — 128 KB of output stores — in the
-    // same few microseconds: a 32 MB write burst every item period, during which the store queues fill and the epilogue passes take
-    // 3-10x their time (s_memtime traces).  A one-off start-up delay spreads the workgroups' phases over `stagger` cycles.
-    if (a.stagger) {
-        const unsigned wait_ = (((blockIdx.x * 37u) & 255u) * a.stagger) >> 8;
-        for (unsigned w_ = 0; w_ < wait_; w_ += 1024) __builtin_amdgcn_s_sleep(16);
-    }
     Coord cc_cur, cc_nxt;
     int es_cur;
     W9_COORD(cc_cur, item);
@@ -691,11 +680,6 @@ int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu,
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb; a.b_bytes = (unsigned)p->Cout * 4u;
     a.flags = p->flags;
-    {   // ~12 % of a workgroup's estimated run time, at most one epilogue-burst period (32 K cycles)
-        const long long per_wg = (blocks + 255) / 256 * ((long long)a.CC * 5000 + 12000);
-        const long long st = per_wg / 8;
-        a.stagger = W9_STAGGER ? (unsigned)(st > 32768 ? 32768 : st) * W9_STAGGER : 0u;
-    }
 #ifdef W9_TRACE
     a.trace = g_w9_trace;
 #endif

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 6   /* 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 7   /* 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -179,6 +179,11 @@ int cnl_conv3x3_winograd_variant(const cnl_conv_params* p);           /* the ker
                                                                          in the reduction: 2/3 of the direct conv's multiplies]; < 0: error code */
 size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout);        /* elements of the transformed weight buffer */
 int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream);
+/* CNL_ALGO_F4 / CNL_ALGO_FORCE + 8 only: the F(4x4,3x3) copy of the weights is a TAIL of the same buffer — allocate
+ * cnl_winograd_f4_weight_floats elements instead, run cnl_winograd_transform_weights_f32 and then cnl_winograd_transform_weights_f4_f32 on it.
+ * (Launching with those algos on a buffer without the tail reads past it.) */
+size_t cnl_winograd_f4_weight_floats(int32_t Cin, int32_t Cout);
+int cnl_winograd_transform_weights_f4_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream);
 
 /*
  * Step before the path: uint8 HWC frames -> normalised fp32 NHWC, replacing albumentations

@@ -437,8 +437,11 @@ def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None, algo=CNL_ALGO_AUT
     Cout = w_oihw.shape[0]
     xd = x_nchw.permute(0, 2, 3, 1).contiguous().cuda()
     wd = w_oihw.permute(0, 2, 3, 1).contiguous().cuda()
-    u = torch.full((lib.cnl_winograd_weight_floats(Cin, Cout),), float("nan"), device="cuda")
+    f4 = algo in (CNL_ALGO_F4, CNL_ALGO_FORCE + 8)              # the F(4x4) copy of the weights is an optional tail of the buffer
+    u = torch.full(((lib.cnl_winograd_f4_weight_floats if f4 else lib.cnl_winograd_weight_floats)(Cin, Cout),), float("nan"), device="cuda")
     _lib.check(lib.cnl_winograd_transform_weights_f32(wd.data_ptr(), u.data_ptr(), Cin, Cout, _stream()))
+    if f4:
+        _lib.check(lib.cnl_winograd_transform_weights_f4_f32(wd.data_ptr(), u.data_ptr(), Cin, Cout, _stream()))
     bd = bias.cuda()
     y = torch.full((N, H, W, Cout), float("nan"), device="cuda")
     p = ConvParams()
@@ -605,8 +608,9 @@ def test_winograd_f4_hands_over_absmax_and_takes_the_hint():
     base = run_winograd(x, w, b, CNL_RELU, algo=CNL_ALGO_FORCE + 8, want=8)
     xd = x.permute(0, 2, 3, 1).contiguous().cuda()
     wd = w.permute(0, 2, 3, 1).contiguous().cuda()
-    u = torch.empty((lib.cnl_winograd_weight_floats(128, 64),), device="cuda")
+    u = torch.empty((lib.cnl_winograd_f4_weight_floats(128, 64),), device="cuda")
     _lib.check(lib.cnl_winograd_transform_weights_f32(wd.data_ptr(), u.data_ptr(), 128, 64, _stream()))
+    _lib.check(lib.cnl_winograd_transform_weights_f4_f32(wd.data_ptr(), u.data_ptr(), 128, 64, _stream()))
     bd = b.cuda()
     y = torch.full((2, 32, 32, 64), float("nan"), device="cuda")
     xm = x.abs().amax(dim=(1, 2, 3)).cuda()
@@ -623,7 +627,7 @@ def test_winograd_f4_hands_over_absmax_and_takes_the_hint():
 
 
 def _exp_lib():
-    """The experiment build (make -C csrc experiments: the superseded Winograd variants of csrc/experiments/), or None."""
+    """The experiment build (make -C csrc experiments: the superseded Winograd variants of tools/experiments/), or None."""
     import os
     path = os.path.join(os.path.dirname(_lib.lib_path()), "libcenternet_gfx950_exp.so")
     if not os.path.exists(path):
@@ -636,7 +640,7 @@ def _exp_lib():
 
 
 def test_winograd_decompositions_are_bit_identical():
-    """experiments/winograd1.hip (16x16-pixel blocks) and winograd2.hip (8x16) do the same arithmetic in the same order: forced onto
+    """tools/experiments/winograd1.hip (16x16-pixel blocks) and winograd2.hip (8x16) do the same arithmetic in the same order: forced onto
     the same inputs they must agree bit for bit (experiment build only)."""
     lib = _exp_lib()
     if lib is None:

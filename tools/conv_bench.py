@@ -89,8 +89,9 @@ def main():
         if args.winograd:
             if k != 3 or stride != 1:
                 continue
-            u = torch.empty(lib.cnl_winograd_weight_floats(Cin, Cout), device="cuda")
+            u = torch.empty(lib.cnl_winograd_f4_weight_floats(Cin, Cout), device="cuda")
             _lib.check(lib.cnl_winograd_transform_weights_f32(w.data_ptr(), u.data_ptr(), Cin, Cout, stream))
+            _lib.check(lib.cnl_winograd_transform_weights_f4_f32(w.data_ptr(), u.data_ptr(), Cin, Cout, stream))
             p.w = u.data_ptr()
             p.flags = flags & 5            # RELU | UPSAMPLE_IN
             fn = lib.cnl_conv3x3_winograd_f32
