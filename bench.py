@@ -114,6 +114,42 @@ def build_model(config, **options):
     return model.cuda()
 
 
+def setup_distributed(gpus):
+    """(rank, world, local_rank) from the torchrun environment; one rank per GPU over RCCL ("nccl" IS RCCL on ROCm).
+    CNL_BENCH_BACKEND=gloo is a functional check of the N>1 flow on a box with fewer GPUs than ranks (ranks then share devices — or have
+    none at all in the CPU test of tests/test_host.py — and the collective goes through the host); the measured configuration is always
+    nccl = RCCL, one GPU per rank."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != gpus:
+        if world == 1 and gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}")
+    backend = os.environ.get("CNL_BENCH_BACKEND", "nccl")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))     # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local_rank
+
+
+def max_over_ranks(elapsed, device):
+    """The slowest rank's wall time of the timed region: what the whole job took."""
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_throughput(images_per_rank, world, steps, elapsed_max):
+    """Whole-job images/s: every rank processes its own batch per step (weak scaling), the job ends when the slowest rank does."""
+    return images_per_rank * world * steps / elapsed_max
+
+
 def run_steps(model, x, tracking, k, steps, collator):
     """`steps` passes of the hot path; the all-gather of step i is collected during step i+1 and the last one drained."""
     pending, out = None, None
@@ -430,25 +466,7 @@ def main():
     ap.add_argument("--layers", action="store_true", help="also print the per-layer conv table to stderr")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    # CNL_BENCH_BACKEND=gloo is a functional check of the N>1 flow on a box with fewer GPUs than ranks (ranks then share
-    # devices and the collective goes through the host); the measured configuration is always nccl = RCCL, one GPU per rank
-    backend = os.environ.get("CNL_BENCH_BACKEND", "nccl")
-    if backend == "nccl":
-        torch.cuda.set_device(local_rank)
-    else:
-        torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))     # RCCL over xGMI
-        else:
-            dist.init_process_group(backend)
+    rank, world, local_rank = setup_distributed(args.gpus)
 
     tracking = args.config == "tracking"
     model = build_model(args.config, algo=args.algo)
@@ -463,9 +481,7 @@ def main():
 
     elapsed = timed(model, x, tracking, args.k, args.warmup, args.steps, collator, barrier)
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed, "cuda")
         # the collate step alone, synchronously (pack + all-gather + unpack), for the record: median of 10
         with torch.no_grad():
             o = model(x)
@@ -488,7 +504,7 @@ def main():
         eng = model._engine
         result = {
             "metric": "images/sec @512x512 ResNet34 CenterNet forward + gather_detection2d",
-            "value": round(world * B * args.steps / elapsed, 2),
+            "value": round(job_throughput(B, world, args.steps, elapsed), 2),
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),

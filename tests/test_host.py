@@ -219,6 +219,51 @@ def test_collate_protocol_gloo_world2():
     assert ret.get(0) is True and ret.get(1) is True
 
 
+def _world8_worker(rank, world, port, ret):
+    """Rank order, slot reuse and the bench's own N > 1 plumbing (environment -> process group, max over ranks, whole-job throughput) at the
+    north star's world size, on CPU over gloo: no 8-GPU node was ever available to this build."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "centernet-lightning_amd"))
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                       "CNL_BENCH_BACKEND": "gloo"})
+    import bench
+    from centernet_lightning_amd import Collator, shard_range
+    try:
+        r, w, lr = bench.setup_distributed(world)                      # what `bench.py --gpus 8` runs first on every rank
+        ok = (r, w, lr) == (rank, world, rank) and dist.get_world_size() == world
+        worst = bench.max_over_ranks(1.0 + 0.25 * rank, "cpu")         # the timed region ends with the slowest rank
+        ok = ok and worst == 1.0 + 0.25 * (world - 1) and bench.job_throughput(32, world, 10, worst) == 32 * world * 10 / worst
+        lo, hi = shard_range(512, rank, world)                         # C3: 512 images over 8 ranks
+        ok = ok and (lo, hi) == (64 * rank, 64 * rank + 64)
+        c = Collator(depth=2)
+        pending, want = None, None
+        for step in range(3):                                          # three pipelined steps: result one step behind submit
+            rec = torch.full((2, 5, 6), float(1000 * step + rank))
+            h = c.submit_records(rec)
+            if pending is not None:
+                got = c.result_records(pending)
+                ok = ok and got.shape == (2 * world, 5, 6) and all(bool((got[2 * q:2 * q + 2] == want + q).all()) for q in range(world))
+            pending, want = h, float(1000 * step)
+        got = c.result_records(pending)
+        ok = ok and all(bool((got[2 * q:2 * q + 2] == want + q).all()) for q in range(world))
+        ok = ok and len(c._slots) == 1 and len(next(iter(c._slots.values()))) == 2      # two persistent slots, reused
+        ret[rank] = bool(ok)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_pipelined_collator_gloo_world8():
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_world8_worker, args=(8, port, ret), nprocs=8, join=True)
+    assert all(ret.get(r) is True for r in range(8)), dict(ret)
+
+
 def test_collate_is_noop_at_world_size_one():
     dets = {"bboxes": torch.zeros(1, 2, 4), "scores": torch.zeros(1, 2), "labels": torch.zeros(1, 2, dtype=torch.int64)}
     assert cl.collate_detections(dets) is dets                       # eval/coco.py:11-13 behaviour
