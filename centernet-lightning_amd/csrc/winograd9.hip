@@ -488,9 +488,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             iq[i] = isu_e * __builtin_ldexpf(1.f, -es_i);
         }
         float omax2[2] = {0.f, 0.f};
+        // pass j + 1's blocks are written (into the other half) BEFORE pass j's are read: the write latency hides under the arithmetic
+#define W9_XWRITE(j_)                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                            \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+                const f32x16& A = st.acc[j_][g];                                                                 \
+                *reinterpret_cast<f32x4*>(sX + ((j_) & 1) * (X_BYTES / 2) + ((g * 4 + wave) * 256 + wslot0 + ((2 * q + h_e) ^ wsw)) * 16) = \
+                    f32x4{A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};                                   \
+            }
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 iql[2] = {f32x2{iq[0][0], iq[0][1]}, f32x2{iq[1][0], iq[1][1]}}, iqh[2] = {f32x2{iq[0][2], iq[0][3]}, f32x2{iq[1][2], iq[1][3]}};
+        const f32x2 bql = {bq[0], bq[1]}, bqh = {bq[2], bq[3]};
+        W9_XWRITE(0);
+        W9_BARRIER();
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            char* X = sX + (j & 1) * (X_BYTES / 2);
+            const char* X = sX + (j & 1) * (X_BYTES / 2);
             const int oy = cc_cur.y0 + j;
             const bool row_ok = oy < a.H && cok_e;
             unsigned yv[2];
@@ -510,40 +523,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
             W9_STAMP(7 + (j & 7));
+            f32x4 Y[2][4];
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x16& A = st.acc[j][g];
-                    *reinterpret_cast<f32x4*>(X + ((g * 4 + wave) * 256 + wslot0 + ((2 * q + h_e) ^ wsw)) * 16) = f32x4{A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};
-                }
-            W9_BARRIER();
-            __builtin_amdgcn_sched_barrier(0);
+                for (int p = 0; p < 4; ++p) Y[i][p] = lds_f4(X + ((g_e * 4 + p) * 256 + rslot[i]) * 16);
+            if (j + 1 < R) { W9_XWRITE(j + 1); }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                f32x4 Y[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) Y[p] = lds_f4(X + ((g_e * 4 + p) * 256 + rslot[i]) * 16);
+                // packed fp32 arithmetic (no MFMA in flight here): two couts per instruction
                 f32x4 o0, o1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float ya = (Y[0][e] + Y[1][e] + Y[2][e]) * iq[i][e];
-                    const float yb = (Y[1][e] - Y[2][e] - Y[3][e]) * iq[i][e];
+                for (int hh = 0; hh < 2; ++hh) {
+                    const f32x2 y0 = {Y[i][0][2 * hh], Y[i][0][2 * hh + 1]}, y1 = {Y[i][1][2 * hh], Y[i][1][2 * hh + 1]};
+                    const f32x2 y2 = {Y[i][2][2 * hh], Y[i][2][2 * hh + 1]}, y3 = {Y[i][3][2 * hh], Y[i][3][2 * hh + 1]};
+                    const f32x2 sc = hh ? iqh[i] : iql[i], bb = hh ? bqh : bql;
+                    f32x2 ya = (y0 + y1 + y2) * sc + bb;
+                    f32x2 yb = (y1 - y2 - y3) * sc + bb;
                     if constexpr (RES) {
-                        o0[e] = fmaxf(ya + bq[e] + rv[i][0][e], lo);
-                        o1[e] = fmaxf(yb + bq[e] + rv[i][1][e], lo);
-                    } else {
-                        o0[e] = fmaxf(ya + bq[e], lo);
-                        o1[e] = fmaxf(yb + bq[e], lo);
+                        ya += f32x2{rv[i][0][2 * hh], rv[i][0][2 * hh + 1]};
+                        yb += f32x2{rv[i][1][2 * hh], rv[i][1][2 * hh + 1]};
                     }
+                    o0[2 * hh] = fmaxf(ya[0], lo); o0[2 * hh + 1] = fmaxf(ya[1], lo);
+                    o1[2 * hh] = fmaxf(yb[0], lo); o1[2 * hh + 1] = fmaxf(yb[1], lo);
                 }
                 if (ok[i][0]) omax2[i] = fmaxf(omax2[i], fmaxf(fmaxf(fabsf(o0[0]), fabsf(o0[1])), fmaxf(fabsf(o0[2]), fabsf(o0[3]))));
                 if (ok[i][1]) omax2[i] = fmaxf(omax2[i], fmaxf(fmaxf(fabsf(o1[0]), fabsf(o1[1])), fmaxf(fabsf(o1[2]), fabsf(o1[3]))));
                 buf_store16(o0, a.y, a.y_bytes, ok[i][0] ? yv[i] : OOB, 0);
                 buf_store16(o1, a.y, a.y_bytes, ok[i][1] ? yv[i] : OOB, (unsigned)(a.ldy * 4));
             }
+            if (j + 1 < R) { W9_BARRIER(); }
             __builtin_amdgcn_sched_barrier(0);
         }
+#undef W9_XWRITE
         if (a.ymax) {          // max |y| of this item into its image's slot: the 8 tiles of an iteration lie in one image (tiles per image: 8, 16 or all)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
