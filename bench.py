@@ -11,7 +11,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
               timed region].  Inputs are resident in HBM.
   workload  = BASELINE.json configs[1] (C1): ResNet34 + simple upsample neck, batch 32 per GPU, 512x512, 80 classes
               (`--config fpn --batch 64` = C2/C3, `--config tracking --batch 32 --height 608 --width 1088` = C4).  At N = 1 the
-              default run appends short C2 and C4 lines under `also` (5 steps each).
+              default run appends short C2 and C4 lines under `also` (10 steps after 3 warm-ups each).
   value     = total images / max-over-ranks wall time of the K timed steps (weak scaling: batch per GPU fixed).
   roofline  = the dominant kernel by time, measured with HIP events on the launch stream around every conv launch of one step.
               The long 3x3 layers form every fp32 product on the fp16 matrix cores (scaled two-way fp16 split, three MFMAs per
@@ -30,8 +30,9 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
   decode    = decode p50 on the forward's own outputs: bytes that must move, GB/s, fraction of 8 TB/s; with a separate sigmoid pass
               in front (what a caller holding logits pays) and without (the path: sigmoid is the heatmap conv's epilogue).
   cpu_baseline = the CPU oracle (oracle/ref_cpu.py + oracle/decode_ref.py: the plain PyTorch restatement of the reference path —
-              kind "port") timed on this box's host cores: C0 exactly (1x3x512x512) and the bench config at N = 8, 2 warm-ups +
-              5 timed passes each (bounded by a time budget), median; decode p50 on the CPU beside the GPU's.  Rank 0, N = 1 only,
+              kind "port") timed on this box's host cores: C0 exactly (1x3x512x512) and the bench shape at N = 32 (the GPU leg's batch),
+              in child processes under two OpenMP placements (runtime default / OMP_PROC_BIND=close OMP_PLACES=cores) and 16 / 32 / 64
+              threads; 1 warm-up + 3 timed passes of the best, median; decode p50 on the CPU beside the GPU's.  Rank 0, N = 1 only,
               AFTER all GPU legs (so that the GPU work of the run is contiguous).
 """
 import argparse
@@ -360,12 +361,55 @@ def feature_errors(config, x2, algo):
     return {k_: float(f"{v:.3e}") for k_, v in e.items()}
 
 
-def cpu_baseline(model, config, tracking, k, H, W, gpu_decode_p50_ms, budget_s=70.0):
-    """Oracle leg: the CPU restatement of forward + decode, C0 exactly and the bench config at N = 8."""
+def _cpu_leg_child(spec):
+    """Runs in a CHILD process (python bench.py --cpu-leg-child '<json>'): OpenMP reads OMP_PROC_BIND / OMP_PLACES once, when torch is
+    imported, so each thread placement needs its own process.  Prints one JSON line."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import decode_ref
     import ref_cpu
+    torch.manual_seed(0)
+    model = synthetic_weights_(cl.build_centernet(os.path.join(ROOT, "centernet-lightning_amd", "configs", CONFIGS[spec["config"]])))
     sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
+    tracking, k, n, h, w = spec["config"] == "tracking", spec["k"], spec["n"], spec["h"], spec["w"]
+
+    def one(x):
+        o = ref_cpu.forward(sd, x, sigmoid=True)
+        t0 = time.perf_counter()
+        decode_ref.decode_detections_torch(o["heatmap"], o["box_2d"], k, 3, reid=o["reid"] if tracking else None)
+        return time.perf_counter() - t0
+
+    x0 = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(1234))
+    torch.set_num_threads(spec["threads"][0])
+    one(x0[:1])                                                             # global warm-up (oneDNN primitive caches, allocator)
+    probes = []
+    for threads in spec["threads"]:
+        for cl_ in (True, False) if spec.get("both_layouts") else (True,):
+            torch.set_num_threads(threads)
+            x = x0.contiguous(memory_format=torch.channels_last) if cl_ else x0
+            t0 = time.perf_counter()
+            one(x)
+            probes.append((time.perf_counter() - t0, threads, cl_))
+    _, threads, cl_ = min(probes)
+    torch.set_num_threads(threads)
+    x = x0.contiguous(memory_format=torch.channels_last) if cl_ else x0
+    for _ in range(spec["warmup"]):
+        one(x)
+    ts, dec = [], []
+    for _ in range(spec["passes"]):
+        t0 = time.perf_counter()
+        dec.append(one(x))
+        ts.append(time.perf_counter() - t0)
+    ts.sort(); dec.sort()
+    print(json.dumps({"threads": threads, "channels_last": cl_, "images_per_s": round(n / ts[len(ts) // 2], 3), "timed_passes": len(ts), "n": n,
+                      "decode_p50_ms": round(dec[len(dec) // 2] * 1e3, 3), "omp": {k_: os.environ.get(k_) for k_ in ("OMP_PROC_BIND", "OMP_PLACES")},
+                      "probes_images_per_s": {f"{t_}thr{'_cl' if c_ else ''}": round(n / s_, 3) for s_, t_, c_ in probes}}))
+
+
+def cpu_baseline(config, k, H, W, gpu_decode_p50_ms):
+    """Oracle leg: the CPU restatement of forward + decode (kind "port") on the box's host cores — C0 exactly (1 x 3 x 512 x 512) and the bench
+    shape at N = 32 (the GPU leg's own batch: ~30 s of CPU work), each under two OpenMP thread placements (the runtime's default, and threads
+    pinned to consecutive cores: OMP_PROC_BIND=close OMP_PLACES=cores) and the probed thread counts; the best is `value`, every probe is listed."""
+    import subprocess
     cores = os.cpu_count()
     cpu_model = "unknown"
     try:
@@ -375,59 +419,39 @@ def cpu_baseline(model, config, tracking, k, H, W, gpu_decode_p50_ms, budget_s=7
                 break
     except OSError:
         pass
+    tlist = sorted({max(1, min(t_, cores)) for t_ in (16, 32, 64)})
 
-    def one(x):
-        o = ref_cpu.forward(sd, x, sigmoid=True)
-        t0 = time.perf_counter()
-        decode_ref.decode_detections_torch(o["heatmap"], o["box_2d"], k, 3, reid=o["reid"] if tracking else None)
-        return time.perf_counter() - t0
+    def child(spec, pinned):
+        env = dict(os.environ)
+        env.pop("OMP_PROC_BIND", None); env.pop("OMP_PLACES", None)
+        if pinned:
+            env.update({"OMP_PROC_BIND": "close", "OMP_PLACES": "cores"})
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg-child", json.dumps(spec)], env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"error": r.stderr[-400:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
 
-    def leg(n, h, w, budget):
-        """Best (threads, memory format) found on single probe passes, then 2 warm-ups + 5 timed passes (median) with it.  The
-        reference exposes channels_last itself (models/meta.py:97-98), so both layouts are legitimate forms of its CPU path."""
-        x0 = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(1234))
-        torch.set_num_threads(max(1, cores // 2))
-        one(x0)                                                                 # global warm-up (oneDNN primitive caches, allocator)
-        probes = []
-        t_start = time.perf_counter()
-        for threads in sorted({max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, min(48, cores)), max(1, min(32, cores)), max(1, min(24, cores)), max(1, min(16, cores)), max(1, min(8, cores))}):    # fewest first: on many-core hosts oneDNN scales negatively here
-            for cl_ in (False, True):
-                if probes and time.perf_counter() - t_start > budget * 0.5:
-                    break
-                torch.set_num_threads(threads)
-                x = x0.contiguous(memory_format=torch.channels_last) if cl_ else x0
-                t0 = time.perf_counter()
-                one(x)
-                probes.append((time.perf_counter() - t0, threads, cl_))
-        _, threads, cl_ = min(probes)
-        torch.set_num_threads(threads)
-        x = x0.contiguous(memory_format=torch.channels_last) if cl_ else x0
-        one(x)
-        one(x)                                                                  # 2 warm-ups
-        ts, dec = [], []
-        t_start = time.perf_counter()
-        while len(ts) < 5 and (len(ts) < 3 or time.perf_counter() - t_start < budget * 0.5):
-            t0 = time.perf_counter()
-            dec.append(one(x))
-            ts.append(time.perf_counter() - t0)
-        ts.sort(); dec.sort()
-        torch.set_num_threads(cores)
-        return {"threads": threads, "channels_last": cl_, "images_per_s": round(n / ts[len(ts) // 2], 3), "timed_passes": len(ts),
-                "decode_p50_ms": round(dec[len(dec) // 2] * 1e3, 3),
-                "probes_images_per_s": {f"{t_}thr{'_cl' if c_ else ''}": round(n / s_, 3) for s_, t_, c_ in probes}}
-
-    c0 = leg(1, 512, 512, budget_s * 0.3)
-    cn = leg(8, H, W, budget_s * 0.7)
+    legs = {}
+    for pinned in (False, True):
+        tag = "pinned_close_cores" if pinned else "omp_default"
+        legs["N32_" + tag] = child({"config": config, "k": k, "n": 32, "h": H, "w": W, "threads": tlist, "warmup": 1, "passes": 3}, pinned)
+    c0 = child({"config": config, "k": k, "n": 1, "h": 512, "w": 512, "threads": sorted({max(1, min(t_, cores)) for t_ in (8, 16, 32)}), "warmup": 2, "passes": 5,
+                "both_layouts": True}, True)
+    good = {k_: v for k_, v in legs.items() if "images_per_s" in v}
+    if not good:
+        return {"error": legs}
+    best_tag = max(good, key=lambda k_: good[k_]["images_per_s"])
+    cn = good[best_tag]
     return {"value": cn["images_per_s"], "unit": "images/s", "cores": cn["threads"], "kind": "port",
             "os_cpu_count": cores, "cpu_model": cpu_model,
-            "sample": f"oracle/ref_cpu.forward + decode_ref.decode_detections_torch (same weights) on 8x3x{H}x{W}, 2 warm-ups + {cn['timed_passes']} timed passes, median; "
-                      f"torch {torch.__version__} CPU fp32, {cn['threads']} threads{', channels_last' if cn['channels_last'] else ''} "
-                      f"(the best of the probed thread counts / layouts: bench_config_N8.probes_images_per_s); decode = the reference's torch op sequence on CPU",
-            "bench_config_N8": cn, "C0_1x3x512x512": c0,
-            "decode_p50_ms": {"cpu_N8": cn["decode_p50_ms"], "cpu_N1_C0": c0["decode_p50_ms"], "gpu_full_batch": gpu_decode_p50_ms}}
+            "sample": f"oracle/ref_cpu.forward + decode_ref.decode_detections_torch (same weights) on 32x3x{H}x{W} (the GPU leg's batch), 1 warm-up + {cn['timed_passes']} timed "
+                      f"passes, median; torch {torch.__version__} CPU fp32, {cn['threads']} threads{', channels_last' if cn['channels_last'] else ''}, placement {best_tag} "
+                      f"(best of two OpenMP placements x thread counts {tlist}: legs[*].probes_images_per_s); decode = the reference's torch op sequence on CPU",
+            "legs": legs, "C0_1x3x512x512": c0,
+            "decode_p50_ms": {"cpu_N32": cn["decode_p50_ms"], "cpu_N1_C0": c0.get("decode_p50_ms"), "gpu_full_batch": gpu_decode_p50_ms}}
 
 
-def short_line(config, B, H, W, k, steps=5, warmup=2):
+def short_line(config, B, H, W, k, steps=10, warmup=3):
     """A short run of another BASELINE configuration (driver-visible C2 / C4 numbers)."""
     tracking = config == "tracking"
     model = build_model(config)
@@ -447,6 +471,9 @@ def short_line(config, B, H, W, k, steps=5, warmup=2):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-leg-child":
+        _cpu_leg_child(json.loads(sys.argv[2]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -607,7 +634,7 @@ def main():
                 except Exception as e:
                     result["accuracy"] = {"error": repr(e)}
             if not args.no_cpu_baseline:
-                result["cpu_baseline"] = cpu_baseline(model, args.config, tracking, args.k, H, W, dec["p50_ms_without_sigmoid"])
+                result["cpu_baseline"] = cpu_baseline(args.config, args.k, H, W, dec["p50_ms_without_sigmoid"])
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
