@@ -116,7 +116,7 @@ class Collator:
 
     def __init__(self, group=None, depth: int = 2, force: bool = False):
         self.group, self.depth, self.force = group, max(1, int(depth)), force
-        self._slots = {}            # (shape, device) -> list of [rec, out, done_event] per slot
+        self._slots = {}            # (shape, device) -> list of [rec, out, done_event, claimed, generation] per slot
         self._next = 0
         self._side = None
 
@@ -132,14 +132,17 @@ class Collator:
             for _ in range(self.depth):
                 rec = torch.empty(shape, device=device, dtype=dtype)
                 out = torch.empty((world * shape[0],) + tuple(shape[1:]), device=device, dtype=dtype)
-                slots.append([rec, out, torch.cuda.Event() if device.type == "cuda" else None, False])
+                slots.append([rec, out, torch.cuda.Event() if device.type == "cuda" else None, False, -1])
             self._slots[key] = slots
         i = self._next % self.depth
         self._next += 1
+        slots[i][4] = self._next                         # generation: which submission owns the slot now
         return slots[i]
 
     def _claim(self, shape, device, dtype):
         """Next slot; the caller's stream first waits for the slot's previous gather (it is about to overwrite its source)."""
+        if self.depth < 2:
+            raise ValueError("Collator(depth=1) cannot be pipelined: submit(i + 1) would overwrite the slot that result(i) reads; use depth >= 2")
         slot = self._slot(shape, device, dtype)
         if slot[2] is not None and slot[3]:
             torch.cuda.current_stream(device).wait_event(slot[2])
@@ -165,12 +168,17 @@ class Collator:
                 slot[2].record(self._side)
         else:
             dist.all_gather_into_tensor(slot[1], slot[0], group=self.group)
-        return ("gathered", slot)
+        return ("gathered", slot, slot[4])
 
     def result_records(self, handle) -> torch.Tensor:
-        kind, payload = handle
+        """The gathered records of a submit: a VIEW of the persistent slot (not a copy), valid until `depth` further submits re-claim
+        the slot — a handle whose slot has been re-claimed raises instead of silently returning a later batch."""
+        kind, payload = handle[0], handle[1]
         if kind == "local":
             return payload
+        if payload[4] != handle[2]:
+            raise RuntimeError("Collator: the slot of this handle was re-claimed by a later submit (results must be collected at most "
+                               "depth - 1 submissions behind; raise depth for a deeper pipeline)")
         if payload[2] is not None:
             torch.cuda.current_stream(payload[1].device).wait_event(payload[2])
         return payload[1]

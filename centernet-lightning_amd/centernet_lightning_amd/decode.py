@@ -59,7 +59,10 @@ def decode(heatmap, box_2d, reid=None, num_detections=100, nms_kernel=3, normali
         prev = torch.cuda.current_device()
         torch.cuda.set_device(dev)
     try:
-        buf = torch.empty((o_ws + ws_bytes,), device=dev, dtype=torch.uint8)
+        # the outputs share ONE allocation (carved after the launch); the stage-1 workspace (N*H*W*8 bytes: tens of MB at large N) is a
+        # SEPARATE one, freed with this call — a caller that keeps `scores` of many batches alive must not pin a workspace per batch
+        buf = torch.empty((o_ws,), device=dev, dtype=torch.uint8)
+        ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
         base = buf.data_ptr()
         p = DecodeParams()
         p.heat = heatmap.data_ptr()
@@ -75,7 +78,7 @@ def decode(heatmap, box_2d, reid=None, num_detections=100, nms_kernel=3, normali
         p.normalize_boxes, p.box_log = int(bool(normalize_boxes)), int(bool(box_log))
         p.box_multiplier, p.stride = float(box_multiplier), float(stride)
         p.scores, p.indices, p.labels, p.boxes = base + o_sc, base + o_idx, base + o_lab, base + o_box
-        p.workspace, p.workspace_bytes = base + o_ws, ws_bytes
+        p.workspace, p.workspace_bytes = ws.data_ptr(), ws_bytes
         _lib.check(lib.cnl_decode_f32(ctypes.byref(p), _stream(dev)), "cnl_decode_f32")
     finally:
         if switch:

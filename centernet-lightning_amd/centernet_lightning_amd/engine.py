@@ -305,8 +305,14 @@ class PackedWeights:
             self.fused_first = _Layer(w, b)
 
 
-    def stale(self):
-        """A source tensor was written in place (load_state_dict on a submodule, manual edits: version counter) or moved since packing."""
+    def stale(self, model=None):
+        """A source tensor was written in place (load_state_dict on a submodule, manual edits: version counter), moved, or REPLACED
+        (load_state_dict(assign=True), `module.weight = nn.Parameter(...)`, a swapped submodule: the module then holds another tensor
+        object than the one captured when packing) since the weights were packed."""
+        if model is not None:
+            now = list(model.parameters()) + list(model.buffers())
+            if len(now) != len(self._sources) or any(t is not s_[0] for t, s_ in zip(now, self._sources)):
+                return True
         for t, v0, p0 in self._sources:
             if t._version != v0 or t.data_ptr() != p0:
                 return True
@@ -972,7 +978,7 @@ class Engine:
 
     def _dispatch_locked(self, x, sigmoid, N, H, W, norm):
         dev = x.device
-        if self.weights is None or self.weights_device != dev or self.weights.stale():
+        if self.weights is None or self.weights_device != dev or self.weights.stale(self.model):
             self.weights = PackedWeights(self.model, dev)
             self.weights_device = dev
             self.plans.clear()

@@ -314,6 +314,11 @@ def test_in_place_weight_edit_is_noticed_without_refresh():
     c = model.get_encoded_outputs(x)
     torch.testing.assert_close(c["box_2d"], b["box_2d"] + 1.0, rtol=0, atol=1e-5)
     assert torch.equal(c["heatmap"], b["heatmap"])
+    # a REPLACED parameter (another tensor object: `module.bias = nn.Parameter(...)`, load_state_dict(assign=True)) is noticed too
+    oc = model.heads["box_2d"].out_conv
+    oc.bias = torch.nn.Parameter(oc.bias.detach().clone() + 2.0)
+    d = model.get_encoded_outputs(x)
+    torch.testing.assert_close(d["box_2d"], c["box_2d"] + 2.0, rtol=0, atol=1e-5)
 
 
 def test_arena_reuse_shrinks_the_footprint_and_keeps_the_bytes():

@@ -248,6 +248,16 @@ def _world8_worker(rank, world, port, ret):
         got = c.result_records(pending)
         ok = ok and all(bool((got[2 * q:2 * q + 2] == want + q).all()) for q in range(world))
         ok = ok and len(c._slots) == 1 and len(next(iter(c._slots.values()))) == 2      # two persistent slots, reused
+        # a handle is valid until its slot is re-claimed (depth - 1 further submits): a stale one raises instead of returning a later batch
+        h0 = c.submit_records(torch.zeros(2, 5, 6)); c.submit_records(torch.ones(2, 5, 6)); c.submit_records(torch.ones(2, 5, 6))
+        try:
+            c.result_records(h0); ok = False
+        except RuntimeError:
+            pass
+        try:
+            Collator(depth=1).submit_records(torch.zeros(2, 5, 6)); ok = False
+        except ValueError:
+            pass
         ret[rank] = bool(ok)
     finally:
         if dist.is_initialized():
