@@ -102,6 +102,8 @@ _SIGNATURES = {
     "cnl_boxes_xyxy_to_xywh_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "cnl_track_costs_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_int32,
                                            c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cnl_track_costs_metric_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_int32,
+                                                  c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cnl_track_apply_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
                                            c_void_p, c_void_p, c_void_p]),
 }

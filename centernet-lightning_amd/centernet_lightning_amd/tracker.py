@@ -27,6 +27,7 @@ from . import _lib
 from .config import load_config
 
 _BOX_MODES = {None: 0, "iou": 1, "giou": 2}
+_REID_METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2}      # metrics with a gfx950 kernel (float64, scipy's operation order)
 
 
 class TrackState(Enum):
@@ -37,17 +38,16 @@ class TrackState(Enum):
 
 
 def match_with_threshold(cost_matrix, threshold):
-    """tracker.py:27-43: optimal assignment, keeping only pairs with cost < threshold."""
+    """tracker.py:27-43: optimal assignment, keeping only pairs with cost < threshold.  Same result and order as the reference's loop
+    (matches in row order, unmatched rows / columns ascending), vectorised: the loop over sets cost more than the Hungarian step itself."""
     row_ind, col_ind = linear_sum_assignment(cost_matrix)
-    matches, matched_row, matched_col = [], set(), set()
-    for row, col in zip(row_ind, col_ind):
-        if cost_matrix[row, col] < threshold:
-            matches.append((int(row), int(col)))
-            matched_row.add(int(row))
-            matched_col.add(int(col))
-    unmatched_row = [x for x in range(cost_matrix.shape[0]) if x not in matched_row]
-    unmatched_col = [x for x in range(cost_matrix.shape[1]) if x not in matched_col]
-    return matches, unmatched_row, unmatched_col
+    keep = cost_matrix[row_ind, col_ind] < threshold
+    rows, cols = row_ind[keep], col_ind[keep]
+    free_r = np.ones(cost_matrix.shape[0], dtype=bool)
+    free_c = np.ones(cost_matrix.shape[1], dtype=bool)
+    free_r[rows] = False
+    free_c[cols] = False
+    return list(zip(rows.tolist(), cols.tolist())), np.flatnonzero(free_r).tolist(), np.flatnonzero(free_c).tolist()
 
 
 class BoxKalman:
@@ -160,14 +160,22 @@ class Tracker:
 
     def __init__(self, model=None, nms_kernel=3, num_detections=300, detection_threshold=0.3, reid_cost="cosine",
                  reid_threshold=0.2, box_cost="iou", box_threshold=0.5, smoothing_factor=0.5, use_kalman=False,
-                 max_inactive_age=30, min_birth_age=2, device=None):
+                 max_inactive_age=30, min_birth_age=2, device=None, allow_host_cost=False):
+        """reid_cost: "cosine" (default), "euclidean", "sqeuclidean" run on the device.  The reference accepts ANY scipy cdist metric name or
+        a callable (tracker.py:51, 62-64), and a callable box_cost: those are computed on the HOST from copies of the frame's kept embeddings /
+        boxes and the track table (two more device -> host copies per frame) — only with allow_host_cost=True, otherwise they raise: a silent
+        CPU detour is not what a caller of a gfx950 tracker expects."""
         self.model = model
         if model is None:
             warnings.warn("A model was not provided. Only `.update()` will work")
-        if reid_cost != "cosine":
-            raise ValueError(f"reid_cost={reid_cost!r}: only 'cosine' (the reference default) has a gfx950 kernel")
-        if box_cost not in _BOX_MODES:
-            raise ValueError(f"box_cost={box_cost!r}: expected 'iou', 'giou' or None")
+        self._host_reid = None if reid_cost in _REID_METRICS else reid_cost
+        self._host_box = box_cost if callable(box_cost) else None
+        if (self._host_reid is not None or self._host_box is not None) and not allow_host_cost:
+            raise ValueError(f"reid_cost={reid_cost!r} / box_cost={box_cost!r}: only {sorted(_REID_METRICS)} and 'iou' / 'giou' / None have gfx950 "
+                             "kernels; pass allow_host_cost=True to compute other scipy metrics or callables on the host (slower: the embeddings "
+                             "then travel to the host every frame)")
+        if self._host_box is None and box_cost not in _BOX_MODES:
+            raise ValueError(f"box_cost={box_cost!r}: expected 'iou', 'giou', None or (with allow_host_cost=True) a callable")
         self.nms_kernel = nms_kernel
         self.num_detections = num_detections
         self.detection_threshold = detection_threshold
@@ -192,6 +200,8 @@ class Tracker:
         self._spare = None          # the other half of the ping-pong pair
         self.last_costs = None      # (reid [n,T] f64, box [n,T] f32 | None, det_index [n]) of the last update (host numpy)
         self._pinned = None         # page-locked staging buffer of the per-frame device -> host copy
+        self._dbuf = None           # persistent device buffer the costs kernel writes (n, det_index, cost matrices)
+        self._src_pin = self._src_dev = None   # page-locked / device pair of the two index lists of cnl_track_apply_f32
 
     @property
     def device(self):
@@ -247,7 +257,11 @@ class Tracker:
         """Update current tracks with one frame's detections (tracker.py:123-201).  Accepts numpy arrays (as the reference) or
         torch tensors; the arrays are moved to the HIP device, where the association costs are computed."""
         dev = self.device
-        to_dev = lambda a: torch.as_tensor(a).to(device=dev, dtype=torch.float32).contiguous()
+
+        def to_dev(a):
+            if isinstance(a, torch.Tensor) and a.device == dev and a.dtype == torch.float32 and a.is_contiguous():
+                return a                                   # already where the kernels read it (each .to() costs ~7 us of host time)
+            return torch.as_tensor(a).to(device=dev, dtype=torch.float32).contiguous()
         host = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
         if all(isinstance(a, torch.Tensor) and a.is_cuda for a in (bboxes, labels, scores)) and bboxes.dim() == 2:
             # device inputs: ONE device -> host copy (and one sync) for the three small arrays the host-side life cycle reads
@@ -271,7 +285,8 @@ class Tracker:
             raise ValueError(f"detections: boxes {tuple(d_box.shape)}, scores {tuple(d_score.shape)}, embeddings {tuple(d_emb.shape)}")
         d_box, d_score, d_emb = d_box.contiguous(), d_score.contiguous(), d_emb.contiguous()
         T = len(self.tracks)
-        box_mode = _BOX_MODES[self.box_cost]
+        box_mode = 0 if self._host_box is not None else _BOX_MODES[self.box_cost]
+        reid_metric = _REID_METRICS.get(self.reid_cost, 0)
         # The host holds the frame's scores too (they travel with the boxes), so it knows the number of kept detections n and can
         # size the one buffer that comes back: [n_det i32, det_index i32 k | reid f64 n*T | box f32 n*T]
         n = int(np.count_nonzero(np.asarray(h_score, dtype=np.float32) >= np.float32(detection_threshold)))
@@ -279,17 +294,20 @@ class Tracker:
         off_box = off_reid + 8 * n * T
         nbytes = off_box + 4 * n * T
         with torch.cuda.device(dev):
-            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            buf = torch.empty((nbytes + 16,), device=dev, dtype=torch.uint8)
+            cur = torch.cuda.current_stream(dev)
+            stream = ctypes.c_void_p(cur.cuda_stream)
+            if self._dbuf is None or self._dbuf.numel() < nbytes + 16:
+                self._dbuf = torch.empty((max(2 * nbytes + 16, 1 << 16),), device=dev, dtype=torch.uint8)      # persistent: nothing allocated per frame
+            buf = self._dbuf
             base = buf.data_ptr()
-            _lib.check(lib.cnl_track_costs_f32(d_emb.data_ptr(), d_box.data_ptr(), d_score.data_ptr(), k, E, float(detection_threshold),
-                                               self._emb.data_ptr() if T else None, self._box.data_ptr() if T else None, T, box_mode,
-                                               base, base + 4, base + off_reid if T else None,
-                                               base + off_box if (T and box_mode) else None, stream), "cnl_track_costs_f32")
+            _lib.check(lib.cnl_track_costs_metric_f32(d_emb.data_ptr(), d_box.data_ptr(), d_score.data_ptr(), k, E, float(detection_threshold),
+                                                      self._emb.data_ptr() if T else None, self._box.data_ptr() if T else None, T, box_mode, reid_metric,
+                                                      base, base + 4, base + off_reid if T else None,
+                                                      base + off_box if (T and box_mode) else None, stream), "cnl_track_costs_metric_f32")
             if self._pinned is None or self._pinned.numel() < nbytes:
                 self._pinned = torch.empty((max(2 * nbytes, 1 << 16),), dtype=torch.uint8).pin_memory()
             self._pinned[:nbytes].copy_(buf[:nbytes], non_blocking=True)      # the frame's only device -> host copy
-            torch.cuda.current_stream(dev).synchronize()
+            cur.synchronize()
             h = self._pinned[:nbytes].numpy()
         if int(h[:4].view(np.int32)[0]) != n:
             raise RuntimeError(f"detection count mismatch between host ({n}) and device ({int(h[:4].view(np.int32)[0])}): "
@@ -303,10 +321,26 @@ class Tracker:
             matches, unmatched_dets, unmatched_tracks = [], list(range(n)), []
         else:
             reid = h[off_reid:off_reid + 8 * n * T].view(np.float64).reshape(n, T)
+            if self._host_reid is not None or self._host_box is not None:
+                # opt-in host fallback (allow_host_cost=True): the reference's own expressions on copies of the operands
+                from scipy.spatial.distance import cdist
+                sel = torch.from_numpy(np.ascontiguousarray(det_index[:n]).astype(np.int64)).to(dev)
+                if self._host_reid is not None:
+                    h_de, h_te = d_emb.index_select(0, sel).cpu().numpy(), self._emb[:T].cpu().numpy()
+                    reid = self._host_reid(h_de, h_te) if callable(self._host_reid) else cdist(h_de, h_te, self._host_reid)
+                    reid = np.asarray(reid, np.float64).reshape(n, T)
             matches, unmatched_dets, unmatched_tracks = match_with_threshold(reid, reid_threshold)
             box = None
-            if box_mode:
+            if self._host_box is not None:
+                # tracker.py:157-162 as written: the callable sees the REMAINING detections' and tracks' boxes
+                h_db, h_tb = d_box.index_select(0, sel).cpu().numpy(), self._box[:T].cpu().numpy()
+                sub = np.asarray(self._host_box(h_db[unmatched_dets], h_tb[unmatched_tracks])).reshape(len(unmatched_dets), len(unmatched_tracks))
+                new_matches, ud, ut = match_with_threshold(sub, box_threshold)
+                matches.extend((unmatched_dets[x], unmatched_tracks[y]) for x, y in new_matches)
+                unmatched_dets, unmatched_tracks = [unmatched_dets[x] for x in ud], [unmatched_tracks[y] for y in ut]
+            elif box_mode:
                 box = h[off_box:off_box + 4 * n * T].view(np.float32).reshape(n, T)
+            if box is not None:
                 # element-wise costs: the remaining-pairs matrix of tracker.py:157-162 is a sub-matrix of the full one
                 sub = box[np.ix_(unmatched_dets, unmatched_tracks)]
                 new_matches, ud, ut = match_with_threshold(sub, box_threshold)
@@ -340,7 +374,14 @@ class Tracker:
             src[0] = [old_rows[i] for i in keep]
             src[1] = [row_det.get(i, -1) for i in keep]
             with torch.cuda.device(dev):
-                d_src = torch.from_numpy(src).to(dev)
+                # the two index lists go up through a page-locked staging buffer (a pageable H2D copy blocks the host)
+                if self._src_pin is None or self._src_pin.shape[1] < T_new:
+                    cap = max(256, 1 << (T_new - 1).bit_length())
+                    self._src_pin = torch.empty((2, cap), dtype=torch.int32).pin_memory()
+                    self._src_dev = torch.empty((2, cap), device=dev, dtype=torch.int32)
+                self._src_pin.numpy()[:, :T_new] = src
+                self._src_dev.copy_(self._src_pin, non_blocking=True)
+                d_src = self._src_dev
                 new_emb, new_box = self._tables(T_new, E)
                 _lib.check(lib.cnl_track_apply_f32(self._emb.data_ptr() if T else None, self._box.data_ptr() if T else None,
                                                    d_emb.data_ptr(), d_box.data_ptr(), d_src[0].data_ptr(), d_src[1].data_ptr(),

@@ -50,7 +50,7 @@ __device__ __forceinline__ void seq_dots(const float* __restrict__ u, const floa
 __global__ __launch_bounds__(256) void costs_kernel(const float* __restrict__ det_emb, const float* __restrict__ det_box,
                                                     const float* __restrict__ det_score, int k, int E, float thr,
                                                     const float* __restrict__ trk_emb, const float* __restrict__ trk_box, int T,
-                                                    int box_mode, int* __restrict__ n_det, int* __restrict__ det_index,
+                                                    int box_mode, int reid_metric, int* __restrict__ n_det, int* __restrict__ det_index,
                                                     double* __restrict__ reid_cost, float* __restrict__ box_cost) {
     __shared__ int sel[MAXK];
     __shared__ int wave_sum[4];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void costs_kernel(const float* __restrict__ de
     if (T <= 0 || p >= (long)n * T) return;
     const int r = (int)(p / T), t = (int)(p - (long)r * T);
     const int d = sel[r];
-    {   // scipy cdist "cosine": 1 - clamp(u.v / (|u| |v|))
+    if (reid_metric == 0) {   // scipy cdist "cosine": 1 - clamp(u.v / (|u| |v|))
         const float* u = det_emb + (long)d * E;
         const float* v = trk_emb + (long)t * E;
         double uu, vv, uv;
@@ -99,6 +99,15 @@ __global__ __launch_bounds__(256) void costs_kernel(const float* __restrict__ de
         double c = uv / (sqrt(uu) * sqrt(vv));
         if (fabs(c) > 1.0) c = copysign(1.0, c);
         reid_cost[p] = (1.0 - c);
+    } else {                  // scipy cdist "euclidean" (1) / "sqeuclidean" (2): s += (u - v)^2 sequentially in float64, then sqrt
+        const float* u = det_emb + (long)d * E;
+        const float* v = trk_emb + (long)t * E;
+        double acc = 0.0;
+        for (int e = 0; e < E; ++e) {
+            const double df = (double)u[e] - (double)v[e];
+            acc = acc + df * df;
+        }
+        reid_cost[p] = reid_metric == 1 ? sqrt(acc) : acc;
     }
     if (box_mode) {   // utils/box.py:49-92 in float32, numpy's operation order
         const float4 a = *reinterpret_cast<const float4*>(det_box + (long)d * 4);
@@ -155,22 +164,31 @@ __global__ __launch_bounds__(64) void apply_kernel(const float* __restrict__ trk
 }  // namespace cnl_track
 using namespace cnl_track;
 
-extern "C" int cnl_track_costs_f32(const float* det_emb, const float* det_box, const float* det_score, int32_t k, int32_t E,
-                                   float detection_threshold, const float* trk_emb, const float* trk_box, int32_t T,
-                                   int32_t box_cost, int32_t* n_det, int32_t* det_index, double* reid_cost,
-                                   float* box_cost_out, void* stream) {
+extern "C" int cnl_track_costs_metric_f32(const float* det_emb, const float* det_box, const float* det_score, int32_t k, int32_t E,
+                                          float detection_threshold, const float* trk_emb, const float* trk_box, int32_t T,
+                                          int32_t box_cost, int32_t reid_metric, int32_t* n_det, int32_t* det_index, double* reid_cost,
+                                          float* box_cost_out, void* stream) {
     CNL_REQUIRE(det_emb && det_box && det_score && n_det && det_index, CNL_E_BAD_ARG, "cnl_track_costs_f32: null pointer");
     CNL_REQUIRE(k > 0 && E > 0 && T >= 0, CNL_E_BAD_ARG, "cnl_track_costs_f32: bad k/E/T");
     CNL_REQUIRE(k <= MAXK, CNL_E_UNSUPPORTED, "cnl_track_costs_f32: k = %d > %d detections per frame", k, MAXK);
     CNL_REQUIRE(box_cost >= 0 && box_cost <= 2, CNL_E_BAD_ARG, "cnl_track_costs_f32: box_cost must be 0 (none), 1 (iou), 2 (giou)");
+    CNL_REQUIRE(reid_metric >= 0 && reid_metric <= 2, CNL_E_BAD_ARG, "cnl_track_costs_metric_f32: reid_metric must be 0 (cosine), 1 (euclidean), 2 (sqeuclidean)");
     CNL_REQUIRE(T == 0 || (trk_emb && reid_cost), CNL_E_BAD_ARG, "cnl_track_costs_f32: T > 0 without track table / reid_cost");
     CNL_REQUIRE(T == 0 || box_cost == 0 || (trk_box && box_cost_out), CNL_E_BAD_ARG,
                 "cnl_track_costs_f32: box cost requested without track boxes / output");
     const long pairs = (long)k * T;
     const unsigned grid = (unsigned)(pairs > 0 ? (pairs + 255) / 256 : 1);
     hipLaunchKernelGGL(costs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, det_emb, det_box, det_score, k, E,
-                       detection_threshold, trk_emb, trk_box, T, box_cost, n_det, det_index, reid_cost, box_cost_out);
+                       detection_threshold, trk_emb, trk_box, T, box_cost, reid_metric, n_det, det_index, reid_cost, box_cost_out);
     return cnl::check_launch("track costs_kernel");
+}
+
+extern "C" int cnl_track_costs_f32(const float* det_emb, const float* det_box, const float* det_score, int32_t k, int32_t E,
+                                   float detection_threshold, const float* trk_emb, const float* trk_box, int32_t T,
+                                   int32_t box_cost, int32_t* n_det, int32_t* det_index, double* reid_cost,
+                                   float* box_cost_out, void* stream) {
+    return cnl_track_costs_metric_f32(det_emb, det_box, det_score, k, E, detection_threshold, trk_emb, trk_box, T, box_cost, 0, n_det, det_index,
+                                      reid_cost, box_cost_out, stream);
 }
 
 extern "C" int cnl_track_apply_f32(const float* trk_emb, const float* trk_box, const float* det_emb, const float* det_box,

@@ -176,11 +176,12 @@ class Tracker:
 
     def __init__(self, detection_threshold=0.3, reid_cost="cosine", reid_threshold=0.2, box_cost="iou", box_threshold=0.5,
                  smoothing_factor=0.5, max_inactive_age=30, min_birth_age=2, use_kalman=False):
-        assert reid_cost == "cosine"
+        # tracker.py:51, 62-64: a scipy cdist metric name, or a callable (det_embeddings, track_embeddings) -> matrix
+        self.reid_cost = reid_cost if callable(reid_cost) else (lambda a, b, m=reid_cost: distance.cdist(a, b, metric=m))
         self.use_kalman = use_kalman
         self.detection_threshold = detection_threshold
         self.reid_threshold = reid_threshold
-        self.box_cost = BOX_COSTS[box_cost] if box_cost is not None else None
+        self.box_cost = box_cost if callable(box_cost) else (BOX_COSTS[box_cost] if box_cost is not None else None)
         self.box_threshold = box_threshold
         self.smoothing_factor = smoothing_factor
         self.max_inactive_age = max_inactive_age
@@ -199,7 +200,7 @@ class Tracker:
         else:
             trk_emb = np.stack([t.embedding for t in self.tracks], axis=0)
             trk_box = np.stack([t.bbox for t in self.tracks], axis=0)
-            reid = cosine_distance_matrix(det_embeddings, trk_emb)
+            reid = self.reid_cost(det_embeddings, trk_emb)
             matches, unmatched_dets, unmatched_tracks = match_with_threshold(reid, self.reid_threshold)
             full_box = None
             if self.box_cost is not None:
