@@ -301,22 +301,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     State st;
     st.row_pitch = (unsigned)(a.Ws * a.ldx * 4);
     // V_p = d[offa] + sg d[offb] over the four pixels 2t-1 .. 2t+2 of a tile:  p = 0: -(d0 - d2) (its weights are stored negated), 1: d1 + d2,
-    // 2: d2 - d1, 3: d1 - d3 — so that the two OUTER pixels d0 / d3 are always operand b.  With several images side by side in a block row
-    // (narrow maps) the outer pixel of an image's first / last tile belongs to the neighbour: there sg = 0, the convolution's zero padding.
+    // 2: d2 - d1, 3: d1 - d3 — so that the two OUTER pixels d0 / d3 are always operand b (see below for images side by side).
     const int offa = wave == 0 ? 2 : (wave == 2 ? 2 : 1);
     const int offb = wave == 0 ? 0 : (wave == 3 ? 3 : (wave == 2 ? 1 : 2));
-    {
-        const int tpi = (a.ipb > 1) ? (1 << (a.lw - 1)) : 64;        // tiles per image in the block row
-        const int lt = t & (tpi - 1);
-        const bool outer_is_neighbour = (wave == 0 && lt == 0) || (wave == 3 && lt == tpi - 1);
-        st.sg = wave == 1 ? 1.f : (a.ipb > 1 && outer_is_neighbour ? 0.f : -1.f);
-    }
+    const int tpi = (a.ipb > 1) ? (1 << (a.lw - 1)) : 64;            // tiles per image in the block row
+    const bool outer_is_neighbour = a.ipb > 1 && ((wave == 0 && (t & (tpi - 1)) == 0) || (wave == 3 && (t & (tpi - 1)) == tpi - 1));
+    st.sg = wave == 1 ? 1.f : -1.f;
     const int si_lane = (a.ipb > 1) ? ((2 * t) >> a.lw) : 0;         // this lane's sub-image (V production: its tile's image)
     // patch image [row][quad][parity][33 px] x 16 B: the lanes of a ds_read_b128 group (same h, 16 distinct t mod 16) read
     // consecutive slots of one plane — all 64 banks, no conflicts
     {
         const int sa = (2 * h) * QUAD_SLOTS + (offa & 1) * PXH + t + (offa >> 1);
-        const int sb = (2 * h) * QUAD_SLOTS + (offb & 1) * PXH + t + (offb >> 1);
+        // ... except where that outer pixel belongs to the neighbouring image: those lanes read patch column 0 instead (x = -1: outside
+        // every image, zero-filled in every row of every chunk) — the zero padding itself, also when the neighbour holds Inf / NaN
+        const int sb = outer_is_neighbour ? (2 * h) * QUAD_SLOTS : (2 * h) * QUAD_SLOTS + (offb & 1) * PXH + t + (offb >> 1);
         st.pa[0] = smem + sa * 16; st.pa[1] = smem + P_BYTES + sa * 16;
         st.pb[0] = smem + sb * 16; st.pb[1] = smem + P_BYTES + sb * 16;
     }

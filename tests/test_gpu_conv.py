@@ -744,6 +744,27 @@ def test_winograd9_many_items_per_workgroup_is_bit_identical_to_one_image_at_a_t
     assert torch.equal(ym, full.abs().amax(dim=(1, 2, 3)))
 
 
+def test_winograd9_images_side_by_side_do_not_see_each_other():
+    """Narrow maps (W = 32): two images share a block row.  An image's first / last Winograd tile must read the convolution's zero
+    padding, not the neighbour's edge pixels — also when those are Inf / NaN (a 0 multiplier would turn them into NaN): every image of
+    the batch is bit for bit what it gives alone, and the non-finite image keeps its non-finite outputs to itself."""
+    g = torch.Generator().manual_seed(23)
+    N = 5                                                                  # (odd: the last block row holds one image and an empty half)
+    x = torch.randn(N, 64, 32, 32, generator=g).clamp_min(0)
+    x[1, :, :, 0] = float("inf")                                           # left edge of image 1 touches image 0's right edge
+    x[1, 3, 5, 31] = float("nan")                                          # (image 1 is the right half of its block row: nothing beside this edge)
+    x[2, :, 7, 31] = float("inf")                                          # right edge of image 2 touches image 3's left edge
+    w = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / (64 * 9)) ** 0.5
+    b = torch.randn(64, generator=g)
+    full = run_winograd(x, w, b, CNL_RELU, algo=CNL_ALGO_FORCE + 9, want=5)
+    for i in (0, 3, 4):
+        assert torch.isfinite(full[i]).all(), i
+    for i in range(N):
+        alone = run_winograd(x[i:i + 1], w, b, CNL_RELU, algo=CNL_ALGO_FORCE + 9)
+        assert torch.equal(full[i:i + 1].isnan(), alone.isnan()), i
+        assert torch.equal(torch.nan_to_num(full[i:i + 1], nan=-1.0), torch.nan_to_num(alone, nan=-1.0)), i
+
+
 def test_split_kernels_on_trained_checkpoint_like_weights():
     """weights as a trained checkpoint with BatchNorm folded has them — per-output-channel scales over four decades
     (10^U(-3, 1)), 5 % dead channels (all-zero filters), inputs in the range of a normalised image (negative values) — must not cost the
