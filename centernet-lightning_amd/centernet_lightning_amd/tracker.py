@@ -11,11 +11,15 @@ match list goes back.  The reference instead copies every frame's k x (6+E) dete
 
 `use_kalman=True` (tracker.py:243-262, 281-323): the per-track 8-state filter is a float64 numpy restatement of filterpy's
 KalmanFilter (third-party, absent) on the host, beside the life cycle; the filtered boxes are uploaded to the device table.
-Not supported (raises): `reid_cost` other than "cosine", callable `reid_cost` / `box_cost`.
-There is no CPU fallback: without the HIP library or a GPU, `update` raises.
+Per frame: ONE kernel launch (cnl_track_frame_f32) writes the frame record — kept-detection indices, boxes / scores / labels, cost
+matrices — straight into mapped host memory, ONE stream synchronisation makes it readable; no copy operation in either direction.
+`reid_cost`: "cosine" / "euclidean" / "sqeuclidean" have kernels; any other scipy cdist name or a callable, and a callable `box_cost`
+(tracker.py:51, 62-64), are computed on the host from copies only with `allow_host_cost=True` (otherwise the constructor raises).
+There is no CPU fallback for the device path: without the HIP library or a GPU, `update` raises.
 """
 import ctypes
 import warnings
+import weakref
 from enum import Enum, auto
 from typing import List
 
@@ -27,7 +31,22 @@ from . import _lib
 from .config import load_config
 
 _BOX_MODES = {None: 0, "iou": 1, "giou": 2}
+_LABEL_KINDS = {torch.int64: 1, torch.int32: 2, torch.float32: 3}     # det_label element types cnl_track_frame_f32 reads
 _REID_METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2}      # metrics with a gfx950 kernel (float64, scipy's operation order)
+
+
+class _Mapped:
+    """Page-locked host memory that the device addresses through the same pointer (cnl_host_alloc): the frame record the association
+    kernel writes and the index lists the table update reads cross PCIe as the kernels' own stores / loads — no copy operation, and one
+    stream synchronisation per frame.  `np` is a uint8 view of the whole block (valid while this object lives)."""
+
+    def __init__(self, nbytes):
+        lib = _lib.load()
+        p = ctypes.c_void_p()
+        _lib.check(lib.cnl_host_alloc(nbytes, ctypes.byref(p)), "cnl_host_alloc")
+        self.ptr, self.nbytes = p.value, nbytes
+        self.np = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(self.ptr))
+        self._finalizer = weakref.finalize(self, lib.cnl_host_free, ctypes.c_void_p(self.ptr))
 
 
 class TrackState(Enum):
@@ -199,9 +218,8 @@ class Tracker:
         self._box = None
         self._spare = None          # the other half of the ping-pong pair
         self.last_costs = None      # (reid [n,T] f64, box [n,T] f32 | None, det_index [n]) of the last update (host numpy)
-        self._pinned = None         # page-locked staging buffer of the per-frame device -> host copy
-        self._dbuf = None           # persistent device buffer the costs kernel writes (n, det_index, cost matrices)
-        self._src_pin = self._src_dev = None   # page-locked / device pair of the two index lists of cnl_track_apply_f32
+        self._rec = None            # mapped host memory the association kernel writes the frame record into (cnl_track_frame_f32)
+        self._src = None            # mapped host memory holding the two index lists cnl_track_apply_f32 reads
 
     @property
     def device(self):
@@ -234,15 +252,10 @@ class Tracker:
         heatmap, box_2d, reid = self.model(images)
         det = self.model.gather_tracking2d(heatmap, box_2d, reid, nms_kernel=nms_kernel, num_detections=num_detections,
                                            normalize_bbox=True)
-        # boxes / labels / scores of the batch go to the host in one copy (they are reported per track); embeddings stay in HBM
-        nb, kk = det["scores"].shape
-        packed = torch.cat([det["bboxes"].reshape(nb, kk, 4), det["scores"].reshape(nb, kk, 1), det["labels"].reshape(nb, kk, 1).to(torch.float32)],
-                           dim=2).cpu().numpy()                      # one copy, one sync (class ids < 2^24 are exact in fp32)
-        host_boxes, host_scores = np.ascontiguousarray(packed[..., :4]), np.ascontiguousarray(packed[..., 4])
-        host_labels = packed[..., 5].astype(np.int64)
+        # the kernel that computes a frame's costs also writes its boxes / scores / labels into the frame record: no separate copy
         out = {"bboxes": [], "track_ids": []}
         for i in range(images.shape[0]):
-            self._update_device(det["bboxes"][i], det["scores"][i], det["embeddings"][i], host_boxes[i], host_labels[i], host_scores[i], **kwargs)
+            self._update_device(det["bboxes"][i], det["scores"][i], det["embeddings"][i], det["labels"][i], None, **kwargs)
             self.frame += 1
             out["bboxes"].append([x.bbox for x in self.tracks if x.active])
             out["track_ids"].append([x.track_id for x in self.tracks if x.active])
@@ -264,17 +277,15 @@ class Tracker:
             return torch.as_tensor(a).to(device=dev, dtype=torch.float32).contiguous()
         host = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
         if all(isinstance(a, torch.Tensor) and a.is_cuda for a in (bboxes, labels, scores)) and bboxes.dim() == 2:
-            # device inputs: ONE device -> host copy (and one sync) for the three small arrays the host-side life cycle reads
-            k = scores.shape[0]
-            packed = torch.cat([bboxes.reshape(k, 4).float(), scores.reshape(k, 1).float(), labels.reshape(k, 1).to(torch.float32)], dim=1).cpu().numpy()
-            h_box, h_score = np.ascontiguousarray(packed[:, :4]), np.ascontiguousarray(packed[:, 4])
-            h_label = packed[:, 5].astype(np.int64)          # class ids are far below 2^24: exact in fp32
+            # device inputs: the three small arrays the host-side life cycle reads come back inside the frame record
+            self._update_device(to_dev(bboxes), to_dev(scores), to_dev(embeddings), labels.to(dev), None, **kwargs)
         else:
-            h_box, h_label, h_score = host(bboxes), host(labels), host(scores)
-        self._update_device(to_dev(bboxes), to_dev(scores), to_dev(embeddings), h_box, h_label, h_score, **kwargs)
+            self._update_device(to_dev(bboxes), to_dev(scores), to_dev(embeddings), None, (host(bboxes), host(labels), host(scores)), **kwargs)
 
     # ------------------------------------------------------------------ one frame
-    def _update_device(self, d_box, d_score, d_emb, h_box, h_label, h_score, **kwargs):
+    def _update_device(self, d_box, d_score, d_emb, d_label, host, **kwargs):
+        """`host`: (boxes, labels, scores) as numpy arrays when the caller holds them on the host already; None: the frame record
+        brings them (d_label: the labels on the device)."""
         detection_threshold = kwargs.get("detection_threshold", self.detection_threshold)
         reid_threshold = kwargs.get("reid_threshold", self.reid_threshold)
         box_threshold = kwargs.get("box_threshold", self.box_threshold)
@@ -287,33 +298,44 @@ class Tracker:
         T = len(self.tracks)
         box_mode = 0 if self._host_box is not None else _BOX_MODES[self.box_cost]
         reid_metric = _REID_METRICS.get(self.reid_cost, 0)
-        # The host holds the frame's scores too (they travel with the boxes), so it knows the number of kept detections n and can
-        # size the one buffer that comes back: [n_det i32, det_index i32 k | reid f64 n*T | box f32 n*T]
-        n = int(np.count_nonzero(np.asarray(h_score, dtype=np.float32) >= np.float32(detection_threshold)))
-        off_reid = (4 * (1 + k) + 7) // 8 * 8
-        off_box = off_reid + 8 * n * T
-        nbytes = off_box + 4 * n * T
+        with_dets = host is None
+        label_kind = 0
+        if with_dets and d_label is not None:
+            if d_label.shape != (k,):
+                raise ValueError(f"detections: labels {tuple(d_label.shape)}, expected ({k},)")
+            label_kind = _LABEL_KINDS.get(d_label.dtype, 0)
+            if not label_kind:
+                d_label, label_kind = d_label.to(torch.int64), 1
+            d_label = d_label.contiguous()
+        need = int(lib.cnl_track_frame_bytes(k, T, int(with_dets)))
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             stream = ctypes.c_void_p(cur.cuda_stream)
-            if self._dbuf is None or self._dbuf.numel() < nbytes + 16:
-                self._dbuf = torch.empty((max(2 * nbytes + 16, 1 << 16),), device=dev, dtype=torch.uint8)      # persistent: nothing allocated per frame
-            buf = self._dbuf
-            base = buf.data_ptr()
-            _lib.check(lib.cnl_track_costs_metric_f32(d_emb.data_ptr(), d_box.data_ptr(), d_score.data_ptr(), k, E, float(detection_threshold),
-                                                      self._emb.data_ptr() if T else None, self._box.data_ptr() if T else None, T, box_mode, reid_metric,
-                                                      base, base + 4, base + off_reid if T else None,
-                                                      base + off_box if (T and box_mode) else None, stream), "cnl_track_costs_metric_f32")
-            if self._pinned is None or self._pinned.numel() < nbytes:
-                self._pinned = torch.empty((max(2 * nbytes, 1 << 16),), dtype=torch.uint8).pin_memory()
-            self._pinned[:nbytes].copy_(buf[:nbytes], non_blocking=True)      # the frame's only device -> host copy
+            if self._rec is None or self._rec.nbytes < need:
+                self._rec = _Mapped(max(2 * need, 1 << 18))          # persistent: nothing allocated per frame
+            rec = self._rec
+            # ONE launch writes the record [header | det_index | boxes scores labels | reid f64 n*T | box f32 n*T] straight into host
+            # memory (packed by the n the kernel finds), ONE synchronisation makes it readable: the frame's only device -> host traffic
+            _lib.check(lib.cnl_track_frame_f32(d_emb.data_ptr(), d_box.data_ptr(), d_score.data_ptr(), d_label.data_ptr() if label_kind else None,
+                                               label_kind, k, E, float(detection_threshold), self._emb.data_ptr() if T else None,
+                                               self._box.data_ptr() if T else None, T, box_mode, reid_metric, int(with_dets), rec.ptr, rec.nbytes,
+                                               stream), "cnl_track_frame_f32")
             cur.synchronize()
-            h = self._pinned[:nbytes].numpy()
-        if int(h[:4].view(np.int32)[0]) != n:
-            raise RuntimeError(f"detection count mismatch between host ({n}) and device ({int(h[:4].view(np.int32)[0])}): "
-                               "scores on the host and on the device differ")
-        det_index = h[4:4 + 4 * n].view(np.int32)
-        self.d2h_bytes = nbytes
+        h = rec.np
+        hdr = h[:32].view(np.int32)
+        n, off_dets, off_reid, off_box = int(hdr[0]), int(hdr[5]), int(hdr[6]), int(hdr[7])
+        if with_dets:
+            # copies: a Track keeps its box, and the record is overwritten by the next frame
+            f = h[off_dets:off_dets + 20 * k].view(np.float32)
+            h_box, h_score = f[:4 * k].reshape(k, 4).copy(), f[4 * k:].copy()
+            h_label = h[off_dets + 20 * k:off_dets + 24 * k].view(np.int32).astype(np.int64)
+        else:
+            h_box, h_label, h_score = host
+            n_host = int(np.count_nonzero(np.asarray(h_score, dtype=np.float32) >= np.float32(detection_threshold)))
+            if n_host != n:
+                raise RuntimeError(f"detection count mismatch between host ({n_host}) and device ({n}): scores on the host and on the device differ")
+        det_index = h[32:32 + 4 * n].view(np.int32).copy()
+        self.d2h_bytes = 32 + 4 * n + (24 * k if with_dets else 0) + (12 if box_mode else 8) * n * T      # bytes the kernel stored over PCIe
         self.last_costs = None
 
         # ---- assignment on the host: tracker.py:139-176 ----
@@ -374,17 +396,16 @@ class Tracker:
             src[0] = [old_rows[i] for i in keep]
             src[1] = [row_det.get(i, -1) for i in keep]
             with torch.cuda.device(dev):
-                # the two index lists go up through a page-locked staging buffer (a pageable H2D copy blocks the host)
-                if self._src_pin is None or self._src_pin.shape[1] < T_new:
-                    cap = max(256, 1 << (T_new - 1).bit_length())
-                    self._src_pin = torch.empty((2, cap), dtype=torch.int32).pin_memory()
-                    self._src_dev = torch.empty((2, cap), device=dev, dtype=torch.int32)
-                self._src_pin.numpy()[:, :T_new] = src
-                self._src_dev.copy_(self._src_pin, non_blocking=True)
-                d_src = self._src_dev
+                # the two index lists sit in mapped host memory that the kernel reads directly (2 x T_new int32 over PCIe): no host ->
+                # device copy; the synchronisation at the top of the next frame orders the kernel's reads before the next overwrite
+                if self._src is None or self._src.nbytes < 8 * T_new:
+                    self._src = _Mapped(8 * max(256, 1 << (T_new - 1).bit_length()))
+                cap = self._src.nbytes // 8
+                self._src.np.view(np.int32).reshape(2, cap)[:, :T_new] = src
+                d_src = (self._src.ptr, self._src.ptr + 4 * cap)
                 new_emb, new_box = self._tables(T_new, E)
                 _lib.check(lib.cnl_track_apply_f32(self._emb.data_ptr() if T else None, self._box.data_ptr() if T else None,
-                                                   d_emb.data_ptr(), d_box.data_ptr(), d_src[0].data_ptr(), d_src[1].data_ptr(),
+                                                   d_emb.data_ptr(), d_box.data_ptr(), d_src[0], d_src[1],
                                                    T_new, E, float(self.smoothing_factor), new_emb.data_ptr(), new_box.data_ptr(),
                                                    stream), "cnl_track_apply_f32")
             self._spare, (self._emb, self._box) = ((self._emb, self._box) if self._emb is not None else None), (new_emb, new_box)

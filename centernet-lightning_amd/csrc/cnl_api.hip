@@ -44,3 +44,28 @@ extern "C" size_t cnl_last_error(char* buf, size_t n) {
     }
     return len;
 }
+
+// Page-locked host memory mapped into the device's address space (coherent): kernels read and write it through the host pointer, so a
+// small per-frame record (the tracker's costs, its index lists) crosses PCIe as the kernel's own loads / stores — no copy-engine
+// packet, no second stream operation to wait for.
+extern "C" int cnl_host_alloc(size_t bytes, void** ptr) {
+    CNL_REQUIRE(ptr && bytes > 0, CNL_E_BAD_ARG, "cnl_host_alloc: null pointer / zero bytes");
+    void* h = nullptr;
+    hipError_t e_ = hipHostMalloc(&h, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e_ != hipSuccess) return cnl::fail(CNL_E_HIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e_));
+    void* d = nullptr;
+    e_ = hipHostGetDevicePointer(&d, h, 0);
+    if (e_ != hipSuccess || d != h) {
+        (void)hipHostFree(h);
+        return cnl::fail(CNL_E_HIP, "cnl_host_alloc: the device does not see the allocation at the host address (%s)", hipGetErrorString(e_));
+    }
+    *ptr = h;
+    return CNL_OK;
+}
+
+extern "C" int cnl_host_free(void* ptr) {
+    if (!ptr) return CNL_OK;
+    hipError_t e_ = hipHostFree(ptr);
+    if (e_ != hipSuccess) return cnl::fail(CNL_E_HIP, "hipHostFree: %s", hipGetErrorString(e_));
+    return CNL_OK;
+}

@@ -45,15 +45,8 @@ __device__ __forceinline__ void seq_dots(const float* __restrict__ u, const floa
     }
 }
 
-// Every workgroup first rebuilds the (tiny) stable compaction {i : score[i] >= thr} in LDS — cheaper than a second launch —
-// then handles 256 (detection, track) pairs.  Workgroup 0 also publishes n_det / det_index.
-__global__ __launch_bounds__(256) void costs_kernel(const float* __restrict__ det_emb, const float* __restrict__ det_box,
-                                                    const float* __restrict__ det_score, int k, int E, float thr,
-                                                    const float* __restrict__ trk_emb, const float* __restrict__ trk_box, int T,
-                                                    int box_mode, int reid_metric, int* __restrict__ n_det, int* __restrict__ det_index,
-                                                    double* __restrict__ reid_cost, float* __restrict__ box_cost) {
-    __shared__ int sel[MAXK];
-    __shared__ int wave_sum[4];
+// The (tiny) stable compaction {i : score[i] >= thr} into LDS, rebuilt by every workgroup — cheaper than a second launch.  Returns n.
+__device__ __forceinline__ int compact_scores(const float* __restrict__ det_score, const int k, const float thr, int* sel, int* wave_sum) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // thread t owns scores 4t..4t+3 (k <= 1024)
     int flag[4], cnt = 0;
@@ -82,11 +75,13 @@ __global__ __launch_bounds__(256) void costs_kernel(const float* __restrict__ de
     for (int i = 0; i < 4; ++i)
         if (flag[i]) sel[pos++] = tid * 4 + i;
     __syncthreads();
-    if (blockIdx.x == 0) {
-        if (tid == 0) *n_det = n;
-        for (int i = tid; i < n; i += 256) det_index[i] = sel[i];
-    }
+    return n;
+}
 
+__device__ __forceinline__ void pair_costs(const int* sel, const int n, const float* __restrict__ det_emb, const float* __restrict__ det_box, const int E,
+                                           const float* __restrict__ trk_emb, const float* __restrict__ trk_box, const int T, const int box_mode,
+                                           const int reid_metric, double* __restrict__ reid_cost, float* __restrict__ box_cost) {
+    const int tid = threadIdx.x;
     const long p = (long)blockIdx.x * 256 + tid;
     if (T <= 0 || p >= (long)n * T) return;
     const int r = (int)(p / T), t = (int)(p - (long)r * T);
@@ -128,6 +123,56 @@ __global__ __launch_bounds__(256) void costs_kernel(const float* __restrict__ de
         }
         box_cost[p] = (1.f - score);
     }
+}
+
+// Every workgroup handles 256 (detection, track) pairs; workgroup 0 also publishes n_det / det_index.
+__global__ __launch_bounds__(256) void costs_kernel(const float* __restrict__ det_emb, const float* __restrict__ det_box,
+                                                    const float* __restrict__ det_score, int k, int E, float thr,
+                                                    const float* __restrict__ trk_emb, const float* __restrict__ trk_box, int T,
+                                                    int box_mode, int reid_metric, int* __restrict__ n_det, int* __restrict__ det_index,
+                                                    double* __restrict__ reid_cost, float* __restrict__ box_cost) {
+    __shared__ int sel[MAXK];
+    __shared__ int wave_sum[4];
+    const int n = compact_scores(det_score, k, thr, sel, wave_sum);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) *n_det = n;
+        for (int i = threadIdx.x; i < n; i += 256) det_index[i] = sel[i];
+    }
+    pair_costs(sel, n, det_emb, det_box, E, trk_emb, trk_box, T, box_mode, reid_metric, reid_cost, box_cost);
+}
+
+// The same, writing ONE self-describing record (include/centernet_gfx950.h: cnl_track_frame_f32) whose cost matrices are packed by the
+// n the kernel itself found — so the host needs no copy of the scores before the launch, and the record may live in page-locked host
+// memory mapped into the device's address space: the frame's only device -> host traffic is these stores, no copy engine involved.
+__global__ __launch_bounds__(256) void frame_kernel(const float* __restrict__ det_emb, const float* __restrict__ det_box,
+                                                    const float* __restrict__ det_score, const void* __restrict__ det_label, int label_kind,
+                                                    int k, int E, float thr, const float* __restrict__ trk_emb,
+                                                    const float* __restrict__ trk_box, int T, int box_mode, int reid_metric, int with_dets,
+                                                    char* __restrict__ record) {
+    __shared__ int sel[MAXK];
+    __shared__ int wave_sum[4];
+    const int n = compact_scores(det_score, k, thr, sel, wave_sum);
+    const int off_index = 32, off_dets = (off_index + 4 * k + 7) & ~7, off_reid = (off_dets + (with_dets ? 24 * k : 0) + 7) & ~7;
+    const long off_box = off_reid + 8l * n * T;
+    if (blockIdx.x == 0) {
+        const int tid = threadIdx.x;
+        int* hdr = reinterpret_cast<int*>(record);
+        if (tid == 0) { hdr[0] = n; hdr[1] = k; hdr[2] = T; hdr[3] = with_dets; hdr[4] = off_index; hdr[5] = off_dets; hdr[6] = off_reid; hdr[7] = (int)off_box; }
+        int* det_index = reinterpret_cast<int*>(record + off_index);
+        for (int i = tid; i < n; i += 256) det_index[i] = sel[i];
+        if (with_dets) {      // the frame's boxes / scores / labels, which the host-side life cycle reads (tracker.py:171-186)
+            float* o = reinterpret_cast<float*>(record + off_dets);
+            for (int i = tid; i < 4 * k; i += 256) o[i] = det_box[i];
+            for (int i = tid; i < k; i += 256) o[4 * k + i] = det_score[i];
+            int* ol = reinterpret_cast<int*>(o + 5 * k);
+            for (int i = tid; i < k; i += 256)
+                ol[i] = label_kind == 1 ? (int)reinterpret_cast<const long long*>(det_label)[i]
+                      : label_kind == 2 ? reinterpret_cast<const int*>(det_label)[i]
+                      : label_kind == 3 ? (int)reinterpret_cast<const float*>(det_label)[i] : 0;
+        }
+    }
+    pair_costs(sel, n, det_emb, det_box, E, trk_emb, trk_box, T, box_mode, reid_metric, reinterpret_cast<double*>(record + off_reid),
+               reinterpret_cast<float*>(record + off_box));
 }
 
 // One wave per row of the new track table.
@@ -181,6 +226,36 @@ extern "C" int cnl_track_costs_metric_f32(const float* det_emb, const float* det
     hipLaunchKernelGGL(costs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, det_emb, det_box, det_score, k, E,
                        detection_threshold, trk_emb, trk_box, T, box_cost, reid_metric, n_det, det_index, reid_cost, box_cost_out);
     return cnl::check_launch("track costs_kernel");
+}
+
+extern "C" int64_t cnl_track_frame_bytes(int32_t k, int32_t T, int32_t with_detections) {
+    if (k <= 0 || T < 0) return 0;
+    const int64_t off_dets = (32 + 4l * k + 7) & ~7l, off_reid = (off_dets + (with_detections ? 24l * k : 0) + 7) & ~7l;
+    return off_reid + 12l * k * T;                  // worst case n = k
+}
+
+extern "C" int cnl_track_frame_f32(const float* det_emb, const float* det_box, const float* det_score, const void* det_label, int32_t label_kind,
+                                   int32_t k, int32_t E, float detection_threshold, const float* trk_emb, const float* trk_box, int32_t T,
+                                   int32_t box_cost, int32_t reid_metric, int32_t with_detections, void* record, int64_t record_bytes,
+                                   void* stream) {
+    CNL_REQUIRE(det_emb && det_box && det_score && record, CNL_E_BAD_ARG, "cnl_track_frame_f32: null pointer");
+    CNL_REQUIRE(k > 0 && E > 0 && T >= 0, CNL_E_BAD_ARG, "cnl_track_frame_f32: bad k/E/T");
+    CNL_REQUIRE(k <= MAXK, CNL_E_UNSUPPORTED, "cnl_track_frame_f32: k = %d > %d detections per frame", k, MAXK);
+    CNL_REQUIRE(box_cost >= 0 && box_cost <= 2, CNL_E_BAD_ARG, "cnl_track_frame_f32: box_cost must be 0 (none), 1 (iou), 2 (giou)");
+    CNL_REQUIRE(reid_metric >= 0 && reid_metric <= 2, CNL_E_BAD_ARG, "cnl_track_frame_f32: reid_metric must be 0 (cosine), 1 (euclidean), 2 (sqeuclidean)");
+    CNL_REQUIRE(label_kind >= 0 && label_kind <= 3 && (label_kind == 0 || det_label), CNL_E_BAD_ARG,
+                "cnl_track_frame_f32: label_kind must be 0 (none), 1 (int64), 2 (int32), 3 (float32) with det_label set");
+    CNL_REQUIRE(T == 0 || trk_emb, CNL_E_BAD_ARG, "cnl_track_frame_f32: T > 0 without track table");
+    CNL_REQUIRE(T == 0 || box_cost == 0 || trk_box, CNL_E_BAD_ARG, "cnl_track_frame_f32: box cost requested without track boxes");
+    CNL_REQUIRE(((uintptr_t)record & 7) == 0, CNL_E_BAD_ARG, "cnl_track_frame_f32: record must be 8-byte aligned");
+    const int64_t need = cnl_track_frame_bytes(k, T, with_detections);
+    CNL_REQUIRE(record_bytes >= need && need < (1l << 31), record_bytes < need ? CNL_E_BAD_ARG : CNL_E_UNSUPPORTED,
+                "cnl_track_frame_f32: record holds %ld bytes, k = %d, T = %d needs %ld (cnl_track_frame_bytes; below 2 GiB)", (long)record_bytes, k, T, (long)need);
+    const long pairs = (long)k * T;
+    const unsigned grid = (unsigned)(pairs > 0 ? (pairs + 255) / 256 : 1);
+    hipLaunchKernelGGL(frame_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, det_emb, det_box, det_score, det_label, label_kind, k, E,
+                       detection_threshold, trk_emb, trk_box, T, box_cost == 0 ? 0 : box_cost, reid_metric, with_detections ? 1 : 0, (char*)record);
+    return cnl::check_launch("track frame_kernel");
 }
 
 extern "C" int cnl_track_costs_f32(const float* det_emb, const float* det_box, const float* det_score, int32_t k, int32_t E,

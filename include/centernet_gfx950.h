@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 7   /* 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 8   /* 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -383,6 +383,26 @@ int cnl_track_costs_f32(const float* det_emb, const float* det_box, const float*
 int cnl_track_costs_metric_f32(const float* det_emb, const float* det_box, const float* det_score, int32_t k, int32_t E,
                                float detection_threshold, const float* trk_emb, const float* trk_box, int32_t T, int32_t box_cost,
                                int32_t reid_metric, int32_t* n_det, int32_t* det_index, double* reid_cost, float* box_cost_out, void* stream);
+/*
+ * One frame's association in ONE launch and ONE record, so that the host makes a single stream synchronisation per frame and no
+ * copy: the same compaction and costs as cnl_track_costs_metric_f32, written as
+ *   int32 header[8] = { n, k, T, with_detections, off_index, off_dets, off_reid, off_box }   (byte offsets into the record)
+ *   int32 det_index[k]                      at off_index  (first n valid)
+ *   f32 boxes[k][4], f32 scores[k], int32 labels[k]   at off_dets   (only with_detections != 0: the frame's detections as the host-side
+ *                                            track life cycle reads them, models/tracker.py:171-186; det_label read as label_kind says:
+ *                                            1 int64, 2 int32, 3 float32; 0 = no labels, zeros)
+ *   f64 reid_cost[n][T]                     at off_reid
+ *   f32 box_cost[n][T]                      at off_box = off_reid + 8 n T   (box_cost != 0)
+ * The kernel packs the matrices by the n it finds itself: the host needs no copy of the scores before the launch.  `record` holds
+ * at least cnl_track_frame_bytes(k, T, with_detections) bytes (the n = k worst case; only the n x T part is written), is 8-byte
+ * aligned and may be device memory or page-locked host memory from cnl_host_alloc — then the record crosses PCIe as the kernel's own
+ * stores (52 KB for 58 x 70 pairs) and no copy-engine operation sits between the launch and the host's wait.
+ */
+int64_t cnl_track_frame_bytes(int32_t k, int32_t T, int32_t with_detections);
+int cnl_track_frame_f32(const float* det_emb, const float* det_box, const float* det_score, const void* det_label, int32_t label_kind,
+                        int32_t k, int32_t E, float detection_threshold, const float* trk_emb, const float* trk_box, int32_t T,
+                        int32_t box_cost, int32_t reid_metric, int32_t with_detections, void* record, int64_t record_bytes, void* stream);
+/* src_trk / src_det may also be cnl_host_alloc memory (2 x T_new int32 read over PCIe by the kernel: no host -> device copy) */
 int cnl_track_apply_f32(const float* trk_emb, const float* trk_box, const float* det_emb, const float* det_box,
                         const int32_t* src_trk, const int32_t* src_det, int32_t T_new, int32_t E, double smoothing,
                         float* new_emb, float* new_box, void* stream);
@@ -396,6 +416,14 @@ int cnl_boxes_xyxy_to_xywh_f32(const float* boxes, float* out, int64_t n, void* 
 int cnl_version(void);
 /* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
 size_t cnl_last_error(char* buf, size_t n);
+/*
+ * Page-locked host memory that the device addresses through the SAME pointer (hipHostMalloc, mapped + coherent): for small records a
+ * kernel writes for the host (cnl_track_frame_f32) or reads from it (cnl_track_apply_f32's index lists).  Kernel stores are visible to
+ * the host after the stream is synchronised.  Not for bulk data: every access crosses PCIe.
+ */
+int cnl_host_alloc(size_t bytes, void** ptr);
+int cnl_host_free(void* ptr);
+
 
 #ifdef __cplusplus
 }

@@ -100,7 +100,7 @@ def main():
         "costs_kernel_algorithmic_bytes": alg_bytes,
         "costs_kernel_GBps": round(alg_bytes / k_us / 1e3, 2), "hbm_peak_GBps": 8000,
         "update_us_p50": round(float(np.median(t_upd[10:])), 1), "update_us_p90": round(float(np.percentile(t_upd[10:], 90)), 1),
-        "d2h_bytes_per_frame_median": int(np.median(d2h)), "reference_d2h_bytes_per_frame": a.k * (6 + a.emb) * 4, "d2h_boxes_labels_scores_bytes_per_frame": a.k * (16 + 8 + 4),
+        "d2h_bytes_per_frame_median": int(np.median(d2h)), "reference_d2h_bytes_per_frame": a.k * (6 + a.emb) * 4, "d2h_includes_boxes_scores_labels_bytes": a.k * 24,
         "cpu_update_us_p50": round(float(np.median(t_cpu[10:])), 1), "cpu_cores_used": 1, "cpu_kind": "port (oracle/tracker_ref.py)",
         "same_track_ids_as_cpu": bool(same),
     }
