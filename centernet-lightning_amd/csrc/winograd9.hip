@@ -120,6 +120,21 @@ __device__ __forceinline__ float split_res_hi(float v, float S, unsigned pk) {
     asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(S), "v"(pk));
     return r;
 }
+// maximum of a non-negative value over the 64 lanes, in every lane: DPP inside the rows of 16, then four v_readlane.  (A __shfl_xor
+// butterfly computes its six ds_bpermute addresses from the lane id: the compiler hoists them to kernel entry, where they live — or
+// spill, each reload with a vmcnt(0) that waits for the epilogue's stores — across everything.)
+__device__ __forceinline__ float wave_max(float v) {
+#define W9_DPP(ctrl_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), (ctrl_), 0xF, 0xF, false))
+    v = fmaxf(v, W9_DPP(0xB1));        // quad_perm [1, 0, 3, 2]
+    v = fmaxf(v, W9_DPP(0x4E));        // quad_perm [2, 3, 0, 1]
+    v = fmaxf(v, W9_DPP(0x141));       // row_half_mirror
+    v = fmaxf(v, W9_DPP(0x140));       // row_mirror
+#undef W9_DPP
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
 __device__ __forceinline__ f32x4 lds_f4(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
 #define W9_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -168,6 +183,9 @@ __device__ __forceinline__ void vop(State& st, const int buf, const float S) {
     } else {
         constexpr int j = O - 24;
         st.vf[buf][1][j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(st.v[2 * j], st.v[2 * j + 1]));
+        // (pinned: left alone, the compiler sinks the last jobs' packs of an item's last chunk below the epilogue — their results are first
+        //  used by the next item — and keeps the 16 unpacked residuals alive across it instead of 8 packed registers)
+        asm volatile("" : "+v"(st.vf[buf][1][j]));
     }
 }
 // LDS read i (0..3) of patch row `row` of buffer `pbuf`
@@ -218,7 +236,15 @@ __device__ __forceinline__ void pwrite_all(State& st, const int pbuf, std::integ
 // One slice: MFMA S of the chunk with parity PAR, and what is issued beside it.  The chunk stream runs on across work items:
 // MODE 0 = a chunk with two more chunks of its item behind it, 1 = the item's last but one (the patch it requests is chunk 0 of the
 // NEXT item), 2 = the item's last (requests chunk 1 of the next item, loads the weights and builds the first two V rows of its chunk 0).
-template <int S, int PAR, int MODE>
+// is slice S the first MFMA of a chunk into its accumulator block (output row, cout half)?  An item's first chunk starts those from
+// C = 0 instead of the kernel zeroing all 256 accumulator registers per item (256 v_accvgpr_write = 1 K cycles with nothing beside them)
+constexpr bool first_use(int S) {
+    const int yo = SEG_ROW[S / 6] - SEG_KY[S / 6], nbh = S & 1;
+    for (int s = 0; s < S; ++s)
+        if (SEG_ROW[s / 6] - SEG_KY[s / 6] == yo && (s & 1) == nbh) return false;
+    return true;
+}
+template <int S, int PAR, int MODE, bool FIRST>
 __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave) {
     constexpr int seg = S / 6;
     constexpr int r = SEG_ROW[seg], ky = SEG_KY[seg];
@@ -230,7 +256,8 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
         W9_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
     }
-    st.acc[r - ky][nbh] = mfma16(st.fb[ky][nbh][ku], st.vf[vbuf][kv], st.acc[r - ky][nbh]);
+    if constexpr (FIRST && first_use(S)) st.acc[r - ky][nbh] = mfma16(st.fb[ky][nbh][ku], st.vf[vbuf][kv], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+    else st.acc[r - ky][nbh] = mfma16(st.fb[ky][nbh][ku], st.vf[vbuf][kv], st.acc[r - ky][nbh]);
     // ---- V production: job j builds the fragment of row j + 2 of this chunk (j < 8) or of row j - 8 of the next chunk ----
     if constexpr (S >= JOB0 && S < JOB0 + 10 * JOB_SLICES) {
         constexpr int j = (S - JOB0) / JOB_SLICES, k = (S - JOB0) % JOB_SLICES;
@@ -268,15 +295,15 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int PAR, int MODE, int... S>
+template <int PAR, int MODE, bool FIRST, int... S>
 __device__ __forceinline__ void chunk_impl(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave,
                                            std::integer_sequence<int, S...>) {
     __builtin_amdgcn_sched_barrier(0);
-    (slice<S, PAR, MODE>(st, a, cn, up, u_plane, u_wave), ...);
+    (slice<S, PAR, MODE, FIRST>(st, a, cn, up, u_plane, u_wave), ...);
 }
-template <int PAR, int MODE>
+template <int PAR, int MODE, bool FIRST = false>        // FIRST: the first chunk of an item (its accumulators start from zero)
 __device__ __forceinline__ void chunk(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave) {
-    chunk_impl<PAR, MODE>(st, a, cn, up, u_plane, u_wave, std::make_integer_sequence<int, NSLICE>{});
+    chunk_impl<PAR, MODE, FIRST>(st, a, cn, up, u_plane, u_wave, std::make_integer_sequence<int, NSLICE>{});
 }
 template <int... O>
 __device__ __forceinline__ void job_all(State& st, const int buf, const float S, std::integer_sequence<int, O...>) {
@@ -326,7 +353,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int er = tid >> 3, ec = 64 + ((tid >> 2) & 1);
         st.wext = tid < 80 ? smem + (er * ROW_SLOTS + q * QUAD_SLOTS + (ec & 1) * PXH + (ec >> 1)) * 16 : smem + (PR * ROW_SLOTS + (tid & 31)) * 16;
     }
-    const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((a.flags & CNL_RELU) ? 0 : (int)0xff800000u));      // ReLU floor or -inf (scalar register)
 
     // coordinates of a work item (scalars) and the per-thread addressing that follows from them
     struct Coord { int n, y0, x0, n0; };
@@ -434,22 +461,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W9_COORD(cc_nxt, more ? next : item);
         W9_ITEM(st.nxt, cc_nxt);
         const float xmax_next = W9_XMAX_OF(cc_nxt.n, si_lane);  // requested now, used behind the chunk loop
-#pragma unroll
-        for (int yo = 0; yo < R; ++yo)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) st.acc[yo][g][e] = 0.f;
         W9_STAMP(5);
 
-        for (int cn = 0; cn < a.CC - 2; cn += 2) {
-            chunk<0, 0>(st, a, cn, up, u_plane, u_wave);
-            chunk<1, 0>(st, a, cn + 1, up, u_plane, u_wave);
+        // the item's first chunk starts the accumulators from zero (first_use); CC = 2: that chunk is also the last but one
+        if (a.CC > 2) {
+            chunk<0, 0, true>(st, a, 0, up, u_plane, u_wave);
+            chunk<1, 0>(st, a, 1, up, u_plane, u_wave);
+            for (int cn = 2; cn < a.CC - 2; cn += 2) {
+                chunk<0, 0>(st, a, cn, up, u_plane, u_wave);
+                chunk<1, 0>(st, a, cn + 1, up, u_plane, u_wave);
+            }
         }
         int es_nxt;
         W9_SCALE_EXP(es_nxt, xmax_next);
         st.nxt.S = __builtin_ldexpf(1.f, es_nxt);
-        chunk<0, 1>(st, a, a.CC - 2, up, u_plane, u_wave);
+        if (a.CC > 2) chunk<0, 1>(st, a, a.CC - 2, up, u_plane, u_wave);
+        else chunk<0, 1, true>(st, a, 0, up, u_plane, u_wave);
         chunk<1, 2>(st, a, a.CC - 1, up, u_plane, u_wave);
         W9_STAMP(6);
 
@@ -486,14 +513,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             iq[i] = isu_e * __builtin_ldexpf(1.f, -es_i);
         }
         float omax2[2] = {0.f, 0.f};
-        // pass j + 1's blocks are written (into the other half) BEFORE pass j's are read: the write latency hides under the arithmetic
-#define W9_XWRITE(j_)                                                                                            \
-        _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                            \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
-                const f32x16& A = st.acc[j_][g];                                                                 \
-                *reinterpret_cast<f32x4*>(sX + ((j_) & 1) * (X_BYTES / 2) + ((g * 4 + wave) * 256 + wslot0 + ((2 * q + h_e) ^ wsw)) * 16) = \
-                    f32x4{A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};                                   \
-            }
+        // pass j + 1's blocks are written (into the other half) while pass j's are finished: ds_write_b128 costs 13 LDS cycles per wave
+        // (MI355X_MICROARCH.md, LDS table) — eight in a row stall the wave behind the LDS queue (measured: 370 of a pass's 1200 cycles); two
+        // per quarter of the arithmetic drain beside it
+#define W9_XWRITE2(j_, g_, q0_)                                                                                  \
+        _Pragma("unroll") for (int q = (q0_); q < (q0_) + 2; ++q) {                                              \
+            const f32x16& A = st.acc[j_][g_];                                                                    \
+            *reinterpret_cast<f32x4*>(sX + ((j_) & 1) * (X_BYTES / 2) + (((g_) * 4 + wave) * 256 + wslot0 + ((2 * q + h_e) ^ wsw)) * 16) = \
+                f32x4{A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};                                       \
+        }
+#define W9_XWRITE(j_) do { W9_XWRITE2(j_, 0, 0); W9_XWRITE2(j_, 0, 2); W9_XWRITE2(j_, 1, 0); W9_XWRITE2(j_, 1, 2); } while (0)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 iql[2] = {f32x2{iq[0][0], iq[0][1]}, f32x2{iq[1][0], iq[1][1]}}, iqh[2] = {f32x2{iq[0][2], iq[0][3]}, f32x2{iq[1][2], iq[1][3]}};
         const f32x2 bql = {bq[0], bq[1]}, bqh = {bq[2], bq[3]};
@@ -526,7 +555,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int p = 0; p < 4; ++p) Y[i][p] = lds_f4(X + ((g_e * 4 + p) * 256 + rslot[i]) * 16);
-            if (j + 1 < R) { W9_XWRITE(j + 1); }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 // packed fp32 arithmetic (no MFMA in flight here): two couts per instruction
@@ -544,6 +572,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                     o0[2 * hh] = fmaxf(ya[0], lo); o0[2 * hh + 1] = fmaxf(ya[1], lo);
                     o1[2 * hh] = fmaxf(yb[0], lo); o1[2 * hh + 1] = fmaxf(yb[1], lo);
+                    if (j + 1 < R) {
+                        if (i == 0 && hh == 0) { W9_XWRITE2(j + 1, 0, 0); }
+                        if (i == 0 && hh == 1) { W9_XWRITE2(j + 1, 0, 2); }
+                        if (i == 1 && hh == 0) { W9_XWRITE2(j + 1, 1, 0); }
+                        if (i == 1 && hh == 1) { W9_XWRITE2(j + 1, 1, 2); }
+                    }
                 }
                 if (ok[i][0]) omax2[i] = fmaxf(omax2[i], fmaxf(fmaxf(fabsf(o0[0]), fabsf(o0[1])), fmaxf(fabsf(o0[2]), fabsf(o0[3]))));
                 if (ok[i][1]) omax2[i] = fmaxf(omax2[i], fmaxf(fmaxf(fabsf(o1[0]), fabsf(o1[1])), fmaxf(fabsf(o1[2]), fabsf(o1[3]))));
@@ -554,12 +588,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef W9_XWRITE
+#undef W9_XWRITE2
         if (a.ymax) {          // max |y| of this item into its image's slot: the 8 tiles of an iteration lie in one image (tiles per image: 8, 16 or all)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                float m = omax2[i];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                const float m = wave_max(omax2[i]);
                 const int img = __builtin_amdgcn_readfirstlane(rimg[i]);
                 if (lane_e == 0 && m > 0.f && img < a.Nimg) atomicMax(a.ymax + img, __float_as_uint(m));
             }
