@@ -82,7 +82,8 @@ constexpr int ROW_BYTES = ROW_SLOTS * 16;   // 4224
 constexpr int P_SLOTS = 2688;               // PR * ROW_SLOTS = 2640 used (+ 48 slots that absorb the idle lanes of the last staging piece)
 constexpr int P_BYTES = P_SLOTS * 16;       // 43008 per buffer (two buffers)
 constexpr int X_BYTES = 65536;              // epilogue exchange: [4 blocks][4 positions][4 quads][64 lanes] x 16 B
-constexpr int LDS_BYTES = 2 * P_BYTES + X_BYTES;     // 151552: one workgroup per CU (the accumulators allow no more)
+constexpr int B_BYTES = 512;                // the item's 64 bias values and 64 inverse weight scales (staged for the epilogue)
+constexpr int LDS_BYTES = 2 * P_BYTES + X_BYTES + B_BYTES;     // 152064: one workgroup per CU (the accumulators allow no more)
 constexpr int NSLICE = 144;                 // MFMAs per wave and chunk
 constexpr int JOB_SLICES = 14;              // one V fragment (28 VALU operations) is produced beside 14 MFMAs
 constexpr int JOB0 = 2;                     // job j runs in slices [JOB0 + 14 j, JOB0 + 14 j + 14)
@@ -119,6 +120,13 @@ __device__ __forceinline__ float split_res_hi(float v, float S, unsigned pk) {
     float r;
     asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(S), "v"(pk));
     return r;
+}
+// the lane id from the hardware (2 VALU) on an opaque input: per-lane values derived from it are computed where they are used instead
+// of at kernel entry, from where they would stay live across the chunk loop
+__device__ __forceinline__ int lane_now() {
+    unsigned z = 0;
+    asm volatile("" : "+v"(z));
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
 }
 // maximum of a non-negative value over the 64 lanes, in every lane: DPP inside the rows of 16, then four v_readlane.  (A __shfl_xor
 // butterfly computes its six ds_bpermute addresses from the lane id: the compiler hoists them to kernel entry, where they live — or
@@ -166,6 +174,8 @@ struct State {
     char* wb;                // LDS write address of piece 0 in buffer 0 (piece i: + i rows), and of piece 10
     char* wext;
     float sg;
+    float bst, ist;          // this lane's bias / inverse weight scale of the item (cout n0 + lane), on their way to LDS
+    char* sB;
 };
 
 // VALU operation o (0..27) of the job that builds V fragment `buf` (S: the scale of the image the fragment belongs to)
@@ -292,6 +302,13 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
         if constexpr (MODE == 0) pload<1, (S - 111) / 4>(st, st.cur, a, cn + 2, up);
         else pload<1, (S - 111) / 4>(st, st.nxt, a, MODE - 1, up);
     }
+    // ---- the item's bias / weight-scale values (requested at the top of the item) -> LDS for the epilogue; every wave writes the same 64
+    //      values (no branch inside the chunk); two chunk barriers lie between this and the first read ----
+    if constexpr (FIRST && S == 60) {
+        float* sb = reinterpret_cast<float*>(st.sB) + lane_now();
+        sb[0] = st.bst;
+        sb[64] = st.ist;
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -326,6 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     typedef std::make_integer_sequence<int, 5> HalfB;      // rows 5..9
 
     State st;
+    st.sB = smem + 2 * P_BYTES + X_BYTES;
     st.row_pitch = (unsigned)(a.Ws * a.ldx * 4);
     // V_p = d[offa] + sg d[offb] over the four pixels 2t-1 .. 2t+2 of a tile:  p = 0: -(d0 - d2) (its weights are stored negated), 1: d1 + d2,
     // 2: d2 - d1, 3: d1 - d3 — so that the two OUTER pixels d0 / d3 are always operand b (see below for images side by side).
@@ -390,7 +408,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         (it_).u_voff = (unsigned)(((c_).n0 + (tid_ & 31)) * 32 + ((tid_ >> 5) & 1) * 16);                        \
     } while (0)
     // max |x| of the image a lane's tile (or an epilogue thread's tile) belongs to; images past the end of the batch: 0 -> scale 1
-#define W9_XMAX_OF(n_, si_) (((n_) * a.ipb + (si_)) < a.Nimg ? a.xmax[(n_) * a.ipb + (si_)] : 0.f)
+#define W9_XMAX_OF(n_, si_) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                        \
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.xmax, 0, a.Nimg * 4, 0x00020000), (unsigned)((n_) * a.ipb + (si_)) * 4u, 0, 0))
+    // (a buffer load, range-checked by the hardware: a branch around a plain load makes the compiler wait for it, vmcnt(0), inside the
+    //  branch — at the top of an item that is a wait for the previous item's stores)
     // power-of-two scale of V from the image's maximum: |V| <= 2 max |x|, 2 max |x| S in [2^13, 2^14); es_ = log2 S
 #define W9_SCALE_EXP(es_, xmax_)                                                                                 \
     do {                                                                                                         \
@@ -461,9 +482,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W9_COORD(cc_nxt, more ? next : item);
         W9_ITEM(st.nxt, cc_nxt);
         const float xmax_next = W9_XMAX_OF(cc_nxt.n, si_lane);  // requested now, used behind the chunk loop
+        {   // this item's bias and inverse weight scales: one value per lane, written to LDS inside the first chunk (slice 60) — the epilogue
+            // then reads them with LDS latency instead of waiting ~1.5 K cycles for global loads
+            const int co = cc_cur.n0 + lane_now();
+            st.bst = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (int)a.b_bytes, 0x00020000),
+                                                                                    co < a.Cout ? (unsigned)co * 4u : OOB, 0, 0));
+            st.ist = a.isu[co];
+        }
         W9_STAMP(5);
 
         // the item's first chunk starts the accumulators from zero (first_use); CC = 2: that chunk is also the last but one
+        int es_nxt;
         if (a.CC > 2) {
             chunk<0, 0, true>(st, a, 0, up, u_plane, u_wave);
             chunk<1, 0>(st, a, 1, up, u_plane, u_wave);
@@ -471,12 +500,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 chunk<0, 0>(st, a, cn, up, u_plane, u_wave);
                 chunk<1, 0>(st, a, cn + 1, up, u_plane, u_wave);
             }
+            // (the next item's maximum is first used HERE, behind the chunks: used at the top of the item it waits for its load, and with it
+            //  for the previous item's stores)
+            W9_SCALE_EXP(es_nxt, xmax_next);
+            st.nxt.S = __builtin_ldexpf(1.f, es_nxt);
+            chunk<0, 1>(st, a, a.CC - 2, up, u_plane, u_wave);
+        } else {
+            W9_SCALE_EXP(es_nxt, xmax_next);
+            st.nxt.S = __builtin_ldexpf(1.f, es_nxt);
+            chunk<0, 1, true>(st, a, 0, up, u_plane, u_wave);
         }
-        int es_nxt;
-        W9_SCALE_EXP(es_nxt, xmax_next);
-        st.nxt.S = __builtin_ldexpf(1.f, es_nxt);
-        if (a.CC > 2) chunk<0, 1>(st, a, a.CC - 2, up, u_plane, u_wave);
-        else chunk<0, 1, true>(st, a, 0, up, u_plane, u_wave);
         chunk<1, 2>(st, a, a.CC - 1, up, u_plane, u_wave);
         W9_STAMP(6);
 
@@ -494,8 +527,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int piece_e = lane_e & 7;
         const int cout_e = cc_cur.n0 + g_e * 32 + piece_e * 4;            // this thread's four couts
         const bool cok_e = cout_e < a.Cout;
-        const f32x4 bq = __builtin_bit_cast(f32x4, buf_load16(a.bias, a.b_bytes, cok_e ? (unsigned)cout_e * 4u : OOB, 0));
-        const f32x4 isu_e = *reinterpret_cast<const f32x4*>(a.isu + cout_e);
+        const f32x4 bq = lds_f4(st.sB + (g_e * 32 + piece_e * 4) * 4);
+        const f32x4 isu_e = lds_f4(st.sB + 256 + (g_e * 32 + piece_e * 4) * 4);
         // writer: lane (h, t) holds piece 2 q + h of tile t;  reader, iteration i: tile 16 (w >> 1) + 8 i + lane / 8, piece lane % 8
         const int wslot0 = t_e * 8, wsw = t_e & 7;
         int rtile[2], rslot[2], rimg[2], rpx[2];
@@ -508,9 +541,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int si = a.ipb > 1 ? ((2 * rtile[i]) >> a.lw) : 0;
             rimg[i] = cc_cur.n * a.ipb + si;
             rpx[i] = a.ipb > 1 ? ((2 * rtile[i]) & (a.W - 1)) : cc_cur.x0 + 2 * rtile[i];
-            int es_i;
-            W9_SCALE_EXP(es_i, W9_XMAX_OF(cc_cur.n, si));
-            iq[i] = isu_e * __builtin_ldexpf(1.f, -es_i);
+            if (a.ipb > 1) {      // the tile's image is not the one this lane builds V for: its scale from its maximum
+                int es_i;
+                W9_SCALE_EXP(es_i, W9_XMAX_OF(cc_cur.n, si));
+                iq[i] = isu_e * __builtin_ldexpf(1.f, -es_i);
+            } else {              // one image per block row: 1 / S from the exponent of the scale in use (S = 2^e exactly)
+                iq[i] = isu_e * __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(unsigned, st.cur.S));
+            }
         }
         float omax2[2] = {0.f, 0.f};
         // pass j + 1's blocks are written (into the other half) while pass j's are finished: ds_write_b128 costs 13 LDS cycles per wave
