@@ -55,6 +55,7 @@ struct Args {
     int ldx, ldy, ldr;
     int CC;                           // Cin / 16 (even)
     int nb, bx, by;                   // blocks along cout (64), x (64 px), y (8 rows)
+    unsigned m_nb, m_bx, m_by;        // floor(2^32 / d) of the three: item index -> coordinates by multiply-high + one correction
     int ipb, lw;                      // images side by side in one 64-pixel block row (W = 32: 2, W = 16: 4; else 1) and log2 W for them; N = groups of ipb images
     int Nimg;                         // images of the launch (N = image groups)
     int blocks;
@@ -375,13 +376,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // coordinates of a work item (scalars) and the per-thread addressing that follows from them
     struct Coord { int n, y0, x0, n0; };
+    // q = b / d, r = b % d for uniform b with m = floor(2^32 / d) (0xFFFFFFFF for d = 1): the multiply-high is at most one short
+#define W9_DIVMOD(q_, r_, b_, d_, m_)                                                                            \
+    do {                                                                                                         \
+        unsigned qq_ = __builtin_amdgcn_readfirstlane(__umulhi((b_), (m_)));                                     \
+        unsigned rr_ = (b_) - qq_ * (unsigned)(d_);                                                              \
+        if (rr_ >= (unsigned)(d_)) { ++qq_; rr_ -= (unsigned)(d_); }                                             \
+        (q_) = qq_; (r_) = rr_;                                                                                  \
+    } while (0)
 #define W9_COORD(c_, item_)                                                                                      \
     do {                                                                                                         \
         unsigned b_ = __builtin_amdgcn_readfirstlane(cnl::xcd_remap((item_), (unsigned)a.blocks));               \
-        const int nbi_ = b_ % a.nb; b_ /= a.nb;                                                                  \
-        const int bxi_ = b_ % a.bx; b_ /= a.bx;                                                                  \
-        const int byi_ = b_ % a.by;                                                                              \
-        (c_).n = b_ / a.by; (c_).y0 = byi_ * R; (c_).x0 = bxi_ * (2 * TW); (c_).n0 = nbi_ * BN;                  \
+        unsigned q_, nbi_, bxi_, byi_;                                                                           \
+        W9_DIVMOD(q_, nbi_, b_, a.nb, a.m_nb); b_ = q_;                                                          \
+        W9_DIVMOD(q_, bxi_, b_, a.bx, a.m_bx); b_ = q_;                                                          \
+        W9_DIVMOD(q_, byi_, b_, a.by, a.m_by);                                                                   \
+        (c_).n = (int)q_; (c_).y0 = (int)byi_ * R; (c_).x0 = (int)bxi_ * (2 * TW); (c_).n0 = (int)nbi_ * BN;     \
     } while (0)
 #define W9_ITEM(it_, c_)                                                                                         \
     do {                                                                                                         \
@@ -645,6 +655,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         st.cur = st.nxt;
     }
 #undef W9_COORD
+#undef W9_DIVMOD
 #undef W9_ITEM
 #undef W9_SCALE_EXP
 #undef W9_XMAX_OF
@@ -748,6 +759,8 @@ int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu,
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
     a.CC = p->Cin / 16;
     a.nb = a.CoutP / BN; a.bx = (a.W + 2 * TW - 1) / (2 * TW); a.by = (a.H + R - 1) / R;
+    const auto magic = [](int d) { return d == 1 ? 0xFFFFFFFFu : (unsigned)(0x100000000ull / (unsigned)d); };
+    a.m_nb = magic(a.nb); a.m_bx = magic(a.bx); a.m_by = magic(a.by);
     const long long blocks = (long long)a.N * a.by * a.bx * a.nb;
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: grid too large");
     a.blocks = (int)blocks;
