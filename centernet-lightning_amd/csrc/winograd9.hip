@@ -62,11 +62,11 @@ struct Args {
     unsigned x_bytes, u_bytes, y_bytes, r_bytes, b_bytes;
     unsigned flags;
 #ifdef W9_TRACE
-    unsigned long long* trace;        // timing build: [item][16] s_memtime stamps of block 0 / thread 0
+    unsigned long long* trace;        // timing build: [item][32] s_memtime stamps of block 0 / thread 0 (16..23: inside the item's last MODE-0 chunk of parity 0)
 #endif
 };
 #ifdef W9_TRACE
-#define W9_STAMP(i_) do { if (blockIdx.x == 0 && tid == 0 && tr_item < 64) a.trace[tr_item * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#define W9_STAMP(i_) do { if (blockIdx.x == 0 && tid == 0 && tr_item < 64) a.trace[tr_item * 32 + (i_)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define W9_STAMP(i_) do {} while (0)
 #endif
@@ -175,6 +175,9 @@ struct State {
     char* wb;                // LDS write address of piece 0 in buffer 0 (piece i: + i rows), and of piece 10
     char* wext;
     float sg;
+#ifdef W9_TRACE
+    unsigned long long* trp;   // timing build: this item's stamp row (block 0 / thread 0), else null
+#endif
     float bst, ist;          // this lane's bias / inverse weight scale of the item (cout n0 + lane), on their way to LDS
     char* sB;
 };
@@ -262,6 +265,12 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
     constexpr int term = (S % 6) / 2, nbh = S & 1;
     constexpr int ku = term == 1 ? 1 : 0, kv = term == 0 ? 1 : 0;         // terms: hi lo', lo hi', hi hi'
     constexpr int vbuf = (r + 2 * PAR) & 3;
+#ifdef W9_TRACE
+    if constexpr (PAR == 0 && MODE == 0 && !FIRST && (S == 0 || S == 28 || S == 60 || S == 97 || S == 99 || S == 114 || S == 126 || S == 143)) {
+        constexpr int k = S == 0 ? 16 : S == 28 ? 17 : S == 60 ? 18 : S == 97 ? 19 : S == 99 ? 20 : S == 114 ? 21 : S == 126 ? 22 : 23;
+        if (st.trp) st.trp[k] = __builtin_readcyclecounter();
+    }
+#endif
     if constexpr (S == BARRIER_SLICE) {
         // every wave is done reading this chunk's patch, and the next chunk's (written a chunk ago) is complete
         W9_BARRIER();
@@ -269,6 +278,9 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
     }
     if constexpr (FIRST && first_use(S)) st.acc[r - ky][nbh] = mfma16(st.fb[ky][nbh][ku], st.vf[vbuf][kv], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
     else st.acc[r - ky][nbh] = mfma16(st.fb[ky][nbh][ku], st.vf[vbuf][kv], st.acc[r - ky][nbh]);
+    // the MFMA leads its slice: left to the scheduler, a slice's buffer load is issued BEFORE its MFMA, and the ~16 cycles the load's
+    // issue takes (1 KB through the address unit) open a bubble in the matrix pipe instead of hiding in the MFMA's 32-cycle shadow
+    __builtin_amdgcn_sched_barrier(0);
     // ---- V production: job j builds the fragment of row j + 2 of this chunk (j < 8) or of row j - 8 of the next chunk ----
     if constexpr (S >= JOB0 && S < JOB0 + 10 * JOB_SLICES) {
         constexpr int j = (S - JOB0) / JOB_SLICES, k = (S - JOB0) % JOB_SLICES;
@@ -486,6 +498,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     rread<0>(st, 0, 2); rread<1>(st, 0, 2); rread<2>(st, 0, 2); rread<3>(st, 0, 2);
     while (true) {
         W9_STAMP(1);
+#ifdef W9_TRACE
+        st.trp = (blockIdx.x == 0 && tid == 0 && tr_item < 64) ? a.trace + tr_item * 32 : nullptr;
+#endif
         // the item after this one (the last item of a workgroup names itself: its fetch-ahead then re-reads valid memory into dead buffers)
         const unsigned next = item + gridDim.x;
         const bool more = next < (unsigned)a.blocks;
