@@ -66,6 +66,16 @@ struct Args {
 #endif
 };
 #ifdef W9_TRACE
+#ifndef W9_P0       // the eight slices stamped inside a chunk (-DW9_P0=.. -DW9_P7=.. to look elsewhere; a stamp costs ~60 cycles itself)
+#define W9_P0 0
+#define W9_P1 28
+#define W9_P2 60
+#define W9_P3 97
+#define W9_P4 99
+#define W9_P5 114
+#define W9_P6 126
+#define W9_P7 143
+#endif
 #define W9_STAMP(i_) do { if (blockIdx.x == 0 && tid == 0 && tr_item < 64) a.trace[tr_item * 32 + (i_)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define W9_STAMP(i_) do {} while (0)
@@ -266,8 +276,8 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
     constexpr int ku = term == 1 ? 1 : 0, kv = term == 0 ? 1 : 0;         // terms: hi lo', lo hi', hi hi'
     constexpr int vbuf = (r + 2 * PAR) & 3;
 #ifdef W9_TRACE
-    if constexpr (PAR == 0 && MODE == 0 && !FIRST && (S == 0 || S == 28 || S == 60 || S == 97 || S == 99 || S == 114 || S == 126 || S == 143)) {
-        constexpr int k = S == 0 ? 16 : S == 28 ? 17 : S == 60 ? 18 : S == 97 ? 19 : S == 99 ? 20 : S == 114 ? 21 : S == 126 ? 22 : 23;
+    if constexpr (PAR == 0 && MODE == 0 && !FIRST && (S == W9_P0 || S == W9_P1 || S == W9_P2 || S == W9_P3 || S == W9_P4 || S == W9_P5 || S == W9_P6 || S == W9_P7)) {
+        constexpr int k = S == W9_P0 ? 16 : S == W9_P1 ? 17 : S == W9_P2 ? 18 : S == W9_P3 ? 19 : S == W9_P4 ? 20 : S == W9_P5 ? 21 : S == W9_P6 ? 22 : 23;
         if (st.trp) st.trp[k] = __builtin_readcyclecounter();
     }
 #endif
