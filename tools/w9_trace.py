@@ -40,5 +40,5 @@ for it in range(6):
 for it in range(1, 5):
     r = t[it]
     if int(r[16]):
-        names = ["s0", "s28", "s60", "s97", "s99(after barrier)", "s114", "s126", "s143"]
+        names = os.environ.get("W9PN", "s0 s28 s60 s97 s99(after-barrier) s114 s126 s143").split()
         print(f"item {it} chunk probe: " + " ".join(f"{names[i]}->{names[i+1]}={int(r[17+i]-r[16+i])}" for i in range(7)))
