@@ -56,7 +56,8 @@ HBM_PEAK_GBPS = 8000.0            # same guide: HBM3E spec peak (6.29 TB/s measu
 # tools/rocpd_summary.py json; kernel-trace averages of the decode kernels): read from the committed profile JSON of the same command, so a
 # quoted number is byte-equal to a field of that file.  Written on the GPU box by tools/_trace/r03_profile.sh.
 PROFILE_JSON = {("simple", 32, 512, 512): "profiles/r03_profile_c1.json"}
-KIND_KERNEL = {"winograd_row_f16x2": "cnl_wino9::winograd9_kernel<false>", "winograd_f16x2": "cnl_wino5::winograd5_kernel",
+# kernel-name PREFIX in the profile JSON (template variants of one kernel — with / without a residual — are combined, weighted by calls)
+KIND_KERNEL = {"winograd_row_f16x2": "cnl_wino9::winograd9_kernel", "winograd_f16x2": "cnl_wino5::winograd5_kernel",
                "winograd_f32": "cnl_wino2::winograd2_kernel", "winograd_f4": "cnl_wino8::winograd8_kernel"}
 
 
@@ -240,9 +241,14 @@ def roofline_block(rows, config, B, H, W):
     ratio, peak = EXEC[dom]
     exec_tf = fl * ratio / (ms * 1e-3) / 1e12
     prof, prof_path = profiled(config, B, H, W)
-    pk = (prof or {}).get("kernels", {}).get(KIND_KERNEL.get(dom, ""), {})
-    traffic = (pk["hbm_MB_per_launch"] * 1e6, f"{prof_path} [kernels][{KIND_KERNEL[dom]}][hbm_MB_per_launch] over {pk.get('pmc_launches')} launches "
-               f"(all its launches of the profiled steps; rocprofv3 average duration there {pk.get('avg_us')} us)") if "hbm_MB_per_launch" in pk else None
+    pks = {k_: v for k_, v in (prof or {}).get("kernels", {}).items() if dom in KIND_KERNEL and k_.startswith(KIND_KERNEL[dom]) and "hbm_MB_per_launch" in v}
+    traffic = None
+    if pks:      # all template variants of the dominant kernel, weighted by their launch counts: the same population as avg_launch_us
+        calls = sum(v["calls"] for v in pks.values())
+        mb = sum(v["calls"] * v["hbm_MB_per_launch"] for v in pks.values()) / calls
+        us = sum(v["calls"] * v["avg_us"] for v in pks.values()) / calls
+        traffic = (round(mb * 1e6), f"{prof_path} [kernels][{' + '.join(sorted(pks))}]: hbm_MB_per_launch and avg_us weighted by calls over {calls} launches "
+                                    f"(all launches of the kernel in the profiled steps; rocprofv3 average duration there {us:.2f} us)")
     roof = {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": round(exec_tf, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(exec_tf / peak, 4),
             "achieved_counts": f"EXECUTED matrix-core flops = direct-conv flops x {ratio:.4f} (Winograd multiplies x split terms); the algorithmic rate is effective_tflops",
@@ -254,7 +260,7 @@ def roofline_block(rows, config, B, H, W):
             "traffic": traffic[0] if traffic else None,
             "traffic_source": (traffic[1] + " — rocprofv3 PMC of an earlier run of this command, not measured here") if traffic else
                               "no PMC profile of this kernel / configuration committed yet (see profiles/)",
-            "sustained_clock_note": "power-limited DVFS: the split-operand kernels hold 1.8-2.0 GHz of 2.4 (profiles/r01_winograd_clocks.txt)"}
+            "sustained_clock_note": "power-limited DVFS: this kernel holds 1.45-1.6 GHz of 2.4 under real data (GRBM_GUI_ACTIVE / duration, profiles/r03_winograd9_variants.txt)"}
     roof["other_kernels"] = {KIND_NAMES[k_].split(" (")[0]: {"launches_per_step": v[0], "kernel_ms_per_step": round(v[1], 3),
                                                             "effective_tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0,
                                                             "executed_frac_of_its_peak": round(v[2] * EXEC[k_][0] / (v[1] * 1e-3) / 1e12 / EXEC[k_][1], 4) if v[1] else 0.0}
