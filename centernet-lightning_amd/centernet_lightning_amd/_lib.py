@@ -15,13 +15,14 @@ CNL_SIGMOID = 1 << 1
 CNL_UPSAMPLE_IN = 1 << 2
 CNL_UPSAMPLE_OUT_ADD = 1 << 3
 CNL_RELU6 = 1 << 4
+CNL_W_SPLIT = 1 << 5          # cnl_conv_params.w is a cnl_conv_split_weights_f32 buffer (fp32 weights + their fp16 split)
 
 # cnl_conv_params.algo: the arithmetic class a launch may use (include/centernet_gfx950.h)
 CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_F4, CNL_ALGO_FORCE = 0, 1, 2, 3, 100
 CNL_WINO_F32, CNL_WINO_F16X2, CNL_WINO_F16X2_F4 = 2, 5, 8
 
 CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4
-ABI_VERSION = 8          # CNL_ABI_VERSION of include/centernet_gfx950.h
+ABI_VERSION = 9          # CNL_ABI_VERSION of include/centernet_gfx950.h
 
 
 class ConvParams(Structure):
@@ -106,6 +107,8 @@ _SIGNATURES = {
                                                   c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cnl_track_apply_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
                                            c_void_p, c_void_p, c_void_p]),
+    "cnl_conv_split_weight_floats": (ctypes.c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "cnl_conv_split_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "cnl_track_frame_bytes": (ctypes.c_int64, [c_int32, c_int32, c_int32]),
     "cnl_track_frame_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                            c_int32, c_int32, c_int32, c_int32, c_void_p, ctypes.c_int64, c_void_p]),

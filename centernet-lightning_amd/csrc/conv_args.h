@@ -30,7 +30,9 @@ struct ConvArgs {
     const float* wmax;
     unsigned* ymax;                      // and where max |y| per image is folded into (or null)
     unsigned algo;                       // cnl_conv_params.algo (CNL_ALGO_*)
-    const float* wscale;                 // sub-pixel phases (SUB): the power-of-two scale of the PRE-SPLIT weights a.w points to    // split over the reduction dimension (conv_f16x2.hip, SPLIT): slice s of `ksplit` multiplies chunks [s*kt_per, (s+1)*kt_per) and stores its
+    const float* wscale;                 // sub-pixel phases (SUB): the power-of-two scale of the PRE-SPLIT weights a.w points to; CNL_W_SPLIT: of wsplit
+    const float* wsplit = nullptr;       // CNL_W_SPLIT: the weights as scaled fp16 pieces in the kernel's B-row layout (cnl_conv_split_weights_f32)
+    // split over the reduction dimension (conv_f16x2.hip, SPLIT): slice s of `ksplit` multiplies chunks [s*kt_per, (s+1)*kt_per) and stores its
     // scaled-back partial sums to part[s][M][Cout]; splitk_reduce_kernel adds them in slice order and applies the epilogue
     int ksplit = 0, kt_per = 0;
     float* part = nullptr;

@@ -66,9 +66,12 @@ __device__ __forceinline__ float pow2_scale(float mx) {
 // KS: compile-time square kernel size (1, 2 or 3).  SUB: the launch is one sub-pixel phase of a conv on the nearest-2x upsampled input
 // (cnl_conv3x3_up2_nhwc_f32): row m = (n, oy, ox) is stored at pixel (2 oy + sub_dy, 2 ox + sub_dx) of the 2x output grid; pad (rows)
 // and pad_x (columns) differ between phases.  No CNL_UPSAMPLE_IN gather, no CNL_UPSAMPLE_OUT_ADD epilogue (those stay on conv_mfma.hip).
-template <int WM, int WN, int TM, int TN, int KS, bool SUB, bool SPLIT = false>
+// PREB: the weights come pre-split (CNL_W_SPLIT: a.wsplit / a.wscale) — the B fragments are read as fp16 pieces, not split per chunk
+// (112 of a stage's ~224 VALU instructions at 128 x 128: the stride-2 3x3 convs were VALU-bound, 99 / 89 / 110 -> 77 / 72 / 72 us).
+template <int WM, int WN, int TM, int TN, int KS, bool SUB, bool SPLIT = false, bool PREB = false>
 __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     using C = Cfg<WM, WN, TM, TN>;
+    constexpr bool PRE = SUB || PREB;            // B rows hold fp16 pieces
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sInv = reinterpret_cast<float*>(smem + C::LDS_BYTES);      // [BM] 1 / (S_row S_w)
     float* sScl = sInv + C::BM;                                       // [BM] S_row
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
         _Pragma("unroll") for (int j = 0; j < C::A_INSTR; ++j)                                                    \
             dma16(a.x, a.x_bytes, sA_ + (j * C::NW + wave) * 1024, a_voff[j], (unsigned)((c0_) * 4));             \
         _Pragma("unroll") for (int j = 0; j < C::B_INSTR; ++j)                                                    \
-            dma16(a.w, a.w_bytes, sB_ + (j * C::NW + wave) * 1024, b_off[j], (unsigned)((kbase_) * 4));           \
+            dma16(PREB ? a.wsplit : a.w, a.w_bytes, sB_ + (j * C::NW + wave) * 1024, b_off[j], (unsigned)((kbase_) * 4)); \
     } while (0)
     int tap = 0, ky = 0, kx = 0, cc = 0;     // position of the chunk being ISSUED
 #define C5_ADVANCE()                                    \
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     C5_ISSUE(0, cc * 32, kt0 * 32);          // first chunk in flight before anything else
 
     // ---- scales: one per row of the tile (its image's), one for the weights ----
-    const float Sw = SUB ? *a.wscale : pow2_scale(*a.wmax);       // SUB: the weights were split when they were packed
+    const float Sw = PRE ? *a.wscale : pow2_scale(*a.wmax);       // PRE: the weights were split when they were packed
     for (int r = threadIdx.x; r < C::BM; r += C::THREADS) {
         const int m = m0 + r;
         const unsigned n = fast_div((unsigned)m, a.mg_hw, a.sh_hw);
@@ -189,8 +192,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     do {                                                                                                          \
         _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                        \
             const int sb_ = (((2 * (2 * (g_) + q_) + hi) ^ swz) << 4);                                            \
-            /* SUB: B rows hold fp16 pieces, slot (2 (2 g + hi) + piece) = this lane's 8 halves of piece q_ */   \
-            const int sbb_ = SUB ? (((2 * (2 * (g_) + hi) + q_) ^ swz) << 4) : sb_;                               \
+            /* PRE: B rows hold fp16 pieces, slot (2 (2 g + hi) + piece) = this lane's 8 halves of piece q_ */   \
+            const int sbb_ = PRE ? (((2 * (2 * (g_) + hi) + q_) ^ swz) << 4) : sb_;                               \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) ra[q_][i] = lds_read16((stage_ptr_) + a_row_byte + i * 32 * 128 + sb_); \
             _Pragma("unroll") for (int j = 0; j < TN; ++j) rb[q_][j] = lds_read16((stage_ptr_) + b_row_byte + j * 32 * 128 + sbb_); \
         }                                                                                                         \
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
     do {                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) split8(ra[0][i], ra[1][i], sA[i], ah[i], al[i]);           \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                          \
-            if constexpr (SUB) {                                                                                  \
+            if constexpr (PRE) {                                                                                  \
                 bh[j] = __builtin_bit_cast(u32x4, rb[0][j]);                                                      \
                 bl[j] = __builtin_bit_cast(u32x4, rb[1][j]);                                                      \
             } else {                                                                                              \
@@ -420,13 +423,13 @@ static int launch_split5(const ConvArgs& in, hipStream_t stream) {
     return cnl::check_launch("splitk_reduce_kernel");
 }
 
-template <int WM, int WN, int TM, int TN, int KS, bool SUB>
+template <int WM, int WN, int TM, int TN, int KS, bool SUB, bool PREB = false>
 static int launch_one5(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<WM, WN, TM, TN>;
     static cnl::DeviceOnce once;            // one per template instantiation
-    const int rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&conv_f16x2_kernel<WM, WN, TM, TN, KS, SUB>), 160 * 1024);
+    const int rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&conv_f16x2_kernel<WM, WN, TM, TN, KS, SUB, false, PREB>), 160 * 1024);
     if (rc != CNL_OK) return rc;
-    hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, TM, TN, KS, SUB>), dim3(a.tiles), dim3(C::THREADS), C::LDS_BYTES + C::BM * 16, stream, a);
+    hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, TM, TN, KS, SUB, false, PREB>), dim3(a.tiles), dim3(C::THREADS), C::LDS_BYTES + C::BM * 16, stream, a);
     return cnl::check_launch("conv_f16x2_kernel");
 }
 
@@ -438,6 +441,7 @@ static int launch_cfg5(const ConvArgs& in, hipStream_t stream) {
     a.tiles_n = (a.Cout + C::BN - 1) / C::BN;
     a.tiles = tiles_m * a.tiles_n;
     if (a.flags & CNL_I_SUBPIXEL) return launch_one5<WM, WN, TM, TN, 2, true>(a, stream);
+    if (a.wsplit) return a.KH == 3 ? launch_one5<WM, WN, TM, TN, 3, false, true>(a, stream) : launch_one5<WM, WN, TM, TN, 1, false, true>(a, stream);
     return a.KH == 3 ? launch_one5<WM, WN, TM, TN, 3, false>(a, stream) : launch_one5<WM, WN, TM, TN, 1, false>(a, stream);
 }
 
@@ -450,7 +454,7 @@ bool f16x2_eligible(const ConvArgs& a) {
     const long long min_out_1x1 = a.algo == CNL_ALGO_FORCE + 5 ? 0 : (1ll << 20);
     if (a.algo == CNL_ALGO_F32 || !a.xmax || (a.flags & (CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD))) return false;
     if (a.flags & CNL_I_SUBPIXEL) return a.KH == 2 && a.KW == 2 && !a.res && a.wscale;       // the phases of cnl_conv3x3_up2_nhwc_f32
-    return a.wmax && a.KH == a.KW && (a.KH == 1 || a.KH == 3) && a.pad == a.pad_x &&
+    return (a.wmax || (a.wsplit && a.ksplit <= 1)) && a.KH == a.KW && (a.KH == 1 || a.KH == 3) && a.pad == a.pad_x &&      // (the reduction-split form reads fp32 weights)
            (a.KH == 3 || a.ksplit > 1 || (long long)a.Ho * a.Wo * a.Cout >= min_out_1x1);      // a split 1x1 is latency-bound on its K loop: the short chunks win
 }
 

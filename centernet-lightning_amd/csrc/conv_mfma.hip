@@ -482,6 +482,7 @@ extern "C" int cnl_conv2d_kernel(const cnl_conv_params* p) {
     ConvArgs a;
     a.KH = p->KH; a.KW = p->KW; a.pad = a.pad_x = p->pad; a.flags = p->flags; a.Cout = p->Cout;
     a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.wscale = nullptr; a.res = p->residual; a.algo = p->algo;
+    a.wsplit = (p->flags & CNL_W_SPLIT) ? p->w : nullptr;              // (presence only)
     a.ksplit = p->splitk > 1 ? p->splitk : 0;
     int32_t ho = 0, wo = 0;
     const int rc = cnl_conv2d_out_hw(p, &ho, &wo);
@@ -517,6 +518,12 @@ extern "C" int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream) {
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
     a.flags = p->flags;
     a.xmax = p->x_absmax; a.wmax = p->w_absmax; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax); a.wscale = nullptr; a.algo = p->algo;
+    if (p->flags & CNL_W_SPLIT) {      // p->w is a cnl_conv_split_weights_f32 buffer: [fp32 OHWI][the same as scaled fp16 pieces][scale, 3 pad]
+        CNL_REQUIRE(p->KH == p->KW && (p->KH == 1 || p->KH == 3), CNL_E_BAD_ARG, "cnl_conv2d_nhwc_f32: CNL_W_SPLIT with a %d x %d kernel", p->KH, p->KW);
+        const size_t total = (size_t)p->Cout * p->KH * p->KW * p->Cin;
+        a.wsplit = p->w + total;
+        a.wscale = p->w + 2 * total;
+    }
     const int up = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
     a.HL = p->H_in * up; a.WL = p->W_in * up;
     a.Ho = (a.HL + 2 * p->pad - p->KH) / p->stride + 1;
@@ -617,6 +624,27 @@ extern "C" int cnl_up2_pack_weights_f32(const float* w_ohwi, float* w_packed, in
     hipLaunchKernelGGL(up2_split_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_packed, reinterpret_cast<unsigned short*>(w_packed + total),
                        w_packed + 2 * total, total);
     return cnl::check_launch("up2_pack_kernel / up2_split_kernel");
+}
+
+// [fp32 OHWI weights][their scaled fp16 split in conv_f16x2.hip's B-row layout, same size][scale + 3 pad floats]
+extern "C" size_t cnl_conv_split_weight_floats(int32_t Cin, int32_t Cout, int32_t KH, int32_t KW) {
+    if (Cin <= 0 || Cout <= 0 || KH != KW || (KH != 1 && KH != 3) || Cin % 32) return 0;
+    return (size_t)2 * Cout * KH * KW * Cin + 4;
+}
+
+extern "C" int cnl_conv_split_weights_f32(const float* w_ohwi, float* w_buf, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, void* stream) {
+    CNL_REQUIRE(w_ohwi && w_buf, CNL_E_BAD_ARG, "cnl_conv_split_weights_f32: null pointer");
+    CNL_REQUIRE(cnl_conv_split_weight_floats(Cin, Cout, KH, KW) != 0, CNL_E_UNSUPPORTED,
+                "cnl_conv_split_weights_f32: Cin=%d Cout=%d kernel %d x %d (needs Cin %% 32 == 0 and a square 1x1 / 3x3 kernel)", Cin, Cout, KH, KW);
+    CNL_REQUIRE(((uintptr_t)w_buf & 15) == 0, CNL_E_BAD_ARG, "cnl_conv_split_weights_f32: w_buf must be 16-byte aligned");
+    const long total = (long)Cout * KH * KW * Cin;
+    if (w_buf != w_ohwi) {
+        const hipError_t e_ = hipMemcpyAsync(w_buf, w_ohwi, (size_t)total * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e_ != hipSuccess) return cnl::fail(CNL_E_HIP, "cnl_conv_split_weights_f32: hipMemcpyAsync: %s", hipGetErrorString(e_));
+    }
+    hipLaunchKernelGGL(cnl_conv::up2_split_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_buf, reinterpret_cast<unsigned short*>(w_buf + total),
+                       w_buf + 2 * total, total);
+    return cnl::check_launch("up2_split_kernel");
 }
 
 static int up2_args(const cnl_conv_params* p, const char* who) {

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 8   /* 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 9   /* 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -68,8 +68,11 @@ enum {
     CNL_UPSAMPLE_OUT_ADD = 1u << 3, /* write y at 2x resolution and add `residual` there:
                                     y[n,2oy+dy,2ox+dx,:] = conv(x)[n,oy,ox,:] + bias + residual[...]
                                     = Fuse.forward's project -> resize("up") -> sum (layers.py:160-174) */
-    CNL_RELU6 = 1u << 4          /* y = min(max(y, 0), 6)              nn.ReLU6     (layers.py:62,66; separable conv);
+    CNL_RELU6 = 1u << 4,         /* y = min(max(y, 0), 6)              nn.ReLU6     (layers.py:62,66; separable conv);
                                     cnl_conv2d_nhwc_f32 / cnl_deconv2x_nhwc_f32 / cnl_depthwise3x3_nhwc_f32 only      */
+    CNL_W_SPLIT = 1u << 5        /* cnl_conv2d_nhwc_f32: p->w is a cnl_conv_split_weights_f32 buffer (the fp32 OHWI weights followed by
+                                    their scaled fp16 split): the fp16-split direct kernel reads the pieces instead of splitting
+                                    the weights of every chunk again — same bits out; kernels that do not split ignore the tail   */
 };
 
 /*
@@ -138,6 +141,15 @@ int cnl_conv2d_kernel(const cnl_conv_params* p);
  * kernel with the pre-split weights (cnl_conv3x3_up2_kernel reports CNL_CONV_F16X2; w_absmax is not needed) and y_absmax is
  * honoured; otherwise on the fp32 matrix cores.
  */
+/*
+ * Weights of a direct conv (square 1x1 / 3x3 kernel, Cin % 32 == 0) with their fp16 split appended, for flags |= CNL_W_SPLIT:
+ * w_buf = [Cout*KH*KW*Cin fp32 OHWI weights (copied from w_ohwi unless w_buf == w_ohwi)][the same count of (hi, lo) fp16 pairs, scaled by the
+ * power of two S_w = 2^(14 - e) of max |w| = m 2^e, in the B-row layout of the kernel][S_w + 3 pad floats];
+ * cnl_conv_split_weight_floats sizes it (0: shape not supported).  Replaces nothing in the reference: it is the weight half of the
+ * operand split that round 2's kernel redid for every 32-channel chunk of every launch (half of its VALU work on the stride-2 3x3 convs).
+ */
+size_t cnl_conv_split_weight_floats(int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
+int cnl_conv_split_weights_f32(const float* w_ohwi, float* w_buf, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, void* stream);
 size_t cnl_up2_weight_floats(int32_t Cin, int32_t Cout);
 int cnl_up2_pack_weights_f32(const float* w_ohwi, float* w_packed, int32_t Cin, int32_t Cout, void* stream);
 int cnl_conv3x3_up2_nhwc_f32(const cnl_conv_params* p, void* stream);

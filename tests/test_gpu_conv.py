@@ -20,7 +20,8 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0, x_off=0, hints=False, algo=CNL_ALGO_AUTO, splitk=0):
+def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0, x_off=0, hints=False, algo=CNL_ALGO_AUTO, splitk=0, presplit=False,
+             no_wmax=False):
     """x_nchw: CPU tensor. Returns NCHW CPU output of cnl_conv2d_nhwc_f32.  hints: hand over max |x| per image (from
     cnl_absmax_per_image_f32) and max |w|, which selects the fp16-split kernel where it applies; then returns (out, kernel, y_absmax)."""
     lib = _lib.load()
@@ -37,6 +38,13 @@ def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0
     p.N, p.H_in, p.W_in, p.Cin, p.Cout = N, H, W, Cin, Cout
     p.KH, p.KW, p.stride, p.pad = KH, KW, stride, (KH - 1) // 2
     p.ldx, p.flags, p.algo = ldx, flags, algo
+    if presplit:                                               # the weights with their fp16 split appended (CNL_W_SPLIT)
+        nfl = lib.cnl_conv_split_weight_floats(Cin, Cout, KH, KW)
+        assert nfl == 2 * wd.numel() + 4
+        wbuf = torch.full((nfl,), float("nan"), device="cuda")
+        _lib.check(lib.cnl_conv_split_weights_f32(wd.data_ptr(), wbuf.data_ptr(), Cin, Cout, KH, KW, _stream()), "split weights")
+        assert torch.equal(wbuf[:wd.numel()], wd.reshape(-1))
+        p.w, p.flags = wbuf.data_ptr(), flags | _lib.CNL_W_SPLIT
     ho, wo = ctypes.c_int32(), ctypes.c_int32()
     _lib.check(lib.cnl_conv2d_out_hw(ctypes.byref(p), ctypes.byref(ho), ctypes.byref(wo)))
     oh, ow = ho.value, wo.value
@@ -53,7 +61,7 @@ def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0
         _lib.check(lib.cnl_absmax_per_image_f32(p.x, N, H * W, Cin, ldx, xm.data_ptr(), _stream()), "absmax")
         wm = wd.abs().max().reshape(1).contiguous()
         ym = torch.zeros(N, device="cuda")
-        p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), wm.data_ptr(), ym.data_ptr()
+        p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), (None if no_wmax else wm.data_ptr()), ym.data_ptr()
     if splitk:
         p.splitk = splitk
         nbytes = lib.cnl_conv2d_splitk_scratch_bytes(ctypes.byref(p))
@@ -255,7 +263,7 @@ def test_conv3x3_on_upsampled_input_as_subpixel_phases(case, hints):
         xm = x.abs().amax(dim=(1, 2, 3)).cuda()
         wm = wp.abs().max().reshape(1)
         ym = torch.zeros(N, device="cuda")
-        p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), wm.data_ptr(), ym.data_ptr()
+        p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), (None if no_wmax else wm.data_ptr()), ym.data_ptr()
     split = hints
     assert lib.cnl_conv3x3_up2_kernel(ctypes.byref(p)) == (5 if split else 2)
     _lib.check(lib.cnl_conv3x3_up2_nhwc_f32(ctypes.byref(p), _stream()), "up2")
@@ -742,6 +750,35 @@ def test_winograd9_many_items_per_workgroup_is_bit_identical_to_one_image_at_a_t
     for i in (0, 3, 7, 11):
         assert torch.equal(full[i:i + 1], run_winograd(x[i:i + 1], w, b, CNL_RELU, res[i:i + 1], algo=CNL_ALGO_FORCE + 9)), i
     assert torch.equal(ym, full.abs().amax(dim=(1, 2, 3)))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 32, 32, 128, 3, 2, CNL_RELU, False), (1, 256, 128, 128, 80, 1, 1, _lib.CNL_SIGMOID, False),
+                                   (2, 128, 16, 16, 256, 3, 2, CNL_RELU, False), (1, 64, 24, 40, 96, 3, 1, 0, True), (2, 96, 9, 11, 40, 3, 2, 0, False)],
+                         ids=lambda c: "N{}c{}_{}x{}_o{}k{}s{}f{}r{}".format(*[int(v) for v in c]))
+def test_presplit_weights_give_the_same_bits(shape):
+    """CNL_W_SPLIT (weights with their fp16 split appended by cnl_conv_split_weights_f32): the fp16-split direct kernel reads the pieces
+    instead of splitting every chunk's weights again — bit for bit the same output and max |y|, with or without w_absmax; a launch that
+    stays on the fp32 matrix cores (no hints) ignores the tail; the reduction-split form (fp32 weights) still works beside the flag."""
+    N, Cin, H, W, Cout, K, stride, flags, res = shape
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(N, Cin, H, W, generator=g).clamp_min(0)
+    w = torch.randn(Cout, Cin, K, K, generator=g) * (2.0 / (Cin * K * K)) ** 0.5 * torch.pow(10.0, torch.rand(Cout, 1, 1, 1, generator=g) * 2 - 1)
+    b = torch.randn(Cout, generator=g)
+    ho, wo = (H + 2 * (K // 2) - K) // stride + 1, (W + 2 * (K // 2) - K) // stride + 1
+    r = torch.randn(N, Cout, ho, wo, generator=g) if res else None
+    algo = CNL_ALGO_FORCE + 5 if K == 1 and ho * wo * Cout < (1 << 20) else CNL_ALGO_AUTO
+    base, k0, ym0 = run_conv(x, w, b, stride, flags, r, hints=True, algo=algo)
+    assert k0 == 5
+    for no_wmax in (False, True):
+        out, k1, ym1 = run_conv(x, w, b, stride, flags, r, hints=True, algo=algo, presplit=True, no_wmax=no_wmax)
+        assert k1 == 5 and torch.equal(out, base) and torch.equal(ym1, ym0), no_wmax
+    assert torch.equal(run_conv(x, w, b, stride, flags, r, presplit=True), run_conv(x, w, b, stride, flags, r))       # fp32 kernel: tail ignored
+    if K == 3:
+        sk, ks, _ = run_conv(x, w, b, stride, flags, r, hints=True, algo=algo, presplit=True, splitk=3)
+        sk0, _, _ = run_conv(x, w, b, stride, flags, r, hints=True, algo=algo, splitk=3)
+        assert torch.equal(sk, sk0)
+    lib = _lib.load()
+    assert lib.cnl_conv_split_weight_floats(48, 64, 3, 3) == 0 and lib.cnl_conv_split_weight_floats(64, 64, 3, 1) == 0 and lib.cnl_conv_split_weight_floats(64, 64, 5, 5) == 0
 
 
 def test_winograd9_images_side_by_side_do_not_see_each_other():

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/centernet_gfx950.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.cnl_version() == 8
+    assert lib.cnl_version() == 9
 
 
 def test_abi_error_convention_without_gpu():

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--hints", action="store_true", help="hand over x_absmax / w_absmax (fp16-split direct kernel where it applies; Winograd: no own absmax pass)")
     ap.add_argument("--algo", type=int, default=0, help="cnl_conv_params.algo: 0 auto, 1 F(2x2) only, 2 fp32 matrix cores, 100+v force Winograd variant v")
     ap.add_argument("--relu-data", action="store_true", help="post-ReLU activations (as inside the network)")
+    ap.add_argument("--presplit", action="store_true", help="direct convs: weights with their fp16 split appended (CNL_W_SPLIT)")
     ap.add_argument("--check", action="store_true", help="also print max |y - y_fp32mfma| / max |y_fp32mfma| (algo 2 on the same inputs)")
     args = ap.parse_args()
     lib = _lib.load()
@@ -104,6 +105,12 @@ def main():
             p.flags = flags & 5
             fn = lib.cnl_conv3x3_up2_nhwc_f32
             w = wp
+        if args.presplit and not args.winograd and not args.up2:
+            nfl = lib.cnl_conv_split_weight_floats(Cin, Cout, k, k)
+            if nfl:
+                wsp = torch.empty(nfl, device="cuda")
+                _lib.check(lib.cnl_conv_split_weights_f32(w.data_ptr(), wsp.data_ptr(), Cin, Cout, k, k, stream))
+                p.w, p.flags = wsp.data_ptr(), p.flags | _lib.CNL_W_SPLIT
         if args.hints and args.winograd:
             xm = x.abs().amax(dim=(1, 2, 3)).contiguous()
             ym = torch.zeros(N, device="cuda")
