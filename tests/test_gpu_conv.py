@@ -263,7 +263,7 @@ def test_conv3x3_on_upsampled_input_as_subpixel_phases(case, hints):
         xm = x.abs().amax(dim=(1, 2, 3)).cuda()
         wm = wp.abs().max().reshape(1)
         ym = torch.zeros(N, device="cuda")
-        p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), (None if no_wmax else wm.data_ptr()), ym.data_ptr()
+        p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), wm.data_ptr(), ym.data_ptr()
     split = hints
     assert lib.cnl_conv3x3_up2_kernel(ctypes.byref(p)) == (5 if split else 2)
     _lib.check(lib.cnl_conv3x3_up2_nhwc_f32(ctypes.byref(p), _stream()), "up2")
