@@ -47,6 +47,7 @@ class _Mapped:
         self.ptr, self.nbytes = p.value, nbytes
         self.np = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(self.ptr))
         self._finalizer = weakref.finalize(self, lib.cnl_host_free, ctypes.c_void_p(self.ptr))
+        self._finalizer.atexit = False          # at interpreter exit the HIP runtime may be gone already; the process frees the pages
 
 
 class TrackState(Enum):
