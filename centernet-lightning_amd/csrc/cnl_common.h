@@ -66,4 +66,30 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + (bid >> 3);
 }
 
+// Maximum of a NON-NEGATIVE value over the wave / over each 32-lane half, in every lane: DPP inside the rows of 16 lanes, then four
+// v_readlane.  (A __shfl_xor butterfly computes its ds_bpermute lane addresses from the lane id; the compiler hoists those five or six
+// registers to kernel entry, where they stay live — or spill, every reload a vmcnt(0) — across a kernel's main loop.)
+__device__ __forceinline__ float row16_max_nonneg(float v) {
+#define CNL_DPP_F(ctrl_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), (ctrl_), 0xF, 0xF, false))
+    v = fmaxf(v, CNL_DPP_F(0xB1));        // quad_perm [1, 0, 3, 2]
+    v = fmaxf(v, CNL_DPP_F(0x4E));        // quad_perm [2, 3, 0, 1]
+    v = fmaxf(v, CNL_DPP_F(0x141));       // row_half_mirror
+    v = fmaxf(v, CNL_DPP_F(0x140));       // row_mirror
+#undef CNL_DPP_F
+    return v;
+}
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    const int b = __builtin_bit_cast(int, row16_max_nonneg(v));
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+// first[0] = maximum over lanes 0..31, first[1] = over lanes 32..63 (both uniform)
+__device__ __forceinline__ void half_max_nonneg(float v, float (&out)[2]) {
+    const int b = __builtin_bit_cast(int, row16_max_nonneg(v));
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    out[0] = fmaxf(r0, r1); out[1] = fmaxf(r2, r3);
+}
+
 }  // namespace cnl

@@ -65,7 +65,8 @@ constexpr int VW_BYTES = 4 * NP * VPIECE;   // 8192 per wave
 constexpr int V_BYTES = 65536;              // V (4 x 8 KB) at its start; the whole region is one epilogue pass
 constexpr int P_SLOTS = 768;                // 760 used; 3 x 256
 constexpr int P_BYTES = P_SLOTS * 16;       // 12288 per buffer (two buffers)
-constexpr int LDS_BYTES = V_BYTES + 2 * P_BYTES;                 // 90112
+constexpr int OFF_BYTES = 3 * 256 * 4;          // per-thread patch offsets of the current item (see W6_SETUP)
+constexpr int LDS_BYTES = V_BYTES + 2 * P_BYTES + OFF_BYTES;     // 93184
 
 __device__ __forceinline__ void dma16(const float* base, unsigned bytes, char* lds_dst, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ds_read_b128 fragment reads (16-lane groups, 32-byte row pitch) bank-conflict-free
     const int dstv = wave * VW_BYTES + (t_tyl * 8 + t_tx) * 32 + (((t_q >> 1) ^ t_tyl) << 4) + (t_q & 1) * 8;   // + it*512 + (j*NP+k)*VPIECE
     const int fragA = wave * VW_BYTES + (lane & 31) * 32 + ((hi ^ ((lane >> 3) & 1)) << 4);                    // + (j*NP+k)*VPIECE + tg*1024
-    const float lo = (a.flags & CNL_RELU) ? 0.f : -__builtin_inff();
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((a.flags & CNL_RELU) ? 0 : (int)0xff800000u));      // ReLU floor or -inf (scalar register)
     // power-of-two scale of V, PER IMAGE (an image's result never depends on its batch neighbours — batch invariance, shard == full
     // batch): |V| <= 4 max |x| (sums of four inputs), 4 max |x| S in [2^13, 2^14) — exact, undone in the epilogue together with the
     // scale of the weights.  S / inv_n belong to the item set up last (W6_SETUP), `inv` to the one in the epilogue.
@@ -214,8 +215,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     int n, y0, x0, n0;
     int ne_n = 0;              // STACK: image of this thread's epilogue tile column, for the item set up last
-    unsigned p_off[3], u_voff;
-    float bias_n[4];           // bias of the item set up last (the next one, from the epilogue's prefetch on)
+    unsigned u_voff;
+    // the three patch-piece offsets of a thread live in LDS, not in registers: they are used once per chunk, the register allocator spilled
+    // them to scratch, and every reload inside the chunk loop came with a vmcnt(0) — a wait for all the loads in flight
+    unsigned* sOff = reinterpret_cast<unsigned*>(smem + V_BYTES + 2 * P_BYTES) + tid;
 #define W6_SETUP(item_)                                                                                          \
     do {                                                                                                         \
         unsigned b_ = cnl::xcd_remap((item_), (unsigned)a.blocks);                                               \
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }                                                                                                    \
             const bool ok_ = py_ < PH && pxx_ < PW && (unsigned)iy_ < (unsigned)a.H && okx_;                     \
             const int sy_ = up ? (iy_ >> 1) : iy_, sx_ = up ? (ix_ >> 1) : ix_;   /* nearest-2x upsample folded in */ \
-            p_off[i] = ok_ ? (unsigned)((((ni_ * a.Hs + sy_) * a.Ws + sx_) * a.ldx + q_ * 4) * 4) : OOB;         \
+            sOff[i * 256] = ok_ ? (unsigned)((((ni_ * a.Hs + sy_) * a.Ws + sx_) * a.ldx + q_ * 4) * 4) : OOB;    \
         }                                                                                                        \
         /* this lane's B fragments: cout row n0 + (lane & 31) (+ 32 for the second group), channel half hi */    \
         u_voff = (unsigned)((n0 + (lane & 31)) * 32 + hi * 16);                                                  \
@@ -259,11 +262,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             S = pow2_scale_v(4.f * a.xmax[n]);                                                                   \
             inv_n = 1.f / (S * Su);                                                                              \
         }                                                                                                        \
-        /* bias of this thread's two epilogue columns: requested now, used after the chunk loop */               \
-        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                       \
-            const int col_ = n0 + g_ * 32 + (tid & 31);                                                          \
-            bias_n[g_] = col_ < a.Cout ? a.bias[col_] : 0.f;                                                     \
-        }                                                                                                        \
     } while (0)
     // the channel-chunk offset rides in the SCALAR offset (the bounds check looks at the vector offset alone, so halo lanes still
     // read zeros); a chunk past the end is not fetched
@@ -272,7 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if ((cc_) < a.CC) {                                                                                      \
             char* d_ = sP + ((cc_) & 1) * P_BYTES;                                                               \
             _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                        \
-                dma16(a.x, a.x_bytes, d_ + (i * 256 + wave * 64) * 16, p_off[i], (unsigned)((cc_) * 64));        \
+                dma16(a.x, a.x_bytes, d_ + (i * 256 + wave * 64) * 16, sOff[i * 256], (unsigned)((cc_) * 64));   \
         }                                                                                                        \
     } while (0)
     // B fragments of position xi0 + j_ of chunk cc_, cout group g_ (three pieces): global -> registers
@@ -419,7 +417,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int ex0 = STACK ? x0 - ne_n * a.SW : x0;         // STACK: this thread's tile column in its own image's coordinates
         const bool full = !STACK && (y0 + 8 <= a.H) && (x0 + 16 <= a.W) && (n0 + BN <= a.Cout);
         const bool img_ok = !STACK || ne_n < a.N;
-        const float bv[4] = {bias_n[0], bias_n[1], bias_n[2], bias_n[3]};
+        // bias of this thread's epilogue columns: requested here (carried from the item's set-up they were four registers live across the
+        // whole chunk loop — the loop's patch offsets spilled instead, each reload a vmcnt(0) inside the loop)
+        float bv[4];
+#pragma unroll
+        for (int g_ = 0; g_ < 4; ++g_) {
+            const int col_ = n0 + g_ * 32 + (tid & 31);
+            bv[g_] = buf_load(a.bias, (unsigned)a.Cout * 4u, col_ < a.Cout ? (unsigned)col_ * 4u : OOB, 0);
+        }
         const float inv = inv_n;
         const unsigned next = item + gridDim.x;
         const bool more = next < (unsigned)a.blocks;
@@ -506,12 +511,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         if (a.ymax) {          // max |y| of this item into its image's slot: one atomic per wave and item (no return value awaited)
             if constexpr (STACK) {     // a half wave = one tile column = one image
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
+                float hm[2];
+                cnl::half_max_nonneg(omax, hm);
+                omax = lane < 32 ? hm[0] : hm[1];
                 if ((lane & 31) == 0 && img_ok && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
             } else {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
+                omax = cnl::wave_max_nonneg(omax);
                 if (lane == 0 && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
             }
             omax = 0.f;

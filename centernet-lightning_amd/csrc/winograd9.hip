@@ -139,21 +139,6 @@ __device__ __forceinline__ int lane_now() {
     asm volatile("" : "+v"(z));
     return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
 }
-// maximum of a non-negative value over the 64 lanes, in every lane: DPP inside the rows of 16, then four v_readlane.  (A __shfl_xor
-// butterfly computes its six ds_bpermute addresses from the lane id: the compiler hoists them to kernel entry, where they live — or
-// spill, each reload with a vmcnt(0) that waits for the epilogue's stores — across everything.)
-__device__ __forceinline__ float wave_max(float v) {
-#define W9_DPP(ctrl_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), (ctrl_), 0xF, 0xF, false))
-    v = fmaxf(v, W9_DPP(0xB1));        // quad_perm [1, 0, 3, 2]
-    v = fmaxf(v, W9_DPP(0x4E));        // quad_perm [2, 3, 0, 1]
-    v = fmaxf(v, W9_DPP(0x141));       // row_half_mirror
-    v = fmaxf(v, W9_DPP(0x140));       // row_mirror
-#undef W9_DPP
-    const int b = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-}
 __device__ __forceinline__ f32x4 lds_f4(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
 #define W9_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -664,7 +649,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (a.ymax) {          // max |y| of this item into its image's slot: the 8 tiles of an iteration lie in one image (tiles per image: 8, 16 or all)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float m = wave_max(omax2[i]);
+                const float m = cnl::wave_max_nonneg(omax2[i]);
                 const int img = __builtin_amdgcn_readfirstlane(rimg[i]);
                 if (lane_e == 0 && m > 0.f && img < a.Nimg) atomicMax(a.ymax + img, __float_as_uint(m));
             }
