@@ -17,6 +17,7 @@ matrices — straight into mapped host memory, ONE stream synchronisation makes 
 (tracker.py:51, 62-64), are computed on the host from copies only with `allow_host_cost=True` (otherwise the constructor raises).
 There is no CPU fallback for the device path: without the HIP library or a GPU, `update` raises.
 """
+import contextlib
 import ctypes
 import warnings
 import weakref
@@ -33,6 +34,15 @@ from .config import load_config
 _BOX_MODES = {None: 0, "iou": 1, "giou": 2}
 _LABEL_KINDS = {torch.int64: 1, torch.int32: 2, torch.float32: 3}     # det_label element types cnl_track_frame_f32 reads
 _REID_METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2}      # metrics with a gfx950 kernel (float64, scipy's operation order)
+
+
+_NO_GUARD = contextlib.nullcontext()
+
+
+def _on(dev):
+    """Device guard for the launches below — skipped when `dev` is the current device already (torch.cuda.device() costs ~6 us per use,
+    twice per frame)."""
+    return _NO_GUARD if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
 
 
 class _Mapped:
@@ -308,8 +318,9 @@ class Tracker:
             if not label_kind:
                 d_label, label_kind = d_label.to(torch.int64), 1
             d_label = d_label.contiguous()
-        need = int(lib.cnl_track_frame_bytes(k, T, int(with_dets)))
-        with torch.cuda.device(dev):
+        # cnl_track_frame_bytes(k, T, with_dets), in Python (a ctypes call costs ~2 us of a 150 us frame)
+        need = ((((32 + 4 * k + 7) & ~7) + (24 * k if with_dets else 0) + 7) & ~7) + 12 * k * T
+        with _on(dev):
             cur = torch.cuda.current_stream(dev)
             stream = ctypes.c_void_p(cur.cuda_stream)
             if self._rec is None or self._rec.nbytes < need:
@@ -396,7 +407,7 @@ class Tracker:
             src = np.empty((2, T_new), np.int32)
             src[0] = [old_rows[i] for i in keep]
             src[1] = [row_det.get(i, -1) for i in keep]
-            with torch.cuda.device(dev):
+            with _on(dev):
                 # the two index lists sit in mapped host memory that the kernel reads directly (2 x T_new int32 over PCIe): no host ->
                 # device copy; the synchronisation at the top of the next frame orders the kernel's reads before the next overwrite
                 if self._src is None or self._src.nbytes < 8 * T_new:
