@@ -29,6 +29,8 @@ SHAPES = {
     "layer2n8": (8, 64, 64, 128, 128, 3, 1, CNL_RELU, True),
     "layer3": (32, 32, 32, 256, 256, 3, 1, CNL_RELU, True),
     "layer4": (32, 16, 16, 512, 512, 3, 1, CNL_RELU, True),
+    "layer4n64": (64, 16, 16, 512, 512, 3, 1, CNL_RELU, True),
+    "layer4h256": (32, 16, 16, 256, 512, 3, 1, CNL_RELU, True),
     "big256px": (8, 256, 256, 64, 64, 3, 1, CNL_RELU, False),
     "neck0": (32, 16, 16, 512, 256, 3, 1, CNL_RELU, False),
     "c4l4": (16, 19, 34, 512, 512, 3, 1, CNL_RELU, False),
