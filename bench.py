@@ -10,21 +10,24 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
               step later (collate.Collator), i.e. overlapped with the next batch's forward; the last one is drained inside the
               timed region].  Inputs are resident in HBM.
   workload  = BASELINE.json configs[1] (C1): ResNet34 + simple upsample neck, batch 32 per GPU, 512x512, 80 classes
-              (`--config fpn --batch 64` = C2/C3, `--config tracking --batch 32 --height 608 --width 1088` = C4).  At N = 1 the
-              default run appends short C2 and C4 lines under `also` (10 steps after 3 warm-ups each).
+              (`--config fpn --batch 64` = C2/C3, `--config tracking --batch 32 --height 608 --width 1088` = C4).  The default run
+              appends short lines of the other BASELINE configurations under `also` (10 steps after 3 warm-ups each; `also_workloads`):
+              at N = 1  C2 (FPN, 64 images) and C4's per-GPU share (tracking, 32 x 608x1088);
+              at N > 1  C3 (FPN, 64 images per GPU: N = 8 is BASELINE's 512-image job) and C4 (tracking, 32 per GPU x 608x1088: N = 8 is
+              its 256-image job) — every rank runs them, sharded like the main line, each with its RCCL all-gather and `collate_ms`.
   value     = total images / max-over-ranks wall time of the K timed steps (weak scaling: batch per GPU fixed).
   roofline  = the dominant kernel by time, measured with HIP events on the launch stream around every conv launch of one step.
               The long 3x3 layers form every fp32 product on the fp16 matrix cores (scaled two-way fp16 split, three MFMAs per
-              product, fp32 accumulation) as Winograd F(2x2,3x3) (`cnl_wino5/6`; with --algo f4 the 256-channel layers over large maps
-              as F(4x4,3x3), `cnl_wino8::winograd8_kernel`); peak = 2.5 PFLOP/s dense fp16.  `achieved` counts the matrix-core flops
-              the kernel EXECUTES (direct-conv flops x 36/144 [F(4x4)] or 16/36 [F(2x2)], x 3 for the split), so `frac` is an honest
+              product, fp32 accumulation) as row-Winograd F(2,3) (`cnl_wino9` / `cnl_wino10`) or 2-D F(2x2,3x3) (`cnl_wino5/6`); peak =
+              2.5 PFLOP/s dense fp16.  `achieved` counts the matrix-core flops
+              the kernel EXECUTES (direct-conv flops x 6/9 [row F(2,3)] or 16/36 [F(2x2)], x 3 for the split), so `frac` is an honest
               hardware fraction — Winograd trades executed flops for transform work, which is why `effective_tflops` (the same time
               against the direct-conv, i.e. algorithmic, flops) is reported beside it.  `traffic` is NOT measured in this run: it is
               the rocprofv3 PMC figure of the named profiles/ file (null where no profile of that configuration exists).
   variants  = the same job in the other arithmetic classes of the plan (KernelOptions.algo; in-process, short runs):
-              f4 = additionally Winograd F(4x4,3x3) on the 256-channel layers over large maps (opt-in), f32 = fp32 matrix cores only.
+              f32 = fp32 matrix cores only.
   accuracy  = max |feature - float64 oracle| / max |float64 oracle| at the neck output and at each head's last 256-channel block
-              output (what out_conv reads), for auto / f4 / f32 and for the CPU fp32 oracle itself, on 2 images of the bench shape.
+              output (what out_conv reads), for auto / f32 and for the CPU fp32 oracle itself, on 2 images of the bench shape.
               (The post-sigmoid heatmap hides feature error by ~3 orders of magnitude; it is reported too.)  Backbone / ConvBnAct
               parity is "unpinned" by the reference itself (torchvision / vision_toolbox absent): the oracle is this repo's restatement.
   decode    = decode p50 on the forward's own outputs: bytes that must move, GB/s, fraction of 8 TB/s; with a separate sigmoid pass
@@ -54,11 +57,12 @@ F16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense fp16 / bf16 (v_mfma_f32_32
 HBM_PEAK_GBPS = 8000.0            # same guide: HBM3E spec peak (6.29 TB/s measured float4 copy)
 # rocprofv3 figures this line quotes but does not measure itself (HBM bytes per launch from the PMC passes: FETCH_SIZE x 2 + WRITE_SIZE, see
 # tools/rocpd_summary.py json; kernel-trace averages of the decode kernels): read from the committed profile JSON of the same command, so a
-# quoted number is byte-equal to a field of that file.  Written on the GPU box by tools/_trace/r03_profile.sh.
-PROFILE_JSON = {("simple", 32, 512, 512): "profiles/r03_profile_c1.json"}
+# quoted number is byte-equal to a field of that file.  Written on the GPU box by tools/profile_round.sh.
+PROFILE_JSON = {("simple", 32, 512, 512): "profiles/r04_profile_c1.json", ("fpn", 64, 512, 512): "profiles/r04_profile_c2.json",
+                ("tracking", 32, 608, 1088): "profiles/r04_profile_c4.json"}
 # kernel-name PREFIX in the profile JSON (template variants of one kernel — with / without a residual — are combined, weighted by calls)
-KIND_KERNEL = {"winograd_row_f16x2": "cnl_wino9::winograd9_kernel", "winograd_f16x2": "cnl_wino5::winograd5_kernel",
-               "winograd_f32": "cnl_wino2::winograd2_kernel", "winograd_f4": "cnl_wino8::winograd8_kernel"}
+KIND_KERNEL = {"winograd_row_f16x2": "cnl_wino9::winograd9_kernel", "winograd_row4_f16x2": "cnl_wino10::winograd10_kernel",
+               "winograd_f16x2": "cnl_wino5::winograd5_kernel", "winograd_f32": "cnl_wino2::winograd2_kernel"}
 
 
 def profiled(config, B, H, W):
@@ -69,8 +73,8 @@ def profiled(config, B, H, W):
 
 
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
-KIND_NAMES = {"winograd_f4": "cnl_wino8::winograd8_kernel (Winograd F(4x4,3x3); fp32 operands scaled per image by a power of two and split into 2 fp16 pieces, "
-                             "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
+KIND_NAMES = {"winograd_row4_f16x2": "cnl_wino10::winograd10_kernel (the row-Winograd arithmetic of cnl_wino9 on 4-row x 64-pixel x 64-cout work items, two "
+                                     "workgroups per CU)",
               "winograd_f16x2": "cnl_wino5::winograd5_kernel / cnl_wino6::winograd6_kernel (Winograd F(2x2,3x3); the same split arithmetic)",
               "winograd_row_f16x2": "cnl_wino9::winograd9_kernel (1-D Winograd F(2,3) along x, the three kernel rows in the reduction: 6 of the direct conv's 9 multiplies "
                                     "per output; fp32 operands scaled per image / per output channel by a power of two and split into 2 fp16 pieces, "
@@ -79,7 +83,7 @@ KIND_NAMES = {"winograd_f4": "cnl_wino8::winograd8_kernel (Winograd F(4x4,3x3); 
               "direct_f16x2": "cnl_conv::conv_f16x2_kernel (direct implicit GEMM, fp16 matrix cores, scaled two-way split)",
               "direct": "cnl_conv::conv_mfma_kernel (direct implicit GEMM, fp32 v_mfma_f32_32x32x2_f32)"}
 # executed matrix flops / direct-conv flops, and the peak they run against
-EXEC = {"winograd_f4": (36.0 / 144.0 * 3.0, F16_MFMA_PEAK_TFLOPS), "winograd_f16x2": (16.0 / 36.0 * 3.0, F16_MFMA_PEAK_TFLOPS),
+EXEC = {"winograd_row4_f16x2": (6.0 / 9.0 * 3.0, F16_MFMA_PEAK_TFLOPS), "winograd_f16x2": (16.0 / 36.0 * 3.0, F16_MFMA_PEAK_TFLOPS),
         "winograd_row_f16x2": (6.0 / 9.0 * 3.0, F16_MFMA_PEAK_TFLOPS),
         "winograd_f32": (16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS), "direct_f16x2": (3.0, F16_MFMA_PEAK_TFLOPS), "direct": (1.0, FP32_MFMA_PEAK_TFLOPS)}
 
@@ -216,7 +220,7 @@ def conv_kernel_profile(model, x, reps=3):
             return "direct_f16x2" if lib.cnl_conv3x3_up2_kernel(ctypes.byref(L.args)) == 5 else "direct"
         if L.fn is not lib.cnl_conv3x3_winograd_f32:
             return "direct_f16x2" if lib.cnl_conv2d_kernel(ctypes.byref(L.args)) == 5 else "direct"
-        return {5: "winograd_f16x2", 6: "winograd_f16x2", 8: "winograd_f4", 9: "winograd_row_f16x2"}.get(lib.cnl_conv3x3_winograd_variant(ctypes.byref(L.args)), "winograd_f32")
+        return {5: "winograd_f16x2", 6: "winograd_f16x2", 9: "winograd_row_f16x2", 10: "winograd_row4_f16x2"}.get(lib.cnl_conv3x3_winograd_variant(ctypes.byref(L.args)), "winograd_f32")
 
     rows = []
     for i, L in enumerate(convs):
@@ -457,29 +461,70 @@ def cpu_baseline(config, k, H, W, gpu_decode_p50_ms):
             "decode_p50_ms": {"cpu_N32": cn["decode_p50_ms"], "cpu_N1_C0": c0.get("decode_p50_ms"), "gpu_full_batch": gpu_decode_p50_ms}}
 
 
-def short_line(config, B, H, W, k, steps=10, warmup=3):
-    """A short run of another BASELINE configuration (driver-visible C2 / C4 numbers)."""
+def also_workloads(world, config, B, H, W):
+    """The other BASELINE configurations a default run (the C1 line) appends under `also`: at one GPU C2 and C4's per-GPU share, at N > 1 the
+    two configurations BASELINE.json DEFINES on 8 GPUs — C3 (FPN, 512 images = 64 per GPU) and C4 (tracking, 256 images = 32 per GPU at
+    608x1088) — sharded over the ranks like the main line, each with its all-gather (reference collective: eval/coco.py:10-18)."""
+    if config != "simple" or (B, H, W) != (32, 512, 512):
+        return []
+    fpn = {"config": "fpn", "batch": 64, "height": 512, "width": 512, "k": 100}
+    trk = {"config": "tracking", "batch": 32, "height": 608, "width": 1088, "k": 100}
+    if world == 1:
+        return [dict(fpn, name="C2"), dict(trk, name="C4 (one GPU's share: 32 of its 256 images)")]
+    return [dict(fpn, name=f"C3 ({64 * world} images over {world} GPUs)"), dict(trk, name=f"C4 ({32 * world} images over {world} GPUs)")]
+
+
+def collate_alone_ms(model, x, tracking, k, collator, barrier):
+    """The collate step alone, synchronously (pack + all-gather + unpack): median of 10."""
+    with torch.no_grad():
+        o = model(x)
+        dets = model.gather_tracking2d(o, num_detections=k) if tracking else model.gather_detection2d(o, num_detections=k)
+        cts = []
+        for _ in range(10):
+            barrier()
+            t0 = time.perf_counter()
+            collator.result(collator.submit(dets))
+            torch.cuda.synchronize()
+            cts.append(time.perf_counter() - t0)
+    cts.sort()
+    return cts[len(cts) // 2] * 1e3
+
+
+def short_line(spec, rank=0, world=1, barrier=None, steps=10, warmup=3):
+    """A short run of another BASELINE configuration (`also_workloads`): EVERY rank runs it on its own batch (weak scaling, the all-gather
+    of the detections behind each step when world > 1); rank 0 returns the line, the others None."""
+    config, B, H, W, k = spec["config"], spec["batch"], spec["height"], spec["width"], spec["k"]
     tracking = config == "tracking"
+    barrier = barrier or torch.cuda.synchronize
     model = build_model(config)
-    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1234)).cuda()
-    sync = torch.cuda.synchronize
-    el = timed(model, x, tracking, k, warmup, steps, cl.Collator(), sync)
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1234 + rank)).cuda()
+    collator = cl.Collator()
+    el = timed(model, x, tracking, k, warmup, steps, collator, barrier)
+    collate_ms = None
+    if world > 1:
+        el = max_over_ranks(el, "cuda")
+        collate_ms = collate_alone_ms(model, x, tracking, k, collator, barrier)
+    if rank != 0:
+        return None
     with torch.no_grad():
         rows, plan = conv_kernel_profile(model, x, reps=2)
     roof, stack = roofline_block(rows, config, B, H, W)
     eng = model._engine
-    return {"config": {"workload": f"ResNet34 + {config} neck, {B} img x {H}x{W}, k={k}"}, "value": round(B * steps / el, 2), "unit": "images/s",
+    line = {"config": {"workload": f"BASELINE {spec['name']}: ResNet34 + {config} neck, {B} img/GPU x {H}x{W}, k={k}", "global_batch": world * B, "per_gpu_batch": B,
+                       "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of detections (side stream, one step behind)" if world > 1 else "")},
+            "value": round(job_throughput(B, world, steps, el), 2), "unit": "images/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 3),
-            "roofline": {kk: roof[kk] for kk in ("kernel", "achieved", "peak", "frac", "effective_tflops", "launches_per_step", "kernel_ms_per_step")},
+            "roofline": {kk: roof[kk] for kk in ("kernel", "achieved", "peak", "frac", "effective_tflops", "launches_per_step", "kernel_ms_per_step", "avg_launch_us",
+                                                 "algorithmic_bytes_per_launch", "traffic", "traffic_source")},
             "conv_stack": stack,
             "activation_arena_MB": {"with_liveness_reuse": round(plan.arena_bytes / 1e6, 1), "every_buffer_separate": round(plan.bytes_without_reuse / 1e6, 1),
                                     "sub_batch": eng.sub_batch(B, H, W)}}
+    if collate_ms is not None:
+        line["collate_ms"] = round(collate_ms, 4)
+    return line
 
 
-def main():
-    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-leg-child":
-        _cpu_leg_child(json.loads(sys.argv[2]))
-        return
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -489,7 +534,7 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--algo", choices=["auto", "f4", "f32"], default="auto", help="KernelOptions.algo of the measured job")
+    ap.add_argument("--algo", choices=["auto", "f32"], default="auto", help="KernelOptions.algo of the measured job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the f2 / f32 legs")
     ap.add_argument("--no-also", action="store_true", help="skip the short C2 / C4 lines")
@@ -497,7 +542,14 @@ def main():
     ap.add_argument("--collate-probe", action="store_true", help="N=1 only: also time the steps with the RCCL all-gather of the detections forced "
                     "through a world-size-1 process group (side stream, one step behind) — the N>1 data path on the one GPU a box has")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer conv table to stderr")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-leg-child":
+        _cpu_leg_child(json.loads(sys.argv[2]))
+        return
+    args = parse_args()
 
     rank, world, local_rank = setup_distributed(args.gpus)
 
@@ -515,19 +567,7 @@ def main():
     elapsed = timed(model, x, tracking, args.k, args.warmup, args.steps, collator, barrier)
     if world > 1:
         elapsed = max_over_ranks(elapsed, "cuda")
-        # the collate step alone, synchronously (pack + all-gather + unpack), for the record: median of 10
-        with torch.no_grad():
-            o = model(x)
-            dets = model.gather_tracking2d(o, num_detections=args.k) if tracking else model.gather_detection2d(o, num_detections=args.k)
-            cts = []
-            for _ in range(10):
-                barrier()
-                t0 = time.perf_counter()
-                collator.result(collator.submit(dets))
-                torch.cuda.synchronize()
-                cts.append(time.perf_counter() - t0)
-            cts.sort()
-            collate_ms = cts[len(cts) // 2] * 1e3
+        collate_ms = collate_alone_ms(model, x, tracking, args.k, collator, barrier)
 
     if rank == 0:
         with torch.no_grad():
@@ -545,7 +585,7 @@ def main():
             "dtype": "f32",
             "dtype_note": "fp32 in / fp32 accumulate / fp32 out; where it pays, each fp32 product is formed on the fp16 matrix cores from a two-way fp16 split of "
                           "both (power-of-two scaled) operands (3 cross terms); KernelOptions.algo = " + args.algo + " (auto: every kernel's error at or below the fp32 MFMA's; "
-                          "f4: additionally Winograd F(4x4,3x3) on the 256-channel layers over large maps; f32: fp32 matrix cores only): see `variants` and `accuracy`",
+                          "f32: fp32 matrix cores only): see `variants` and `accuracy`",
             "data": "synthetic (seeded rand images; random-init weights of the named architecture)",
             "config": {"workload": f"BASELINE C{'1' if args.config == 'simple' else ('4' if tracking else '2/3')}: ResNet34 + {args.config} neck, "
                                    f"{B} img/GPU x {H}x{W}, heads {'2+4+reid64' if tracking else '80+4'} (w256), k={args.k}, nms 3",
@@ -567,7 +607,7 @@ def main():
             sync = torch.cuda.synchronize
             if not args.no_variants:
                 result["variants"] = {}
-                for algo in ("f4", "f32"):
+                for algo in ("f32",):
                     if algo == args.algo:
                         continue
                     try:
@@ -621,18 +661,25 @@ def main():
                                                              "(reduction of the small-grid convs split over workgroups; off by default)")
                 except Exception as e:
                     result["latency_ms_N1"] = {"error": repr(e)}
-            if not args.no_also and args.config == "simple" and (B, H, W) == (32, 512, 512):
-                result["also"] = []
-                for cfg, b_, h_, w_, k_ in (("fpn", 64, 512, 512, 100), ("tracking", 32, 608, 1088, 100)):
-                    try:
-                        result["also"].append(short_line(cfg, b_, h_, w_, k_))
-                    except Exception as e:
-                        result["also"].append({"config": cfg, "error": repr(e)})
+    # the other BASELINE configurations: EVERY rank takes part (at N > 1 these are C3 and C4, the two configurations defined on 8 GPUs)
+    if not args.no_also:
+        lines = []
+        for spec in also_workloads(world, args.config, B, H, W):
+            try:
+                lines.append(short_line(spec, rank, world, barrier))
+            except Exception as e:
+                if world > 1:
+                    raise                                   # a rank that drops out of a collective would hang the others: fail the job loudly
+                lines.append({"config": spec, "error": repr(e)})
+        if rank == 0 and lines:
+            result["also"] = lines
+    if rank == 0:
+        if world == 1:
             torch.cuda.empty_cache()
             if not args.no_accuracy:
                 x2 = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(4242))
                 try:
-                    acc = {a: feature_errors(args.config, x2, a) for a in ("auto", "f4", "f32", "cpu")}
+                    acc = {a: feature_errors(args.config, x2, a) for a in ("auto", "f32", "cpu")}
                     result["accuracy"] = {"max_err_over_max_ref_vs_float64_oracle": acc, "tolerance": 1e-4,
                                           "sample": f"2 images of the bench shape, same weights; 'cpu' = the CPU fp32 oracle's own distance from float64",
                                           "parity_note": "backbone + ConvBnAct parity is unpinned by the reference (torchvision / vision_toolbox absent): the oracle is this repo's restatement; "

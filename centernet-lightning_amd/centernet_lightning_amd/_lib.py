@@ -18,11 +18,11 @@ CNL_RELU6 = 1 << 4
 CNL_W_SPLIT = 1 << 5          # cnl_conv_params.w is a cnl_conv_split_weights_f32 buffer (fp32 weights + their fp16 split)
 
 # cnl_conv_params.algo: the arithmetic class a launch may use (include/centernet_gfx950.h)
-CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_F4, CNL_ALGO_FORCE = 0, 1, 2, 3, 100
-CNL_WINO_F32, CNL_WINO_F16X2, CNL_WINO_F16X2_F4 = 2, 5, 8
+CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_FORCE = 0, 1, 2, 100
+CNL_WINO_F32, CNL_WINO_F16X2 = 2, 5
 
 CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4
-ABI_VERSION = 9          # CNL_ABI_VERSION of include/centernet_gfx950.h
+ABI_VERSION = 10         # CNL_ABI_VERSION of include/centernet_gfx950.h
 
 
 class ConvParams(Structure):
@@ -67,8 +67,6 @@ _SIGNATURES = {
     "cnl_absmax_per_image_f32": (ctypes.c_int, [c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_void_p, c_void_p]),
     "cnl_winograd_weight_floats": (c_size_t, [c_int32, c_int32]),
     "cnl_winograd_transform_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
-    "cnl_winograd_f4_weight_floats": (c_size_t, [c_int32, c_int32]),
-    "cnl_winograd_transform_weights_f4_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "cnl_deconv2x_nhwc_f32": (ctypes.c_int, [POINTER(DeconvParams), c_void_p]),
     "cnl_deconv_phase_geometry": (ctypes.c_int, [c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
     "cnl_deconv_weight_floats": (c_size_t, [c_int32, c_int32, c_int32]),

@@ -141,8 +141,8 @@ class Collator:
 
     def _claim(self, shape, device, dtype):
         """Next slot; the caller's stream first waits for the slot's previous gather (it is about to overwrite its source)."""
-        if self.depth < 2:
-            raise ValueError("Collator(depth=1) cannot be pipelined: submit(i + 1) would overwrite the slot that result(i) reads; use depth >= 2")
+        # (depth = 1 is valid for strictly sequential use — submit, result, submit ...; collecting a result behind a later submit is what
+        #  the generation check of result_records() catches, at any depth)
         slot = self._slot(shape, device, dtype)
         if slot[2] is not None and slot[3]:
             torch.cuda.current_stream(device).wait_event(slot[2])

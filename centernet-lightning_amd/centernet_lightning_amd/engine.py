@@ -21,8 +21,8 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_F4, CNL_RELU, CNL_RELU6, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD, CNL_W_SPLIT,
-                   CNL_WINO_F16X2, CNL_WINO_F16X2_F4, ConvParams, DeconvParams)
+from ._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_RELU, CNL_RELU6, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD, CNL_W_SPLIT,
+                   CNL_WINO_F16X2, ConvParams, DeconvParams)
 
 BN_EPS_DEFAULT = 1e-5
 
@@ -33,8 +33,6 @@ class KernelOptions:
     reads nothing from the environment.
       algo             "auto": fp32-grade kernels on the fp16-split matrix cores where they pay (every kernel's error vs float64 at or
                        below the fp32 matrix core's; "f2" is a synonym);
-                       "f4":   the same plus Winograd F(4x4,3x3) on the long 3x3 layers over large maps (error ~4x F(2x2)'s, still ~1e-6 of
-                               the layer maximum; opt-in: measured within +-5 % of "auto" on MI355X);
                        "f32":  fp32 matrix cores only (no split operands, no hints).
       winograd         False: every conv on the direct implicit-GEMM kernels (A/B and parity checks)
       up2              the fused first head blocks behind a nearest upsample as four sub-pixel phase convs
@@ -60,9 +58,9 @@ class KernelOptions:
     @property
     def algo_id(self):
         try:
-            return {"auto": CNL_ALGO_AUTO, "f2": CNL_ALGO_F2, "f4": CNL_ALGO_F4, "f32": CNL_ALGO_F32}[self.algo]
+            return {"auto": CNL_ALGO_AUTO, "f2": CNL_ALGO_F2, "f32": CNL_ALGO_F32}[self.algo]
         except KeyError:
-            raise ValueError(f"KernelOptions.algo must be 'auto', 'f2', 'f4' or 'f32', got {self.algo!r}") from None
+            raise ValueError(f"KernelOptions.algo must be 'auto', 'f2' or 'f32', got {self.algo!r}") from None
 
 
 def fold_conv_bn(conv_w, conv_b, bn=None):
@@ -89,29 +87,18 @@ class _Layer:
         self.pad = (self.kh - 1) // 2
         self.wmax = w_ohwi.abs().max().reshape(1).contiguous()      # cnl_conv_params.w_absmax (fp16-split direct kernel)
         self.u = None
-        self.u_has_f4 = False
         if self.kh == 3 and self.kw == 3 and stride == 1 and self.cin % 8 == 0 and w_ohwi.is_cuda:
-            self._transform(f4=False)
+            self._transform()
 
-    def _transform(self, f4):
+    def _transform(self):
         lib = _lib.load()
         w = self.w
-        n = (lib.cnl_winograd_f4_weight_floats if f4 else lib.cnl_winograd_weight_floats)(self.cin, self.cout)
+        n = lib.cnl_winograd_weight_floats(self.cin, self.cout)
         with torch.cuda.device(w.device):
             self.u = torch.empty((n,), device=w.device, dtype=torch.float32)
             stream = ctypes.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
             _lib.check(lib.cnl_winograd_transform_weights_f32(w.data_ptr(), self.u.data_ptr(), self.cin, self.cout, stream),
                        "cnl_winograd_transform_weights_f32")
-            if f4:
-                _lib.check(lib.cnl_winograd_transform_weights_f4_f32(w.data_ptr(), self.u.data_ptr(), self.cin, self.cout, stream),
-                           "cnl_winograd_transform_weights_f4_f32")
-        self.u_has_f4 = f4
-
-    def ensure_f4(self):
-        """The F(4x4,3x3) copy of the weights (an opt-in arithmetic class: KernelOptions(algo="f4")) is built on the first plan that
-        launches this layer on winograd8 — not on every weight load (0.4 GB and 78 launches over a ResNet-34 CenterNet)."""
-        if self.u is not None and not self.u_has_f4:
-            self._transform(f4=True)
 
 
 def _layer_split_w(self):
@@ -255,6 +242,14 @@ class PackedWeights:
         # what the packed copy was made from: (tensor, version at packing time); Engine.forward rebuilds when a parameter or buffer was
         # replaced or written in place since (load_state_dict on a submodule, optimizer steps, manual edits)
         self._sources = [(t, t._version, t.data_ptr()) for t in list(model.parameters()) + list(model.buffers())]
+        # where each of them (and each submodule) hangs: flat (dict, key, object) triples, so that the per-forward staleness check is a few
+        # hundred identity comparisons instead of a recursive walk over the module tree
+        self._slots = []
+        for m in model.modules():
+            self._slots += [(m._modules, k, c) for k, c in m._modules.items()]
+            self._slots += [(m._parameters, k, t) for k, t in m._parameters.items()]
+            self._slots += [(m._buffers, k, t) for k, t in m._buffers.items()]
+        self._slot_sizes = [(d, len(d)) for d in {id(d): d for d, _, _ in self._slots}.values()]
         bb, neck, heads = model.backbone, model.neck, model.heads
         dev = lambda t: t.to(device)
         L = lambda conv, bn=None, stride=None: _Layer(*map(dev, fold_conv_bn(conv.weight, conv.bias, bn)),
@@ -332,9 +327,12 @@ class PackedWeights:
         (load_state_dict(assign=True), `module.weight = nn.Parameter(...)`, a swapped submodule: the module then holds another tensor
         object than the one captured when packing) since the weights were packed."""
         if model is not None:
-            now = list(model.parameters()) + list(model.buffers())
-            if len(now) != len(self._sources) or any(t is not s_[0] for t, s_ in zip(now, self._sources)):
-                return True
+            for d, k, obj in self._slots:
+                if d.get(k) is not obj:
+                    return True
+            for d, n in self._slot_sizes:          # a parameter / buffer / submodule was added
+                if len(d) != n:
+                    return True
         for t, v0, p0 in self._sources:
             if t._version != v0 or t.data_ptr() != p0:
                 return True
@@ -524,7 +522,7 @@ class Plan:
         for L in self.launches:         # plan order: a direct conv only reports max |y| if it got its own hint
             if not isinstance(L.args, ConvParams):
                 continue
-            is_wino5 = L.fn is wino and lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)) in (CNL_WINO_F16X2, CNL_WINO_F16X2_F4)
+            is_wino5 = L.fn is wino and lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)) == CNL_WINO_F16X2
             if not is_wino5 and not would_split(L):
                 continue
             x = L.keep[0]
@@ -603,14 +601,10 @@ class Plan:
             p.w = layer.u.data_ptr()
             fn = self.lib.cnl_conv3x3_winograd_f32
             what += " [winograd]"
-            if self.lib.cnl_conv3x3_winograd_kernel(ctypes.byref(p)) == CNL_WINO_F16X2_F4:
-                layer.ensure_f4()                       # lazily: only plans of the opt-in class pay for the F(4x4) weight copy
-                p.w = layer.u.data_ptr()
-        rowwino = False
-        if fn is self.lib.cnl_conv3x3_winograd_f32 and self.algo not in (CNL_ALGO_F32, CNL_ALGO_F4) and layer.cin % 32 == 0 and layer.cout % 4 == 0:
-            # the dispatcher's rule for winograd9.hip (8-row x 64-pixel work items pad the map by < 1.5x): it folds the upsample into its
-            # patch gather and beats the sub-pixel phases below (C1: 8.93 -> 8.82 ms per forward)
-            rowwino = -(-ho.value // 8) * 8 * -(-wo.value // 64) * 64 * 100 <= ho.value * wo.value * 150
+        # the row-Winograd kernels (winograd9.hip / winograd10.hip) fold the upsample into their patch gather and beat the sub-pixel phases
+        # below (C1: 8.93 -> 8.82 ms per forward); whether a layer takes one is the dispatcher's decision — asked, not re-derived here
+        rowwino = (fn is self.lib.cnl_conv3x3_winograd_f32 and self.algo != CNL_ALGO_F32
+                   and self.lib.cnl_conv3x3_winograd_variant(ctypes.byref(p)) in (9, 10))
         if (self.options.up2 and (flags & CNL_UPSAMPLE_IN) and not (flags & ~(CNL_RELU | CNL_UPSAMPLE_IN)) and residual is None
                 and layer.wants_up2() and not rowwino):
             # short channel loop, many couts, conv on the nearest-2x upsampled input (the fused first head blocks behind the simple

@@ -231,6 +231,7 @@ class Tracker:
         self.last_costs = None      # (reid [n,T] f64, box [n,T] f32 | None, det_index [n]) of the last update (host numpy)
         self._rec = None            # mapped host memory the association kernel writes the frame record into (cnl_track_frame_f32)
         self._src = None            # mapped host memory holding the two index lists cnl_track_apply_f32 reads
+        self._apply_stream = None   # the stream the last cnl_track_apply_f32 was launched on
 
     @property
     def device(self):
@@ -323,6 +324,10 @@ class Tracker:
         with _on(dev):
             cur = torch.cuda.current_stream(dev)
             stream = ctypes.c_void_p(cur.cuda_stream)
+            if self._apply_stream is not None and self._apply_stream != cur:
+                # the caller changed streams between frames: the previous frame's table update (which reads the mapped index lists and
+                # writes the tables this frame reads) ran on another stream — finish it first (same stream: stream order does it)
+                self._apply_stream.synchronize()
             if self._rec is None or self._rec.nbytes < need:
                 self._rec = _Mapped(max(2 * need, 1 << 18))          # persistent: nothing allocated per frame
             rec = self._rec
@@ -420,6 +425,7 @@ class Tracker:
                                                    d_emb.data_ptr(), d_box.data_ptr(), d_src[0], d_src[1],
                                                    T_new, E, float(self.smoothing_factor), new_emb.data_ptr(), new_box.data_ptr(),
                                                    stream), "cnl_track_apply_f32")
+                self._apply_stream = cur
             self._spare, (self._emb, self._box) = ((self._emb, self._box) if self._emb is not None else None), (new_emb, new_box)
         for r, t in enumerate(self.tracks):
             t._row = r

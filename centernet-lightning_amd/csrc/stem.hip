@@ -205,7 +205,7 @@ static int stem_launch(const char* who, bool pool, const float* x, int64_t sn, i
     const int tiles_x = (Wo + ST_TW - 1) / ST_TW, tiles_y = (Ho + ST_TH - 1) / ST_TH;
     const long long blocks = (long long)N * tiles_x * tiles_y;
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "%s: grid too large", who);
-    CNL_REQUIRE(algo <= CNL_ALGO_F4, CNL_E_BAD_ARG, "%s: unknown algo %u", who, algo);
+    CNL_REQUIRE(algo <= CNL_ALGO_F32, CNL_E_BAD_ARG, "%s: unknown algo %u", who, algo);
     if (algo != CNL_ALGO_F32 || pool)           // (the fused max-pool exists in the fp16-split kernel only)
         return cnl_stem5_launch(x, false, nullptr, nullptr, (long)sn, (int)sc, (int)sh, (int)sw, (unsigned)img_bytes, w + ST_KP * 64, bias, y, N, H, W,
                                 Ho, Wo, tiles_x, tiles_y, (unsigned)blocks, pool, stream);

@@ -10,8 +10,8 @@
 //   5  winograd5.hip  F(2x2,3x3) with every fp32 product formed on the fp16 matrix cores (scaled two-way fp16 split, three cross
 //                     terms, fp32 accumulation: error at or below the fp32 MFMA's), 16x16-pixel x 64-cout work items;
 //   6  winograd6.hip  the same on 8x16-pixel x 128-cout work items (short channel loop with many couts, or maps that 16-row blocks pad);
-//   8  winograd8.hip  F(4x4,3x3) with the same split: 0.56x the matrix work and split work per output, error ~4x kernel 5's
-//                     (~1e-6 of the layer maximum) — long channel loops on large maps its 32x16-pixel items tile well, CNL_ALGO_F4 only.
+//   9  winograd9.hip  1-D F(2,3) along x with the kernel rows folded into the reduction, same split: 8-row x 64-pixel x 64-cout items.
+//   (8, the F(4x4,3x3) split kernel of round 2, was removed in ABI v10: slower than 9 at 4x its rounding error.)
 // The 16x16-pixel-block fp32 kernel this file used to hold, the exact three-way bf16 split (winograd3/4) and the two-waves-per-SIMD
 // form of 5 (winograd7) are measured-and-superseded variants: tools/experiments/ (`make -C csrc experiments`, algo = CNL_ALGO_FORCE + variant).
 #include "cnl_common.h"
@@ -56,11 +56,6 @@ int cnl_wino5_transform_weights(const float* w_ohwi, const float* u_f32, size_t 
 int cnl_wino5_own_absmax(const cnl_conv_params* p, float* scal, void* stream);
 int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream);
 int cnl_wino6_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream);        // winograd6.hip
-size_t cnl_wino8_weight_bytes(int Cin, int Cout);                                  // winograd8.hip
-size_t cnl_wino8_scalar_floats();
-int cnl_wino8_transform_weights(const float* w_ohwi, void* u8, float* scal, int Cin, int Cout, void* stream);
-bool cnl_wino8_eligible(const cnl_conv_params* p);
-int cnl_wino8_launch(const cnl_conv_params* p, const void* u8, const float* scal, const float* xmax, void* stream);
 size_t cnl_wino9_weight_bytes(int Cin, int Cout);                                  // winograd9.hip
 size_t cnl_wino9_scalar_floats(int Cin, int Cout);
 int cnl_wino9_transform_weights(const float* w_ohwi, void* u9, float* isu, int Cin, int Cout, void* stream);
@@ -78,15 +73,14 @@ static size_t cnl_wino3_weight_bytes(int, int) { return 0; }
 #endif
 
 // Layout of the transformed-weight buffer (floats): [fp32 U = [ci/8][16][CoutP][8]] [experiment builds: bf16 x 3 pieces]
-// [fp16 x 2 pieces of F(2x2)] [its scalars] [fp16 x 2 pieces of the row-Winograd kernel] [its per-cout scales]
-// [optional tail: fp16 x 2 pieces of F(4x4)] [its scalars]; the split copies exist for Cin % 16 == 0 only.  The F(4x4) tail (0.4 GB over a
-// ResNet-34 CenterNet, 2 launches per layer) is produced by cnl_winograd_transform_weights_f4_f32 only: for callers that opt into CNL_ALGO_F4.
+// [fp16 x 2 pieces of F(2x2)] [its scalars] [fp16 x 2 pieces of the row-Winograd kernel] [its per-cout scales]; the split copies exist
+// for Cin % 16 == 0 only.
 static size_t wino_f32_floats(int Cin, int Cout) {
     const size_t CoutP = (size_t)((Cout + 63) / 64) * 64;
     return (size_t)(Cin / 8) * 16 * CoutP * 8;
 }
 struct WeightLayout {
-    size_t u3, u5, s5, u9, s9, u8, s8, total, total_f4;     // float offsets
+    size_t u3, u5, s5, u9, s9, total;     // float offsets
     WeightLayout(int Cin, int Cout) {
         const bool split = Cin % 16 == 0;
         u3 = wino_f32_floats(Cin, Cout);
@@ -95,9 +89,6 @@ struct WeightLayout {
         u9 = s5 + (split ? cnl_wino5_scalar_floats() : 0);
         s9 = u9 + cnl_wino9_weight_bytes(Cin, Cout) / 4;
         total = s9 + cnl_wino9_scalar_floats(Cin, Cout);
-        u8 = total;
-        s8 = u8 + cnl_wino8_weight_bytes(Cin, Cout) / 4;
-        total_f4 = s8 + (split ? cnl_wino8_scalar_floats() : 0);
     }
 };
 
@@ -105,18 +96,6 @@ extern "C" size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8) return 0;
     return WeightLayout(Cin, Cout).total;
 }
-extern "C" size_t cnl_winograd_f4_weight_floats(int32_t Cin, int32_t Cout) {
-    if (Cin <= 0 || Cout <= 0 || Cin % 8) return 0;
-    return WeightLayout(Cin, Cout).total_f4;
-}
-extern "C" int cnl_winograd_transform_weights_f4_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream) {
-    CNL_REQUIRE(w_ohwi && u, CNL_E_BAD_ARG, "cnl_winograd_transform_weights_f4_f32: null pointer");
-    CNL_REQUIRE(Cin > 0 && Cout > 0 && Cin % 8 == 0, CNL_E_UNSUPPORTED, "cnl_winograd_transform_weights_f4_f32: Cin %% 8 != 0");
-    if (Cin % 16) return CNL_OK;                       // no split kernels for this layer: nothing to add
-    const WeightLayout L(Cin, Cout);
-    return cnl_wino8_transform_weights(w_ohwi, u + L.u8, u + L.s8, Cin, Cout, stream);
-}
-
 extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream) {
     CNL_REQUIRE(w_ohwi && u, CNL_E_BAD_ARG, "cnl_winograd_transform_weights_f32: null pointer");
     CNL_REQUIRE(Cin > 0 && Cout > 0 && Cin % 8 == 0, CNL_E_UNSUPPORTED, "cnl_winograd_transform_weights_f32: Cin %% 8 != 0");
@@ -145,22 +124,13 @@ static int wino_choice(const cnl_conv_params* p) {
     if (p->algo >= CNL_ALGO_FORCE) {
         const int v = (int)p->algo - CNL_ALGO_FORCE;
         if (v <= 2 || p->Cin % 16) return v == 1 ? 1 : 2;
-        if (v == 8 && !cnl_wino8_eligible(p)) return 5;
+        if (v == 8) return 5;                              // (removed in ABI v10)
         if (v == 9 && !cnl_wino9_eligible(p)) return 5;
         if (v == 6 && p->Cout % 128) return 5;
         return v;
     }
     if (p->algo == CNL_ALGO_F32 || p->Cin % 16) return 2;
     const long long area = (long long)H * W;
-    if (p->algo == CNL_ALGO_F4 && items_per_image >= 8 && p->Cin >= 256 && area >= 64 * 64 && cnl_wino8_eligible(p)) {
-        // F(4x4): 32x16-pixel items.  Measured against kernel 5 / 6 on one box (profiles/r02_winograd8_variants.txt): 0.89-0.93 of
-        // their time on the 256 -> 256 head blocks at 128x128, 0.93-0.97 at 152x272, no gain on the backbone's 32x32 / 64x64 maps
-        // (few items per CU: the per-item prologue / epilogue weigh more) — taken only for the long channel loops on large maps,
-        // where the padding of the map to 32x16-pixel items stays below 15 %.  (An opt-in class: since round 3 the default's
-        // row-Winograd kernel is faster on these layers at a quarter of the rounding error.)
-        const long long pad8 = (long long)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32);
-        if (pad8 * 100 <= area * 115) return 8;
-    }
     // row-Winograd (winograd9.hip): 8-row x 64-pixel x 64-cout work items.  Measured against kernels 2 / 5 / 6 on every 3x3 shape of the
     // three configurations (profiles/r03_winograd9_variants.txt): 0.5-0.8x their time wherever its blocks pad the map by less than ~1.5x
     // (maps at least ~44 pixels wide), channel loops from 32 up, with or without residual / folded upsample
@@ -184,7 +154,7 @@ extern "C" int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p) {
     CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: null params");
     CNL_REQUIRE(p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: non-positive dimension");
     const int c = wino_choice(p);
-    return c == 8 ? CNL_WINO_F16X2_F4 : (c == 5 || c == 6 || c == 7 || c == 9) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
+    return (c == 5 || c == 6 || c == 7 || c == 9) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
 }
 
 extern "C" int cnl_conv3x3_winograd_variant(const cnl_conv_params* p) {
@@ -206,14 +176,14 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 "cnl_conv3x3_winograd_f32: Cin %% 8 != 0 or bad pixel stride");
     CNL_REQUIRE(((uintptr_t)p->x & 15) == 0 && ((uintptr_t)p->w & 15) == 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unaligned x / u");
     CNL_REQUIRE(!p->residual || p->ldr >= p->Cout, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: ldr < Cout");
-    CNL_REQUIRE(p->algo <= CNL_ALGO_F4 || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 9), CNL_E_BAD_ARG,
+    CNL_REQUIRE(p->algo <= CNL_ALGO_F32 || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 9), CNL_E_BAD_ARG,
                 "cnl_conv3x3_winograd_f32: unknown algo %u", p->algo);
     const int choice = wino_choice(p);
     const WeightLayout L(p->Cin, p->Cout);
     float* u = const_cast<float*>(p->w);
-    if (choice == 8 || choice == 5 || choice == 6 || choice == 7 || choice == 9) {
+    if (choice == 5 || choice == 6 || choice == 7 || choice == 9) {
         float* s5 = u + L.s5;
-        if (choice == 8 || choice == 9) {
+        if (choice == 9) {
             // the per-image maxima: handed over by the producer, else one pass over the input (stream-ordered, scratch = the F(2x2)
             // scalars of this layer: one launch at a time per layer and stream, see the header)
             const float* xmax = p->x_absmax;
@@ -222,8 +192,7 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 if (rc != CNL_OK) return rc;
                 xmax = s5 + 16;
             }
-            if (choice == 9) return cnl_wino9_launch(p, u + L.u9, u + L.s9, xmax, stream);
-            return cnl_wino8_launch(p, u + L.u8, u + L.s8, xmax, stream);
+            return cnl_wino9_launch(p, u + L.u9, u + L.s9, xmax, stream);
         }
 #ifdef CNL_EXPERIMENTS
         if (choice == 7) return cnl_wino7_launch(p, u + L.u5, s5, stream);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 9   /* 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 10   /* 10: the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -45,17 +45,13 @@ enum {
  *                  float64 is at or below the fp32 matrix core's (tests/test_gpu_conv.py pins that per kernel).
  *   CNL_ALGO_F2    synonym of CNL_ALGO_AUTO (Winograd tiles no larger than F(2x2,3x3)).
  *   CNL_ALGO_F32   fp32 matrix cores only (v_mfma_f32_32x32x2_f32), no split operands anywhere; hints are ignored.
- *   CNL_ALGO_F4    AUTO, plus Winograd F(4x4,3x3) (csrc/winograd8.hip) on the long 3x3 layers over large maps: 0.56x the matrix work,
- *                  error ~1e-6 of the layer's largest output (~4x F(2x2)).  Opt-in: on MI355X it is bound by the same weight stream
- *                  from the L2 / Infinity Cache as the F(2x2) kernels and ends up within +-5 % of them.
- *   CNL_ALGO_FORCE + v  tests / A-B measurements: pin kernel variant v (2, 5, 6, 8, 9; 1, 3, 4, 7 in `make experiments` builds) wherever
+ *   CNL_ALGO_FORCE + v  tests / A-B measurements: pin kernel variant v (2, 5, 6, 9; 1, 3, 4, 7 in `make experiments` builds) wherever
  *                  it can run at all.
  */
 enum {
     CNL_ALGO_AUTO = 0,
     CNL_ALGO_F2 = 1,
-    CNL_ALGO_F32 = 2,
-    CNL_ALGO_F4 = 3,
+    CNL_ALGO_F32 = 2,                /* (3 was CNL_ALGO_F4 until ABI v9: rejected now) */
     CNL_ALGO_FORCE = 100
 };
 
@@ -172,7 +168,7 @@ int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);
  * core (csrc/winograd2.hip), or — where the channel loop is long (Cin >= 128 or Cout >= 256, Cin % 16 == 0) — the fp16 matrix core
  * fed with a two-way fp16 split of both fp32 operands under a per-image power-of-two scale (three cross terms, fp32
  * accumulation: csrc/winograd5.hip, winograd6.hip; measured error at or below the fp32 matrix core's, half-precision rate = 16x), as
- * F(2x2,3x3) or, under CNL_ALGO_F4 on large maps that 32x16-pixel work items tile well, F(4x4,3x3) (csrc/winograd8.hip).  Round 3: wherever
+ * F(2x2,3x3).  Round 3: wherever
  * 8-row x 64-pixel work items pad the map by less than 1.5x (Cin % 32 == 0, Cout % 4 == 0), the same split arithmetic runs as 1-D Winograd
  * F(2,3) along x with the three kernel rows in the reduction (csrc/winograd9.hip: per-output-channel weight scales; 0.5-0.8x the time of the
  * 2-D kernels, rounding error below theirs) — same class CNL_WINO_F16X2.
@@ -183,20 +179,13 @@ int cnl_conv2d_out_hw(const cnl_conv_params* p, int32_t* H_out, int32_t* W_out);
 #define CNL_WINO_F32 2
 #define CNL_WINO_BF16X3 3      /* experiment builds only */
 #define CNL_WINO_F16X2 5
-#define CNL_WINO_F16X2_F4 8
 int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream);
 int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p);            /* CNL_WINO_* for this layer shape, < 0: error code */
 int cnl_conv3x3_winograd_variant(const cnl_conv_params* p);           /* the kernel behind the class (reporting only): 2 winograd2, 5 / 6 winograd5 / 6
-                                                                         [F(2x2,3x3)], 8 winograd8 [F(4x4,3x3)], 9 winograd9 [F(2,3) along x, kernel rows
+                                                                         [F(2x2,3x3)], 9 winograd9 [F(2,3) along x, kernel rows
                                                                          in the reduction: 2/3 of the direct conv's multiplies]; < 0: error code */
 size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout);        /* elements of the transformed weight buffer */
 int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream);
-/* CNL_ALGO_F4 / CNL_ALGO_FORCE + 8 only: the F(4x4,3x3) copy of the weights is a TAIL of the same buffer — allocate
- * cnl_winograd_f4_weight_floats elements instead, run cnl_winograd_transform_weights_f32 and then cnl_winograd_transform_weights_f4_f32 on it.
- * (Launching with those algos on a buffer without the tail reads past it.) */
-size_t cnl_winograd_f4_weight_floats(int32_t Cin, int32_t Cout);
-int cnl_winograd_transform_weights_f4_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream);
-
 /*
  * Step before the path: uint8 HWC frames -> normalised fp32 NHWC, replacing albumentations
  * A.Normalize + ToTensorV2 of the reference's inference pre-processing (README.md:79-87, datasets/utils.py:9-21):

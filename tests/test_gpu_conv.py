@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from centernet_lightning_amd import _lib
-from centernet_lightning_amd._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_F4, CNL_ALGO_FORCE, CNL_RELU, CNL_SIGMOID, CNL_UPSAMPLE_IN,
+from centernet_lightning_amd._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_FORCE, CNL_RELU, CNL_SIGMOID, CNL_UPSAMPLE_IN,
                                           CNL_UPSAMPLE_OUT_ADD, ConvParams)
 
 pytestmark = pytest.mark.gpu
@@ -437,7 +437,7 @@ def test_maxpool_matches_cpu_bit_exact(shape):
 
 # ----------------------------------------------------------------------------- Winograd F(2x2,3x3) path
 def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None, algo=CNL_ALGO_AUTO, lib=None, want=None, ymax=False):
-    """`want`: assert that the dispatcher reports this kernel class (2 fp32 / 5 fp16-split F(2x2) / 8 fp16-split F(4x4))."""
+    """`want`: assert that the dispatcher reports this kernel class (2 fp32 / 5 fp16-split)."""
     lib = lib or _lib.load()
     N, Cin, Hs, Ws = x_nchw.shape
     upf = 2 if flags & CNL_UPSAMPLE_IN else 1
@@ -445,11 +445,8 @@ def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None, algo=CNL_ALGO_AUT
     Cout = w_oihw.shape[0]
     xd = x_nchw.permute(0, 2, 3, 1).contiguous().cuda()
     wd = w_oihw.permute(0, 2, 3, 1).contiguous().cuda()
-    f4 = algo in (CNL_ALGO_F4, CNL_ALGO_FORCE + 8)              # the F(4x4) copy of the weights is an optional tail of the buffer
-    u = torch.full(((lib.cnl_winograd_f4_weight_floats if f4 else lib.cnl_winograd_weight_floats)(Cin, Cout),), float("nan"), device="cuda")
+    u = torch.full((lib.cnl_winograd_weight_floats(Cin, Cout),), float("nan"), device="cuda")
     _lib.check(lib.cnl_winograd_transform_weights_f32(wd.data_ptr(), u.data_ptr(), Cin, Cout, _stream()))
-    if f4:
-        _lib.check(lib.cnl_winograd_transform_weights_f4_f32(wd.data_ptr(), u.data_ptr(), Cin, Cout, _stream()))
     bd = bias.cuda()
     y = torch.full((N, H, W, Cout), float("nan"), device="cuda")
     p = ConvParams()
@@ -525,9 +522,7 @@ def test_winograd_exact_on_small_integers():
 
 def test_winograd_split_kernels_exact_on_small_integers():
     """The same exactness check on a layer that takes a split-operand kernel (Cin = 256): small integers are exact in the first
-    piece (and stay so under the power-of-two scaling), so every product and partial sum is exact there too.  F(2x2) only: the
-    F(4x4) transforms multiply by 5/8, 3/2, ... and are not integer-exact (its own test below pins indexing the same way through
-    an error bound far below one unit)."""
+    piece (and stay so under the power-of-two scaling), so every product and partial sum is exact there too."""
     g = torch.Generator().manual_seed(3)
     x = torch.randint(-3, 4, (1, 256, 32, 32), generator=g).float()
     w = torch.randint(-2, 3, (128, 256, 3, 3), generator=g).float() * 4
@@ -535,19 +530,17 @@ def test_winograd_split_kernels_exact_on_small_integers():
     for v in (5, 6, 9):
         assert torch.equal(run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + v, want=5), ref_conv(x, w, b, 1, 0)), v
     assert torch.equal(run_winograd(x, w, b, 0, algo=CNL_ALGO_F2, want=5), ref_conv(x, w, b, 1, 0))
-    out = run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + 8, want=8)               # F(4x4): integers up to ~4e3, error << 0.5
-    assert (out - ref_conv(x, w, b, 1, 0)).abs().max().item() < 2e-2
 
 
 def test_winograd_is_batch_invariant_across_magnitudes():
     """An image's output must not depend on its batch neighbours (shard == full batch) — also on the fp16-split
     kernels, whose power-of-two input scale therefore is taken per image: images of very different magnitude in one launch give
-    bit for bit what each gives alone.  Both Winograd tile sizes."""
+    bit for bit what each gives alone."""
     g = torch.Generator().manual_seed(17)
     x = torch.randn(3, 256, 32, 32, generator=g).clamp_min(0) * torch.tensor([1.0, 1e-3, 300.0]).view(3, 1, 1, 1)
     w = torch.randn(128, 256, 3, 3, generator=g) * (2.0 / (256 * 9)) ** 0.5
     b = torch.randn(128, generator=g)
-    for algo, want in ((CNL_ALGO_FORCE + 8, 8), (CNL_ALGO_FORCE + 9, 5), (CNL_ALGO_FORCE + 5, 5), (CNL_ALGO_F2, 5), (CNL_ALGO_F32, 2)):
+    for algo, want in ((CNL_ALGO_FORCE + 9, 5), (CNL_ALGO_FORCE + 5, 5), (CNL_ALGO_F2, 5), (CNL_ALGO_F32, 2)):
         full = run_winograd(x, w, b, CNL_RELU, algo=algo, want=want)
         for i in range(3):
             assert torch.equal(full[i:i + 1], run_winograd(x[i:i + 1], w, b, CNL_RELU, algo=algo)), (algo, i)
@@ -574,64 +567,6 @@ def test_winograd6_images_side_by_side_is_bit_identical_to_one_image_at_a_time(s
         one = run_winograd(x[i:i + 1], w, b, CNL_RELU, residual=res[i:i + 1], algo=CNL_ALGO_FORCE + 6)
         assert torch.equal(full[i:i + 1], one), i
     torch.testing.assert_close(full, ref_conv(x, w, b, 1, CNL_RELU, res), rtol=RTOL, atol=ATOL * 300)
-
-
-F4_CASES = [
-    # N, Cin, H, W, Cout, flags, residual            (forced with CNL_ALGO_FORCE + 8 where the shape rule would not take F(4x4))
-    (1, 128, 16, 32, 64, CNL_RELU, False),             # exactly one work item per cout block
-    (2, 256, 32, 32, 256, CNL_RELU, True),             # K = 2304, residual, pairs of cout blocks
-    (1, 128, 19, 34, 96, CNL_RELU, True),              # ragged 32x16 items (608x1088 /32 grid), Cout tail 96 -> 128 (odd block count)
-    (3, 144, 20, 40, 64, 0, False),                    # Cin = 9 chunks, several images, no ReLU
-    (1, 128, 7, 5, 32, 0, False),                      # map smaller than one item, Cout < 64
-    (1, 128, 8, 12, 64, CNL_RELU | CNL_UPSAMPLE_IN, False),    # nearest-2x upsample folded into the patch gather
-    (1, 256, 64, 64, 128, CNL_RELU, False),            # many items per CU
-]
-
-
-@pytest.mark.parametrize("case", F4_CASES, ids=lambda c: "N{}c{}_{}x{}_o{}f{}r{}".format(*[int(v) for v in c]))
-def test_winograd_f4_matches_cpu(case):
-    """csrc/winograd8.hip (F(4x4,3x3), fp16-split) against conv2d on the CPU: the path's 1e-4 tolerance, plus the kernel's own bar —
-    max error <= 1e-5 of the layer's largest output against float64."""
-    N, Cin, H, W, Cout, flags, use_res = case
-    x, w, b = mk(N, Cin, H, W, Cout, 3, seed=Cin + Cout + H + W)
-    x[N - 1] *= 11.0
-    up = 2 if flags & CNL_UPSAMPLE_IN else 1
-    res = torch.randn(N, Cout, H * up, W * up, generator=torch.Generator().manual_seed(6)) if use_res else None
-    ref = ref_conv(x, w, b, 1, flags, res)
-    out = run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 8, want=8)
-    assert not torch.isnan(out).any()
-    torch.testing.assert_close(out, ref, rtol=RTOL, atol=ATOL * max(1.0, ref.abs().max().item() / 10))
-    ref64 = ref_conv(x.double(), w.double(), b.double(), 1, flags, res.double() if use_res else None)
-    for n in range(N):
-        assert (out[n].double() - ref64[n]).abs().max().item() <= 1e-5 * ref64[n].abs().max().item(), n
-
-
-def test_winograd_f4_hands_over_absmax_and_takes_the_hint():
-    """x_absmax / y_absmax hand-over through the F(4x4) kernel: with the hint it makes no pass of its own and gives the same bits;
-    the maximum it reports is exactly the maximum of what it stored."""
-    lib = _lib.load()
-    x, w, b = mk(2, 128, 32, 32, 64, 3, seed=77)
-    x = x.clamp_min(0)
-    x[1] *= 1e-3
-    base = run_winograd(x, w, b, CNL_RELU, algo=CNL_ALGO_FORCE + 8, want=8)
-    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
-    wd = w.permute(0, 2, 3, 1).contiguous().cuda()
-    u = torch.empty((lib.cnl_winograd_f4_weight_floats(128, 64),), device="cuda")
-    _lib.check(lib.cnl_winograd_transform_weights_f32(wd.data_ptr(), u.data_ptr(), 128, 64, _stream()))
-    _lib.check(lib.cnl_winograd_transform_weights_f4_f32(wd.data_ptr(), u.data_ptr(), 128, 64, _stream()))
-    bd = b.cuda()
-    y = torch.full((2, 32, 32, 64), float("nan"), device="cuda")
-    xm = x.abs().amax(dim=(1, 2, 3)).cuda()
-    ym = torch.zeros(2, device="cuda")
-    p = ConvParams()
-    p.x, p.w, p.bias, p.y = xd.data_ptr(), u.data_ptr(), bd.data_ptr(), y.data_ptr()
-    p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.ldx, p.ldy, p.flags = 2, 32, 32, 128, 64, 3, 3, 1, 1, 128, 64, CNL_RELU
-    p.x_absmax, p.y_absmax, p.algo = xm.data_ptr(), ym.data_ptr(), CNL_ALGO_FORCE + 8
-    _lib.check(lib.cnl_conv3x3_winograd_f32(ctypes.byref(p), _stream()), "winograd")
-    torch.cuda.synchronize()
-    out = y.cpu().permute(0, 3, 1, 2)
-    assert torch.equal(out, base)
-    assert torch.equal(ym.cpu(), out.abs().amax(dim=(1, 2, 3)))
 
 
 def _exp_lib():
@@ -670,9 +605,7 @@ def test_winograd_split_kernels_error_not_above_fp32_mfma():
     """winograd5.hip / winograd6.hip (scaled two-way fp16 split, three cross terms, F(2x2)) form fp32 products on the 16x faster matrix
     cores and accumulate in fp32: their error against float64 must be no larger than that of the fp32 matrix-core kernel on the same
     layer (K = 2304) — also with channels spanning six decades of magnitude and with a tensor whose values are all tiny or all huge
-    (the scale follows the image's maximum).  winograd8.hip (F(4x4)) pays for its smaller matrix work with rounding error in the
-    transforms: its bar is absolute — <= 4e-6 of the layer's largest output (measured ~1e-6; the F(2x2) kernels ~3e-7) — and at most
-    8x the fp32 matrix core's.  With the experiment build the superseded variants 3 (exact bf16 split) and 7 are held to the F(2x2) bar."""
+    (the scale follows the image's maximum).  With the experiment build the superseded variants 3 (exact bf16 split) and 7 are held to the F(2x2) bar."""
     exp = _exp_lib()
     g = torch.Generator().manual_seed(11)
     for case in ("plain", "spread", "tiny", "huge"):
@@ -687,16 +620,15 @@ def test_winograd_split_kernels_error_not_above_fp32_mfma():
         b = torch.zeros(256)
         ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
         err = {}
-        for v in (2, 5, 6, 8, 9) + ((3, 7) if exp is not None else ()):
+        for v in (2, 5, 6, 9) + ((3, 7) if exp is not None else ()):
             out = run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + v, lib=exp if v in (3, 7) else None)
             assert torch.isfinite(out).all(), (case, v)
             err[v] = (out.double() - ref).abs().max().item()
         scale = ref.abs().max().item()
         for v in err:
-            if v in (2, 8):
+            if v == 2:
                 continue
             assert err[v] <= 1.25 * err[2] + 1e-7 * scale, (case, v, err, scale)
-        assert err[8] <= 4e-6 * scale and err[8] <= 8 * err[2] + 1e-7 * scale, (case, err, scale)
         assert err[2] < 2e-5 * scale, (case, err, scale)
 
 
@@ -836,7 +768,7 @@ def test_split_kernels_on_trained_checkpoint_like_weights():
 
 def test_winograd_dispatch_is_a_function_of_shape_and_algo_only():
     """cnl_conv3x3_winograd_kernel: the kernel class follows the layer shape and the caller's algo — never the batch size, never the
-    environment.  F(4x4) only under CNL_ALGO_F4, on long channel loops (Cin >= 256) over large maps."""
+    environment.  (The F(4x4) class of ABI <= 9 is gone: algo 3 is rejected.)"""
     lib = _lib.load()
 
     def kind(N, Cin, H, W, Cout, algo):
@@ -845,12 +777,11 @@ def test_winograd_dispatch_is_a_function_of_shape_and_algo_only():
         return lib.cnl_conv3x3_winograd_kernel(ctypes.byref(p))
 
     for N in (1, 7, 32):
-        assert kind(N, 256, 128, 128, 256, CNL_ALGO_F4) == 8            # head blocks, F(4x4) allowed
-        assert kind(N, 256, 152, 272, 256, CNL_ALGO_F4) == 8            # ... of 608 x 1088 frames
-        assert kind(N, 256, 128, 128, 256, CNL_ALGO_AUTO) == 5          # the default never takes F(4x4)
+        assert kind(N, 256, 128, 128, 256, CNL_ALGO_AUTO) == 5          # head blocks
+        assert kind(N, 256, 152, 272, 256, CNL_ALGO_AUTO) == 5          # ... of 608 x 1088 frames
         assert kind(N, 256, 128, 128, 256, CNL_ALGO_F2) == 5
         assert kind(N, 256, 128, 128, 256, CNL_ALGO_F32) == 2
-        assert kind(N, 256, 32, 32, 256, CNL_ALGO_F4) == 5              # layer3: F(2x2) even when F(4x4) is allowed
+        assert kind(N, 256, 32, 32, 256, CNL_ALGO_AUTO) == 5            # layer3
         assert kind(N, 128, 64, 64, 128, CNL_ALGO_AUTO) == 5            # layer2
         assert kind(N, 64, 128, 128, 64, CNL_ALGO_AUTO) == 5            # layer1: row-Winograd on the fp16 matrix cores (round 3)
         assert kind(N, 64, 16, 16, 64, CNL_ALGO_AUTO) == 2              # short channel loop on a map its 64-pixel blocks would pad 4x: fp32 matrix cores

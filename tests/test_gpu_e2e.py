@@ -42,7 +42,9 @@ def compare_detections(dets, ref, k, indices=None):
     gap_next = np.abs(np.diff(ref["scores"], axis=1, append=-np.inf))
     safe = (gap_prev > GAP) & (gap_next > GAP)
     safe[:, -1] = False                       # the k-th may swap with the (k+1)-th
-    assert safe.mean() > 0.5, safe.mean()
+    # the share of the top-k ranks this comparison actually pins end to end (the rest is pinned on identical bytes only: Level A below)
+    print(f"compare_detections: safe fraction {safe.mean():.3f} of {safe.size} ranks (gap > {GAP:g} on both sides)")
+    assert safe.mean() >= 0.8, safe.mean()
     assert np.array_equal(l[safe], ref["labels"][safe])
     if indices is not None:                   # top-k indices bit-exact
         assert np.array_equal(indices.cpu().numpy()[safe], ref["indices"][safe])
@@ -214,19 +216,16 @@ def _feature_errors(cfg, shape, algo, mutate=None, x=None):
 def test_feature_level_error_against_float64(cfg, shape):
     """The sharp end-to-end gate.  The outputs behind out_conv (sigma = 0.01 weights, sigmoid' = 0.09) hide feature errors
     by three orders of magnitude, so this test looks at the FEATURES: the neck output and each head's last block output, against the
-    float64 oracle, as max |err| / max |ref|, for three arithmetic classes of the plan:
+    float64 oracle, as max |err| / max |ref|, for the arithmetic classes of the plan:
       f32   every conv on the fp32 matrix cores (no split operands)          — the yardstick
       auto  the default: fp16-split matrix cores, Winograd F(2x2)            — must be <= 1.25 x f32 (+ 1e-6)
-      f4    opt-in: F(4x4,3x3) on the long 3x3 layers over large maps        — must be <= 4 x max(f32, CPU fp32 oracle)
     and all of them <= 1e-4, the path's tolerance (fp32 rounding through 33 conv layers is itself ~1e-5 of the maximum: the CPU
     oracle's own distance from float64 is printed and used as the second yardstick)."""
-    e = {a: _feature_errors(cfg, shape, a) for a in ("f32", "auto", "f4", "cpu")}
+    e = {a: _feature_errors(cfg, shape, a) for a in ("f32", "auto", "cpu")}
     print("feature errors vs float64 (max err / max ref):", cfg, e)
     for key in e["f32"]:
-        yard = max(e["f32"][key], e["cpu"][key])
         assert e["auto"][key] <= 1.25 * e["f32"][key] + 1e-6, (key, e)
-        assert e["f4"][key] <= 4.0 * yard + 1e-6, (key, e)
-        for a in ("f32", "auto", "f4"):
+        for a in ("f32", "auto"):
             assert e[a][key] <= 1e-4, (a, key, e)
 
 

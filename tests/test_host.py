@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/centernet_gfx950.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.cnl_version() == 9
+    assert lib.cnl_version() == _lib.ABI_VERSION == 10
 
 
 def test_abi_error_convention_without_gpu():
@@ -236,6 +236,15 @@ def _world8_worker(rank, world, port, ret):
         ok = ok and worst == 1.0 + 0.25 * (world - 1) and bench.job_throughput(32, world, 10, worst) == 32 * world * 10 / worst
         lo, hi = shard_range(512, rank, world)                         # C3: 512 images over 8 ranks
         ok = ok and (lo, hi) == (64 * rank, 64 * rank + 64)
+        # `bench.py --gpus 8 --steps K --warmup W` (the driver's command): the default workload is C1 and the run ALSO schedules the two
+        # configurations BASELINE.json defines on 8 GPUs — C3 (FPN, 64 per GPU) and C4 (tracking, 32 per GPU at 608 x 1088, k = 100)
+        a = bench.parse_args(["--gpus", str(world), "--steps", "5", "--warmup", "2"])
+        ok = ok and (a.gpus, a.config, a.batch, a.height, a.width, a.no_also) == (world, "simple", 32, 512, 512, False)
+        also = bench.also_workloads(w, a.config, a.batch, a.height, a.width)
+        ok = ok and [(s_["config"], s_["batch"], s_["height"], s_["width"], s_["k"]) for s_ in also] == [("fpn", 64, 512, 512, 100), ("tracking", 32, 608, 1088, 100)]
+        ok = ok and also[0]["name"].startswith("C3 (512 images") and also[1]["name"].startswith("C4 (256 images")
+        ok = ok and [s_["name"][:2] for s_ in bench.also_workloads(1, "simple", 32, 512, 512)] == ["C2", "C4"]
+        ok = ok and bench.also_workloads(w, "fpn", 64, 512, 512) == []          # only the default (C1) run appends them
         c = Collator(depth=2)
         pending, want = None, None
         for step in range(3):                                          # three pipelined steps: result one step behind submit
@@ -254,9 +263,14 @@ def _world8_worker(rank, world, port, ret):
             c.result_records(h0); ok = False
         except RuntimeError:
             pass
+        # one slot: strictly sequential use works, a result collected behind a later submit raises (the same generation check)
+        c1 = Collator(depth=1)
+        g1 = c1.result_records(c1.submit_records(torch.full((2, 5, 6), float(rank))))
+        ok = ok and all(bool((g1[2 * q:2 * q + 2] == q).all()) for q in range(world))
+        h1 = c1.submit_records(torch.zeros(2, 5, 6)); c1.submit_records(torch.ones(2, 5, 6))
         try:
-            Collator(depth=1).submit_records(torch.zeros(2, 5, 6)); ok = False
-        except ValueError:
+            c1.result_records(h1); ok = False
+        except RuntimeError:
             pass
         ret[rank] = bool(ok)
     finally:

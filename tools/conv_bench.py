@@ -92,9 +92,8 @@ def main():
         if args.winograd:
             if k != 3 or stride != 1:
                 continue
-            u = torch.empty(lib.cnl_winograd_f4_weight_floats(Cin, Cout), device="cuda")
+            u = torch.empty(lib.cnl_winograd_weight_floats(Cin, Cout), device="cuda")
             _lib.check(lib.cnl_winograd_transform_weights_f32(w.data_ptr(), u.data_ptr(), Cin, Cout, stream))
-            _lib.check(lib.cnl_winograd_transform_weights_f4_f32(w.data_ptr(), u.data_ptr(), Cin, Cout, stream))
             p.w = u.data_ptr()
             p.flags = flags & 5            # RELU | UPSAMPLE_IN
             fn = lib.cnl_conv3x3_winograd_f32
@@ -133,7 +132,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
         flops = 2.0 * N * Ho * Wo * Cout * k * k * Cin
-        kern = lib.cnl_conv3x3_winograd_kernel(ctypes.byref(p)) if args.winograd else lib.cnl_conv2d_kernel(ctypes.byref(p))
+        kern = lib.cnl_conv3x3_winograd_variant(ctypes.byref(p)) if args.winograd else lib.cnl_conv2d_kernel(ctypes.byref(p))
         extra = ""
         if args.check:
             got = y.clone()

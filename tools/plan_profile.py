@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-launch table of one forward's plan (HIP events around every launch, whole plan replayed in order):
-python tools/plan_profile.py [--config simple|fpn|tracking] [--batch N] [--size H W] [--algo auto|f4|f32]"""
+python tools/plan_profile.py [--config simple|fpn|tracking] [--batch N] [--size H W] [--algo auto|f32]"""
 import argparse
 import os
 import sys
