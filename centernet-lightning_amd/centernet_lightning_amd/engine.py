@@ -21,7 +21,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_RELU, CNL_RELU6, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD, CNL_W_SPLIT,
+from ._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_LATENCY, CNL_RELU, CNL_RELU6, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD, CNL_W_SPLIT,
                    CNL_WINO_F16X2, ConvParams, DeconvParams)
 
 BN_EPS_DEFAULT = 1e-5
@@ -42,6 +42,10 @@ class KernelOptions:
       presplit_weights the direct convs' weights carry their fp16 split (CNL_W_SPLIT): the fp16-split direct kernel reads the pieces
                        instead of splitting every chunk's weights again — same bits out, -20..-35 % on the stride-2 3x3 convs
       reuse_buffers    activation buffers share one arena by liveness; False keeps every intermediate (tests read them)
+      latency          latency class for one-image batches (default off): every 3x3 / stride-1 layer the row-Winograd kernels can run
+                       takes csrc/winograd10.hip's 4-row x 64-pixel x 32-cout work items (cnl_conv_params.algo = CNL_ALGO_LATENCY) — four times the
+                       work items of the default's, two workgroups per CU.  An option of the plan, never a function of the batch size: a plan built
+                       with it is batch-invariant like any other (same bits as the default wherever the default takes a row-Winograd kernel).
       split_small      latency mode for small batches (default off): launches whose output is too small to fill the chip (one image: the
                        16x16 .. 64x64 maps) run as direct convs with the reduction split over several workgroups per output tile and a
                        fixed-order reduce (cnl_conv_params.splitk).  The choice then depends on the batch size, so results are no longer
@@ -54,6 +58,7 @@ class KernelOptions:
     presplit_weights: bool = True
     reuse_buffers: bool = True
     split_small: bool = False
+    latency: bool = False
 
     @property
     def algo_id(self):
@@ -601,16 +606,19 @@ class Plan:
             p.w = layer.u.data_ptr()
             fn = self.lib.cnl_conv3x3_winograd_f32
             what += " [winograd]"
+            if self.options.latency and self.algo in (CNL_ALGO_AUTO, CNL_ALGO_F2):
+                p.algo = CNL_ALGO_LATENCY
         # the row-Winograd kernels (winograd9.hip / winograd10.hip) fold the upsample into their patch gather and beat the sub-pixel phases
         # below (C1: 8.93 -> 8.82 ms per forward); whether a layer takes one is the dispatcher's decision — asked, not re-derived here
         rowwino = (fn is self.lib.cnl_conv3x3_winograd_f32 and self.algo != CNL_ALGO_F32
-                   and self.lib.cnl_conv3x3_winograd_variant(ctypes.byref(p)) in (9, 10))
+                   and self.lib.cnl_conv3x3_winograd_variant(ctypes.byref(p)) in (9, 10, 11))
         if (self.options.up2 and (flags & CNL_UPSAMPLE_IN) and not (flags & ~(CNL_RELU | CNL_UPSAMPLE_IN)) and residual is None
                 and layer.wants_up2() and not rowwino):
             # short channel loop, many couts, conv on the nearest-2x upsampled input (the fused first head blocks behind the simple
             # neck): four 2x2 sub-pixel phase convs on the low-resolution input (fp16-split direct kernel) beat Winograd there
             p.w = layer.up2().data_ptr()
             p.w_absmax = layer.up2_wmax.data_ptr()
+            p.algo = self.algo
             fn = self.lib.cnl_conv3x3_up2_nhwc_f32
             what = what.replace(" [winograd]", "") + " [sub-pixel phases]"
         if fn is self.lib.cnl_conv2d_nhwc_f32 and self.options.presplit_weights and self.algo != CNL_ALGO_F32:

@@ -11,6 +11,8 @@
 //                     terms, fp32 accumulation: error at or below the fp32 MFMA's), 16x16-pixel x 64-cout work items;
 //   6  winograd6.hip  the same on 8x16-pixel x 128-cout work items (short channel loop with many couts, or maps that 16-row blocks pad);
 //   9  winograd9.hip  1-D F(2,3) along x with the kernel rows folded into the reduction, same split: 8-row x 64-pixel x 64-cout items.
+//  10  winograd10.hip the same arithmetic (and weights) on 4-row x 64-pixel x 64-cout items, two workgroups per CU: 16-pixel-wide maps;
+//  11                 ... on 4-row x 64-pixel x 32-cout items: 16-pixel maps with Cout <= 256, and the latency class (CNL_ALGO_LATENCY).
 //   (8, the F(4x4,3x3) split kernel of round 2, was removed in ABI v10: slower than 9 at 4x its rounding error.)
 // The 16x16-pixel-block fp32 kernel this file used to hold, the exact three-way bf16 split (winograd3/4) and the two-waves-per-SIMD
 // form of 5 (winograd7) are measured-and-superseded variants: tools/experiments/ (`make -C csrc experiments`, algo = CNL_ALGO_FORCE + variant).
@@ -61,6 +63,8 @@ size_t cnl_wino9_scalar_floats(int Cin, int Cout);
 int cnl_wino9_transform_weights(const float* w_ohwi, void* u9, float* isu, int Cin, int Cout, void* stream);
 bool cnl_wino9_eligible(const cnl_conv_params* p);
 int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream);
+bool cnl_wino10_eligible(const cnl_conv_params* p);                                // winograd10.hip (reads winograd9.hip's weights)
+int cnl_wino10_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, bool cout32, void* stream);
 #ifdef CNL_EXPERIMENTS
 int cnl_wino1_launch(const cnl_conv_params* p, void* stream);                       // tools/experiments/winograd1.hip
 size_t cnl_wino3_weight_bytes(int Cin, int Cout);                                  // tools/experiments/winograd3.hip
@@ -126,11 +130,22 @@ static int wino_choice(const cnl_conv_params* p) {
         if (v <= 2 || p->Cin % 16) return v == 1 ? 1 : 2;
         if (v == 8) return 5;                              // (removed in ABI v10)
         if (v == 9 && !cnl_wino9_eligible(p)) return 5;
+        if ((v == 10 || v == 11) && !cnl_wino10_eligible(p)) return 5;
         if (v == 6 && p->Cout % 128) return 5;
         return v;
     }
     if (p->algo == CNL_ALGO_F32 || p->Cin % 16) return 2;
     const long long area = (long long)H * W;
+    // the latency class (one-image batches, BASELINE C0): 4-row x 64-pixel x 32-cout row-Winograd items, two workgroups per CU — four times the
+    // work items of winograd9's (a 32 x 32 map of one image: 64 instead of 16).  Measured at N = 1 against the default choice
+    // (profiles/r04_winograd_variants.txt): layer1 22 -> 16 us, layer2 29 -> 16, layer3 46 -> 23, layer4 61 -> 38, 512 -> 256 @16x16 69 -> 36;
+    // not behind a folded upsample (64 -> 512 first head blocks: 44 us on winograd9, 60 here).  An arithmetic class of its own: the caller
+    // asks for it, the batch size never does.
+    if (p->algo == CNL_ALGO_LATENCY && upf == 1 && cnl_wino10_eligible(p)) return 11;
+    // 16-pixel-wide maps (four images side by side in a block row): the half-height items of winograd10.hip give the chip twice the work
+    // items of winograd9's and a second workgroup per CU to overlap with — 512 -> 512 @16x16 x 32: 83 us (winograd5: 90-93, winograd9: 97-107),
+    // 512 -> 256: 61-65 us with 32-cout items (fp32 kernel: 89-92)
+    if (upf == 1 && W == 16 && cnl_wino10_eligible(p)) return p->Cout <= 256 ? 11 : 10;
     // row-Winograd (winograd9.hip): 8-row x 64-pixel x 64-cout work items.  Measured against kernels 2 / 5 / 6 on every 3x3 shape of the
     // three configurations (profiles/r03_winograd9_variants.txt): 0.5-0.8x their time wherever its blocks pad the map by less than ~1.5x
     // (maps at least ~44 pixels wide), channel loops from 32 up, with or without residual / folded upsample
@@ -154,7 +169,7 @@ extern "C" int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p) {
     CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: null params");
     CNL_REQUIRE(p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: non-positive dimension");
     const int c = wino_choice(p);
-    return (c == 5 || c == 6 || c == 7 || c == 9) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
+    return (c == 5 || c == 6 || c == 7 || c == 9 || c == 10 || c == 11) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
 }
 
 extern "C" int cnl_conv3x3_winograd_variant(const cnl_conv_params* p) {
@@ -176,14 +191,14 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 "cnl_conv3x3_winograd_f32: Cin %% 8 != 0 or bad pixel stride");
     CNL_REQUIRE(((uintptr_t)p->x & 15) == 0 && ((uintptr_t)p->w & 15) == 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unaligned x / u");
     CNL_REQUIRE(!p->residual || p->ldr >= p->Cout, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: ldr < Cout");
-    CNL_REQUIRE(p->algo <= CNL_ALGO_F32 || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 9), CNL_E_BAD_ARG,
+    CNL_REQUIRE(p->algo <= CNL_ALGO_F32 || p->algo == CNL_ALGO_LATENCY || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 11), CNL_E_BAD_ARG,
                 "cnl_conv3x3_winograd_f32: unknown algo %u", p->algo);
     const int choice = wino_choice(p);
     const WeightLayout L(p->Cin, p->Cout);
     float* u = const_cast<float*>(p->w);
-    if (choice == 5 || choice == 6 || choice == 7 || choice == 9) {
+    if (choice == 5 || choice == 6 || choice == 7 || choice >= 9) {
         float* s5 = u + L.s5;
-        if (choice == 9) {
+        if (choice >= 9) {
             // the per-image maxima: handed over by the producer, else one pass over the input (stream-ordered, scratch = the F(2x2)
             // scalars of this layer: one launch at a time per layer and stream, see the header)
             const float* xmax = p->x_absmax;
@@ -192,7 +207,8 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 if (rc != CNL_OK) return rc;
                 xmax = s5 + 16;
             }
-            return cnl_wino9_launch(p, u + L.u9, u + L.s9, xmax, stream);
+            if (choice == 9) return cnl_wino9_launch(p, u + L.u9, u + L.s9, xmax, stream);
+            return cnl_wino10_launch(p, u + L.u9, u + L.s9, xmax, choice == 11, stream);
         }
 #ifdef CNL_EXPERIMENTS
         if (choice == 7) return cnl_wino7_launch(p, u + L.u5, s5, stream);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 10   /* 10: the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 10   /* 10: CNL_ALGO_LATENCY and the half-height row-Winograd kernel (csrc/winograd10.hip, variants 10 / 11); the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -45,13 +45,17 @@ enum {
  *                  float64 is at or below the fp32 matrix core's (tests/test_gpu_conv.py pins that per kernel).
  *   CNL_ALGO_F2    synonym of CNL_ALGO_AUTO (Winograd tiles no larger than F(2x2,3x3)).
  *   CNL_ALGO_F32   fp32 matrix cores only (v_mfma_f32_32x32x2_f32), no split operands anywhere; hints are ignored.
- *   CNL_ALGO_FORCE + v  tests / A-B measurements: pin kernel variant v (2, 5, 6, 9; 1, 3, 4, 7 in `make experiments` builds) wherever
+ *   CNL_ALGO_LATENCY  cnl_conv3x3_winograd_f32 only: AUTO's arithmetic on small work items (csrc/winograd10.hip: 4 rows x 64 pixels x 32 couts, two
+ *                  workgroups per CU) wherever the row-Winograd kernels apply — for one-image batches, where the default's 8-row x 64-cout items leave
+ *                  most CUs idle (a 256 -> 256 conv on a 32 x 32 map: 46 -> 23 us).  Same bits as AUTO wherever AUTO takes a row-Winograd kernel.
+ *   CNL_ALGO_FORCE + v  tests / A-B measurements: pin kernel variant v (2, 5, 6, 9, 10, 11; 1, 3, 4, 7 in `make experiments` builds) wherever
  *                  it can run at all.
  */
 enum {
     CNL_ALGO_AUTO = 0,
     CNL_ALGO_F2 = 1,
     CNL_ALGO_F32 = 2,                /* (3 was CNL_ALGO_F4 until ABI v9: rejected now) */
+    CNL_ALGO_LATENCY = 4,
     CNL_ALGO_FORCE = 100
 };
 
@@ -183,7 +187,8 @@ int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream);
 int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p);            /* CNL_WINO_* for this layer shape, < 0: error code */
 int cnl_conv3x3_winograd_variant(const cnl_conv_params* p);           /* the kernel behind the class (reporting only): 2 winograd2, 5 / 6 winograd5 / 6
                                                                          [F(2x2,3x3)], 9 winograd9 [F(2,3) along x, kernel rows
-                                                                         in the reduction: 2/3 of the direct conv's multiplies]; < 0: error code */
+                                                                         in the reduction: 2/3 of the direct conv's multiplies], 10 / 11 winograd10
+                                                                         [the same on 4-row x 64- / 32-cout items]; < 0: error code */
 size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout);        /* elements of the transformed weight buffer */
 int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream);
 /*

@@ -527,7 +527,7 @@ def test_winograd_split_kernels_exact_on_small_integers():
     x = torch.randint(-3, 4, (1, 256, 32, 32), generator=g).float()
     w = torch.randint(-2, 3, (128, 256, 3, 3), generator=g).float() * 4
     b = torch.randint(-5, 6, (128,), generator=g).float()
-    for v in (5, 6, 9):
+    for v in (5, 6, 9, 10, 11):
         assert torch.equal(run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + v, want=5), ref_conv(x, w, b, 1, 0)), v
     assert torch.equal(run_winograd(x, w, b, 0, algo=CNL_ALGO_F2, want=5), ref_conv(x, w, b, 1, 0))
 
@@ -540,7 +540,7 @@ def test_winograd_is_batch_invariant_across_magnitudes():
     x = torch.randn(3, 256, 32, 32, generator=g).clamp_min(0) * torch.tensor([1.0, 1e-3, 300.0]).view(3, 1, 1, 1)
     w = torch.randn(128, 256, 3, 3, generator=g) * (2.0 / (256 * 9)) ** 0.5
     b = torch.randn(128, generator=g)
-    for algo, want in ((CNL_ALGO_FORCE + 9, 5), (CNL_ALGO_FORCE + 5, 5), (CNL_ALGO_F2, 5), (CNL_ALGO_F32, 2)):
+    for algo, want in ((CNL_ALGO_FORCE + 9, 5), (CNL_ALGO_FORCE + 10, 5), (CNL_ALGO_FORCE + 11, 5), (CNL_ALGO_FORCE + 5, 5), (CNL_ALGO_F2, 5), (CNL_ALGO_F32, 2)):
         full = run_winograd(x, w, b, CNL_RELU, algo=algo, want=want)
         for i in range(3):
             assert torch.equal(full[i:i + 1], run_winograd(x[i:i + 1], w, b, CNL_RELU, algo=algo)), (algo, i)
@@ -620,7 +620,7 @@ def test_winograd_split_kernels_error_not_above_fp32_mfma():
         b = torch.zeros(256)
         ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
         err = {}
-        for v in (2, 5, 6, 9) + ((3, 7) if exp is not None else ()):
+        for v in (2, 5, 6, 9, 10, 11) + ((3, 7) if exp is not None else ()):
             out = run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + v, lib=exp if v in (3, 7) else None)
             assert torch.isfinite(out).all(), (case, v)
             err[v] = (out.double() - ref).abs().max().item()
@@ -633,7 +633,7 @@ def test_winograd_split_kernels_error_not_above_fp32_mfma():
 
 
 W9_CASES = [
-    # N, Cin, H, W, Cout, flags, residual — winograd9.hip (row-Winograd): 8-row x 64-pixel x 64-cout work items
+    # N, Cin, H, W, Cout, flags, residual — winograd9.hip / winograd10.hip (row-Winograd): 8- / 4-row x 64-pixel x 64-cout work items
     (1, 32, 8, 64, 64, 0, False),                       # one work item, two chunks (the shortest channel loop)
     (1, 32, 8, 64, 64, CNL_RELU, True),
     (2, 64, 16, 128, 64, CNL_RELU, False),              # two blocks across, two down, layer1 channels
@@ -648,26 +648,31 @@ W9_CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [9, 10, 11])
 @pytest.mark.parametrize("case", W9_CASES, ids=lambda c: "N{}c{}_{}x{}_o{}f{}r{}".format(*[int(v) for v in c]))
-def test_winograd9_matches_cpu_and_reports_absmax(case):
-    """winograd9.hip forced on shapes that exercise its edges: the path's 1e-4 bar against conv2d on the CPU, error against float64 at or
-    below the fp32 matrix-core kernel's (+ 1e-7 of the layer maximum), max |y| per image handed over exactly."""
+def test_winograd9_matches_cpu_and_reports_absmax(case, variant):
+    """winograd9.hip / winograd10.hip forced on shapes that exercise their edges: the path's 1e-4 bar against conv2d on the CPU, error against
+    float64 at or below the fp32 matrix-core kernel's (+ 1e-7 of the layer maximum), max |y| per image handed over exactly; and the two
+    kernels — the same arithmetic chain per accumulator on different work items — agree bit for bit."""
     N, Cin, H, W, Cout, flags, use_res = case
     x, w, b = mk(N, Cin, H, W, Cout, 3, seed=Cin + Cout + H + W)
     up = 2 if flags & CNL_UPSAMPLE_IN else 1
     res = torch.randn(N, Cout, H * up, W * up, generator=torch.Generator().manual_seed(6)) if use_res else None
     ref = ref_conv(x, w, b, 1, flags, res)
-    out, ym = run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 9, want=5, ymax=True)
+    out, ym = run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + variant, want=5, ymax=True)
     assert not torch.isnan(out).any()
     torch.testing.assert_close(out, ref, rtol=RTOL, atol=ATOL)
     assert torch.equal(ym, out.abs().amax(dim=(1, 2, 3)))
+    if variant != 9:
+        assert torch.equal(out, run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 9, want=5))
     ref64 = ref_conv(x.double(), w.double(), b.double(), 1, flags, res.double() if use_res else None)
     e9 = (out.double() - ref64).abs().max().item()
     e2 = (run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 2).double() - ref64).abs().max().item()
     assert e9 <= 1.25 * e2 + 1e-7 * ref64.abs().max().item(), (e9, e2)
 
 
-def test_winograd9_many_items_per_workgroup_is_bit_identical_to_one_image_at_a_time():
+@pytest.mark.parametrize("variant", [9, 10, 11])
+def test_winograd9_many_items_per_workgroup_is_bit_identical_to_one_image_at_a_time(variant):
     """More work items than CUs (the chunk stream then runs on from one item into the next: patches, weights and the first V rows of
     item i + 1 are fetched inside the last two chunks of item i): the batch must give bit for bit what each image gives alone, with
     images of very different magnitude side by side (the scale changes between consecutive items of a workgroup)."""
@@ -677,10 +682,10 @@ def test_winograd9_many_items_per_workgroup_is_bit_identical_to_one_image_at_a_t
     w = torch.randn(128, 64, 3, 3, generator=g) * (2.0 / (64 * 9)) ** 0.5
     b = torch.randn(128, generator=g)
     res = torch.randn(N, 128, 64, 128, generator=g)
-    full, ym = run_winograd(x, w, b, CNL_RELU, res, algo=CNL_ALGO_FORCE + 9, want=5, ymax=True)      # 12 * 8 * 2 * 2 = 384 items on 256 CUs
+    full, ym = run_winograd(x, w, b, CNL_RELU, res, algo=CNL_ALGO_FORCE + variant, want=5, ymax=True)      # 9: 12 * 8 * 2 * 2 = 384 items on 256 CUs; 10: 768 on 512 workgroups
     torch.testing.assert_close(full, ref_conv(x, w, b, 1, CNL_RELU, res), rtol=RTOL, atol=ATOL * 100)
     for i in (0, 3, 7, 11):
-        assert torch.equal(full[i:i + 1], run_winograd(x[i:i + 1], w, b, CNL_RELU, res[i:i + 1], algo=CNL_ALGO_FORCE + 9)), i
+        assert torch.equal(full[i:i + 1], run_winograd(x[i:i + 1], w, b, CNL_RELU, res[i:i + 1], algo=CNL_ALGO_FORCE + variant)), i
     assert torch.equal(ym, full.abs().amax(dim=(1, 2, 3)))
 
 
@@ -713,7 +718,8 @@ def test_presplit_weights_give_the_same_bits(shape):
     assert lib.cnl_conv_split_weight_floats(48, 64, 3, 3) == 0 and lib.cnl_conv_split_weight_floats(64, 64, 3, 1) == 0 and lib.cnl_conv_split_weight_floats(64, 64, 5, 5) == 0
 
 
-def test_winograd9_images_side_by_side_do_not_see_each_other():
+@pytest.mark.parametrize("variant", [9, 10, 11])
+def test_winograd9_images_side_by_side_do_not_see_each_other(variant):
     """Narrow maps (W = 32): two images share a block row.  An image's first / last Winograd tile must read the convolution's zero
     padding, not the neighbour's edge pixels — also when those are Inf / NaN (a 0 multiplier would turn them into NaN): every image of
     the batch is bit for bit what it gives alone, and the non-finite image keeps its non-finite outputs to itself."""
@@ -725,11 +731,11 @@ def test_winograd9_images_side_by_side_do_not_see_each_other():
     x[2, :, 7, 31] = float("inf")                                          # right edge of image 2 touches image 3's left edge
     w = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / (64 * 9)) ** 0.5
     b = torch.randn(64, generator=g)
-    full = run_winograd(x, w, b, CNL_RELU, algo=CNL_ALGO_FORCE + 9, want=5)
+    full = run_winograd(x, w, b, CNL_RELU, algo=CNL_ALGO_FORCE + variant, want=5)
     for i in (0, 3, 4):
         assert torch.isfinite(full[i]).all(), i
     for i in range(N):
-        alone = run_winograd(x[i:i + 1], w, b, CNL_RELU, algo=CNL_ALGO_FORCE + 9)
+        alone = run_winograd(x[i:i + 1], w, b, CNL_RELU, algo=CNL_ALGO_FORCE + variant)
         assert torch.equal(full[i:i + 1].isnan(), alone.isnan()), i
         assert torch.equal(torch.nan_to_num(full[i:i + 1], nan=-1.0), torch.nan_to_num(alone, nan=-1.0)), i
 
@@ -751,14 +757,14 @@ def test_split_kernels_on_trained_checkpoint_like_weights():
     cmax = ref.abs().amax(dim=(0, 2, 3))
     live = cmax > 0
     err = {}
-    for v in (2, 5, 6, 9):
+    for v in (2, 5, 6, 9, 10, 11):
         out = run_winograd(x, w, b, 0, algo=CNL_ALGO_FORCE + v)
         assert torch.isfinite(out).all(), v
         d = out.double() - ref
         e = d.abs().amax(dim=(0, 2, 3))
         assert float(e[~live].max()) == 0.0 if (~live).any() else True, v          # dead channels give exact zeros
         err[v] = (e[live] / cmax[live], d.pow(2).mean(dim=(0, 2, 3)).sqrt()[live] / cmax[live])
-    for v in (5, 6, 9):
+    for v in (5, 6, 9, 10, 11):
         # per channel: rms error within 1.25x the fp32 matrix core's; the MAXIMUM over a channel's 2048 outputs is a noisy statistic -> 2x
         worst_rms = float((err[v][1] / (1.25 * err[2][1] + 2e-8)).max())
         worst_max = float((err[v][0] / (2.0 * err[2][0] + 1e-7)).max())

@@ -330,6 +330,45 @@ def test_split_small_latency_mode_matches_oracle(cfg, shape):
     model.get_encoded_outputs(recipes.images(78, (16,) + tuple(shape[1:])).cuda()) if shape[2] <= 256 else None
 
 
+@pytest.mark.parametrize("cfg,shape", [("resnet34_simple.yaml", (1, 3, 512, 512)), ("resnet34_fpn.yaml", (1, 3, 256, 256)),
+                                       ("tracking_resnet34_fpn.yaml", (2, 3, 96, 160))])
+def test_latency_class_matches_oracle(cfg, shape):
+    """KernelOptions(latency=True): the 3x3 / stride-1 layers run on winograd10.hip's 4-row x 32-cout work items (variant 11).
+    Same parity bars as the default plan — outputs within 1e-4 of the CPU oracle, features fp32-grade against float64 — the class really is
+    in the plan, it does not depend on the batch (shard == full batch bit for bit), and the DEFAULT plan of the same model is untouched by it
+    (bit for bit what a model that never saw the option gives)."""
+    import ctypes
+    model, sd = build(cfg, latency=True, reuse_buffers=False)
+    x = recipes.images(79, shape)
+    ref = ref_cpu.forward(sd, x, sigmoid=False)
+    enc = model.get_encoded_outputs(x.cuda())
+    for name, r in ref.items():
+        torch.testing.assert_close(enc[name].cpu(), r, rtol=TOL, atol=TOL)
+    plan = model._engine.plan_for(x.cuda(), sigmoid=False)
+    lib = plan.lib
+    variants = [lib.cnl_conv3x3_winograd_variant(ctypes.byref(L.args)) for L in plan.launches if L.fn is lib.cnl_conv3x3_winograd_f32]
+    assert sum(v == 11 for v in variants) >= 20 and 9 not in variants[:-6], variants           # (the first head blocks behind a folded upsample stay on winograd9)
+    _, _, neck64, heads64 = ref_cpu.forward_float64(sd, x, sigmoid=False, return_intermediates="heads")
+    nb, _, _, nc, nup = plan.neck_out
+    neck = plan.tensor(nb)[..., :nc].permute(0, 3, 1, 2).cpu()
+    if nup:
+        neck = torch.nn.functional.interpolate(neck, scale_factor=2, mode="nearest")
+    assert float((neck.double() - neck64).abs().max() / neck64.abs().max()) <= 5e-5
+    # batch invariance inside the class: three copies of the batch give three times the same bits
+    x3 = torch.cat([x, x, x], dim=0).cuda()
+    enc3 = model.get_encoded_outputs(x3)
+    n = shape[0]
+    for name in enc:
+        assert torch.equal(enc3[name][:n], enc[name]) and torch.equal(enc3[name][2 * n:], enc[name]), name
+    # the default plan of the same weights: untouched by the option
+    base, _ = build(cfg)
+    want = base.get_encoded_outputs(x.cuda())
+    model.set_kernel_options(latency=False)
+    got = model.get_encoded_outputs(x.cuda())
+    for name in want:
+        assert torch.equal(got[name], want[name]), name
+
+
 def test_in_place_weight_edit_is_noticed_without_refresh():
     """model.backbone.load_state_dict(...) / in-place edits after the first forward must not run on stale packed weights."""
     model, sd = build("resnet34_simple.yaml")

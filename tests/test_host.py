@@ -312,11 +312,13 @@ def test_inline_asm_kernels_keep_valu_to_mfma_distance():
         assert total > 50 and not violations, (name, violations[:3])
 
 
-def test_winograd9_compiles_without_register_spills():
+@pytest.mark.parametrize("src,kernels", [("winograd9.hip", 3), ("winograd10.hip", 4)])
+def test_winograd9_compiles_without_register_spills(src, kernels):
     """csrc/winograd9.hip sits at the edge of the register file (256 accumulator + 256 vector registers per lane): a spill inside its
     chunk loop comes back as a scratch load with a vmcnt(0) — a wait for every load in flight — and harmless-looking edits of the
     epilogue have produced 40-110 of them.  The device code of both variants (with / without residual) and of the
-    weight transform must compile with ZERO spilled vector registers under the Makefile's flags."""
+    weight transform must compile with ZERO spilled vector registers under the Makefile's flags.  csrc/winograd10.hip (two workgroups per CU: 256
+    registers per wave, accumulators included) likewise — and it must keep its two waves per SIMD."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -325,8 +327,11 @@ def test_winograd9_compiles_without_register_spills():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "centernet-lightning_amd", "csrc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(root, "include"), "-mllvm", "-pragma-unroll-threshold=4000000",
-           "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", os.path.join(csrc, "winograd9.hip"), "-o", os.devnull]
+           "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", os.path.join(csrc, src), "-o", os.devnull]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     spills = [int(l.split("VGPRs Spill:")[1].split()[0]) for l in r.stderr.splitlines() if "VGPRs Spill:" in l]
-    assert len(spills) == 3 and all(v == 0 for v in spills), spills
+    assert len(spills) == kernels and all(v == 0 for v in spills), spills
+    if src == "winograd10.hip":
+        occ = [int(l.split("Occupancy [waves/SIMD]:")[1].split()[0]) for l in r.stderr.splitlines() if "Occupancy [waves/SIMD]:" in l]
+        assert occ == [2] * kernels, occ

@@ -47,6 +47,14 @@ SHAPES = {
     "lat512": (32, 16, 16, 512, 256, 1, 1, 0, False),
     "out80": (32, 128, 128, 256, 80, 1, 1, CNL_SIGMOID, False),
     "out4": (32, 128, 128, 256, 4, 1, 1, 0, False),
+    # one-image batches (BASELINE C0): the latency class
+    "n1head": (1, 128, 128, 256, 256, 3, 1, CNL_RELU, False),
+    "n1first": (1, 64, 64, 64, 512, 3, 1, CNL_RELU | CNL_UPSAMPLE_IN, False),
+    "n1l1": (1, 128, 128, 64, 64, 3, 1, CNL_RELU, True),
+    "n1l2": (1, 64, 64, 128, 128, 3, 1, CNL_RELU, True),
+    "n1l3": (1, 32, 32, 256, 256, 3, 1, CNL_RELU, True),
+    "n1l4": (1, 16, 16, 512, 512, 3, 1, CNL_RELU, True),
+    "n1neck0": (1, 16, 16, 512, 256, 3, 1, CNL_RELU, False),
 }
 
 
