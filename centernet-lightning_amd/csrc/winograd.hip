@@ -143,9 +143,9 @@ static int wino_choice(const cnl_conv_params* p) {
     // asks for it, the batch size never does.
     if (p->algo == CNL_ALGO_LATENCY && upf == 1 && cnl_wino10_eligible(p)) return 11;
     // 16-pixel-wide maps (four images side by side in a block row): the half-height items of winograd10.hip give the chip twice the work
-    // items of winograd9's and a second workgroup per CU to overlap with — 512 -> 512 @16x16 x 32: 83 us (winograd5: 90-93, winograd9: 97-107),
+    // items of winograd9's and a second workgroup per CU to overlap with (long channel loops: what was measured) — 512 -> 512 @16x16 x 32: 83 us (winograd5: 90-93, winograd9: 97-107),
     // 512 -> 256: 61-65 us with 32-cout items (fp32 kernel: 89-92)
-    if (upf == 1 && W == 16 && cnl_wino10_eligible(p)) return p->Cout <= 256 ? 11 : 10;
+    if (upf == 1 && W == 16 && p->Cin >= 256 && cnl_wino10_eligible(p)) return p->Cout <= 256 ? 11 : 10;
     // row-Winograd (winograd9.hip): 8-row x 64-pixel x 64-cout work items.  Measured against kernels 2 / 5 / 6 on every 3x3 shape of the
     // three configurations (profiles/r03_winograd9_variants.txt): 0.5-0.8x their time wherever its blocks pad the map by less than ~1.5x
     // (maps at least ~44 pixels wide), channel loops from 32 up, with or without residual / folded upsample

@@ -782,6 +782,12 @@ def test_winograd_dispatch_is_a_function_of_shape_and_algo_only():
         p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.ldx, p.ldy, p.flags, p.algo = N, H, W, Cin, Cout, 3, 3, 1, 1, Cin, Cout, 0, algo
         return lib.cnl_conv3x3_winograd_kernel(ctypes.byref(p))
 
+    def variant(N, Cin, H, W, Cout, algo):
+        p = ConvParams()
+        p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.ldx, p.ldy, p.flags, p.algo = N, H, W, Cin, Cout, 3, 3, 1, 1, Cin, Cout, 0, algo
+        p.y = 1 << 20                                                   # (the row-Winograd kernels ask for a 16-byte aligned output)
+        return lib.cnl_conv3x3_winograd_variant(ctypes.byref(p))
+
     for N in (1, 7, 32):
         assert kind(N, 256, 128, 128, 256, CNL_ALGO_AUTO) == 5          # head blocks
         assert kind(N, 256, 152, 272, 256, CNL_ALGO_AUTO) == 5          # ... of 608 x 1088 frames
@@ -793,3 +799,11 @@ def test_winograd_dispatch_is_a_function_of_shape_and_algo_only():
         assert kind(N, 64, 16, 16, 64, CNL_ALGO_AUTO) == 2              # short channel loop on a map its 64-pixel blocks would pad 4x: fp32 matrix cores
         assert kind(N, 64, 128, 128, 64, CNL_ALGO_F32) == 2
         assert kind(N, 24, 128, 128, 64, CNL_ALGO_AUTO) == 2            # Cin % 16 != 0
+        # the kernel behind the class (cnl_conv3x3_winograd_variant): round 4's half-height row-Winograd items on 16-pixel-wide maps with long
+        # channel loops, and wherever a row-Winograd kernel applies under the latency class — which the CALLER chooses, never the batch size
+        assert variant(N, 256, 128, 128, 256, CNL_ALGO_AUTO) == 9 and variant(N, 256, 32, 32, 256, CNL_ALGO_AUTO) == 9
+        assert variant(N, 512, 16, 16, 512, CNL_ALGO_AUTO) == 10 and variant(N, 512, 16, 16, 256, CNL_ALGO_AUTO) == 11
+        assert variant(N, 512, 19, 34, 512, CNL_ALGO_AUTO) == 6
+        for shp in ((256, 128, 128, 256), (256, 32, 32, 256), (128, 64, 64, 128), (64, 128, 128, 64), (512, 16, 16, 512)):
+            assert variant(N, *shp, _lib.CNL_ALGO_LATENCY) == 11, shp
+        assert variant(N, 24, 128, 128, 64, _lib.CNL_ALGO_LATENCY) == 2

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-launch table of one forward's plan (HIP events around every launch, whole plan replayed in order):
-python tools/plan_profile.py [--config simple|fpn|tracking] [--batch N] [--size H W] [--algo auto|f32]"""
+python tools/plan_profile.py [--config simple|fpn|tracking] [--batch N] [--size H W] [--algo auto|f32] [--latency] [--opt field=0|1 ...]"""
 import argparse
 import os
 import sys
@@ -20,8 +20,11 @@ def main():
     ap.add_argument("--algo", default="auto")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--split-small", action="store_true")
+    ap.add_argument("--latency", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="KernelOptions field=0|1 (e.g. --opt reverse_out_conv=0)")
     a = ap.parse_args()
-    model = bench.build_model(a.config, algo=a.algo, split_small=a.split_small)
+    extra = {kv.split("=")[0]: bool(int(kv.split("=")[1])) for kv in a.opt}
+    model = bench.build_model(a.config, algo=a.algo, split_small=a.split_small, latency=a.latency, **extra)
     x = torch.rand(a.batch, 3, *a.size, device="cuda")
     rows, plan = bench.conv_kernel_profile(model, x, reps=a.reps)
     tot = sum(r[2] for r in rows)
