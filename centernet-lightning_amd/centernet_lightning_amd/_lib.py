@@ -82,12 +82,12 @@ _SIGNATURES = {
     "cnl_normalize_u8_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float), c_void_p]),
     "cnl_resize_bilinear_u8": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "cnl_stem_conv7x7_u8": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p,
-                                           c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+                                           c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "cnl_stem_packed_weight_floats": (c_size_t, []),
     "cnl_stem_pack_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
-    "cnl_stem_conv7x7_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+    "cnl_stem_conv7x7_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_int32, c_int32, c_int32, c_uint32, c_void_p]),
-    "cnl_stem_conv7x7_maxpool_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+    "cnl_stem_conv7x7_maxpool_f32": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_int32, c_int32, c_int32, c_void_p]),
     "cnl_maxpool3x3s2_nhwc_f32": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "cnl_decode_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

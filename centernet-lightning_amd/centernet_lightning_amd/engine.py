@@ -524,6 +524,7 @@ class Plan:
         slot_of, pairs, passes, reports = {}, [], [], set()       # reports: launches that run an fp16-split kernel
         shared = []                                               # launches that take the slot of their group's explicit pass
         own_pass = {}                                             # input buffer -> fp16-split Winograd launches without a reporting producer
+        stem_group = []                                           # fp16-split Winograd launches that read the stem's (pooled) output
         for L in self.launches:         # plan order: a direct conv only reports max |y| if it got its own hint
             if not isinstance(L.args, ConvParams):
                 continue
@@ -537,6 +538,11 @@ class Plan:
                     and P.args.Cout == P.args.ldy):
                 pairs.append((P, L, slot_of.setdefault(id(P), len(slot_of))))
                 reports.add(id(L))
+            elif is_wino5 and x is self.backbone_in:
+                # the stem's output: the fp16-split stem kernel reports max |y| per image (max-pooling keeps the maximum of its
+                # non-negative input, so the figure holds for the pooled map whichever launch pooled it)
+                reports.add(id(L))
+                stem_group.append(L)
             elif is_wino5:
                 # no reporting producer: an explicit cnl_absmax_per_image_f32 pass into a slot of THIS plan's absmax tensor (the library's own
                 # pass parks the maxima in scratch inside the shared weight buffer: two streams running one model would race on it — ADVICE r2).
@@ -551,6 +557,8 @@ class Plan:
         for key, group in own_pass.items():
             passes.append((group[0], slot_of.setdefault(("shared", key), len(slot_of))))
             shared.extend((L, key) for L in group[1:])
+        if stem_group:
+            slot_of[("stem",)] = len(slot_of)
         # one float per (tensor, image): an image's scale must not depend on its batch neighbours
         self.absmax = torch.zeros((max(len(slot_of), 1), self.N), device=self.device, dtype=torch.float32) if slot_of else None
         for P, L, i in pairs:
@@ -558,6 +566,10 @@ class Plan:
             L.args.x_absmax = self.absmax.data_ptr() + 4 * i * self.N
         for L, key in shared:
             L.args.x_absmax = self.absmax.data_ptr() + 4 * slot_of[("shared", key)] * self.N
+        if stem_group:
+            self.stem_absmax = self.absmax.data_ptr() + 4 * slot_of[("stem",)] * self.N
+            for L in stem_group:
+                L.args.x_absmax = self.stem_absmax
         for L, i in passes:
             a = L.args
             L.args.x_absmax = self.absmax.data_ptr() + 4 * i * self.N
@@ -763,6 +775,8 @@ class Plan:
         s1 = self._buf(N, h2, w2, 64) if need_s1 else None
         self.stem_out = s1 if need_s1 else cur
         self.stem_fused_pool = not need_s1
+        self.backbone_in = cur                 # the pooled stem output: its per-image maximum comes from the stem kernel itself (y_absmax)
+        self.stem_absmax = None                # device pointer of that slot once _wire_absmax has placed it
         self.launches.append(_Launch("stem", None, "stem7x7+bn+relu" + ("" if need_s1 else "+maxpool3x3s2"), 2 * N * h2 * w2 * 64 * 147,
                                      keep=(self.stem_out,)))
         if need_s1:
@@ -936,14 +950,14 @@ class Plan:
             if x.dtype == torch.uint8:                       # [N,H,W,3] uint8: byte strides of the logical (n, c, y, x) axes
                 sn, sh, sw, sc = x.stride()
                 return lib.cnl_stem_conv7x7_u8(x.data_ptr(), sn, sc, sh, sw, self._norm[0], self._norm[1], self._wt_stem_packed.data_ptr(),
-                                               self._wt_stem.b.data_ptr(), self.stem_out.data_ptr(), self.N, self.H, self.W,
+                                               self._wt_stem.b.data_ptr(), self.stem_out.data_ptr(), self.stem_absmax, self.N, self.H, self.W,
                                                1 if self.stem_fused_pool else 0, stream)
             sn, sc, sh, sw = x.stride()
             if self.stem_fused_pool:
                 return lib.cnl_stem_conv7x7_maxpool_f32(x.data_ptr(), sn, sc, sh, sw, self._wt_stem_packed.data_ptr(), self._wt_stem.b.data_ptr(),
-                                                        self.stem_out.data_ptr(), self.N, self.H, self.W, stream)
+                                                        self.stem_out.data_ptr(), self.stem_absmax, self.N, self.H, self.W, stream)
             return lib.cnl_stem_conv7x7_f32(x.data_ptr(), sn, sc, sh, sw, self._wt_stem_packed.data_ptr(), self._wt_stem.b.data_ptr(),
-                                            self.stem_out.data_ptr(), self.N, self.H, self.W, self.algo, stream)
+                                            self.stem_out.data_ptr(), self.stem_absmax, self.N, self.H, self.W, self.algo, stream)
         if L.fn == "maxpool":
             src, dst, n, h, w, c = L.args
             return lib.cnl_maxpool3x3s2_nhwc_f32(src.data_ptr(), dst.data_ptr(), n, h, w, c, stream)

@@ -181,7 +181,7 @@ using namespace cnl_stem;
 size_t cnl_stem5_extra_floats();
 int cnl_stem5_pack(const float* w_ohwi, float* extra, void* stream);
 int cnl_stem5_launch(const void* x, bool u8, const float* mean255, const float* inv_std255, long sn, int sc, int sh, int sw, unsigned img_bytes,
-                     const float* extra, const float* bias, float* y, int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y,
+                     const float* extra, const float* bias, float* y, float* y_absmax, int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y,
                      unsigned blocks, bool pool, void* stream);
 
 extern "C" size_t cnl_stem_packed_weight_floats(void) { return (size_t)ST_KP * 64 + cnl_stem5_extra_floats(); }
@@ -194,7 +194,7 @@ extern "C" int cnl_stem_pack_weights_f32(const float* w_ohwi, float* w_packed, v
 }
 
 static int stem_launch(const char* who, bool pool, const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
-                       const float* bias, float* y, int32_t N, int32_t H, int32_t W, uint32_t algo, void* stream) {
+                       const float* bias, float* y, float* y_absmax, int32_t N, int32_t H, int32_t W, uint32_t algo, void* stream) {
     CNL_REQUIRE(x && w && bias && y, CNL_E_BAD_ARG, "%s: null tensor pointer", who);
     CNL_REQUIRE(N > 0 && H > 0 && W > 0, CNL_E_BAD_ARG, "%s: non-positive dimension", who);
     CNL_REQUIRE(sc > 0 && sh > 0 && sw > 0 && sn >= 0, CNL_E_UNSUPPORTED, "%s: non-positive strides", who);
@@ -207,7 +207,7 @@ static int stem_launch(const char* who, bool pool, const float* x, int64_t sn, i
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "%s: grid too large", who);
     CNL_REQUIRE(algo <= CNL_ALGO_F32, CNL_E_BAD_ARG, "%s: unknown algo %u", who, algo);
     if (algo != CNL_ALGO_F32 || pool)           // (the fused max-pool exists in the fp16-split kernel only)
-        return cnl_stem5_launch(x, false, nullptr, nullptr, (long)sn, (int)sc, (int)sh, (int)sw, (unsigned)img_bytes, w + ST_KP * 64, bias, y, N, H, W,
+        return cnl_stem5_launch(x, false, nullptr, nullptr, (long)sn, (int)sc, (int)sh, (int)sw, (unsigned)img_bytes, w + ST_KP * 64, bias, y, y_absmax, N, H, W,
                                 Ho, Wo, tiles_x, tiles_y, (unsigned)blocks, pool, stream);
     const int lds = ST_LDS_BYTES;
     static cnl::DeviceOnce once;
@@ -219,18 +219,18 @@ static int stem_launch(const char* who, bool pool, const float* x, int64_t sn, i
 }
 
 extern "C" int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
-                                    const float* bias, float* y, int32_t N, int32_t H, int32_t W, uint32_t algo, void* stream) {
-    return stem_launch("cnl_stem_conv7x7_f32", false, x, sn, sc, sh, sw, w, bias, y, N, H, W, algo, stream);
+                                    const float* bias, float* y, float* y_absmax, int32_t N, int32_t H, int32_t W, uint32_t algo, void* stream) {
+    return stem_launch("cnl_stem_conv7x7_f32", false, x, sn, sc, sh, sw, w, bias, y, y_absmax, N, H, W, algo, stream);
 }
 
 extern "C" int cnl_stem_conv7x7_maxpool_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w,
-                                            const float* bias, float* y, int32_t N, int32_t H, int32_t W, void* stream) {
-    return stem_launch("cnl_stem_conv7x7_maxpool_f32", true, x, sn, sc, sh, sw, w, bias, y, N, H, W, CNL_ALGO_AUTO, stream);
+                                            const float* bias, float* y, float* y_absmax, int32_t N, int32_t H, int32_t W, void* stream) {
+    return stem_launch("cnl_stem_conv7x7_maxpool_f32", true, x, sn, sc, sh, sw, w, bias, y, y_absmax, N, H, W, CNL_ALGO_AUTO, stream);
 }
 
 // uint8 frames straight into the stem: A.Normalize happens on the staged patch inside the kernel (stem_f16x2.hip)
 extern "C" int cnl_stem_conv7x7_u8(const uint8_t* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* mean255,
-                                   const float* inv_std255, const float* w, const float* bias, float* y, int32_t N, int32_t H, int32_t W,
+                                   const float* inv_std255, const float* w, const float* bias, float* y, float* y_absmax, int32_t N, int32_t H, int32_t W,
                                    int32_t fuse_maxpool, void* stream) {
     const char* who = "cnl_stem_conv7x7_u8";
     CNL_REQUIRE(x && w && bias && y && mean255 && inv_std255, CNL_E_BAD_ARG, "%s: null pointer", who);
@@ -243,7 +243,7 @@ extern "C" int cnl_stem_conv7x7_u8(const uint8_t* x, int64_t sn, int64_t sc, int
     const int tiles_x = (Wo + ST_TW - 1) / ST_TW, tiles_y = (Ho + ST_TH - 1) / ST_TH;
     const long long blocks = (long long)N * tiles_x * tiles_y;
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "%s: grid too large", who);
-    return cnl_stem5_launch(x, true, mean255, inv_std255, (long)sn, (int)sc, (int)sh, (int)sw, (unsigned)img_bytes, w + ST_KP * 64, bias, y, N, H, W, Ho,
+    return cnl_stem5_launch(x, true, mean255, inv_std255, (long)sn, (int)sc, (int)sh, (int)sw, (unsigned)img_bytes, w + ST_KP * 64, bias, y, y_absmax, N, H, W, Ho,
                             Wo, tiles_x, tiles_y, (unsigned)blocks, fuse_maxpool != 0, stream);
 }
 

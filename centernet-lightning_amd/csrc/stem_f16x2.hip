@@ -10,9 +10,12 @@
 // LDS-DMA from whatever strides the caller has), but K is laid out in groups of 8 for v_mfma_f32_32x32x16_f16: group g = 3 ky + q
 // holds t = 8q .. 8q+7 of kernel row ky (t = kx*3 + c; t >= 21 are pads: zero weights, and the A operand is masked there because
 // the patch slot holds a neighbouring pixel and 0 x inf would not be 0); 21 groups + one all-zero = 11 steps of 16 instead of 77 of
-// 2.  A lane's operand is 8 consecutive patch floats (four ds_read_b64) split in registers (3 VALU per element); the split weights
-// sit in LDS as [piece][group][cout][8] so a lane's operand is one ds_read_b128.  Per step and wave: 4 rows x 2 cout groups x 3
-// MFMAs of 32 cycles against 88 x 64 in stem.hip — the kernel becomes bound by its 537 MB of output.
+// 2.  Round 4: the staged patch is split ONCE per workgroup — the scan that finds the patch maximum keeps its values in registers, and
+// after the scale is known each thread writes the hi / lo fp16 pieces of its values over the fp32 patch as two planes [row][256] — so a
+// lane's operand is 8 consecutive halfs of each plane (two ds_read2_b32 per piece), no VALU.  (Rounds 1-3 split the operand of every
+// MFMA in registers: each patch element ~8 times, 10.6 VALU per MFMA — the loop was VALU-bound, 120 of the kernel's 216 us.)  The split
+// weights sit in LDS as [piece][group][cout][8] so a lane's operand is one ds_read_b128.  Per step and wave: 4 rows x 2 cout groups x 3
+// MFMAs of 32 cycles.
 #include "cnl_common.h"
 
 namespace cnl_stem5 {
@@ -30,7 +33,9 @@ constexpr int NG = 21;                                // K groups of 8 that hold
 constexpr int STEPS = 11;                             // 22 groups / 2 lane halves
 constexpr int W_PIECE_BYTES = NG * 64 * 16;           // 21504: one piece (hi or lo) of the split weights
 constexpr int W_BYTES = 2 * W_PIECE_BYTES;            // 43008 = 42 x 1 KB
-constexpr int PATCH_BYTES = PR * RS * 4;              // 37888
+constexpr int PATCH_BYTES = PR * RS * 4;              // 37888: the fp32 patch as staged, then its two fp16 planes (hi at 0, lo at PLANE_BYTES)
+constexpr int PLANE_BYTES = PR * RS * 2;              // 18944
+constexpr int SCAN_IT = (PR * (RS / 4) + 255) / 256;  // 10 float4 per thread
 constexpr int LDS_BYTES = PATCH_BYTES + W_BYTES + 64; // 80960 -> 2 workgroups / CU
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
@@ -89,8 +94,8 @@ template <bool POOL, bool U8>
 __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restrict__ x, long sn, int sc, int sh, int sw,
                                                             unsigned x_img_bytes, const void* __restrict__ w_split,
                                                             const float* __restrict__ scal, const float* __restrict__ bias,
-                                                            float* __restrict__ y, int N, int H, int W, int Ho, int Wo, int tiles_x,
-                                                            int tiles_y, const Norm nrm) {
+                                                            float* __restrict__ y, unsigned* __restrict__ ymax, int N, int H, int W, int Ho, int Wo,
+                                                            int tiles_x, int tiles_y, const Norm nrm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* patch = reinterpret_cast<float*>(smem);
     char* wl = smem + PATCH_BYTES;
@@ -136,34 +141,53 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- the patch's scale: max |x| over the staged patch (out-of-image slots hold zeros) ----
+    // ---- the patch's scale: max |x| over the staged patch (out-of-image slots hold zeros); the values stay in registers ----
     float mx = 0.f;
-    for (int e = tid; e < (S5_EXP == 5 ? 1 : PR * (RS / 4)); e += 256) {
-        float4 v = *reinterpret_cast<const float4*>(patch + e * 4);
-        if (U8) {                        // the slots hold zero-extended bytes: normalise in place
-#pragma clang fp contract(off)           // one rounding per operation: bit-parity with cnl_normalize_u8_nhwc_f32
-            const int r = e >> 6, f0 = (e & 63) * 4;                           // RS / 4 = 64 float4 per patch row
-            const bool row_ok = (unsigned)(iy0 + r) < (unsigned)H;
-            float o[4];
-            const unsigned u[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    float4 pv[SCAN_IT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int f = f0 + i, col = f / 3, c = f - col * 3;
-                const bool ok = row_ok && f < PC * 3 && (unsigned)(ix0 + col) < (unsigned)W;
-                const float m_ = c == 0 ? nrm.m[0] : (c == 1 ? nrm.m[1] : nrm.m[2]), r_ = c == 0 ? nrm.r[0] : (c == 1 ? nrm.r[1] : nrm.r[2]);
-                o[i] = ok ? ((float)u[i] - m_) * r_ : 0.f;
+    for (int it = 0; it < SCAN_IT; ++it) {
+        const int e = tid + it * 256;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < PR * (RS / 4) && (S5_EXP != 5 || it == 0)) {
+            v = *reinterpret_cast<const float4*>(patch + e * 4);
+            if (U8) {                        // the slots hold zero-extended bytes: A.Normalize (in registers; the fp32 image never exists)
+#pragma clang fp contract(off)               // one rounding per operation: bit-parity with cnl_normalize_u8_nhwc_f32
+                const int r = e >> 6, f0 = (e & 63) * 4;                           // RS / 4 = 64 float4 per patch row
+                const bool row_ok = (unsigned)(iy0 + r) < (unsigned)H;
+                float o[4];
+                const unsigned u[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = f0 + i, col = f / 3, c = f - col * 3;
+                    const bool ok = row_ok && f < PC * 3 && (unsigned)(ix0 + col) < (unsigned)W;
+                    const float m_ = c == 0 ? nrm.m[0] : (c == 1 ? nrm.m[1] : nrm.m[2]), r_ = c == 0 ? nrm.r[0] : (c == 1 ? nrm.r[1] : nrm.r[2]);
+                    o[i] = ok ? ((float)u[i] - m_) * r_ : 0.f;
+                }
+                v = make_float4(o[0], o[1], o[2], o[3]);
             }
-            v = make_float4(o[0], o[1], o[2], o[3]);
-            *reinterpret_cast<float4*>(patch + e * 4) = v;
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         }
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        pv[it] = v;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) red[wave] = mx;
-    __syncthreads();
+    __syncthreads();                                  // (every thread has read its part of the fp32 patch: the planes may overwrite it)
     const float Sx = pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
     const float inv = 1.f / (Sx * scal[0]);
+    // ---- x S = hi + lo, ONCE per element: two fp16 planes over the patch ----
+#pragma unroll
+    for (int it = 0; it < SCAN_IT; ++it) {
+        const int e = tid + it * 256;
+        if (e < PR * (RS / 4)) {
+            unsigned h0, l0, h1, l1;
+            split2(pv[it].x, pv[it].y, Sx, h0, l0);
+            split2(pv[it].z, pv[it].w, Sx, h1, l1);
+            *reinterpret_cast<uint2*>(smem + e * 8) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(smem + PLANE_BYTES + e * 8) = make_uint2(l0, l1);
+        }
+    }
+    __syncthreads();
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -173,8 +197,8 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // lane's A base: output row (wave*4 + i), column px -> patch row 2*(wave*4+i) + ky, floats 6*px + 8q .. + 7
-    const float* pa = patch + (wave * 8) * RS + px * 6;
+    // lane's A base: output row (wave*4 + i), column px -> patch row 2*(wave*4+i) + ky, elements 6*px + 8q .. + 7 of each plane
+    const char* pa = smem + ((wave * 8) * RS + px * 6) * 2;
     const char* pb = wl + px * 16;                                // + piece * W_PIECE_BYTES + (g * 64 + 32 j) * 16
 #pragma unroll
     for (int s = 0; s < (S5_EXP == 3 ? 1 : STEPS); ++s) {
@@ -200,14 +224,11 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float* p = pa + (2 * i) * RS + a_off;
-            const f32x2 v0 = *reinterpret_cast<const f32x2*>(p), v1 = *reinterpret_cast<const f32x2*>(p + 2);
-            const f32x2 v2 = *reinterpret_cast<const f32x2*>(p + 4), v3 = *reinterpret_cast<const f32x2*>(p + 6);
+            const unsigned* ph = reinterpret_cast<const unsigned*>(pa + ((2 * i) * RS + a_off) * 2);      // (4-byte aligned: 12 px + 16 q)
+            const unsigned* pl = reinterpret_cast<const unsigned*>(pa + PLANE_BYTES + ((2 * i) * RS + a_off) * 2);
             unsigned h[4], l[4];
-            split2(v0[0], v0[1], Sx, h[0], l[0]);
-            split2(v1[0], v1[1], Sx, h[1], l[1]);
-            split2(v2[0], v2[1], Sx, h[2], l[2]);
-            split2(v3[0], v3[1], Sx, h[3], l[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[e] = ph[e]; l[e] = pl[e]; }
             if (dead1) { h[0] &= m01; h[1] &= m01; l[0] &= m01; l[1] &= m01; }
             if (dead1 || q0 == 2 || q1 == 2) { h[2] &= m2; h[3] &= m3; l[2] &= m2; l[3] &= m3; }
             const u32x4 ah = {h[0], h[1], h[2], h[3]}, al = {l[0], l[1], l[2], l[3]};
@@ -220,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
         }
     }
 
+    float omax = 0.f;                   // max of what this thread contributes to y (post-ReLU: >= 0)
     if constexpr (!POOL) {
         // epilogue: scale back, bias + ReLU, NHWC store (col = lane&31 -> channel, rows -> pixels of the row)
 #pragma unroll
@@ -234,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
                     const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (oy < Ho && ox < Wo && (S5_EXP != 4 || acc[i][j][r] == 12345.f)) {
                         const float v = fmaxf(acc[i][j][r] * inv + bv, 0.f);
+                        omax = fmaxf(omax, v);
                         __builtin_nontemporal_store(v, &y[(((size_t)n * Ho + oy) * Wo + ox) * 64 + co]);
                     }
                 }
@@ -274,6 +297,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
                     const float v = acc[i][j][r] * inv + bv;
                     const bool ok = wave * 4 + i < rows_ok && (r & 3) + 8 * (r >> 2) + 4 * hi < cols_ok;
                     acc[i][j][r] = (ok && v > 0.f) ? v : 0.f;            // ReLU; never -0 or NaN
+                    omax = fmaxf(omax, acc[i][j][r]);                  // (every valid conv value lies in some pooling window: max y = max of these)
                 }
             float in3[16], p3[9];
 #pragma unroll
@@ -326,6 +350,13 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
         }
 #undef S5_COLPOOL
     }
+    if (ymax) {                          // max |y| of image n (hand-over to the first Winograd layer: cnl_conv_params.x_absmax)
+        // (16 K waves report into 32 floats of ONE cache line: unconditional atomics serialise in the L2 — 70 us at C1.  A wave first looks at
+        //  the slot (agent-scope load: the L2's copy) and only raises it: after an image's first few tiles almost every wave skips.)
+        const float m = cnl::wave_max_nonneg(omax);
+        if (lane == 0 && m > 0.f && __float_as_uint(m) > __hip_atomic_load(ymax + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(ymax + n, __float_as_uint(m));
+    }
 }
 
 // OHWI [64][7][7][3] (BN folded) -> [piece][group][cout][8] fp16 with the power-of-two scale S_w (scal[0]); one workgroup
@@ -369,7 +400,7 @@ int cnl_stem5_pack(const float* w_ohwi, float* extra, void* stream) {
 }
 
 int cnl_stem5_launch(const void* x, bool u8, const float* mean255, const float* inv_std255, long sn, int sc, int sh, int sw, unsigned img_bytes,
-                     const float* extra, const float* bias, float* y, int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y,
+                     const float* extra, const float* bias, float* y, float* y_absmax, int N, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y,
                      unsigned blocks, bool pool, void* stream) {
     Norm nrm = {{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
     if (u8) {
@@ -387,7 +418,7 @@ int cnl_stem5_launch(const void* x, bool u8, const float* mean255, const float* 
     }
 #define S5_LAUNCH(P_, U_)                                                                                                          \
     hipLaunchKernelGGL((stem_f16x2_kernel<P_, U_>), dim3(blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes, \
-                       (const void*)extra, extra + W_BYTES / 4, bias, y, N, H, W, Ho, Wo, tiles_x, tiles_y, nrm)
+                       (const void*)extra, extra + W_BYTES / 4, bias, y, reinterpret_cast<unsigned*>(y_absmax), N, H, W, Ho, Wo, tiles_x, tiles_y, nrm)
     switch (which) {
         case 0: S5_LAUNCH(false, false); break;
         case 1: S5_LAUNCH(true, false); break;

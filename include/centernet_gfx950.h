@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 10   /* 10: CNL_ALGO_LATENCY and the half-height row-Winograd kernel (csrc/winograd10.hip, variants 10 / 11); the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 10   /* 10: the stem entry points take y_absmax; CNL_ALGO_LATENCY and the half-height row-Winograd kernel (csrc/winograd10.hip, variants 10 / 11); the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -218,11 +218,14 @@ int cnl_resize_bilinear_u8(const uint8_t* x, uint8_t* y, int32_t N, int32_t H_in
  * scaled two-way fp16 split [piece][21 groups of 8 k][64][8] and its power-of-two scale (csrc/stem_f16x2.hip: the default kernel
  * forms each fp32 product on the fp16 matrix cores, input scaled per workgroup patch; algo = CNL_ALGO_F32 selects the fp32
  * matrix-core kernel); cnl_stem_packed_weight_floats() sizes the buffer; bias: [64].
+ * y_absmax (all three stem entry points, ABI v10): NULL, or N floats zeroed by the caller on the stream — the fp16-split kernel folds max |y| of
+ * image n into y_absmax[n] (atomic max on the bit pattern; the values are post-ReLU), the hand-over the first Winograd layer takes as
+ * cnl_conv_params.x_absmax instead of a pass over the stem's output.  The fp32 kernel (CNL_ALGO_F32 without the fused pool) ignores it.
  */
 size_t cnl_stem_packed_weight_floats(void);
 int cnl_stem_pack_weights_f32(const float* w_ohwi, float* w_packed, void* stream);
 int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
-                         const float* w, const float* bias, float* y,
+                         const float* w, const float* bias, float* y, float* y_absmax,
                          int32_t N, int32_t H, int32_t W, uint32_t algo, void* stream);
 
 /* The stem and resnet.maxpool in ONE launch: y = MaxPool2d(3, stride 2, padding 1)(ReLU(BN(conv7x7/2(x)))) as NHWC
@@ -230,7 +233,7 @@ int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int
  * cnl_maxpool3x3s2_nhwc_f32 (always the fp16-split stem kernel), without the stride-2 feature map ever reaching memory.  The call
  * zero-fills y itself (stream-ordered).                                                                                         */
 int cnl_stem_conv7x7_maxpool_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
-                                 const float* w, const float* bias, float* y,
+                                 const float* w, const float* bias, float* y, float* y_absmax,
                                  int32_t N, int32_t H, int32_t W, void* stream);
 
 /* The stem on uint8 frames: x is [N, H, W, 3]-like uint8 addressed through BYTE strides (sn, sc, sh, sw); A.Normalize
@@ -239,7 +242,7 @@ int cnl_stem_conv7x7_maxpool_f32(const float* x, int64_t sn, int64_t sc, int64_t
  * arrays of 3 floats.  fuse_maxpool != 0: y is the pooled map of cnl_stem_conv7x7_maxpool_f32, else the conv output of
  * cnl_stem_conv7x7_f32.  Bit-identical to cnl_normalize_u8_nhwc_f32 followed by the fp32-input entry points (CNL_ALGO_AUTO).            */
 int cnl_stem_conv7x7_u8(const uint8_t* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* mean255,
-                        const float* inv_std255, const float* w, const float* bias, float* y, int32_t N, int32_t H, int32_t W,
+                        const float* inv_std255, const float* w, const float* bias, float* y, float* y_absmax, int32_t N, int32_t H, int32_t W,
                         int32_t fuse_maxpool, void* stream);
 
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC (torchvision resnet.maxpool). C % 4 == 0. */

@@ -325,7 +325,7 @@ def test_stem_matches_cpu(shape, channels_last):
     N, _, H, W = shape
     y = torch.full((N, ref.shape[2], ref.shape[3], 64), float("nan"), device="cuda")
     sn, sc, sh, sw = xd.stride()
-    _lib.check(lib.cnl_stem_conv7x7_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), y.data_ptr(), N, H, W, CNL_ALGO_AUTO, _stream()))
+    _lib.check(lib.cnl_stem_conv7x7_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), y.data_ptr(), None, N, H, W, CNL_ALGO_AUTO, _stream()))
     torch.cuda.synchronize()
     torch.testing.assert_close(y.cpu().permute(0, 3, 1, 2), ref, rtol=RTOL, atol=ATOL)
 
@@ -341,7 +341,7 @@ def _run_stem(lib, x, w, b, channels_last=False, algo=CNL_ALGO_AUTO):
     N, _, H, W = x.shape
     y = torch.full((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), float("nan"), device="cuda")
     sn, sc, sh, sw = xd.stride()
-    _lib.check(lib.cnl_stem_conv7x7_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), y.data_ptr(), N, H, W, algo, _stream()))
+    _lib.check(lib.cnl_stem_conv7x7_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), y.data_ptr(), None, N, H, W, algo, _stream()))
     torch.cuda.synchronize()
     return y.cpu().permute(0, 3, 1, 2)
 
@@ -395,11 +395,13 @@ def test_stem_with_fused_maxpool_is_bit_identical_to_two_launches(shape):
         y1 = torch.empty((N, Ho, Wo, 64), device="cuda")
         y2 = torch.empty((N, Hp, Wp, 64), device="cuda")
         yf = torch.full((N, Hp, Wp, 64), float("nan"), device="cuda")
-        _lib.check(lib.cnl_stem_conv7x7_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), y1.data_ptr(), N, H, W, CNL_ALGO_AUTO, _stream()))
+        ym1, ymf = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")       # y_absmax: max |y| per image, folded in by the kernel
+        _lib.check(lib.cnl_stem_conv7x7_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), y1.data_ptr(), ym1.data_ptr(), N, H, W, CNL_ALGO_AUTO, _stream()))
         _lib.check(lib.cnl_maxpool3x3s2_nhwc_f32(y1.data_ptr(), y2.data_ptr(), N, Ho, Wo, 64, _stream()))
-        _lib.check(lib.cnl_stem_conv7x7_maxpool_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), yf.data_ptr(), N, H, W, _stream()))
+        _lib.check(lib.cnl_stem_conv7x7_maxpool_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), yf.data_ptr(), ymf.data_ptr(), N, H, W, _stream()))
         torch.cuda.synchronize()
         assert torch.equal(yf, y2), (shape, cl_)
+        assert torch.equal(ym1, y1.amax(dim=(1, 2, 3))) and torch.equal(ymf, yf.amax(dim=(1, 2, 3))) and torch.equal(ym1, ymf), (shape, cl_)
         ref = F.max_pool2d(F.relu(F.conv2d(x, w, b, stride=2, padding=3)), 3, 2, 1)
         torch.testing.assert_close(yf.cpu().permute(0, 3, 1, 2), ref, rtol=RTOL, atol=ATOL)
 

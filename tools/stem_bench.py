@@ -11,11 +11,21 @@ y = torch.empty(32, 256, 256, 64, device="cuda")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 lib.cnl_stem_pack_weights_f32(w.data_ptr(), wp.data_ptr(), st)
 sn, sc, sh, sw = x.stride()
-f = lambda: lib.cnl_stem_conv7x7_f32(x.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), b.data_ptr(), y.data_ptr(), 32, 512, 512, 0, st)
+f = lambda: lib.cnl_stem_conv7x7_f32(x.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), b.data_ptr(), y.data_ptr(), None, 32, 512, 512, 0, st)
 for _ in range(5): f()
 torch.cuda.synchronize()
 ts = []
 for _ in range(20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
-ts.sort(); print("stagger=%s stem %.1f us" % (os.environ.get("CNL_STEM_STAGGER", "5"), ts[10]))
+ts.sort(); print("stem conv7x7 (no pool) %.1f us" % ts[10])
+yp = torch.empty(32, 128, 128, 64, device="cuda")
+ym = torch.zeros(32, device="cuda")
+g = lambda: lib.cnl_stem_conv7x7_maxpool_f32(x.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), b.data_ptr(), yp.data_ptr(), ym.data_ptr(), 32, 512, 512, st)
+for _ in range(5): g()
+torch.cuda.synchronize()
+ts = []
+for _ in range(20):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); g(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
+ts.sort(); print("stem conv7x7 + maxpool (incl. the zero-fill of y) %.1f us" % ts[10])
