@@ -66,6 +66,25 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + (bid >> 3);
 }
 
+// max |y| hand-over (cnl_conv_params.y_absmax): every wave of a launch folds its maximum into N floats — ONE or two cache lines.  Device-scope
+// atomics are resolved at the memory side and serialise per address: unconditional reports cost a 64-channel layer a quarter of its time
+// (profiles/r04_ymax_atomics.txt: layer1 107 -> 83 us, layer3 82 -> 72 us without them).  So a wave looks first — an agent-scope load of the slot,
+// requested early where the kernel can (peek_max) — and only RAISES the slot: after an image's first tiles almost every report is a no-op.
+// (A stale, lower peek only costs a redundant atomic: the result is exact either way.)
+__device__ __forceinline__ unsigned peek_max(const unsigned* slot) {
+#ifdef CNL_NO_PEEK      // A/B builds (tools/ymax_ab.sh): every report is an atomic, as in rounds 1-3
+    return 0u;
+#else
+    return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void raise_max(unsigned* slot, float m, unsigned seen) {
+    if (m > 0.f && __float_as_uint(m) > seen) atomicMax(slot, __float_as_uint(m));
+}
+__device__ __forceinline__ void report_max(unsigned* slot, float m) {      // peek and raise in one place (waits for the load)
+    if (m > 0.f && __float_as_uint(m) > peek_max(slot)) atomicMax(slot, __float_as_uint(m));
+}
+
 // Maximum of a NON-NEGATIVE value over the wave / over each 32-lane half, in every lane: DPP inside the rows of 16 lanes, then four
 // v_readlane.  (A __shfl_xor butterfly computes its ds_bpermute lane addresses from the lane id; the compiler hoists those five or six
 // registers to kernel entry, where they stay live — or spill, every reload a vmcnt(0) — across a kernel's main loop.)

@@ -351,11 +351,8 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
 #undef S5_COLPOOL
     }
     if (ymax) {                          // max |y| of image n (hand-over to the first Winograd layer: cnl_conv_params.x_absmax)
-        // (16 K waves report into 32 floats of ONE cache line: unconditional atomics serialise in the L2 — 70 us at C1.  A wave first looks at
-        //  the slot (agent-scope load: the L2's copy) and only raises it: after an image's first few tiles almost every wave skips.)
-        const float m = cnl::wave_max_nonneg(omax);
-        if (lane == 0 && m > 0.f && __float_as_uint(m) > __hip_atomic_load(ymax + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(ymax + n, __float_as_uint(m));
+        const float m = cnl::wave_max_nonneg(omax);          // (16 K waves, 32 floats of one cache line: see cnl::report_max)
+        if (lane == 0) cnl::report_max(ymax + n, m);
     }
 }
 

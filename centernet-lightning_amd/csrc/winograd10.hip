@@ -516,6 +516,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < NI; ++i) yv0[i] = ((unsigned)((rimg[i] * a.H + cc.y0) * a.W + rpx[i]) * (unsigned)a.ldy + (unsigned)cout_e) * 4u;
         const unsigned y_row = (unsigned)(a.W * a.ldy) * 4u;
+        // what the images' max |y| slots hold so far: requested HERE, ahead of the item's stores, read behind the last pass (cnl::peek_max)
+        unsigned yseen[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) yseen[i] = a.ymax ? cnl::peek_max(a.ymax + (rimg[i] < a.Nimg ? rimg[i] : 0)) : 0u;
 #define W10_XWRITE2(j_, g_, q0_)                                                                                 \
         _Pragma("unroll") for (int q = (q0_); q < (q0_) + 2; ++q) {                                              \
             const f32x16& A = st.acc[j_][g_];                                                                    \
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < NI; ++i) {
                 const float m = cnl::wave_max_nonneg(omax2[i]);
                 const int img = __builtin_amdgcn_readfirstlane(rimg[i]);
-                if (lane_e == 0 && m > 0.f && img < a.Nimg) atomicMax(a.ymax + img, __float_as_uint(m));
+                if (lane_e == 0 && img < a.Nimg) cnl::raise_max(a.ymax + img, m, (unsigned)__builtin_amdgcn_readfirstlane((int)yseen[i]));
             }
         }
         W10_STAMP(7);

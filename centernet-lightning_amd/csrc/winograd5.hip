@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         if (a.ymax) {          // max |y| of this item into its image's slot: one atomic per wave and item (no return value awaited)
             omax = cnl::wave_max_nonneg(omax);
-            if (lane == 0 && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
+            if (lane == 0) cnl::report_max(a.ymax + en, omax);
             omax = 0.f;
         }
         if (!more) break;

@@ -514,10 +514,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 float hm[2];
                 cnl::half_max_nonneg(omax, hm);
                 omax = lane < 32 ? hm[0] : hm[1];
-                if ((lane & 31) == 0 && img_ok && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
+                if ((lane & 31) == 0 && img_ok) cnl::report_max(a.ymax + en, omax);
             } else {
                 omax = cnl::wave_max_nonneg(omax);
-                if (lane == 0 && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
+                if (lane == 0) cnl::report_max(a.ymax + en, omax);
             }
             omax = 0.f;
         }

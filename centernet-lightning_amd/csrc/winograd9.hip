@@ -574,6 +574,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < 2; ++i) yv0[i] = ((unsigned)((rimg[i] * a.H + cc_cur.y0) * a.W + rpx[i]) * (unsigned)a.ldy + (unsigned)cout_e) * 4u;
         const unsigned y_row = (unsigned)(a.W * a.ldy) * 4u;
+        // what the images' max |y| slots hold so far: requested HERE, ahead of the item's stores, read behind the last pass (cnl::peek_max)
+        unsigned yseen[2] = {0u, 0u};
+        if (a.ymax) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) yseen[i] = cnl::peek_max(a.ymax + (rimg[i] < a.Nimg ? rimg[i] : 0));
+        }
         // pass j + 1's blocks are written (into the other half) while pass j's are finished: ds_write_b128 costs 13 LDS cycles per wave
         // (MI355X_MICROARCH.md, LDS table) — eight in a row stall the wave behind the LDS queue (measured: 370 of a pass's 1200 cycles); two
         // per quarter of the arithmetic drain beside it
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int i = 0; i < 2; ++i) {
                 const float m = cnl::wave_max_nonneg(omax2[i]);
                 const int img = __builtin_amdgcn_readfirstlane(rimg[i]);
-                if (lane_e == 0 && m > 0.f && img < a.Nimg) atomicMax(a.ymax + img, __float_as_uint(m));
+                if (lane_e == 0 && img < a.Nimg) cnl::raise_max(a.ymax + img, m, (unsigned)__builtin_amdgcn_readfirstlane((int)yseen[i]));
             }
         }
         W9_STAMP(15);

@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--algo", type=int, default=0, help="cnl_conv_params.algo: 0 auto, 1 F(2x2) only, 2 fp32 matrix cores, 100+v force Winograd variant v")
     ap.add_argument("--relu-data", action="store_true", help="post-ReLU activations (as inside the network)")
     ap.add_argument("--presplit", action="store_true", help="direct convs: weights with their fp16 split appended (CNL_W_SPLIT)")
+    ap.add_argument("--no-ymax", action="store_true", help="with --hints: hand over x_absmax only (the kernel reports no max |y|)")
     ap.add_argument("--check", action="store_true", help="also print max |y - y_fp32mfma| / max |y_fp32mfma| (algo 2 on the same inputs)")
     args = ap.parse_args()
     lib = _lib.load()
@@ -123,7 +124,7 @@ def main():
         if args.hints and args.winograd:
             xm = x.abs().amax(dim=(1, 2, 3)).contiguous()
             ym = torch.zeros(N, device="cuda")
-            p.x_absmax, p.y_absmax = xm.data_ptr(), ym.data_ptr()
+            p.x_absmax, p.y_absmax = xm.data_ptr(), (None if args.no_ymax else ym.data_ptr())
         if args.hints and not args.winograd:
             xm = x.abs().amax(dim=(1, 2, 3)).contiguous()
             wm = w.abs().max().reshape(1).contiguous()
