@@ -53,6 +53,7 @@ class DecodeParams(Structure):
 
 _SIGNATURES = {
     "cnl_version": (ctypes.c_int, []),
+    "cnl_absmax_stride": (ctypes.c_int, []),
     "cnl_last_error": (c_size_t, [c_char_p, c_size_t]),
     "cnl_conv2d_nhwc_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
     "cnl_conv2d_out_hw": (ctypes.c_int, [POINTER(ConvParams), POINTER(c_int32), POINTER(c_int32)]),
@@ -169,3 +170,27 @@ def check(rc, what=""):
     if rc in (CNL_E_BAD_ARG, CNL_E_UNSUPPORTED):
         raise ValueError(msg)
     raise RuntimeError(msg)
+
+
+def absmax_stride():
+    """Floats between the per-image slots of an x_absmax / y_absmax array (one 128-byte line per image: include/centernet_gfx950.h)."""
+    return load().cnl_absmax_stride()
+
+
+def absmax_buffer(n, device="cuda"):
+    """A zeroed per-image maxima array for n images (n * absmax_stride() floats)."""
+    import torch
+    return torch.zeros((n * absmax_stride(),), device=device, dtype=torch.float32)
+
+
+def absmax_pack(values):
+    """Per-image maxima (a tensor of n floats) -> the strided array the kernels read."""
+    buf = absmax_buffer(values.numel(), values.device)
+    buf[::absmax_stride()] = values.to(buf.dtype)
+    return buf
+
+
+def absmax_values(buf, n=None):
+    """The n per-image values of a strided maxima array."""
+    v = buf[::absmax_stride()]
+    return v if n is None else v[:n]

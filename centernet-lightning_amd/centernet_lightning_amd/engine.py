@@ -560,19 +560,21 @@ class Plan:
         if stem_group:
             slot_of[("stem",)] = len(slot_of)
         # one float per (tensor, image): an image's scale must not depend on its batch neighbours
-        self.absmax = torch.zeros((max(len(slot_of), 1), self.N), device=self.device, dtype=torch.float32) if slot_of else None
+        ams = _lib.absmax_stride()             # floats between the per-image slots: one cache line per image
+        row = 4 * self.N * ams                 # bytes per tensor
+        self.absmax = torch.zeros((max(len(slot_of), 1), self.N, ams), device=self.device, dtype=torch.float32) if slot_of else None
         for P, L, i in pairs:
-            P.args.y_absmax = self.absmax.data_ptr() + 4 * i * self.N
-            L.args.x_absmax = self.absmax.data_ptr() + 4 * i * self.N
+            P.args.y_absmax = self.absmax.data_ptr() + i * row
+            L.args.x_absmax = self.absmax.data_ptr() + i * row
         for L, key in shared:
-            L.args.x_absmax = self.absmax.data_ptr() + 4 * slot_of[("shared", key)] * self.N
+            L.args.x_absmax = self.absmax.data_ptr() + slot_of[("shared", key)] * row
         if stem_group:
-            self.stem_absmax = self.absmax.data_ptr() + 4 * slot_of[("stem",)] * self.N
+            self.stem_absmax = self.absmax.data_ptr() + slot_of[("stem",)] * row
             for L in stem_group:
                 L.args.x_absmax = self.stem_absmax
         for L, i in passes:
             a = L.args
-            L.args.x_absmax = self.absmax.data_ptr() + 4 * i * self.N
+            L.args.x_absmax = self.absmax.data_ptr() + i * row
             self.launches.insert(self.launches.index(L), _Launch(
                 lib.cnl_absmax_per_image_f32, [a.x, self.N, a.H_in * a.W_in, a.Cin, a.ldx, L.args.x_absmax], L.what + ".absmax",
                 0, keep=(self.absmax, L.keep[0])))

@@ -33,6 +33,7 @@ int cu_count(int dev, int* n_cu) {
 }  // namespace cnl
 
 extern "C" int cnl_version(void) { return CNL_ABI_VERSION; }
+extern "C" int cnl_absmax_stride(void) { return CNL_ABSMAX_STRIDE; }
 
 extern "C" size_t cnl_last_error(char* buf, size_t n) {
     const char* s = cnl::last_error_buf();

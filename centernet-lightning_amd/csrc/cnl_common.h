@@ -13,6 +13,13 @@
 #ifndef CNL_NT_STORES
 #define CNL_NT_STORES 2
 #endif
+// Floats between the per-image slots of an x_absmax / y_absmax array (cnl_absmax_stride()): 32 = one 128-byte line per image.  Device-scope
+// atomics are resolved line by line at the memory side; with the N slots of a launch packed into one line (stride 1, rounds 1-3) every
+// report of every image queued behind every other (profiles/r04_ymax_atomics.txt).
+#ifndef CNL_ABSMAX_STRIDE
+#define CNL_ABSMAX_STRIDE 32
+#endif
+constexpr int AMS = CNL_ABSMAX_STRIDE;
 
 namespace cnl {
 

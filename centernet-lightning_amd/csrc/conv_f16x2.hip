@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
         const int m = m0 + r;
         const unsigned n = fast_div((unsigned)m, a.mg_hw, a.sh_hw);
         const bool ok = m < a.M;
-        const float S = ok ? pow2_scale(a.xmax[n]) : 1.f;
+        const float S = ok ? pow2_scale(a.xmax[n * AMS]) : 1.f;
         sScl[r] = S;
         sInv[r] = 1.f / (S * Sw);
         sImg[r] = ok ? (int)n : -1;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
                     const int img = sImg[rl + (r & 3) + 8 * (r >> 2)];
                     if (img == img0) omax = fmaxf(omax, av);
                     else if (img == img0 + 1) omax1 = fmaxf(omax1, av);                  // a tile that spans two images
-                    else if (av > 0.f) cnl::report_max(a.ymax + img, av);     // maps smaller than the tile: rare rows
+                    else if (av > 0.f) cnl::report_max(a.ymax + img * AMS, av);     // maps smaller than the tile: rare rows
                 }
             }
         }
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
             omax = fmaxf(omax, __shfl_xor(omax, o, 64));
             omax1 = fmaxf(omax1, __shfl_xor(omax1, o, 64));
         }
-        if (lane == 0) cnl::report_max(a.ymax + img0, omax);
-        if (lane == 0) cnl::report_max(a.ymax + img0 + 1, omax1);
+        if (lane == 0) cnl::report_max(a.ymax + img0 * AMS, omax);
+        if (lane == 0) cnl::report_max(a.ymax + (img0 + 1) * AMS, omax1);
     }
 }
 
@@ -398,9 +398,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
         if (same) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
-            if ((threadIdx.x & 63) == 0 && img0 >= 0) cnl::report_max(a.ymax + img0, omax);
+            if ((threadIdx.x & 63) == 0 && img0 >= 0) cnl::report_max(a.ymax + img0 * AMS, omax);
         } else if (img >= 0 && omax > 0.f) {
-            atomicMax(a.ymax + img, __float_as_uint(omax));
+            atomicMax(a.ymax + img * AMS, __float_as_uint(omax));
         }
     }
 }

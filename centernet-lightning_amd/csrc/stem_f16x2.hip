@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
     }
     if (ymax) {                          // max |y| of image n (hand-over to the first Winograd layer: cnl_conv_params.x_absmax)
         const float m = cnl::wave_max_nonneg(omax);          // (16 K waves, 32 floats of one cache line: see cnl::report_max)
-        if (lane == 0) cnl::report_max(ymax + n, m);
+        if (lane == 0) cnl::report_max(ymax + n * AMS, m);
     }
 }
 

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } while (0)
     // max |x| of the image a lane's tile belongs to; images past the end of the batch: 0 -> scale 1
 #define W10_XMAX_OF(n_, si_) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                       \
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.xmax, 0, a.Nimg * 4, 0x00020000), (unsigned)((n_) * a.ipb + (si_)) * 4u, 0, 0))
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.xmax, 0, a.Nimg * 4 * AMS, 0x00020000), (unsigned)((n_) * a.ipb + (si_)) * (4u * AMS), 0, 0))
     // power-of-two scale of V from the image's maximum: |V| <= 2 max |x|, 2 max |x| S in [2^13, 2^14); es_ = log2 S
 #define W10_SCALE_EXP(es_, xmax_)                                                                                \
     do {                                                                                                         \
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // what the images' max |y| slots hold so far: requested HERE, ahead of the item's stores, read behind the last pass (cnl::peek_max)
         unsigned yseen[NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) yseen[i] = a.ymax ? cnl::peek_max(a.ymax + (rimg[i] < a.Nimg ? rimg[i] : 0)) : 0u;
+        for (int i = 0; i < NI; ++i) yseen[i] = a.ymax ? cnl::peek_max(a.ymax + (rimg[i] < a.Nimg ? rimg[i] : 0) * AMS) : 0u;
 #define W10_XWRITE2(j_, g_, q0_)                                                                                 \
         _Pragma("unroll") for (int q = (q0_); q < (q0_) + 2; ++q) {                                              \
             const f32x16& A = st.acc[j_][g_];                                                                    \
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < NI; ++i) {
                 const float m = cnl::wave_max_nonneg(omax2[i]);
                 const int img = __builtin_amdgcn_readfirstlane(rimg[i]);
-                if (lane_e == 0 && img < a.Nimg) cnl::raise_max(a.ymax + img, m, (unsigned)__builtin_amdgcn_readfirstlane((int)yseen[i]));
+                if (lane_e == 0 && img < a.Nimg) cnl::raise_max(a.ymax + img * AMS, m, (unsigned)__builtin_amdgcn_readfirstlane((int)yseen[i]));
             }
         }
         W10_STAMP(7);

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         /* this lane's B fragments: cout row n0 + (lane & 31) (+ 32 for the second group), channel half hi */    \
         u_voff = (unsigned)((n0 + (lane & 31)) * 32 + hi * 16);                                                  \
         {                                                                                                        \
-            const float mx4_ = 4.f * a.xmax[n];                                                                  \
+            const float mx4_ = 4.f * a.xmax[n * AMS];                                                                  \
             S = 1.f;                                                                                             \
             if (mx4_ > 0.f && mx4_ < __builtin_inff()) {                                                         \
                 int e_;                                                                                          \
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         if (a.ymax) {          // max |y| of this item into its image's slot: one atomic per wave and item (no return value awaited)
             omax = cnl::wave_max_nonneg(omax);
-            if (lane == 0) cnl::report_max(a.ymax + en, omax);
+            if (lane == 0) cnl::report_max(a.ymax + en * AMS, omax);
             omax = 0.f;
         }
         if (!more) break;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     const int c4 = C >> 2;
     const long total = pixels * c4;
     x += (long)blockIdx.y * pixels * ld;
-    out += blockIdx.y;
+    out += blockIdx.y * AMS;
     float m = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long px = i / c4;
@@ -580,7 +580,7 @@ size_t cnl_wino5_weight_bytes(int Cin, int Cout) {
     const size_t CoutP = (size_t)((Cout + 63) / 64) * 64;
     return (size_t)(Cin / 16) * 16 * cnl_wino5::NP * CoutP * 32;
 }
-size_t cnl_wino5_scalar_floats() { return 16 + 4096; }  // [1] S_u, [2] max |U|, [16 + n] max |x| of image n of the current launch (own pass)
+size_t cnl_wino5_scalar_floats() { return 16 + 1024 * AMS; }  // [1] S_u, [2] max |U|, [16 + n AMS] max |x| of image n of the current launch (own pass)
 
 // u_f32 = the fp32 U of the layer (already computed), u5 = destination of the pieces, scal = the layer's scalars
 int cnl_wino5_transform_weights(const float* w_ohwi, const float* u_f32, size_t u_f32_floats, void* u5, float* scal, int Cin, int Cout,
@@ -601,7 +601,7 @@ extern "C" int cnl_absmax_per_image_f32(const float* x, int32_t N, int64_t pixel
     CNL_REQUIRE(N > 0 && N <= 65535 && pixels > 0 && C > 0, CNL_E_BAD_ARG, "cnl_absmax_per_image_f32: N in 1..65535, pixels and C positive");
     CNL_REQUIRE(C % 4 == 0 && ld % 4 == 0 && ld >= C && ((uintptr_t)x & 15) == 0, CNL_E_UNSUPPORTED,
                 "cnl_absmax_per_image_f32: C=%d, ld=%d must be multiples of 4 (ld >= C) and x 16-byte aligned", C, ld);
-    CNL_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, (hipStream_t)stream));
+    CNL_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)N * AMS, (hipStream_t)stream));
     const long long vec4 = (long long)pixels * (C / 4);
     const long long want = (vec4 + 256 * 16 - 1) / (256 * 16);
     const unsigned mgrid = (unsigned)(want < 1 ? 1 : (want > 64 ? 64 : want));
@@ -613,8 +613,8 @@ extern "C" int cnl_absmax_per_image_f32(const float* x, int32_t N, int64_t pixel
 // max |x| per image of p's input into scal[16 + n] (the layer's scratch: callers without the x_absmax hint; one such launch at a
 // time per layer — the hint-carrying plan of engine.py never comes here)
 int cnl_wino5_own_absmax(const cnl_conv_params* p, float* scal, void* stream) {
-    CNL_REQUIRE(p->N <= 4096, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: more than 4096 images per launch need x_absmax");
-    CNL_HIP(hipMemsetAsync(scal + 16, 0, sizeof(float) * (size_t)p->N, (hipStream_t)stream));
+    CNL_REQUIRE(p->N <= 1024, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: more than 1024 images per launch need x_absmax");
+    CNL_HIP(hipMemsetAsync(scal + 16, 0, sizeof(float) * (size_t)p->N * AMS, (hipStream_t)stream));
     const long long vec4 = (long long)p->H_in * p->W_in * (p->Cin / 4);         // per image
     const long long want = (vec4 + 256 * 16 - 1) / (256 * 16);                  // >= 16 float4 per thread
     const unsigned mgrid = (unsigned)(want < 1 ? 1 : (want > 64 ? 64 : want));

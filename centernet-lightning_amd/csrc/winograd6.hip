@@ -255,11 +255,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (STACK) {                                                                                   \
             /* the transform lane's tile column and the epilogue thread's tile column each have their own image */ \
             const int nt_ = min((int)fast_div6((unsigned)(x0 + 2 * t_tx), a.mg_sw, a.sh_sw), a.N - 1);           \
-            S = pow2_scale_v(4.f * a.xmax[nt_]);                                                                 \
+            S = pow2_scale_v(4.f * a.xmax[nt_ * AMS]);                                                                 \
             ne_n = (int)fast_div6((unsigned)(x0 + 2 * ((tid >> 5) & 7)), a.mg_sw, a.sh_sw);                      \
-            inv_n = 1.f / (pow2_scale_v(4.f * a.xmax[min(ne_n, a.N - 1)]) * Su);                                 \
+            inv_n = 1.f / (pow2_scale_v(4.f * a.xmax[min(ne_n, a.N - 1) * AMS]) * Su);                                 \
         } else {                                                                                                 \
-            S = pow2_scale_v(4.f * a.xmax[n]);                                                                   \
+            S = pow2_scale_v(4.f * a.xmax[n * AMS]);                                                                   \
             inv_n = 1.f / (S * Su);                                                                              \
         }                                                                                                        \
     } while (0)
@@ -514,10 +514,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 float hm[2];
                 cnl::half_max_nonneg(omax, hm);
                 omax = lane < 32 ? hm[0] : hm[1];
-                if ((lane & 31) == 0 && img_ok) cnl::report_max(a.ymax + en, omax);
+                if ((lane & 31) == 0 && img_ok) cnl::report_max(a.ymax + en * AMS, omax);
             } else {
                 omax = cnl::wave_max_nonneg(omax);
-                if (lane == 0) cnl::report_max(a.ymax + en, omax);
+                if (lane == 0) cnl::report_max(a.ymax + en * AMS, omax);
             }
             omax = 0.f;
         }
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     const int c4 = C >> 2;
     const long total = pixels * c4;
     x += (long)blockIdx.y * pixels * ld;
-    out += blockIdx.y;
+    out += blockIdx.y * AMS;
     float m = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long px = i / c4;

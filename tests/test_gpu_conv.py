@@ -57,10 +57,10 @@ def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0
         rd = residual.permute(0, 2, 3, 1).contiguous().cuda()
         p.residual, p.ldr = rd.data_ptr(), Cout
     if hints:
-        xm = torch.full((N,), float("nan"), device="cuda")
+        xm = torch.full((N * _lib.absmax_stride(),), float("nan"), device="cuda")      # (strided: one cache line per image)
         _lib.check(lib.cnl_absmax_per_image_f32(p.x, N, H * W, Cin, ldx, xm.data_ptr(), _stream()), "absmax")
         wm = wd.abs().max().reshape(1).contiguous()
-        ym = torch.zeros(N, device="cuda")
+        ym = _lib.absmax_buffer(N)
         p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), (None if no_wmax else wm.data_ptr()), ym.data_ptr()
     if splitk:
         p.splitk = splitk
@@ -72,8 +72,8 @@ def run_conv(x_nchw, w_oihw, bias, stride=1, flags=0, residual=None, ldx_extra=0
     _lib.check(lib.cnl_conv2d_nhwc_f32(ctypes.byref(p), _stream()), "conv")
     torch.cuda.synchronize()
     if hints:
-        assert torch.equal(xm.cpu(), x_nchw.abs().amax(dim=(1, 2, 3)))
-        return y.cpu().permute(0, 3, 1, 2), lib.cnl_conv2d_kernel(ctypes.byref(p)), ym.cpu()
+        assert torch.equal(_lib.absmax_values(xm).cpu(), x_nchw.abs().amax(dim=(1, 2, 3)))
+        return y.cpu().permute(0, 3, 1, 2), lib.cnl_conv2d_kernel(ctypes.byref(p)), _lib.absmax_values(ym).cpu()
     return y.cpu().permute(0, 3, 1, 2)
 
 
@@ -260,9 +260,9 @@ def test_conv3x3_on_upsampled_input_as_subpixel_phases(case, hints):
     p.KH, p.KW, p.stride, p.pad = 3, 3, 1, 1
     p.ldx, p.ldy, p.flags = Cin, Cout, flags | CNL_UPSAMPLE_IN
     if hints:
-        xm = x.abs().amax(dim=(1, 2, 3)).cuda()
+        xm = _lib.absmax_pack(x.abs().amax(dim=(1, 2, 3)).cuda())
         wm = wp.abs().max().reshape(1)
-        ym = torch.zeros(N, device="cuda")
+        ym = _lib.absmax_buffer(N)
         p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), wm.data_ptr(), ym.data_ptr()
     split = hints
     assert lib.cnl_conv3x3_up2_kernel(ctypes.byref(p)) == (5 if split else 2)
@@ -272,10 +272,10 @@ def test_conv3x3_on_upsampled_input_as_subpixel_phases(case, hints):
     assert not torch.isnan(out).any()
     torch.testing.assert_close(out, ref, rtol=RTOL, atol=ATOL * max(1.0, ref.abs().max().item() / 10))
     if split:
-        assert torch.equal(ym.cpu(), out.abs().amax(dim=(1, 2, 3)))
+        assert torch.equal(_lib.absmax_values(ym).cpu(), out.abs().amax(dim=(1, 2, 3)))
         for n in range(N):                                   # batch invariance: image n alone gives the same bits
             p.N, p.x, p.y = 1, xd[n].data_ptr(), y.data_ptr()
-            p.x_absmax, p.y_absmax = xm[n:].data_ptr(), ym.data_ptr()
+            p.x_absmax, p.y_absmax = xm[n * _lib.absmax_stride():].data_ptr(), ym.data_ptr()
             _lib.check(lib.cnl_conv3x3_up2_nhwc_f32(ctypes.byref(p), _stream()), "up2")
             torch.cuda.synchronize()
             assert torch.equal(y[0].cpu().permute(2, 0, 1), out[n]), n
@@ -395,13 +395,14 @@ def test_stem_with_fused_maxpool_is_bit_identical_to_two_launches(shape):
         y1 = torch.empty((N, Ho, Wo, 64), device="cuda")
         y2 = torch.empty((N, Hp, Wp, 64), device="cuda")
         yf = torch.full((N, Hp, Wp, 64), float("nan"), device="cuda")
-        ym1, ymf = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")       # y_absmax: max |y| per image, folded in by the kernel
+        ym1, ymf = _lib.absmax_buffer(N), _lib.absmax_buffer(N)                       # y_absmax: max |y| per image, folded in by the kernel
         _lib.check(lib.cnl_stem_conv7x7_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), y1.data_ptr(), ym1.data_ptr(), N, H, W, CNL_ALGO_AUTO, _stream()))
         _lib.check(lib.cnl_maxpool3x3s2_nhwc_f32(y1.data_ptr(), y2.data_ptr(), N, Ho, Wo, 64, _stream()))
         _lib.check(lib.cnl_stem_conv7x7_maxpool_f32(xd.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), bd.data_ptr(), yf.data_ptr(), ymf.data_ptr(), N, H, W, _stream()))
         torch.cuda.synchronize()
         assert torch.equal(yf, y2), (shape, cl_)
-        assert torch.equal(ym1, y1.amax(dim=(1, 2, 3))) and torch.equal(ymf, yf.amax(dim=(1, 2, 3))) and torch.equal(ym1, ymf), (shape, cl_)
+        v1, vf = _lib.absmax_values(ym1), _lib.absmax_values(ymf)
+        assert torch.equal(v1, y1.amax(dim=(1, 2, 3))) and torch.equal(vf, yf.amax(dim=(1, 2, 3))) and torch.equal(v1, vf), (shape, cl_)
         ref = F.max_pool2d(F.relu(F.conv2d(x, w, b, stride=2, padding=3)), 3, 2, 1)
         torch.testing.assert_close(yf.cpu().permute(0, 3, 1, 2), ref, rtol=RTOL, atol=ATOL)
 
@@ -461,15 +462,15 @@ def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None, algo=CNL_ALGO_AUT
         rd = residual.permute(0, 2, 3, 1).contiguous().cuda()
         p.residual, p.ldr = rd.data_ptr(), Cout
     if ymax:                                                   # also hand the input's maxima over and collect the output's
-        xm = x_nchw.abs().amax(dim=(1, 2, 3)).cuda()
-        ym = torch.zeros(N, device="cuda")
+        xm = _lib.absmax_pack(x_nchw.abs().amax(dim=(1, 2, 3)).cuda())
+        ym = _lib.absmax_buffer(N)
         p.x_absmax, p.y_absmax = xm.data_ptr(), ym.data_ptr()
     if want is not None:
         assert lib.cnl_conv3x3_winograd_kernel(ctypes.byref(p)) == want
     _lib.check(lib.cnl_conv3x3_winograd_f32(ctypes.byref(p), _stream()), "winograd")
     torch.cuda.synchronize()
     if ymax:
-        return y.cpu().permute(0, 3, 1, 2), ym.cpu()
+        return y.cpu().permute(0, 3, 1, 2), _lib.absmax_values(ym).cpu()
     return y.cpu().permute(0, 3, 1, 2)
 
 

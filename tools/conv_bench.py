@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--algo", type=int, default=0, help="cnl_conv_params.algo: 0 auto, 1 F(2x2) only, 2 fp32 matrix cores, 100+v force Winograd variant v")
     ap.add_argument("--relu-data", action="store_true", help="post-ReLU activations (as inside the network)")
     ap.add_argument("--presplit", action="store_true", help="direct convs: weights with their fp16 split appended (CNL_W_SPLIT)")
+    ap.add_argument("--zero-ymax", action="store_true", help="with --hints: zero the y_absmax array before every launch (what a plan does once per forward)")
     ap.add_argument("--no-ymax", action="store_true", help="with --hints: hand over x_absmax only (the kernel reports no max |y|)")
     ap.add_argument("--check", action="store_true", help="also print max |y - y_fp32mfma| / max |y_fp32mfma| (algo 2 on the same inputs)")
     args = ap.parse_args()
@@ -122,13 +123,13 @@ def main():
                 _lib.check(lib.cnl_conv_split_weights_f32(w.data_ptr(), wsp.data_ptr(), Cin, Cout, k, k, stream))
                 p.w, p.flags = wsp.data_ptr(), p.flags | _lib.CNL_W_SPLIT
         if args.hints and args.winograd:
-            xm = x.abs().amax(dim=(1, 2, 3)).contiguous()
-            ym = torch.zeros(N, device="cuda")
+            xm = _lib.absmax_pack(x.abs().amax(dim=(1, 2, 3)))
+            ym = _lib.absmax_buffer(N)
             p.x_absmax, p.y_absmax = xm.data_ptr(), (None if args.no_ymax else ym.data_ptr())
         if args.hints and not args.winograd:
-            xm = x.abs().amax(dim=(1, 2, 3)).contiguous()
+            xm = _lib.absmax_pack(x.abs().amax(dim=(1, 2, 3)))
             wm = w.abs().max().reshape(1).contiguous()
-            ym = torch.zeros(N, device="cuda")
+            ym = _lib.absmax_buffer(N)
             p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), wm.data_ptr(), ym.data_ptr()
         for _ in range(2):
             _lib.check(fn(ctypes.byref(p), stream))
@@ -136,6 +137,8 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
+            if args.zero_ymax and args.hints:
+                ym.zero_()                   # as inside a plan: the slots start from zero in every forward (nobody's peek finds a maximum yet)
             fn(ctypes.byref(p), stream)
         e1.record()
         torch.cuda.synchronize()

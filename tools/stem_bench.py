@@ -20,7 +20,7 @@ for _ in range(20):
     e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
 ts.sort(); print("stem conv7x7 (no pool) %.1f us" % ts[10])
 yp = torch.empty(32, 128, 128, 64, device="cuda")
-ym = torch.zeros(32, device="cuda")
+ym = _lib.absmax_buffer(32)
 g = lambda: lib.cnl_stem_conv7x7_maxpool_f32(x.data_ptr(), sn, sc, sh, sw, wp.data_ptr(), b.data_ptr(), yp.data_ptr(), ym.data_ptr(), 32, 512, 512, st)
 for _ in range(5): g()
 torch.cuda.synchronize()

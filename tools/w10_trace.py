@@ -19,7 +19,7 @@ b = torch.randn(Cout, device="cuda")
 y = torch.empty(N, H, W, Cout, device="cuda")
 u = torch.empty(lib.cnl_winograd_weight_floats(Cin, Cout), device="cuda")
 _lib.check(lib.cnl_winograd_transform_weights_f32(w.data_ptr(), u.data_ptr(), Cin, Cout, stream))
-xm = x.abs().amax(dim=(1, 2, 3)).contiguous(); ym = torch.zeros(N, device="cuda")
+xm = _lib.absmax_pack(x.abs().amax(dim=(1, 2, 3))); ym = _lib.absmax_buffer(N)
 p = ConvParams()
 p.x, p.w, p.bias, p.y = x.data_ptr(), u.data_ptr(), b.data_ptr(), y.data_ptr()
 p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad = N, H, W, Cin, Cout, 3, 3, 1, 1
