@@ -35,9 +35,10 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
   cpu_baseline = the CPU oracle (oracle/ref_cpu.py + oracle/decode_ref.py: the plain PyTorch restatement of the reference path —
               kind "port") timed on this box's host cores: C0 exactly (1x3x512x512) and the bench shape at N = 32 (the GPU leg's batch),
               in child processes under two OpenMP placements (runtime default / OMP_PROC_BIND=close OMP_PLACES=cores) and 16 / 32 / 64
-              threads; 1 warm-up + 3 timed passes of the best, median; then SEVERAL oracle processes at once on disjoint core sets (one per
-              NUMA node, one per 32 / 16 cores: a single process does not feed a 2 x 64-core host), throughput summed; `value` = the best
-              of all legs, `cores` = the cores that leg used.  Decode p50 on the CPU beside the GPU's.  Rank 0, N = 1 only, AFTER all GPU
+              threads; 1 warm-up + 3 timed passes of the best, median; with --cpu-multi also SEVERAL oracle processes at once on disjoint
+              core sets (one per NUMA node, one per 16 cores), throughput summed — measured once per round, it does not beat one process
+              on the GPU box's host (profiles/r04_bench_c1_with_cpu_multi.json) and costs minutes; `value` = the best of the legs that ran,
+              `cores` = the cores that leg used; `host` = affinity mask size, cgroup CPU quota, NUMA nodes.  Decode p50 on the CPU beside the GPU's.  Rank 0, N = 1 only, AFTER all GPU
               legs (so that the GPU work of the run is contiguous).
 """
 import argparse
@@ -423,6 +424,26 @@ def _cpu_leg_child(spec):
                       "probes_images_per_s": {f"{t_}thr{'_cl' if c_ else ''}": round(n / s_, 3) for s_, t_, c_ in probes}}))
 
 
+MULTI_NOTE = ("not run (--cpu-multi): measured once per round — profiles/r04_bench_c1_with_cpu_multi.json: 16 oracle processes x 16 logical CPUs on disjoint core "
+              "sets sum to 9.3 images/s (2.5 by wall clock, stragglers included), 2 x 128: 0.95 — no more than ONE 16-thread process (9.9): this host does not feed "
+              "the oracle beyond ~10 images/s however it is placed")
+
+
+def host_limits():
+    """What the container may use of the host: logical CPUs in the affinity mask, the cgroup CPU quota, NUMA nodes."""
+    out = {"affinity_cpus": len(os.sched_getaffinity(0))}
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            out["cgroup:" + f.rsplit("/", 1)[1]] = open(f).read().strip()
+        except OSError:
+            pass
+    try:
+        out["numa_nodes"] = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except OSError:
+        pass
+    return out
+
+
 def cpu_groups(cpus):
     """Process counts for the multi-process CPU legs: one per NUMA node, and one per 16 cores (a pair of CCDs)."""
     counts = set()
@@ -437,7 +458,7 @@ def cpu_groups(cpus):
     return sorted(c for c in counts if c >= 2)
 
 
-def cpu_baseline(config, k, H, W, gpu_decode_p50_ms):
+def cpu_baseline(config, k, H, W, gpu_decode_p50_ms, multi_process=False):
     """Oracle leg: the CPU restatement of forward + decode (kind "port") on the box's host cores — C0 exactly (1 x 3 x 512 x 512) and the bench
     shape at N = 32 (the GPU leg's own batch: ~30 s of CPU work), each under two OpenMP thread placements (the runtime's default, and threads
     pinned to consecutive cores: OMP_PROC_BIND=close OMP_PLACES=cores) and the probed thread counts; the best is `value`, every probe is listed."""
@@ -472,7 +493,7 @@ def cpu_baseline(config, k, H, W, gpu_decode_p50_ms):
     multi = {}
     try:
         cpus = sorted(os.sched_getaffinity(0))
-        for P_ in cpu_groups(cpus):
+        for P_ in (cpu_groups(cpus) if multi_process else []):
             groups = [cpus[i * len(cpus) // P_:(i + 1) * len(cpus) // P_] for i in range(P_)]
             n_each = max(1, 32 // P_)
             t_start = time.time() + 30.0                      # children import torch, build the model, warm up; then start together
@@ -512,9 +533,10 @@ def cpu_baseline(config, k, H, W, gpu_decode_p50_ms):
                 "sample": f"oracle/ref_cpu.forward + decode_ref.decode_detections_torch (same weights), {mtag.replace('_', ' ')} run CONCURRENTLY on disjoint core sets (os.sched_setaffinity), "
                           f"each {mv['images_per_process_per_pass']} x 3 x {H} x {W} images per pass, 1 warm-up + 2 timed passes started together; value = all images of the timed passes / "
                           f"(last end - first start); best of {{one process: legs, several: multi_process_legs}}; torch {torch.__version__} CPU fp32",
-                "multi_process_legs": multi, "legs": legs, "C0_1x3x512x512": c0, "single_process_best": {"images_per_s": cn["images_per_s"], "threads": cn["threads"], "placement": best_tag},
+                "multi_process_legs": multi, "host": host_limits(), "legs": legs, "C0_1x3x512x512": c0, "single_process_best": {"images_per_s": cn["images_per_s"], "threads": cn["threads"], "placement": best_tag},
                 "decode_p50_ms": {"cpu_N32": cn["decode_p50_ms"], "cpu_N1_C0": c0.get("decode_p50_ms"), "gpu_full_batch": gpu_decode_p50_ms}}
-    return {"value": cn["images_per_s"], "unit": "images/s", "cores": cn["threads"], "kind": "port", "multi_process_legs": multi,
+    return {"value": cn["images_per_s"], "unit": "images/s", "cores": cn["threads"], "kind": "port", "multi_process_legs": multi or MULTI_NOTE,
+            "host": host_limits(),
             "os_cpu_count": cores, "cpu_model": cpu_model,
             "sample": f"oracle/ref_cpu.forward + decode_ref.decode_detections_torch (same weights) on 32x3x{H}x{W} (the GPU leg's batch), 1 warm-up + {cn['timed_passes']} timed "
                       f"passes, median; torch {torch.__version__} CPU fp32, {cn['threads']} threads{', channels_last' if cn['channels_last'] else ''}, placement {best_tag} "
@@ -598,6 +620,8 @@ def parse_args(argv=None):
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--algo", choices=["auto", "f32"], default="auto", help="KernelOptions.algo of the measured job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-multi", action="store_true", help="CPU baseline: also run several oracle processes at once on disjoint core sets (one per NUMA node, one per 16 "
+                    "cores), throughput summed — minutes of wall time; measured once per round (profiles/r04_bench_c1_with_cpu_multi.json: no gain on the GPU box's host)")
     ap.add_argument("--no-variants", action="store_true", help="skip the f2 / f32 legs")
     ap.add_argument("--no-also", action="store_true", help="skip the short C2 / C4 lines")
     ap.add_argument("--no-accuracy", action="store_true")
@@ -751,7 +775,7 @@ def main():
                 except Exception as e:
                     result["accuracy"] = {"error": repr(e)}
             if not args.no_cpu_baseline:
-                result["cpu_baseline"] = cpu_baseline(args.config, args.k, H, W, dec["p50_ms_without_sigmoid"])
+                result["cpu_baseline"] = cpu_baseline(args.config, args.k, H, W, dec["p50_ms_without_sigmoid"], multi_process=args.cpu_multi)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
