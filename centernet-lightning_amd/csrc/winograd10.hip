@@ -11,9 +11,12 @@
 //   What it costs: 6 patch rows per 4 output rows instead of 10 per 8 (V production and patch traffic x 1.2), each weight fragment
 //   serves 4 rows instead of 8 (weight fragments from L2 x 2 per MFMA), and 128 instead of 256 non-accumulator registers.
 // Same weights as winograd9.hip (its buffer and per-cout scales are used as they are), same scaling rules (weights per output channel,
-// activations per image: batch-invariant), same bits out?  No: the summation order over ky differs per accumulator only in the order of
-// fp32 additions inside the MFMA chain — it is the same chain (chunk-major, then input row, ky); results are bit-identical to winograd9's
-// wherever both run (tests/test_gpu_conv.py pins that).
+// activations per image: batch-invariant), and the SAME chain of fp32 additions per accumulator (chunk-major, then input row, kernel row, split
+// term): the results are bit-identical to winograd9's wherever both run (tests/test_gpu_conv.py pins that with torch.equal).
+// Measured (profiles/r04_w10_trace.txt): the two workgroups of a CU are not equals — the issue arbitration is by age, the
+// first-dispatched one runs almost as if alone and the second fills what is left; together they raise the matrix-pipe utilisation of the
+// 256-channel head blocks from 0.72 to 0.80-0.85, and the power limit takes it back as clock.  The kernel is dispatched where the half-height
+// items are what matters: 16-pixel-wide maps with long channel loops, and the latency class (one-image batches).
 //
 // Schedule of a 16-channel chunk (72 MFMAs per wave, one per sched_barrier slice; wave p = transform position p):
 //   segments (input row r, kernel row ky) -> output row r - ky, rows in order, ky-major inside a row:
