@@ -346,13 +346,20 @@ def decode_block(model, x, tracking, k, config=None):
                     "what a caller holding logits pays"}
 
 
+_REF64 = {}
+
+
 def feature_errors(config, x2, algo):
     """max |feature - float64 oracle| / max |float64 oracle| at the neck output and each head's last-block output + the heatmap."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref_cpu
     model = build_model(config, algo=algo, reuse_buffers=False) if algo != "cpu" else build_model(config)
     sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
-    out64, _, neck64, heads64 = ref_cpu.forward_float64(sd, x2, sigmoid=True, return_intermediates="heads")
+    key = (config, tuple(x2.shape), float(x2.double().sum()))          # the float64 oracle once per (weights recipe, input): the same for every class
+    if key not in _REF64:
+        _REF64.clear()
+        _REF64[key] = ref_cpu.forward_float64(sd, x2, sigmoid=True, return_intermediates="heads")
+    out64, _, neck64, heads64 = _REF64[key]
     if algo == "cpu":
         out, _, neck, heads = ref_cpu.forward(sd, x2, sigmoid=True, return_intermediates="heads")
         heat = out["heatmap"]
@@ -638,6 +645,12 @@ def main():
     args = parse_args()
 
     rank, world, local_rank = setup_distributed(args.gpus)
+    t_wall = {"start": time.perf_counter()}
+
+    def lap(name):                      # wall seconds per section of this run (rank 0's line: `bench_wall_s`)
+        now = time.perf_counter()
+        t_wall[name] = round(now - t_wall.get("_last", t_wall["start"]), 1)
+        t_wall["_last"] = now
 
     tracking = args.config == "tracking"
     model = build_model(args.config, algo=args.algo)
@@ -650,7 +663,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    lap("build")
     elapsed = timed(model, x, tracking, args.k, args.warmup, args.steps, collator, barrier)
+    lap("timed_steps")
     if world > 1:
         elapsed = max_over_ranks(elapsed, "cuda")
         collate_ms = collate_alone_ms(model, x, tracking, args.k, collator, barrier)
@@ -689,6 +704,7 @@ def main():
         if args.layers:
             for what, fl, ms, kd, _nb in rows:
                 print(f"{what:44s} {kd:16s} {fl / 1e9:10.2f} GFLOP {ms * 1e3:10.1f} us {fl / (ms * 1e-3) / 1e12 if ms else 0:8.1f} TF", file=sys.stderr)
+        lap("roofline+decode")
         if world == 1:
             sync = torch.cuda.synchronize
             if not args.no_variants:
@@ -708,6 +724,7 @@ def main():
                         del m2
                     except Exception as e:      # reported, never fatal: `value` above is the measurement
                         result["variants"][algo] = {"error": repr(e)}
+            lap("variants")
             if args.collate_probe:
                 try:
                     import socket
@@ -749,6 +766,7 @@ def main():
                                                              "workgroups); both off by default")
                 except Exception as e:
                     result["latency_ms_N1"] = {"error": repr(e)}
+    lap("latency_N1")
     # the other BASELINE configurations: EVERY rank takes part (at N > 1 these are C3 and C4, the two configurations defined on 8 GPUs)
     if not args.no_also:
         lines = []
@@ -761,6 +779,7 @@ def main():
                 lines.append({"config": spec, "error": repr(e)})
         if rank == 0 and lines:
             result["also"] = lines
+    lap("also")
     if rank == 0:
         if world == 1:
             torch.cuda.empty_cache()
@@ -774,12 +793,15 @@ def main():
                                                          "decode / head wiring / neck options are pinned by goldens generated from the reference (tests/golden/)"}
                 except Exception as e:
                     result["accuracy"] = {"error": repr(e)}
+            lap("accuracy")
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(args.config, args.k, H, W, dec["p50_ms_without_sigmoid"], multi_process=args.cpu_multi)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        lap("cpu_baseline")
+        result["bench_wall_s"] = {k_: v for k_, v in t_wall.items() if k_ not in ("start", "_last")}
         # the ONE JSON line goes out last: RCCL writes a version banner through C stdio, which a pipe would otherwise deliver after Python's line
         try:
             import ctypes
