@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
 
     // ---- staging by LDS-DMA (see stem.hip) ----
 #ifndef S5_EXP
-#define S5_EXP 0        // timing builds (results wrong): 1 no patch DMA, 2 no weight DMA, 3 one K step, 4 no stores, 5 no patch scan
+#define S5_EXP 0        // timing builds (results wrong): 1 no patch DMA, 2 no weight DMA, 3 one K step, 4 no stores, 5 no patch scan, 6 / 7 border cells of the pooled map stored plainly / not at all
 #endif
     if (S5_EXP != 2)
     for (int q = wave; q < W_BYTES / 1024; q += 4) dma16(w_split, (unsigned)W_BYTES, wl + q * 1024, (unsigned)(q * 1024 + lane * 16));
@@ -341,7 +341,9 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
                     if (gx >= Wp) continue;
                     float* dst = yc + ((size_t)gy * Wp + gx) * 64;
                     if (row_border || pc == 0 || pc == 16) {
-                        if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
+                        if (S5_EXP == 6) __builtin_nontemporal_store(m, dst);      // timing build: the border cells as plain stores (wrong there)
+                        else if (S5_EXP == 7) { }                                  // timing build: border cells not written at all
+                        else if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
                     } else {
                         __builtin_nontemporal_store(m, dst);
                     }

@@ -807,6 +807,9 @@ int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu,
     int rc = p->residual ? cnl::kernel_setup(once_res, reinterpret_cast<const void*>(&winograd9_kernel<true>), LDS_BYTES, &n_cu)
                          : cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd9_kernel<false>), LDS_BYTES, &n_cu);
     if (rc != CNL_OK) return rc;
+#ifdef W9_MAX_CUS      // experiment builds: the persistent grid on fewer CUs (is a power-bound launch any slower on 240 of 256?)
+    if (n_cu > W9_MAX_CUS) n_cu = W9_MAX_CUS;
+#endif
     const unsigned grid = (unsigned)(blocks < (long long)n_cu ? blocks : (long long)n_cu);
     if (p->residual) hipLaunchKernelGGL(winograd9_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(winograd9_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);

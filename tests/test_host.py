@@ -312,6 +312,18 @@ def test_inline_asm_kernels_keep_valu_to_mfma_distance():
         assert total > 50 and not violations, (name, violations[:3])
 
 
+def test_absmax_arrays_are_one_cache_line_per_image():
+    """ABI v10: image n's maximum sits at element n * cnl_absmax_stride() of an x_absmax / y_absmax array — 32 floats = one 128-byte line per
+    image (device-scope atomics serialise per line: DESIGN.md 3.4); the host helpers pack / unpack that layout."""
+    import torch
+    lib = _lib.load()
+    assert lib.cnl_absmax_stride() == 32 == _lib.absmax_stride()
+    buf = _lib.absmax_pack(torch.tensor([1.0, 2.5, 0.0]))
+    assert buf.numel() == 3 * 32 and float(buf[32]) == 2.5 and float(buf.sum()) == 3.5
+    assert torch.equal(_lib.absmax_values(buf), torch.tensor([1.0, 2.5, 0.0]))
+    assert _lib.absmax_buffer(4, device="cpu").numel() == 128
+
+
 @pytest.mark.parametrize("src,kernels", [("winograd9.hip", 3), ("winograd10.hip", 4)])
 def test_winograd9_compiles_without_register_spills(src, kernels):
     """csrc/winograd9.hip sits at the edge of the register file (256 accumulator + 256 vector registers per lane): a spill inside its

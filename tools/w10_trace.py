@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Per-item phase timing of winograd10_kernel (block 0, thread 0; s_memtime stamps) from the W10_TRACE build: `make -C centernet-lightning_amd/csrc w10trace
-W10_TAG=trace`, then `python tools/w10_trace.py [Cin [H=W [Cout]]]` (W10N = batch, W10LIB = library under tools/_trace)."""
+W10_TAG=trace`, then `python tools/w10_trace.py [Cin [H=W [Cout]]]` (W10N = batch, W10LIB = library under tools/ablibs)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["CENTERNET_GFX950_LIB"] = os.path.join(ROOT, "tools/_trace/" + os.environ.get("W10LIB", "libcnl_w10trace.so"))
+os.environ["CENTERNET_GFX950_LIB"] = os.path.join(ROOT, "tools/ablibs/" + os.environ.get("W10LIB", "libcnl_w10trace.so"))
 sys.path.insert(0, os.path.join(ROOT, "centernet-lightning_amd"))
 import torch
 from centernet_lightning_amd import _lib

@@ -3,7 +3,7 @@
 then `python tools/w9_trace.py [Cin [H=W [Cout]]]` (W9N = batch).  Prints the phases of six work items and the eight stamps inside a chunk."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["CENTERNET_GFX950_LIB"] = os.path.join(ROOT, "tools/_trace/" + os.environ.get("W9LIB", "libcnl_w9trace.so"))
+os.environ["CENTERNET_GFX950_LIB"] = os.path.join(ROOT, "tools/ablibs/" + os.environ.get("W9LIB", "libcnl_w9trace.so"))
 sys.path.insert(0, os.path.join(ROOT, "centernet-lightning_amd"))
 import torch
 from centernet_lightning_amd import _lib
