@@ -86,7 +86,7 @@ __device__ __forceinline__ float pow2_scale(float mx) {
 struct Norm {
     float m[3], r[3];
 };
-// POOL: y is the output of MaxPool2d(3, s2, p1) applied to the conv output ([N, Hp, Wp, 64], ZERO-FILLED by the caller's launch
+// POOL: y is the output of MaxPool2d(3, s2, p1) applied to the conv output ([N, Hp, Wp, 64], its tile seams ZEROED by the caller's launch
 // function): the workgroup pools its 16x32 conv tile through LDS; the 7x15 pooled cells whose 3x3 window lies inside the tile are
 // stored, the border cells (whose window continues in a neighbouring tile) are merged with atomic max on the bit pattern — exact
 // and order-independent, the values being post-ReLU (>= +0).  The 537 MB conv output never exists.
@@ -386,6 +386,32 @@ __global__ __launch_bounds__(256) void stem_split_pack_kernel(const float* __res
     }
 }
 
+// The pooled map's cells that several workgroups merge with atomic max — pooled rows gy % 8 == 0 and columns gx % 16 == 0, the seams of the
+// 8 x 16-cell tiles — start from +0; one float4 per thread.  (Rounds 1-3 zero-filled the whole map: 134 MB at C1 for 25 MB of seams.)
+__global__ __launch_bounds__(256) void stem_zero_borders_kernel(float* __restrict__ y, int N, int Hp, int Wp) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int R8 = (Hp + 7) / 8, C16 = (Wp + 15) / 16;
+    const long rows = (long)N * R8 * Wp * 16;
+    long cell;                                  // (n * Hp + gy) * Wp + gx
+    int q;
+    if (t < rows) {
+        q = (int)(t & 15);
+        long c = t >> 4;
+        const int gx = (int)(c % Wp); c /= Wp;
+        const int r = (int)(c % R8); const long n = c / R8;
+        cell = (n * Hp + (long)r * 8) * Wp + gx;
+    } else {
+        long u = t - rows;
+        if (u >= (long)N * Hp * C16 * 16) return;
+        q = (int)(u & 15);
+        u >>= 4;
+        const int cix = (int)(u % C16); u /= C16;
+        const int gy = (int)(u % Hp); const long n = u / Hp;
+        cell = (n * Hp + gy) * Wp + (long)cix * 16;
+    }
+    *reinterpret_cast<float4*>(y + cell * 64 + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 }  // namespace cnl_stem5
 using namespace cnl_stem5;
 
@@ -411,9 +437,16 @@ int cnl_stem5_launch(const void* x, bool u8, const float* mean255, const float* 
     const int which = (u8 ? 2 : 0) + (pool ? 1 : 0);
     const int rc = cnl::kernel_setup(once[which], fns[which], LDS_BYTES);
     if (rc != CNL_OK) return rc;
-    if (pool) {                  // the border cells are merged with atomic max: start from +0 everywhere
-        const size_t Hp = (size_t)(Ho - 1) / 2 + 1, Wp = (size_t)(Wo - 1) / 2 + 1;
+    if (pool) {                  // the border cells of the tiles are merged with atomic max: THEY start from +0 (every other cell is stored once)
+        const int Hp = (Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1;
+        const long total = ((long)N * ((Hp + 7) / 8) * Wp + (long)N * Hp * ((Wp + 15) / 16)) * 16;
+#ifdef S5_FULL_ZERO              // A/B build: rounds 1-3's fill of the whole map
         CNL_HIP(hipMemsetAsync(y, 0, (size_t)N * Hp * Wp * 64 * sizeof(float), (hipStream_t)stream));
+        if (false)
+#endif
+        hipLaunchKernelGGL(stem_zero_borders_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, N, Hp, Wp);
+        const int rcz = cnl::check_launch("stem_zero_borders_kernel");
+        if (rcz != CNL_OK) return rcz;
     }
 #define S5_LAUNCH(P_, U_)                                                                                                          \
     hipLaunchKernelGGL((stem_f16x2_kernel<P_, U_>), dim3(blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes, \

@@ -236,7 +236,7 @@ int cnl_stem_conv7x7_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int
 /* The stem and resnet.maxpool in ONE launch: y = MaxPool2d(3, stride 2, padding 1)(ReLU(BN(conv7x7/2(x)))) as NHWC
  * [N, (Ho-1)/2+1, (Wo-1)/2+1, 64] with Ho = (H-1)/2+1, Wo = (W-1)/2+1; bit-identical to cnl_stem_conv7x7_f32 followed by
  * cnl_maxpool3x3s2_nhwc_f32 (always the fp16-split stem kernel), without the stride-2 feature map ever reaching memory.  The call
- * zero-fills y itself (stream-ordered).                                                                                         */
+ * initialises y itself (stream-ordered: the cells that several workgroups merge are zeroed, every other cell is stored once).                                                                                         */
 int cnl_stem_conv7x7_maxpool_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
                                  const float* w, const float* bias, float* y, float* y_absmax,
                                  int32_t N, int32_t H, int32_t W, void* stream);

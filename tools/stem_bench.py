@@ -28,4 +28,4 @@ ts = []
 for _ in range(20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
-ts.sort(); print("stem conv7x7 + maxpool (incl. the zero-fill of y) %.1f us" % ts[10])
+ts.sort(); print("stem conv7x7 + maxpool (incl. the zeroing of y's tile seams) %.1f us" % ts[10])
