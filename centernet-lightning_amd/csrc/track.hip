@@ -94,7 +94,7 @@ __device__ __forceinline__ void pair_costs(const int* sel, const int n, const fl
         double c = uv / (sqrt(uu) * sqrt(vv));
         if (fabs(c) > 1.0) c = copysign(1.0, c);
         reid_cost[p] = (1.0 - c);
-    } else {                  // scipy cdist "euclidean" (1) / "sqeuclidean" (2): s += (u - v)^2 sequentially in float64, then sqrt
+    } else if (reid_metric <= 2) {   // scipy cdist "euclidean" (1) / "sqeuclidean" (2): s += (u - v)^2 sequentially in float64, then sqrt
         const float* u = det_emb + (long)d * E;
         const float* v = trk_emb + (long)t * E;
         double acc = 0.0;
@@ -103,6 +103,24 @@ __device__ __forceinline__ void pair_costs(const int* sel, const int n, const fl
             acc = acc + df * df;
         }
         reid_cost[p] = reid_metric == 1 ? sqrt(acc) : acc;
+    } else {                  // "cityblock" (3), "chebyshev" (4), "canberra" (5), "braycurtis" (6): scipy's element order, float64
+        const float* u = det_emb + (long)d * E;
+        const float* v = trk_emb + (long)t * E;
+        double acc = 0.0, den = 0.0;
+        for (int e = 0; e < E; ++e) {
+            const double x = (double)u[e], y = (double)v[e];
+            const double ad = fabs(x - y);
+            if (reid_metric == 3) acc = acc + ad;
+            else if (reid_metric == 4) acc = ad > acc ? ad : acc;
+            else if (reid_metric == 5) {
+                const double q = fabs(x) + fabs(y);
+                acc = acc + ad / (q + (q == 0.0 ? 1.0 : 0.0));           // 0 / 0 counts as 0
+            } else {
+                acc = acc + ad;
+                den = den + fabs(x + y);
+            }
+        }
+        reid_cost[p] = reid_metric == 6 ? acc / den : acc;
     }
     if (box_mode) {   // utils/box.py:49-92 in float32, numpy's operation order
         const float4 a = *reinterpret_cast<const float4*>(det_box + (long)d * 4);
@@ -217,7 +235,7 @@ extern "C" int cnl_track_costs_metric_f32(const float* det_emb, const float* det
     CNL_REQUIRE(k > 0 && E > 0 && T >= 0, CNL_E_BAD_ARG, "cnl_track_costs_f32: bad k/E/T");
     CNL_REQUIRE(k <= MAXK, CNL_E_UNSUPPORTED, "cnl_track_costs_f32: k = %d > %d detections per frame", k, MAXK);
     CNL_REQUIRE(box_cost >= 0 && box_cost <= 2, CNL_E_BAD_ARG, "cnl_track_costs_f32: box_cost must be 0 (none), 1 (iou), 2 (giou)");
-    CNL_REQUIRE(reid_metric >= 0 && reid_metric <= 2, CNL_E_BAD_ARG, "cnl_track_costs_metric_f32: reid_metric must be 0 (cosine), 1 (euclidean), 2 (sqeuclidean)");
+    CNL_REQUIRE(reid_metric >= 0 && reid_metric <= 6, CNL_E_BAD_ARG, "cnl_track_costs_metric_f32: reid_metric must be 0 (cosine), 1 (euclidean), 2 (sqeuclidean), 3 (cityblock), 4 (chebyshev), 5 (canberra) or 6 (braycurtis)");
     CNL_REQUIRE(T == 0 || (trk_emb && reid_cost), CNL_E_BAD_ARG, "cnl_track_costs_f32: T > 0 without track table / reid_cost");
     CNL_REQUIRE(T == 0 || box_cost == 0 || (trk_box && box_cost_out), CNL_E_BAD_ARG,
                 "cnl_track_costs_f32: box cost requested without track boxes / output");
@@ -242,7 +260,7 @@ extern "C" int cnl_track_frame_f32(const float* det_emb, const float* det_box, c
     CNL_REQUIRE(k > 0 && E > 0 && T >= 0, CNL_E_BAD_ARG, "cnl_track_frame_f32: bad k/E/T");
     CNL_REQUIRE(k <= MAXK, CNL_E_UNSUPPORTED, "cnl_track_frame_f32: k = %d > %d detections per frame", k, MAXK);
     CNL_REQUIRE(box_cost >= 0 && box_cost <= 2, CNL_E_BAD_ARG, "cnl_track_frame_f32: box_cost must be 0 (none), 1 (iou), 2 (giou)");
-    CNL_REQUIRE(reid_metric >= 0 && reid_metric <= 2, CNL_E_BAD_ARG, "cnl_track_frame_f32: reid_metric must be 0 (cosine), 1 (euclidean), 2 (sqeuclidean)");
+    CNL_REQUIRE(reid_metric >= 0 && reid_metric <= 6, CNL_E_BAD_ARG, "cnl_track_frame_f32: reid_metric must be 0 (cosine) .. 6 (braycurtis)");
     CNL_REQUIRE(label_kind >= 0 && label_kind <= 3 && (label_kind == 0 || det_label), CNL_E_BAD_ARG,
                 "cnl_track_frame_f32: label_kind must be 0 (none), 1 (int64), 2 (int32), 3 (float32) with det_label set");
     CNL_REQUIRE(T == 0 || trk_emb, CNL_E_BAD_ARG, "cnl_track_frame_f32: T > 0 without track table");
