@@ -90,6 +90,12 @@ struct Norm {
 // function): the workgroup pools its 16x32 conv tile through LDS; the 7x15 pooled cells whose 3x3 window lies inside the tile are
 // stored, the border cells (whose window continues in a neighbouring tile) are merged with atomic max on the bit pattern — exact
 // and order-independent, the values being post-ReLU (>= +0).  The 537 MB conv output never exists.
+#ifdef S5_TRACE            // timing build: per workgroup [8] = s_memrealtime (100 MHz) at start / patch staged / planes written / K loop done / end, HW_ID, XCC_ID, -
+__device__ unsigned long long* s5_trace_ptr;
+#define S5_STAMP(i_) do { if (tid == 0 && s5_trace_ptr) s5_trace_ptr[(size_t)blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define S5_STAMP(i_) do {} while (0)
+#endif
 template <bool POOL, bool U8>
 __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restrict__ x, long sn, int sc, int sh, int sw,
                                                             unsigned x_img_bytes, const void* __restrict__ w_split,
@@ -110,6 +116,13 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
     const int n = b / tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    S5_STAMP(0);
+#ifdef S5_TRACE
+    if (tid == 0 && s5_trace_ptr) {
+        s5_trace_ptr[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        s5_trace_ptr[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
 
     // ---- staging by LDS-DMA (see stem.hip) ----
 #ifndef S5_EXP
@@ -140,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    S5_STAMP(1);
 
     // ---- the patch's scale: max |x| over the staged patch (out-of-image slots hold zeros); the values stay in registers ----
     float mx = 0.f;
@@ -188,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
         }
     }
     __syncthreads();
+    S5_STAMP(2);
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -241,6 +256,10 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
         }
     }
 
+#ifdef S5_TRACE
+    asm volatile("s_nop 0" :: "v"(acc[3][1][15]), "v"(acc[0][0][0]));      // the stamp waits for the last MFMAs
+#endif
+    S5_STAMP(3);
     float omax = 0.f;                   // max of what this thread contributes to y (post-ReLU: >= 0)
     if constexpr (!POOL) {
         // epilogue: scale back, bias + ReLU, NHWC store (col = lane&31 -> channel, rows -> pixels of the row)
@@ -342,9 +361,9 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
                     float* dst = yc + ((size_t)gy * Wp + gx) * 64;
                     if (row_border || pc == 0 || pc == 16) {
                         if (S5_EXP == 6) __builtin_nontemporal_store(m, dst);      // timing build: the border cells as plain stores (wrong there)
-                        else if (S5_EXP == 7) { }                                  // timing build: border cells not written at all
+                        else if (S5_EXP == 7 || S5_EXP == 4) { }                                  // timing build: border cells not written at all
                         else if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
-                    } else {
+                    } else if (S5_EXP != 4 || m == 12345.f) {
                         __builtin_nontemporal_store(m, dst);
                     }
                 }
@@ -356,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
         const float m = cnl::wave_max_nonneg(omax);          // (16 K waves, 32 floats of one cache line: see cnl::report_max)
         if (lane == 0) cnl::report_max(ymax + n * AMS, m);
     }
+    S5_STAMP(4);
 }
 
 // OHWI [64][7][7][3] (BN folded) -> [piece][group][cout][8] fp16 with the power-of-two scale S_w (scal[0]); one workgroup
@@ -415,6 +435,9 @@ __global__ __launch_bounds__(256) void stem_zero_borders_kernel(float* __restric
 }  // namespace cnl_stem5
 using namespace cnl_stem5;
 
+#ifdef S5_TRACE
+extern "C" int cnl_stem5_set_trace(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(s5_trace_ptr), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+#endif
 // floats appended to the fp32 packed weights: the two fp16 pieces + 4 scalars
 size_t cnl_stem5_extra_floats() { return (size_t)W_BYTES / 4 + 4; }
 
