@@ -96,7 +96,7 @@ __device__ unsigned long long* s5_trace_ptr;
 #else
 #define S5_STAMP(i_) do {} while (0)
 #endif
-template <bool POOL, bool U8>
+template <bool POOL, bool U8, bool FULL>
 __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restrict__ x, long sn, int sc, int sh, int sw,
                                                             unsigned x_img_bytes, const void* __restrict__ w_split,
                                                             const float* __restrict__ scal, const float* __restrict__ bias,
@@ -306,6 +306,10 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
             (out_)[8] = hi ? (in_)[15] : 0.f;                                                                     \
         } while (0)
         __syncthreads();                                               // everyone is done with the LDS images
+        // FULL (Ho % 16 == 0 and Wo % 32 == 0: every tile of the launch lies inside the conv map — 512 x 512 and 608 x 1088 inputs): no
+        // validity masks, and every address is a wave-uniform base + one per-lane offset (the general path's per-value masks and 64-bit per-lane addresses made 2 500
+        // instructions with ~320 SGPR spill moves of this epilogue: 7.5 us of a workgroup's 22, profiles/r04_stem_trace.txt).
+        {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float bv = bias[j * 32 + px];
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[i][j][r] * inv + bv;
-                    const bool ok = wave * 4 + i < rows_ok && (r & 3) + 8 * (r >> 2) + 4 * hi < cols_ok;
+                    const bool ok = FULL || (wave * 4 + i < rows_ok && (r & 3) + 8 * (r >> 2) + 4 * hi < cols_ok);
                     acc[i][j][r] = (ok && v > 0.f) ? v : 0.f;            // ReLU; never -0 or NaN
                     omax = fmaxf(omax, acc[i][j][r]);                  // (every valid conv value lies in some pooling window: max y = max of these)
                 }
@@ -326,6 +330,8 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
             for (int k = 0; k < 9; ++k) X[((j * 4 + wave) * 9 + k) * 64 + lane] = p3[k];
         }
         __syncthreads();
+        float* const yimg = y + (size_t)n * Hp * Wp * 64;              // wave-uniform
+        const int lane_off = hi * 128 + px;                            // + 32 j: the lane's part of every cell offset (floats)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float in_o[16], in_e[16], po[9], pe[9];
@@ -340,7 +346,6 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
 #pragma unroll
                 for (int k = 0; k < 9; ++k) pe[k] = fmaxf(pe[k], X[((j * 4 + wave - 1) * 9 + k) * 64 + lane]);
             }
-            float* yc = y + (size_t)n * Hp * Wp * 64 + j * 32 + px;
             // rows: 0 = pooled row 2w (even), 1 = pooled row 2w+1 (odd), 2 = pooled row 8 (wave 3 only: its conv row 15 alone)
 #pragma unroll
             for (int rw = 0; rw < 3; ++rw) {
@@ -349,17 +354,19 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
                 const int gy = py0 + pr;
                 if (gy >= Hp) continue;
                 const bool row_border = pr == 0 || pr == 8;
+                float* const yrow = yimg + ((size_t)gy * Wp + px0) * 64 + j * 32;          // wave-uniform
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    const int pc = k == 8 ? 16 : (4 * (k & 3) + 2 * hi + (k >> 2));
-                    const int gx = px0 + pc;
+                    // pooled column of the lane: pc = 4 (k & 3) + (k >> 2) + 2 hi; k == 8: column 16 (lane half 1 only)
+                    const int pcu = k == 8 ? 14 : (4 * (k & 3) + (k >> 2));                 // the wave-uniform part
                     float m;
                     if (rw == 2) m = X[((j * 4 + 3) * 9 + k) * 64 + lane];      // own column-pooled row 15
                     else m = rw ? po[k] : pe[k];
                     if (k == 8 && !hi) continue;
-                    if (gx >= Wp) continue;
-                    float* dst = yc + ((size_t)gy * Wp + gx) * 64;
-                    if (row_border || pc == 0 || pc == 16) {
+                    if ((!FULL || k == 8) && px0 + pcu + 2 * hi >= Wp) continue;
+                    float* dst = yrow + pcu * 64 + lane_off;
+                    const bool col_border = (k == 0 && !hi) || k == 8;          // pc == 0 / pc == 16
+                    if (row_border || col_border) {
                         if (S5_EXP == 6) __builtin_nontemporal_store(m, dst);      // timing build: the border cells as plain stores (wrong there)
                         else if (S5_EXP == 7 || S5_EXP == 4) { }                                  // timing build: border cells not written at all
                         else if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
@@ -368,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
                     }
                 }
             }
+        }
         }
 #undef S5_COLPOOL
     }
@@ -454,10 +462,13 @@ int cnl_stem5_launch(const void* x, bool u8, const float* mean255, const float* 
     if (u8) {
         for (int c = 0; c < 3; ++c) { nrm.m[c] = mean255[c]; nrm.r[c] = inv_std255[c]; }
     }
-    static cnl::DeviceOnce once[4];
-    const void* fns[4] = {(const void*)stem_f16x2_kernel<false, false>, (const void*)stem_f16x2_kernel<true, false>,
-                          (const void*)stem_f16x2_kernel<false, true>, (const void*)stem_f16x2_kernel<true, true>};
-    const int which = (u8 ? 2 : 0) + (pool ? 1 : 0);
+    static cnl::DeviceOnce once[8];
+    const void* fns[8] = {(const void*)stem_f16x2_kernel<false, false, false>, (const void*)stem_f16x2_kernel<true, false, false>,
+                          (const void*)stem_f16x2_kernel<false, true, false>,  (const void*)stem_f16x2_kernel<true, true, false>,
+                          (const void*)stem_f16x2_kernel<false, false, true>,  (const void*)stem_f16x2_kernel<true, false, true>,
+                          (const void*)stem_f16x2_kernel<false, true, true>,   (const void*)stem_f16x2_kernel<true, true, true>};
+    const bool full = Ho % TH == 0 && Wo % TW == 0;              // no partial tile in the launch
+    const int which = (full ? 4 : 0) + (u8 ? 2 : 0) + (pool ? 1 : 0);
     const int rc = cnl::kernel_setup(once[which], fns[which], LDS_BYTES);
     if (rc != CNL_OK) return rc;
     if (pool) {                  // the border cells of the tiles are merged with atomic max: THEY start from +0 (every other cell is stored once)
@@ -471,14 +482,18 @@ int cnl_stem5_launch(const void* x, bool u8, const float* mean255, const float* 
         const int rcz = cnl::check_launch("stem_zero_borders_kernel");
         if (rcz != CNL_OK) return rcz;
     }
-#define S5_LAUNCH(P_, U_)                                                                                                          \
-    hipLaunchKernelGGL((stem_f16x2_kernel<P_, U_>), dim3(blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes, \
+#define S5_LAUNCH(P_, U_, F_)                                                                                                      \
+    hipLaunchKernelGGL((stem_f16x2_kernel<P_, U_, F_>), dim3(blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes, \
                        (const void*)extra, extra + W_BYTES / 4, bias, y, reinterpret_cast<unsigned*>(y_absmax), N, H, W, Ho, Wo, tiles_x, tiles_y, nrm)
     switch (which) {
-        case 0: S5_LAUNCH(false, false); break;
-        case 1: S5_LAUNCH(true, false); break;
-        case 2: S5_LAUNCH(false, true); break;
-        default: S5_LAUNCH(true, true); break;
+        case 0: S5_LAUNCH(false, false, false); break;
+        case 1: S5_LAUNCH(true, false, false); break;
+        case 2: S5_LAUNCH(false, true, false); break;
+        case 3: S5_LAUNCH(true, true, false); break;
+        case 4: S5_LAUNCH(false, false, true); break;
+        case 5: S5_LAUNCH(true, false, true); break;
+        case 6: S5_LAUNCH(false, true, true); break;
+        default: S5_LAUNCH(true, true, true); break;
     }
 #undef S5_LAUNCH
     return cnl::check_launch("stem_f16x2_kernel");
