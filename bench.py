@@ -760,10 +760,10 @@ def main():
                         with torch.no_grad():
                             lat[name] = round(gpu_ms_back_to_back(lambda: gather3(m3(x1), num_detections=args.k), calls=30, rounds=3), 4)
                         del m3
-                    result["latency_ms_N1"] = dict(lat, note=f"1 x 3 x {H} x {W} (BASELINE C0's shape), forward + decode, 30 calls back to back; latency = KernelOptions(latency=True): "
-                                                             "the 3x3 / stride-1 layers on 4-row x 32-cout row-Winograd items (csrc/winograd10.hip), an option of the plan that never "
-                                                             "looks at the batch size; split_small = KernelOptions(split_small=True) (reduction of the small-grid convs split over "
-                                                             "workgroups); both off by default")
+                    result["latency_ms_N1"] = dict(lat, note=f"1 x 3 x {H} x {W} (BASELINE C0's shape), forward + decode, 30 calls back to back; default: launches of at most 128 winograd9 work items "
+                                                             "take the bit-identical 4-row x 32-cout items (csrc/winograd10.hip); latency = KernelOptions(latency=True): every eligible "
+                                                             "3x3 / stride-1 layer does, also those whose default is another kernel; split_small = KernelOptions(split_small=True) "
+                                                             "(reduction of the small-grid convs split over workgroups); both options off by default")
                 except Exception as e:
                     result["latency_ms_N1"] = {"error": repr(e)}
     lap("latency_N1")

@@ -44,8 +44,8 @@ class KernelOptions:
       reuse_buffers    activation buffers share one arena by liveness; False keeps every intermediate (tests read them)
       latency          latency class for one-image batches (default off): every 3x3 / stride-1 layer the row-Winograd kernels can run
                        takes csrc/winograd10.hip's 4-row x 64-pixel x 32-cout work items (cnl_conv_params.algo = CNL_ALGO_LATENCY) — four times the
-                       work items of the default's, two workgroups per CU.  An option of the plan, never a function of the batch size: a plan built
-                       with it is batch-invariant like any other (same bits as the default wherever the default takes a row-Winograd kernel).
+                       work items of winograd9's, two workgroups per CU.  (The default already does this for winograd9's own layers when a launch has
+                       at most 128 work items — same bits; the option adds the layers whose default is another kernel.)
       split_small      latency mode for small batches (default off): launches whose output is too small to fill the chip (one image: the
                        16x16 .. 64x64 maps) run as direct convs with the reduction split over several workgroups per output tile and a
                        fixed-order reduce (cnl_conv_params.splitk).  The choice then depends on the batch size, so results are no longer

@@ -139,8 +139,8 @@ static int wino_choice(const cnl_conv_params* p) {
     // the latency class (one-image batches, BASELINE C0): 4-row x 64-pixel x 32-cout row-Winograd items, two workgroups per CU — four times the
     // work items of winograd9's (a 32 x 32 map of one image: 64 instead of 16).  Measured at N = 1 against the default choice
     // (profiles/r04_winograd_variants.txt): layer1 22 -> 16 us, layer2 29 -> 16, layer3 46 -> 23, layer4 61 -> 38, 512 -> 256 @16x16 69 -> 36;
-    // not behind a folded upsample (64 -> 512 first head blocks: 44 us on winograd9, 60 here).  An arithmetic class of its own: the caller
-    // asks for it, the batch size never does.
+    // not behind a folded upsample (64 -> 512 first head blocks: 44 us on winograd9, 60 here).  The caller's option takes EVERY eligible layer there
+    // (also those whose default is winograd5 / 6 or the fp32 kernel: other arithmetic); the default plan moves only winograd9's own layers (below).
     if (p->algo == CNL_ALGO_LATENCY && upf == 1 && cnl_wino10_eligible(p)) return 11;
     // 16-pixel-wide maps (four images side by side in a block row): the half-height items of winograd10.hip give the chip twice the work
     // items of winograd9's and a second workgroup per CU to overlap with (long channel loops: what was measured) — 512 -> 512 @16x16 x 32: 83 us (winograd5: 90-93, winograd9: 97-107),
@@ -154,7 +154,16 @@ static int wino_choice(const cnl_conv_params* p) {
         // (the kernel does it when forced), but there kernels 5 / 6 win: 512 -> 512 @16x16 85 vs 110 us, 512 -> 256 77 vs 98
         const int side = (upf == 1 && W == 32) ? 2 : 1;
         const long long pad9 = (long long)((H + 7) / 8 * 8) * ((W * side + 63) / 64 * 64);
-        if (pad9 * 100 <= area * side * 150) return 9;
+        if (pad9 * 100 <= area * side * 150) {
+            // Small grids (small batches: BASELINE C0 is one image): when winograd9's 8-row x 64-cout items number at most half the chip's
+            // 256 CUs, the SAME arithmetic runs on 4-row x 32-cout items (winograd10.hip, variant 11: four times the items, two workgroups
+            // per CU) — bit for bit the same output (tests/test_gpu_conv.py), so a shard and the full batch still agree exactly although
+            // they may take different work-item shapes.  Measured (profiles/r04_small_batch_variants.txt), items of winograd9 -> us 9 / 11:
+            // 8: 48 / 24, 16: 32 / 18, 32: 25 / 18, 64: 33 / 22, 128: 63 / 56 (head block), 37 / 30, 28 / 24; 256: 82 / 92 -> stays.
+            const long long items9 = (long long)((p->N + side - 1) / side) * ((H + 7) / 8) * ((W * side + 63) / 64) * (CoutP / 64);
+            if (items9 <= 128 && upf == 1 && cnl_wino10_eligible(p)) return 11;
+            return 9;
+        }
     }
     if (items_per_image >= 8 && (p->Cin >= 128 || p->Cout >= 256)) {      // (Cin 64 -> 256 / 512 / 768: the first head blocks, per head or fused)
         // the 8x16-pixel x 128-cout work items of winograd6.hip: where the channel loop is short and the couts many, and on maps

@@ -193,7 +193,9 @@ int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p);            /* CNL_WIN
 int cnl_conv3x3_winograd_variant(const cnl_conv_params* p);           /* the kernel behind the class (reporting only): 2 winograd2, 5 / 6 winograd5 / 6
                                                                          [F(2x2,3x3)], 9 winograd9 [F(2,3) along x, kernel rows
                                                                          in the reduction: 2/3 of the direct conv's multiplies], 10 / 11 winograd10
-                                                                         [the same on 4-row x 64- / 32-cout items]; < 0: error code */
+                                                                         [the same on 4-row x 64- / 32-cout items: bit for bit winograd9's
+                                                                         output — the class never depends on N, but a launch of at most
+                                                                         128 winograd9 items takes 11]; < 0: error code */
 size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout);        /* elements of the transformed weight buffer */
 int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream);
 /*

@@ -776,8 +776,8 @@ def test_split_kernels_on_trained_checkpoint_like_weights():
 
 
 def test_winograd_dispatch_is_a_function_of_shape_and_algo_only():
-    """cnl_conv3x3_winograd_kernel: the kernel class follows the layer shape and the caller's algo — never the batch size, never the
-    environment.  (The F(4x4) class of ABI <= 9 is gone: algo 3 is rejected.)"""
+    """cnl_conv3x3_winograd_kernel: the kernel CLASS (the arithmetic) follows the layer shape and the caller's algo — never the batch size,
+    never the environment.  (The F(4x4) class of ABI <= 9 is gone: algo 3 is rejected.)"""
     lib = _lib.load()
 
     def kind(N, Cin, H, W, Cout, algo):
@@ -804,7 +804,10 @@ def test_winograd_dispatch_is_a_function_of_shape_and_algo_only():
         assert kind(N, 24, 128, 128, 64, CNL_ALGO_AUTO) == 2            # Cin % 16 != 0
         # the kernel behind the class (cnl_conv3x3_winograd_variant): round 4's half-height row-Winograd items on 16-pixel-wide maps with long
         # channel loops, and wherever a row-Winograd kernel applies under the latency class — which the CALLER chooses, never the batch size
-        assert variant(N, 256, 128, 128, 256, CNL_ALGO_AUTO) == 9 and variant(N, 256, 32, 32, 256, CNL_ALGO_AUTO) == 9
+        # (within the row-Winograd class the work-item shape follows the grid size: at most 128 of winograd9's items -> its bit-identical
+        # 4-row x 32-cout form, variant 11 — the only place the batch size is looked at, and it cannot change a result)
+        assert variant(N, 256, 128, 128, 256, CNL_ALGO_AUTO) == (11 if N == 1 else 9)
+        assert variant(N, 256, 32, 32, 256, CNL_ALGO_AUTO) == (9 if N == 32 else 11)
         assert variant(N, 512, 16, 16, 512, CNL_ALGO_AUTO) == 10 and variant(N, 512, 16, 16, 256, CNL_ALGO_AUTO) == 11
         assert variant(N, 512, 19, 34, 512, CNL_ALGO_AUTO) == 6
         for shp in ((256, 128, 128, 256), (256, 32, 32, 256), (128, 64, 64, 128), (64, 128, 128, 64), (512, 16, 16, 512)):

@@ -62,6 +62,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("names", nargs="*", default=["head256"])
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=0, help="override the shape's batch size")
     ap.add_argument("--winograd", action="store_true")
     ap.add_argument("--up2", action="store_true", help="3x3 convs with CNL_UPSAMPLE_IN through cnl_conv3x3_up2_nhwc_f32 (sub-pixel phases)")
     ap.add_argument("--hints", action="store_true", help="hand over x_absmax / w_absmax (fp16-split direct kernel where it applies; Winograd: no own absmax pass)")
@@ -76,6 +77,7 @@ def main():
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for name in args.names:
         N, H, W, Cin, Cout, k, stride, flags, res = SHAPES[name]
+        N = args.batch or N
         up = 2 if flags & CNL_UPSAMPLE_IN else 1
         Ho, Wo = (H * up + 2 * ((k - 1) // 2) - k) // stride + 1, (W * up + 2 * ((k - 1) // 2) - k) // stride + 1
         x = torch.randn(N, H, W, Cin, device="cuda")
