@@ -451,6 +451,21 @@ def host_limits():
     return out
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants per period (cpu.max "quota period" / cfs_quota_us), or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(q) // int(per))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, q // per)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_groups(cpus):
     """Process counts for the multi-process CPU legs: one per NUMA node, and one per 16 cores (a pair of CCDs)."""
     counts = set()
@@ -479,7 +494,10 @@ def cpu_baseline(config, k, H, W, gpu_decode_p50_ms, multi_process=False):
                 break
     except OSError:
         pass
-    tlist = sorted({max(1, min(t_, cores)) for t_ in (16, 32, 64)})
+    quota = cpu_quota()                        # more threads than the cgroup's CPU quota only share it (the GPU boxes: 16 of a 256-CPU host)
+    cap = min(cores, quota) if quota else cores
+    tlist = sorted({max(1, min(t_, cap)) for t_ in (16, 32, 64)})
+    quota_note = f", capped by the cgroup quota of {quota} CPUs" if quota else ""
 
     def child(spec, pinned):
         env = dict(os.environ)
@@ -525,7 +543,7 @@ def cpu_baseline(config, k, H, W, gpu_decode_p50_ms, multi_process=False):
                 multi[f"{P_}_processes"] = {"error": [o.get("error") for o in outs if "error" in o][:1]}
     except Exception as e:
         multi["error"] = repr(e)
-    c0 = child({"config": config, "k": k, "n": 1, "h": 512, "w": 512, "threads": sorted({max(1, min(t_, cores)) for t_ in (8, 16, 32)}), "warmup": 2, "passes": 5,
+    c0 = child({"config": config, "k": k, "n": 1, "h": 512, "w": 512, "threads": sorted({max(1, min(t_, cap)) for t_ in (8, 16, 32)}), "warmup": 2, "passes": 5,
                 "both_layouts": True}, True)
     good = {k_: v for k_, v in legs.items() if "images_per_s" in v}
     if not good:
@@ -547,7 +565,7 @@ def cpu_baseline(config, k, H, W, gpu_decode_p50_ms, multi_process=False):
             "os_cpu_count": cores, "cpu_model": cpu_model,
             "sample": f"oracle/ref_cpu.forward + decode_ref.decode_detections_torch (same weights) on 32x3x{H}x{W} (the GPU leg's batch), 1 warm-up + {cn['timed_passes']} timed "
                       f"passes, median; torch {torch.__version__} CPU fp32, {cn['threads']} threads{', channels_last' if cn['channels_last'] else ''}, placement {best_tag} "
-                      f"(best of two OpenMP placements x thread counts {tlist}: legs[*].probes_images_per_s); decode = the reference's torch op sequence on CPU",
+                      f"(best of two OpenMP placements x thread counts {tlist}{quota_note}: legs[*].probes_images_per_s); decode = the reference's torch op sequence on CPU",
             "legs": legs, "C0_1x3x512x512": c0,
             "decode_p50_ms": {"cpu_N32": cn["decode_p50_ms"], "cpu_N1_C0": c0.get("decode_p50_ms"), "gpu_full_batch": gpu_decode_p50_ms}}
 
