@@ -267,7 +267,7 @@ def roofline_block(rows, config, B, H, W):
             "traffic": traffic[0] if traffic else None,
             "traffic_source": (traffic[1] + " — rocprofv3 PMC of an earlier run of this command, not measured here") if traffic else
                               "no PMC profile of this kernel / configuration committed yet (see profiles/)",
-            "sustained_clock_note": "power-limited DVFS: on the 256-channel head blocks this kernel holds 1.37-1.48 GHz of 2.4 under real data (GRBM_GUI_ACTIVE / duration, profiles/r04_winograd_variants.txt, r04_winograd9_skip4.txt): a denser schedule lowers the clock, 25 % fewer MFMAs buy 12.6 % (DESIGN.md 3.1)"}
+            "sustained_clock_note": "power-limited DVFS: on the 256-channel head blocks this kernel holds 1.37-1.48 GHz of 2.4 under real data (GRBM_GUI_ACTIVE / duration, profiles/r04_winograd_variants.txt, r04_winograd9_skip4.txt): a denser schedule lowers the clock, 25 % fewer MFMAs buy 12.6 % (DESIGN.md 3.1); a loop of nothing but this MFMA on random fp16 operands sustains 1.84-1.90 PFLOP/s at 1.84-1.90 GHz (profiles/r04_mfma_order.txt), 0.74-0.76 of `peak`"}
     roof["other_kernels"] = {KIND_NAMES[k_].split(" (")[0]: {"launches_per_step": v[0], "kernel_ms_per_step": round(v[1], 3),
                                                             "effective_tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0,
                                                             "executed_frac_of_its_peak": round(v[2] * EXEC[k_][0] / (v[1] * 1e-3) / 1e12 / EXEC[k_][1], 4) if v[1] else 0.0}
