@@ -101,9 +101,16 @@ constexpr int JOB0 = 2;                     // job j runs in slices [JOB0 + 14 j
 constexpr int BARRIER_SLICE = 98;           // before job 7 (the first to read the next patch)
 constexpr int NSTG = 6;                     // staging registers per thread: a patch (10 pieces (row i, pixel tid / 4, quad tid % 4) + 1 for the two last pixel columns) travels in two halves
 
+#ifndef W9_AUX_X
+#define W9_AUX_X 0    /* cache policy of the patch loads / the weight loads (A/B builds: 2 = nt, 1 = sc0, 16 = sc1) */
+#endif
+#ifndef W9_AUX_U
+#define W9_AUX_U 0
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ u32x4 buf_load16(const void* base, unsigned bytes, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-    return (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
+    return (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, AUX);
 }
 __device__ __forceinline__ void buf_store16(f32x4 v, float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
@@ -208,7 +215,7 @@ template <int KY>
 __device__ __forceinline__ void load_b(State& st, const Args& a, const unsigned u_voff, const int cc, const int i, const unsigned u_plane, const unsigned u_wave) {
     const int nbh = i >> 1, piece = i & 1;
     const unsigned so = (unsigned)cc * (24u * u_plane) + u_wave + (unsigned)(KY * 2 + piece) * u_plane + (unsigned)nbh * 1024u;
-    st.fb[KY][nbh][piece] = buf_load16(a.u9, a.u_bytes, u_voff, so);
+    st.fb[KY][nbh][piece] = buf_load16<W9_AUX_U>(a.u9, a.u_bytes, u_voff, so);
 }
 // The patch of a chunk travels global -> staging registers -> LDS in two halves that share the registers: half A = rows 0..4 + the
 // piece with the two last pixel columns of all rows (stg[5]), half B = rows 5..9.  Piece I of half HALF of chunk cc of item `it`:
@@ -221,10 +228,10 @@ __device__ __forceinline__ void pload(State& st, const Item& it, const Args& a, 
         const bool ok = (unsigned)iy < (unsigned)a.H;                               //  compiler, which then wraps every load in a waterfall loop)
         const int sy = ok ? (up ? (iy >> 1) : iy) : 0;
         const unsigned so = __builtin_amdgcn_readfirstlane(it.img_base + (unsigned)sy * st.row_pitch + (unsigned)cc * 64u);
-        st.stg[I] = buf_load16(a.x, a.x_bytes, ok ? it.vcol : OOB, so);
+        st.stg[I] = buf_load16<W9_AUX_X>(a.x, a.x_bytes, ok ? it.vcol : OOB, so);
     } else {
         static_assert(HALF == 0, "the column piece belongs to half A");
-        st.stg[5] = buf_load16(a.x, a.x_bytes, it.vext, __builtin_amdgcn_readfirstlane(it.img_base + (unsigned)cc * 64u));   // (threads >= 80: out of range -> zeros)
+        st.stg[5] = buf_load16<W9_AUX_X>(a.x, a.x_bytes, it.vext, __builtin_amdgcn_readfirstlane(it.img_base + (unsigned)cc * 64u));   // (threads >= 80: out of range -> zeros)
     }
 }
 // ... staging register -> patch buffer `pbuf`
