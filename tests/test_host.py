@@ -52,6 +52,28 @@ def test_abi_error_convention_without_gpu():
     assert lib.cnl_conv2d_out_hw(ctypes.byref(p), ctypes.byref(ho), ctypes.byref(wo)) == 0 and (ho.value, wo.value) == (4, 4)
 
 
+def test_winograd_dispatcher_is_host_code_and_keeps_the_arithmetic_class_whatever_the_batch():
+    """cnl_conv3x3_winograd_kernel / _variant are pure host functions of the parameters (no GPU needed): the arithmetic CLASS of a layer never
+    depends on N; within the row-Winograd class a launch of at most 128 of winograd9's work items takes the bit-identical 4-row x 32-cout
+    items (variant 11) — the rule the GPU tests pin bit for bit (tests/test_gpu_conv.py)."""
+    lib = _lib.load()
+
+    def ask(fn, N, Cin, H, W, Cout, algo=_lib.CNL_ALGO_AUTO, flags=0):
+        p = _lib.ConvParams()
+        p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.ldx, p.ldy, p.flags, p.algo = N, H, W, Cin, Cout, 3, 3, 1, 1, Cin, Cout, flags, algo
+        p.y = 1 << 20
+        return fn(ctypes.byref(p))
+
+    for shape in ((256, 128, 128, 256), (64, 128, 128, 64), (128, 64, 64, 128), (256, 32, 32, 256), (512, 16, 16, 512), (512, 19, 34, 512)):
+        assert len({ask(lib.cnl_conv3x3_winograd_kernel, N, *shape) for N in (1, 2, 5, 32, 64)}) == 1, shape
+    # winograd9 items: N x ceil(H / 8) x ceil(W / 64) x Cout / 64 (two images side by side on 32-pixel maps)
+    assert [ask(lib.cnl_conv3x3_winograd_variant, N, 256, 128, 128, 256) for N in (1, 2, 32)] == [11, 9, 9]          # 128, 256, 4096 items
+    assert [ask(lib.cnl_conv3x3_winograd_variant, N, 64, 128, 128, 64) for N in (1, 4, 5, 32)] == [11, 11, 9, 9]    # 32 per image
+    assert [ask(lib.cnl_conv3x3_winograd_variant, N, 256, 32, 32, 256) for N in (1, 16, 17, 32)] == [11, 11, 9, 9]  # 16 per image pair
+    assert ask(lib.cnl_conv3x3_winograd_variant, 1, 64, 64, 64, 512, flags=_lib.CNL_UPSAMPLE_IN) == 9               # not behind a folded upsample
+    assert ask(lib.cnl_conv3x3_winograd_variant, 1, 64, 128, 128, 64, algo=_lib.CNL_ALGO_F32) == 2
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setenv("CENTERNET_GFX950_LIB", str(tmp_path / "nope.so"))
