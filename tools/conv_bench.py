@@ -47,6 +47,9 @@ SHAPES = {
     "lat512": (32, 16, 16, 512, 256, 1, 1, 0, False),
     "out80": (32, 128, 128, 256, 80, 1, 1, CNL_SIGMOID, False),
     "out4": (32, 128, 128, 256, 4, 1, 1, 0, False),
+    "out64c4": (32, 152, 272, 256, 64, 1, 1, 0, False),
+    "out80ns": (32, 128, 128, 256, 80, 1, 1, 0, False),
+    "out80n64": (64, 128, 128, 256, 80, 1, 1, CNL_SIGMOID, False),
     # one-image batches (BASELINE C0): the latency class
     "n1head": (1, 128, 128, 256, 256, 3, 1, CNL_RELU, False),
     "n1first": (1, 64, 64, 64, 512, 3, 1, CNL_RELU | CNL_UPSAMPLE_IN, False),
@@ -132,7 +135,7 @@ def main():
             xm = _lib.absmax_pack(x.abs().amax(dim=(1, 2, 3)))
             wm = w.abs().max().reshape(1).contiguous()
             ym = _lib.absmax_buffer(N)
-            p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), wm.data_ptr(), ym.data_ptr()
+            p.x_absmax, p.w_absmax, p.y_absmax = xm.data_ptr(), wm.data_ptr(), (None if args.no_ymax else ym.data_ptr())
         for _ in range(2):
             _lib.check(fn(ctypes.byref(p), stream))
         torch.cuda.synchronize()
