@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """bench.py — images/sec of the CenterNet hot path (forward + gather_detection2d [+ RCCL all-gather]) on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
-`python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 either launched under
+`python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU, RCCL) or started plainly — without WORLD_SIZE in the environment
+the script launches those N ranks itself (`self_launch`) and exits non-zero if any rank fails.  Rank 0 prints ONE JSON line.
 
   step      = one pass of the hot path over one synthetic batch per GPU:
               CenterNet.forward (ResNet-34 -> neck -> heads, sigmoid) + gather_detection2d (k=100, nms 3)
@@ -131,9 +132,7 @@ def setup_distributed(gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != gpus:
-        if world == 1 and gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if world != gpus:                    # (a plain `bench.py --gpus N` never gets here: main() starts the ranks itself, `self_launch`)
         raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}")
     backend = os.environ.get("CNL_BENCH_BACKEND", "nccl")
     if torch.cuda.is_available():
@@ -145,6 +144,76 @@ def setup_distributed(gpus):
         else:
             dist.init_process_group(backend)
     return rank, world, local_rank
+
+
+def self_launch(gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and NO launcher environment (WORLD_SIZE unset): start the N ranks ourselves — the same
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <argv>` the driver's
+    contract names, on a free port — pass rank 0's one JSON line through on stdout and return the launcher's exit code (non-zero if ANY
+    rank failed).  Under torchrun (WORLD_SIZE set) this is never called: that path is unchanged."""
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+class _StubModel:
+    """CNL_BENCH_STUB=1 — the launcher self-test of tests/test_host.py on a box WITHOUT GPUs: stands in for the model leg only (a "forward" that
+    hands back host records), so that everything around it — self_launch, the rendezvous, barriers, the pipelined Collator over gloo, max over
+    ranks, rank 0's single JSON line, the exit code — runs for real.  Its line says `"data": "STUB ..."`: never a measurement."""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def __call__(self, x):
+        return x
+
+    def gather_detection2d(self, o, num_detections=100):
+        return torch.full((o.shape[0], num_detections, 6), float(self.rank))
+
+    gather_tracking2d = gather_detection2d
+
+
+class _StubCollator:
+    """records in, records out through the product's Collator (submit_records / result_records: the gloo path of the protocol tests)."""
+
+    def __init__(self):
+        self.c = cl.Collator()
+
+    def submit(self, rec):
+        return self.c.submit_records(rec)
+
+    def result(self, h):
+        return self.c.result_records(h)
+
+
+def stub_main(args, rank, world):
+    if os.environ.get("CNL_BENCH_STUB_FAIL_RANK") == str(rank):      # (the self-test's "one rank dies" case: the launcher must report it)
+        raise SystemExit(f"rank {rank}: failing on request (CNL_BENCH_STUB_FAIL_RANK)")
+    x = torch.zeros(args.batch, 1)
+    barrier = dist.barrier if world > 1 else (lambda: None)
+    collator = _StubCollator()
+    model = _StubModel(rank)
+    elapsed = timed(model, x, False, args.k, args.warmup, args.steps, collator, barrier)
+    out = run_steps(model, x, False, args.k, 1, collator)
+    ok = tuple(out.shape) == (world * args.batch, args.k, 6) and all(bool((out[q * args.batch:(q + 1) * args.batch] == q).all()) for q in range(world))
+    if world > 1:
+        elapsed = max_over_ranks(elapsed, "cpu")
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(f"rank {rank}: gathered records are not in rank order")
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec @512x512 ResNet34 CenterNet forward + gather_detection2d", "value": round(job_throughput(args.batch, world, args.steps, elapsed), 2),
+                          "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "STUB (CNL_BENCH_STUB=1: launcher / collate self-test without a GPU — NOT a measurement)",
+                          "config": {"workload": "stub", "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"batch-shard x{world}"}}), flush=True)
 
 
 def max_over_ranks(elapsed, device):
@@ -661,8 +730,14 @@ def main():
         _cpu_leg_child(json.loads(sys.argv[2]))
         return
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))          # no launcher around us: become one
 
     rank, world, local_rank = setup_distributed(args.gpus)
+    if os.environ.get("CNL_BENCH_STUB") == "1":
+        if torch.cuda.is_available():
+            raise SystemExit("CNL_BENCH_STUB=1 is the no-GPU launcher self-test; on a GPU box the bench measures the real model")
+        return stub_main(args, rank, world)
     t_wall = {"start": time.perf_counter()}
 
     def lap(name):                      # wall seconds per section of this run (rank 0's line: `bench_wall_s`)
