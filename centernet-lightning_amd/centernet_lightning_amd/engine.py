@@ -529,6 +529,9 @@ class Plan:
             if not isinstance(L.args, ConvParams):
                 continue
             is_wino5 = L.fn is wino and lib.cnl_conv3x3_winograd_kernel(ctypes.byref(L.args)) == CNL_WINO_F16X2
+            if L.fn is direct and (L.args.flags & CNL_UPSAMPLE_OUT_ADD):
+                reports.add(id(L))          # the Fuse epilogue (project -> up -> + skip) reports max |y| from the fp32 kernel too: a producer only
+                continue
             if not is_wino5 and not would_split(L):
                 continue
             x = L.keep[0]

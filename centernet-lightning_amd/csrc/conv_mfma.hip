@@ -328,6 +328,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         }
         const unsigned col0 = (unsigned)(n0 + wn * TN * 32 + (lane & 31));
         const unsigned Wo2 = 2u * (unsigned)a.Wo;
+        // max |y| hand-over of the Fuse epilogue (the 3x3 output conv behind it takes it as x_absmax instead of a pass over this tensor): a tile's
+        // rows lie in its first image or the next one (maps smaller than a tile: the rare rows report on their own)
+        const bool want_max = a.ymax && !sub;
+        const unsigned img0 = fast_div((unsigned)m0, a.mg_hw, a.sh_hw);
+        float om0 = 0.f, om1 = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + (wm * TM + i) * 32 + 4 * hi;
@@ -357,11 +362,28 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int d = 0; d < 4; ++d)
                             rv[d] = buf_load(a.res, a.r_bytes, ok ? r_v : OOB, (((d >> 1) * Wo2 + (d & 1)) * (unsigned)a.ldr + j * 32u) * 4u);
+                        float ov = 0.f;
 #pragma unroll
-                        for (int d = 0; d < 4; ++d)
-                            buf_store(fmaxf(v + rv[d], lo), a.y, a.y_bytes, ok ? y_v : OOB, (((d >> 1) * Wo2 + (d & 1)) * (unsigned)a.ldy + j * 32u) * 4u);
+                        for (int d = 0; d < 4; ++d) {
+                            const float o = fmaxf(v + rv[d], lo);
+                            ov = fmaxf(ov, fabsf(o));
+                            buf_store(o, a.y, a.y_bytes, ok ? y_v : OOB, (((d >> 1) * Wo2 + (d & 1)) * (unsigned)a.ldy + j * 32u) * 4u);
+                        }
+                        if (want_max && ok) {
+                            if (n == img0) om0 = fmaxf(om0, ov);
+                            else if (n == img0 + 1) om1 = fmaxf(om1, ov);
+                            else cnl::report_max(a.ymax + n * AMS, ov);
+                        }
                     }
                 }
+            }
+        }
+        if (want_max) {
+            om0 = cnl::wave_max_nonneg(om0);
+            om1 = cnl::wave_max_nonneg(om1);
+            if (lane == 0) {
+                cnl::report_max(a.ymax + img0 * AMS, om0);
+                if (om1 > 0.f) cnl::report_max(a.ymax + (img0 + 1) * AMS, om1);
             }
         }
     }

@@ -63,6 +63,7 @@ size_t cnl_wino9_scalar_floats(int Cin, int Cout);
 int cnl_wino9_transform_weights(const float* w_ohwi, void* u9, float* isu, int Cin, int Cout, void* stream);
 bool cnl_wino9_eligible(const cnl_conv_params* p);
 int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream);
+int cnl_wino_packed_stride(const cnl_conv_params* p);                               // packed rows of the row kernels (winograd9.hip)
 bool cnl_wino10_eligible(const cnl_conv_params* p);                                // winograd10.hip (reads winograd9.hip's weights)
 int cnl_wino10_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, bool cout32, void* stream);
 #ifdef CNL_EXPERIMENTS
@@ -120,15 +121,25 @@ extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u,
     return cnl_wino9_transform_weights(w_ohwi, u + L.u9, u + L.s9, Cin, Cout, stream);
 }
 
+// half the CUs of the current device (MI355X: 128) — the small-grid threshold of the row kernels; a process without a device (the CPU tests of
+// the dispatcher) gets the MI355X value
+static long long half_the_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || cnl::cu_count(dev, &n) != CNL_OK || n <= 0) {
+        (void)hipGetLastError();
+        n = 256;
+    }
+    return n / 2;
+}
+
 // which kernel a layer takes (see the file header); CNL_ALGO_FORCE + v pins variant v wherever it can run at all
 static int wino_choice(const cnl_conv_params* p) {
     const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
     const int H = p->H_in * upf, W = p->W_in * upf, CoutP = (p->Cout + 63) / 64 * 64;
     const int items_per_image = ((H + 15) / 16) * ((W + 15) / 16) * (CoutP / 64);
     if (p->algo >= CNL_ALGO_FORCE) {
-        const int v = (int)p->algo - CNL_ALGO_FORCE;
+        const int v = (int)p->algo - CNL_ALGO_FORCE - (p->algo >= CNL_ALGO_FORCE + 32 ? 32 : 0);     // (+ 32: the row kernels without packed rows)
         if (v <= 2 || p->Cin % 16) return v == 1 ? 1 : 2;
-        if (v == 8) return 5;                              // (removed in ABI v10)
         if (v == 9 && !cnl_wino9_eligible(p)) return 5;
         if ((v == 10 || v == 11) && !cnl_wino10_eligible(p)) return 5;
         if (v == 6 && p->Cout % 128) return 5;
@@ -153,15 +164,25 @@ static int wino_choice(const cnl_conv_params* p) {
         // 32-pixel-wide maps: two images side by side in a block row (a function of the shape alone).  16-pixel-wide maps could take four
         // (the kernel does it when forced), but there kernels 5 / 6 win: 512 -> 512 @16x16 85 vs 110 us, 512 -> 256 77 vs 98
         const int side = (upf == 1 && W == 32) ? 2 : 1;
-        const long long pad9 = (long long)((H + 7) / 8 * 8) * ((W * side + 63) / 64 * 64);
-        if (pad9 * 100 <= area * side * 150) {
+        // widths that are not a multiple of 64 (34, 68, 136, 272: the maps of 608 x 1088 frames): packed rows — the images of the launch side by
+        // side in one virtual row, W + 2 columns each (cnl_wino_packed_stride, winograd9.hip).  The CLASS is chosen from the shape alone, with the
+        // padding a long virtual row has ((W + 2) / W); whether a launch then packs (its N decides) cannot change a bit of the result.
+        const bool packable = upf == 1 && W % 2 == 0 && W >= 14 && W != 32 && W != 16 && W % 64 != 0;
+        const int R9 = (H + 7) / 8 * 8, R10 = (H + 3) / 4 * 4;
+        const long long wpad = packable ? (W + 2) : ((W * side + 63) / 64 * 64);
+        const long long pad9 = (long long)R9 * wpad, pad10 = (long long)R10 * wpad;
+        if ((pad9 < pad10 ? pad9 : pad10) * 100 <= area * side * 150) {
             // Small grids (small batches: BASELINE C0 is one image): when winograd9's 8-row x 64-cout items number at most half the chip's
-            // 256 CUs, the SAME arithmetic runs on 4-row x 32-cout items (winograd10.hip, variant 11: four times the items, two workgroups
+            // CUs, the SAME arithmetic runs on 4-row x 32-cout items (winograd10.hip, variant 11: four times the items, two workgroups
             // per CU) — bit for bit the same output (tests/test_gpu_conv.py), so a shard and the full batch still agree exactly although
             // they may take different work-item shapes.  Measured (profiles/r04_small_batch_variants.txt), items of winograd9 -> us 9 / 11:
             // 8: 48 / 24, 16: 32 / 18, 32: 25 / 18, 64: 33 / 22, 128: 63 / 56 (head block), 37 / 30, 28 / 24; 256: 82 / 92 -> stays.
-            const long long items9 = (long long)((p->N + side - 1) / side) * ((H + 7) / 8) * ((W * side + 63) / 64) * (CoutP / 64);
-            if (items9 <= 128 && upf == 1 && cnl_wino10_eligible(p)) return 11;
+            const int pk = cnl_wino_packed_stride(p);
+            const long long bx = pk ? ((long long)p->N * pk + 63) / 64 : (long long)((p->N + side - 1) / side) * ((W * side + 63) / 64);
+            const long long items9 = bx * (R9 / 8) * (CoutP / 64);
+            if (items9 <= half_the_cus() && upf == 1 && cnl_wino10_eligible(p)) return 11;
+            // maps whose height 8-row items pad by a sixth or more over 4-row items (19 rows: 24 vs 20): the half-height items
+            if (upf == 1 && R9 * 100 >= R10 * 115 && cnl_wino10_eligible(p)) return p->Cout <= 256 ? 11 : 10;
             return 9;
         }
     }
@@ -200,8 +221,9 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 "cnl_conv3x3_winograd_f32: Cin %% 8 != 0 or bad pixel stride");
     CNL_REQUIRE(((uintptr_t)p->x & 15) == 0 && ((uintptr_t)p->w & 15) == 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unaligned x / u");
     CNL_REQUIRE(!p->residual || p->ldr >= p->Cout, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: ldr < Cout");
-    CNL_REQUIRE(p->algo <= CNL_ALGO_F32 || p->algo == CNL_ALGO_LATENCY || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 11), CNL_E_BAD_ARG,
-                "cnl_conv3x3_winograd_f32: unknown algo %u", p->algo);
+    CNL_REQUIRE(p->algo <= CNL_ALGO_F32 || p->algo == CNL_ALGO_LATENCY || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 11 && p->algo != CNL_ALGO_FORCE + 8) ||
+                    (p->algo >= CNL_ALGO_FORCE + 32 + 9 && p->algo <= CNL_ALGO_FORCE + 32 + 11),
+                CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unknown algo %u (FORCE + 8, the F(4x4) kernel, was removed in ABI v10)", p->algo);
     const int choice = wino_choice(p);
     const WeightLayout L(p->Cin, p->Cout);
     float* u = const_cast<float*>(p->w);

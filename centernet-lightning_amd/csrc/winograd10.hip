@@ -58,6 +58,8 @@ struct Args {
     unsigned m_nb, m_bx, m_by;        // floor(2^32 / d) of the three
     int ipb, lw;                      // images side by side in one 64-pixel block row (W = 32: 2, W = 16: 4; else 1) and log2 W for them
     int Nimg;                         // images of the launch (N = image groups)
+    int pk;                           // packed rows (0: off): the launch's images side by side in ONE virtual row, each in a strip of pk = W + 2 columns
+    unsigned m_pk;                    //   (its W pixels + the two columns of zero padding that separate it from the next image); floor(2^32 / pk)
     int blocks;
     unsigned x_bytes, u_bytes, y_bytes, r_bytes, b_bytes;
     unsigned flags;
@@ -346,9 +348,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (rr_ >= (unsigned)(d_)) { ++qq_; rr_ -= (unsigned)(d_); }                                             \
         (q_) = qq_; (r_) = rr_;                                                                                  \
     } while (0)
-    // max |x| of the image a lane's tile belongs to; images past the end of the batch: 0 -> scale 1
-#define W10_XMAX_OF(n_, si_) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                       \
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.xmax, 0, a.Nimg * 4 * AMS, 0x00020000), (unsigned)((n_) * a.ipb + (si_)) * (4u * AMS), 0, 0))
+    // the same per lane (packed rows: virtual column -> image, pixel)
+#define W10_VDIVMOD(q_, r_, b_, d_, m_)                                                                          \
+    do {                                                                                                         \
+        unsigned qq_ = __umulhi((b_), (m_));                                                                     \
+        unsigned rr_ = (b_) - qq_ * (unsigned)(d_);                                                              \
+        if (rr_ >= (unsigned)(d_)) { ++qq_; rr_ -= (unsigned)(d_); }                                             \
+        (q_) = qq_; (r_) = rr_;                                                                                  \
+    } while (0)
+    // max |x| of image img_ (the one a lane's tile belongs to); images past the end of the batch: 0 -> scale 1
+#define W10_XMAX_OF(img_) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                          \
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.xmax, 0, a.Nimg * 4 * AMS, 0x00020000), (unsigned)(img_) * (4u * AMS), 0, 0))
     // power-of-two scale of V from the image's maximum: |V| <= 2 max |x|, 2 max |x| S in [2^13, 2^14); es_ = log2 S
 #define W10_SCALE_EXP(es_, xmax_)                                                                                \
     do {                                                                                                         \
@@ -393,7 +403,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             asm volatile("" : "+v"(tid_));      // keeps the per-thread decode inside the item loop
             const int q_ = tid_ & 3, ix_ = cc.x0 - 1 + (tid_ >> 2);
             const int er_ = tid_ >> 3, ex_ = cc.x0 + 63 + ((tid_ >> 2) & 1), ey_ = cc.y0 - 1 + er_;
-            if (a.ipb > 1) {   // block row = ipb images of width 2^lw side by side (x0 = 0): column -> (sub-image, pixel)
+            if (a.pk) {        // packed rows: virtual column -> (image, pixel of its strip); the strip's last two columns, a column before the
+                               // first strip or behind the last are the zero padding (out of range -> zeros)
+                unsigned si_, px_, esi_, epx_;
+                W10_VDIVMOD(si_, px_, (unsigned)ix_, a.pk, a.m_pk);
+                const bool okc_ = ix_ >= 0 && (int)px_ < a.W && (int)si_ < a.Nimg;
+                st.cur.vcol = okc_ ? (unsigned)((((int)si_ * a.H * a.W + (int)px_) * a.ldx + q_ * 4) * 4) : OOB;
+                W10_VDIVMOD(esi_, epx_, (unsigned)ex_, a.pk, a.m_pk);
+                const bool oke_ = tid_ < 8 * PR && (unsigned)ey_ < (unsigned)a.H && (int)epx_ < a.W && (int)esi_ < a.Nimg;
+                st.cur.vext = oke_ ? (unsigned)(((((int)esi_ * a.H + ey_) * a.W + (int)epx_) * a.ldx + q_ * 4) * 4) : OOB;
+            } else if (a.ipb > 1) {   // block row = ipb images of width 2^lw side by side (x0 = 0): column -> (sub-image, pixel)
                 const int si_ = ix_ >> a.lw, px_ = ix_ & (a.W - 1);
                 const bool okc_ = (unsigned)ix_ < 64u && cc.n * a.ipb + si_ < a.Nimg;
                 st.cur.vcol = okc_ ? (unsigned)(((si_ * a.H * a.W + px_) * a.ldx + q_ * 4) * 4) : OOB;
@@ -409,7 +428,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             st.cur.u_voff = (unsigned)((cc.n0 + (tid_ & 31)) * 32 + ((tid_ >> 5) & 1) * 16);
         }
-        const float xmax_cur = W10_XMAX_OF(cc.n, si_lane);     // requested now, used behind the patch requests (its wait is also a wait for
+        int img_lane = cc.n * a.ipb + si_lane;                 // the image of this lane's tile (V production)
+        if (a.pk) {
+            unsigned q_, r_;
+            W10_VDIVMOD(q_, r_, (unsigned)(cc.x0 + 2 * (lane_now() & 31)), a.pk, a.m_pk);
+            img_lane = (int)q_;
+        }
+        const float xmax_cur = W10_XMAX_OF(img_lane);          // requested now, used behind the patch requests (its wait is also a wait for
                                                                 // the previous item's stores)
         {   // this item's bias and inverse weight scales: one value per lane, written to LDS inside the first chunk (slice 30)
             const int co = cc.n0 + lane_now();
@@ -504,9 +529,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int si = a.ipb > 1 ? ((2 * rtile) >> a.lw) : 0;
             rimg[i] = cc.n * a.ipb + si;
             rpx[i] = a.ipb > 1 ? ((2 * rtile) & (a.W - 1)) : cc.x0 + 2 * rtile;
-            if (a.ipb > 1) {      // the tile's image is not the one this lane builds V for: its scale from its maximum
+            if (a.pk) {           // packed rows: the tile's virtual column -> (image, pixel); a strip's two padding columns (pixel >= W) are not stored
+                unsigned q_, r_;
+                W10_VDIVMOD(q_, r_, (unsigned)(cc.x0 + 2 * rtile), a.pk, a.m_pk);
+                rimg[i] = (int)q_; rpx[i] = (int)r_;
+            }
+            if (a.ipb > 1 || a.pk) {      // the tile's image is not the one this lane builds V for: its scale from its maximum
                 int es_i;
-                W10_SCALE_EXP(es_i, W10_XMAX_OF(cc.n, si));
+                W10_SCALE_EXP(es_i, W10_XMAX_OF(rimg[i]));
                 iq[i] = isu_e * __builtin_ldexpf(1.f, -es_i);
             } else {              // 1 / S from the exponent of the scale in use (S = 2^e exactly)
                 iq[i] = isu_e * __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(unsigned, st.cur.S));
@@ -596,11 +626,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #undef W10_XWRITE
 #undef W10_XWRITE2
-        if (a.ymax) {          // max |y| of this item into its image's slot: the 8 tiles of an iteration lie in one image
+        if (a.ymax) {          // max |y| of this item into its image's slot: the 8 tiles of an iteration lie in one image ...
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const float m = cnl::wave_max_nonneg(omax2[i]);
                 const int img = __builtin_amdgcn_readfirstlane(rimg[i]);
+                if (a.pk) {    // ... or, in packed rows, in two neighbouring strips (pk >= 16): the first tile's image and the one behind it
+                    const float m1 = cnl::wave_max_nonneg(rimg[i] != img ? omax2[i] : 0.f);
+                    if (lane_e == 0 && img + 1 < a.Nimg) cnl::report_max(a.ymax + (img + 1) * AMS, m1);
+                    omax2[i] = rimg[i] == img ? omax2[i] : 0.f;
+                }
+                const float m = cnl::wave_max_nonneg(omax2[i]);
                 if (lane_e == 0 && img < a.Nimg) cnl::raise_max(a.ymax + img * AMS, m, (unsigned)__builtin_amdgcn_readfirstlane((int)yseen[i]));
             }
         }
@@ -618,6 +653,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #endif
 #undef W10_DIVMOD
+#undef W10_VDIVMOD
 #undef W10_SCALE_EXP
 #undef W10_XMAX_OF
 }
@@ -632,6 +668,7 @@ extern "C" void cnl_w10_set_trace(void* p) { g_w10_trace = (unsigned long long*)
 bool cnl_wino9_eligible(const cnl_conv_params* p);
 size_t cnl_wino9_weight_bytes(int Cin, int Cout);
 bool cnl_wino10_eligible(const cnl_conv_params* p) { return cnl_wino9_eligible(p); }
+int cnl_wino_packed_stride(const cnl_conv_params* p);
 
 // Launch (arguments already validated by cnl_conv3x3_winograd_f32); u9 / isu: the weight pieces and per-cout scales of winograd9.hip;
 // xmax = N per-image maxima of the input.
@@ -648,10 +685,14 @@ static int wino10_launch(const cnl_conv_params* p, const void* u9, const float* 
     a.ipb = (upf == 1 && (a.W == 32 || a.W == 16)) ? 64 / a.W : 1;
     a.lw = a.W == 32 ? 5 : 4;
     a.N = (p->N + a.ipb - 1) / a.ipb;
+    // other widths that 64-pixel blocks pad: packed rows (cnl_wino_packed_stride, winograd9.hip) — same arithmetic chain per output, same bits
+    a.pk = cnl_wino_packed_stride(p);
+    a.m_pk = a.pk ? (unsigned)(0x100000000ull / (unsigned)a.pk) : 0u;
+    if (a.pk) a.N = 1;
     a.CoutP = (p->Cout + 63) / 64 * 64;
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
     a.CC = p->Cin / 16;
-    a.nb = a.CoutP / BN; a.bx = (a.W + 2 * TW - 1) / (2 * TW); a.by = (a.H + R - 1) / R;
+    a.nb = a.CoutP / BN; a.bx = a.pk ? (int)(((long long)p->N * a.pk + 2 * TW - 1) / (2 * TW)) : (a.W + 2 * TW - 1) / (2 * TW); a.by = (a.H + R - 1) / R;
     const auto magic = [](int d) { return d == 1 ? 0xFFFFFFFFu : (unsigned)(0x100000000ull / (unsigned)d); };
     a.m_nb = magic(a.nb); a.m_bx = magic(a.bx); a.m_by = magic(a.by);
     const long long blocks = (long long)a.N * a.by * a.bx * a.nb;

@@ -627,7 +627,7 @@ int cnl_wino5_own_absmax(const cnl_conv_params* p, float* scal, void* stream) {
 int cnl_wino5_launch(const cnl_conv_params* p, const void* u5, float* scal, void* stream) {
     using namespace cnl_wino5;
     Args a;
-    CNL_REQUIRE(p->x_absmax || p->N <= 4096, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: more than 4096 images per launch need x_absmax");
+    CNL_REQUIRE(p->x_absmax || p->N <= 1024, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: more than 1024 images per launch need x_absmax");
     a.x = p->x; a.u3 = u5; a.xmax = p->x_absmax ? p->x_absmax : scal + 16; a.su = scal + 1; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
     a.bias = p->bias; a.res = p->residual; a.y = p->y;
     const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;

@@ -34,6 +34,7 @@
 #ifndef W9_NT_Y
 #define W9_NT_Y 2     /* cache policy (aux) of the output stores: nt (see winograd5.hip) */
 #endif
+int cnl_wino_packed_stride(const cnl_conv_params* p);
 namespace cnl_wino9 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -58,6 +59,8 @@ struct Args {
     unsigned m_nb, m_bx, m_by;        // floor(2^32 / d) of the three: item index -> coordinates by multiply-high + one correction
     int ipb, lw;                      // images side by side in one 64-pixel block row (W = 32: 2, W = 16: 4; else 1) and log2 W for them; N = groups of ipb images
     int Nimg;                         // images of the launch (N = image groups)
+    int pk;                           // packed rows (0: off): the launch's images side by side in ONE virtual row, each in a strip of pk = W + 2 columns
+    unsigned m_pk;                    //   (its W pixels + the two columns of zero padding that separate it from the next image); floor(2^32 / pk)
     int blocks;
     unsigned x_bytes, u_bytes, y_bytes, r_bytes, b_bytes;
     unsigned flags;
@@ -404,6 +407,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (rr_ >= (unsigned)(d_)) { ++qq_; rr_ -= (unsigned)(d_); }                                             \
         (q_) = qq_; (r_) = rr_;                                                                                  \
     } while (0)
+    /* the same per lane (packed rows: virtual column -> image, pixel) */                                        
+#define W9_VDIVMOD(q_, r_, b_, d_, m_)                                                                           \
+    do {                                                                                                         \
+        unsigned qq_ = __umulhi((b_), (m_));                                                                     \
+        unsigned rr_ = (b_) - qq_ * (unsigned)(d_);                                                              \
+        if (rr_ >= (unsigned)(d_)) { ++qq_; rr_ -= (unsigned)(d_); }                                             \
+        (q_) = qq_; (r_) = rr_;                                                                                  \
+    } while (0)
 #define W9_COORD(c_, item_)                                                                                      \
     do {                                                                                                         \
         unsigned b_ = __builtin_amdgcn_readfirstlane(cnl::xcd_remap((item_), (unsigned)a.blocks));               \
@@ -421,7 +432,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("" : "+v"(tid_));      /* keeps the per-thread decode inside the item loop (hoisted, its values live across the main loop) */ \
         const int q_ = tid_ & 3, ix_ = (c_).x0 - 1 + (tid_ >> 2);                                                \
         const int er_ = tid_ >> 3, ex_ = (c_).x0 + 63 + ((tid_ >> 2) & 1), ey_ = (c_).y0 - 1 + er_;              \
-        if (a.ipb > 1) {   /* block row = ipb images of width 2^lw side by side (x0 = 0): column -> (sub-image, pixel) */ \
+        if (a.pk) {        /* packed rows: virtual column -> (image, pixel of its strip); the strip's last two columns, a column before the */ \
+                           /* first strip or behind the last are the zero padding (out of range -> zeros) */   \
+            unsigned si_, px_, esi_, epx_;                                                                       \
+            W9_VDIVMOD(si_, px_, (unsigned)ix_, a.pk, a.m_pk);                                                   \
+            const bool okc_ = ix_ >= 0 && (int)px_ < a.W && (int)si_ < a.Nimg;                                   \
+            (it_).vcol = okc_ ? (unsigned)((((int)si_ * a.H * a.W + (int)px_) * a.ldx + q_ * 4) * 4) : OOB;      \
+            W9_VDIVMOD(esi_, epx_, (unsigned)ex_, a.pk, a.m_pk);                                                 \
+            const bool oke_ = tid_ < 80 && (unsigned)ey_ < (unsigned)a.H && (int)epx_ < a.W && (int)esi_ < a.Nimg; \
+            (it_).vext = oke_ ? (unsigned)(((((int)esi_ * a.H + ey_) * a.W + (int)epx_) * a.ldx + q_ * 4) * 4) : OOB; \
+        } else if (a.ipb > 1) {   /* block row = ipb images of width 2^lw side by side (x0 = 0): column -> (sub-image, pixel) */ \
             const int si_ = ix_ >> a.lw, px_ = ix_ & (a.W - 1);                                                  \
             const bool okc_ = (unsigned)ix_ < 64u && (c_).n * a.ipb + si_ < a.Nimg;                              \
             (it_).vcol = okc_ ? (unsigned)(((si_ * a.H * a.W + px_) * a.ldx + q_ * 4) * 4) : OOB;                \
@@ -438,8 +458,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         (it_).u_voff = (unsigned)(((c_).n0 + (tid_ & 31)) * 32 + ((tid_ >> 5) & 1) * 16);                        \
     } while (0)
     // max |x| of the image a lane's tile (or an epilogue thread's tile) belongs to; images past the end of the batch: 0 -> scale 1
-#define W9_XMAX_OF(n_, si_) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                        \
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.xmax, 0, a.Nimg * 4 * AMS, 0x00020000), (unsigned)((n_) * a.ipb + (si_)) * (4u * AMS), 0, 0))
+#define W9_XMAX_OF(img_) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                           \
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.xmax, 0, a.Nimg * 4 * AMS, 0x00020000), (unsigned)(img_) * (4u * AMS), 0, 0))
+    /* the image of this lane's tile (V production) in work item c_ */
+#define W9_IMG_LANE(out_, c_)                                                                                    \
+    do {                                                                                                         \
+        (out_) = (c_).n * a.ipb + si_lane;                                                                       \
+        if (a.pk) {                                                                                              \
+            unsigned q_, r_;                                                                                     \
+            W9_VDIVMOD(q_, r_, (unsigned)((c_).x0 + 2 * (lane_now() & 31)), a.pk, a.m_pk);                       \
+            (out_) = (int)q_;                                                                                    \
+        }                                                                                                        \
+    } while (0)
     // (a buffer load, range-checked by the hardware: a branch around a plain load makes the compiler wait for it, vmcnt(0), inside the
     //  branch — at the top of an item that is a wait for the previous item's stores)
     // power-of-two scale of V from the image's maximum: |V| <= 2 max |x|, 2 max |x| S in [2^13, 2^14); es_ = log2 S
@@ -464,7 +494,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int es_cur;
     W9_COORD(cc_cur, item);
     W9_ITEM(st.cur, cc_cur);
-    W9_SCALE_EXP(es_cur, W9_XMAX_OF(cc_cur.n, si_lane));
+    {
+        int img_lane;
+        W9_IMG_LANE(img_lane, cc_cur);
+        W9_SCALE_EXP(es_cur, W9_XMAX_OF(img_lane));
+    }
     st.cur.S = __builtin_ldexpf(1.f, es_cur);
     // the first item's prologue (afterwards the chunk stream itself fetches ahead): patches 0 / 1, weights and first V rows of chunk 0
     {   // all four half-patches are requested before the first is written (the fragment registers are still free: one memory latency, not four)
@@ -514,7 +548,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bool more = next < (unsigned)a.blocks;
         W9_COORD(cc_nxt, more ? next : item);
         W9_ITEM(st.nxt, cc_nxt);
-        const float xmax_next = W9_XMAX_OF(cc_nxt.n, si_lane);  // requested now, used behind the chunk loop
+        int img_next;
+        W9_IMG_LANE(img_next, cc_nxt);
+        const float xmax_next = W9_XMAX_OF(img_next);          // requested now, used behind the chunk loop
         {   // this item's bias and inverse weight scales: one value per lane, written to LDS inside the first chunk (slice 60) — the epilogue
             // then reads them with LDS latency instead of waiting ~1.5 K cycles for global loads
             const int co = cc_cur.n0 + lane_now();
@@ -574,9 +610,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int si = a.ipb > 1 ? ((2 * rtile[i]) >> a.lw) : 0;
             rimg[i] = cc_cur.n * a.ipb + si;
             rpx[i] = a.ipb > 1 ? ((2 * rtile[i]) & (a.W - 1)) : cc_cur.x0 + 2 * rtile[i];
-            if (a.ipb > 1) {      // the tile's image is not the one this lane builds V for: its scale from its maximum
+            if (a.pk) {           // packed rows: the tile's virtual column -> (image, pixel); a strip's two padding columns (pixel >= W) are not stored
+                unsigned q_, r_;
+                W9_VDIVMOD(q_, r_, (unsigned)(cc_cur.x0 + 2 * rtile[i]), a.pk, a.m_pk);
+                rimg[i] = (int)q_; rpx[i] = (int)r_;
+            }
+            if (a.ipb > 1 || a.pk) {      // the tile's image is not the one this lane builds V for: its scale from its maximum
                 int es_i;
-                W9_SCALE_EXP(es_i, W9_XMAX_OF(cc_cur.n, si));
+                W9_SCALE_EXP(es_i, W9_XMAX_OF(rimg[i]));
                 iq[i] = isu_e * __builtin_ldexpf(1.f, -es_i);
             } else {              // one image per block row: 1 / S from the exponent of the scale in use (S = 2^e exactly)
                 iq[i] = isu_e * __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(unsigned, st.cur.S));
@@ -671,8 +712,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (a.ymax) {          // max |y| of this item into its image's slot: the 8 tiles of an iteration lie in one image (tiles per image: 8, 16 or all)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float m = cnl::wave_max_nonneg(omax2[i]);
                 const int img = __builtin_amdgcn_readfirstlane(rimg[i]);
+                if (a.pk) {    // packed rows: the 8 tiles may lie in two neighbouring strips (pk >= 16): the first tile's image and the one behind it
+                    const float m1 = cnl::wave_max_nonneg(rimg[i] != img ? omax2[i] : 0.f);
+                    if (lane_e == 0 && img + 1 < a.Nimg) cnl::report_max(a.ymax + (img + 1) * AMS, m1);
+                    omax2[i] = rimg[i] == img ? omax2[i] : 0.f;
+                }
+                const float m = cnl::wave_max_nonneg(omax2[i]);
                 if (lane_e == 0 && img < a.Nimg) cnl::raise_max(a.ymax + img * AMS, m, (unsigned)__builtin_amdgcn_readfirstlane((int)yseen[i]));
             }
         }
@@ -688,6 +734,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 #undef W9_COORD
 #undef W9_DIVMOD
+#undef W9_VDIVMOD
+#undef W9_IMG_LANE
 #undef W9_ITEM
 #undef W9_SCALE_EXP
 #undef W9_XMAX_OF
@@ -775,6 +823,22 @@ bool cnl_wino9_eligible(const cnl_conv_params* p) {
            (!p->residual || (p->ldr % 4 == 0 && ((uintptr_t)p->residual & 15) == 0));
 }
 
+// Packed rows (winograd9.hip / winograd10.hip): maps whose width is not a multiple of the 64-pixel block row — the 19 x 34, 38 x 68, 76 x 136 and
+// 152 x 272 maps of 608 x 1088 frames (reference datasets/utils.py:29-33: the MOT input shape) — would leave up to half of every block row empty.
+// There the launch's images are laid side by side in ONE virtual row, image n in the strip [n pk, n pk + W) with pk = W + 2: the two columns
+// behind an image ARE its right and the next image's left zero padding (out-of-range loads), so no tile ever sees a neighbour's pixels and
+// nothing is masked; a block row is any 64 consecutive virtual columns (W even: strips start on tile boundaries).  One tile in W/2 + 1 is spent
+// on the padding columns instead of up to one block in two.  Every output keeps its chain of fp32 additions and its image's scale: the
+// result is bit-identical to the unpacked form (tests/test_gpu_conv.py), so — like the work-item shape — the choice may look at N.
+// Returns pk, or 0 where the plain block grid is at least as good (W a multiple of 64, the two / four-images-per-block forms of W = 32 / 16).
+int cnl_wino_packed_stride(const cnl_conv_params* p) {
+    if ((p->flags & CNL_UPSAMPLE_IN) || p->W_in % 2 || p->W_in < 14 || p->W_in == 32 || p->W_in == 16) return 0;
+    if (p->algo >= CNL_ALGO_FORCE + 32) return 0;          // tests: FORCE + 32 + v = variant v (9 / 10 / 11) on the plain block grid
+    const long long pk = p->W_in + 2;
+    const long long plain = (long long)p->N * ((p->W_in + 63) / 64), packed = ((long long)p->N * pk + 63) / 64;
+    return packed < plain ? (int)pk : 0;
+}
+
 // Launch (arguments already validated by cnl_conv3x3_winograd_f32); xmax = N per-image maxima of the input.
 int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream) {
     using namespace cnl_wino9;
@@ -787,10 +851,14 @@ int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu,
     a.ipb = (upf == 1 && (a.W == 32 || a.W == 16)) ? 64 / a.W : 1;
     a.lw = a.W == 32 ? 5 : 4;
     a.N = (p->N + a.ipb - 1) / a.ipb;
+    // other widths that 64-pixel blocks pad: packed rows (cnl_wino_packed_stride) — same arithmetic chain per output, same bits
+    a.pk = cnl_wino_packed_stride(p);
+    a.m_pk = a.pk ? (unsigned)(0x100000000ull / (unsigned)a.pk) : 0u;
+    if (a.pk) a.N = 1;
     a.CoutP = (p->Cout + 63) / 64 * 64;
     a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
     a.CC = p->Cin / 16;
-    a.nb = a.CoutP / BN; a.bx = (a.W + 2 * TW - 1) / (2 * TW); a.by = (a.H + R - 1) / R;
+    a.nb = a.CoutP / BN; a.bx = a.pk ? (int)(((long long)p->N * a.pk + 2 * TW - 1) / (2 * TW)) : (a.W + 2 * TW - 1) / (2 * TW); a.by = (a.H + R - 1) / R;
     const auto magic = [](int d) { return d == 1 ? 0xFFFFFFFFu : (unsigned)(0x100000000ull / (unsigned)d); };
     a.m_nb = magic(a.nb); a.m_bx = magic(a.bx); a.m_by = magic(a.by);
     const long long blocks = (long long)a.N * a.by * a.bx * a.nb;

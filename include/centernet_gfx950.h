@@ -97,12 +97,16 @@ typedef struct cnl_conv_params {
     int32_t ldx, ldy, ldr;  /* pixel strides in elements                                             */
     uint32_t flags;         /* CNL_RELU | CNL_SIGMOID | CNL_UPSAMPLE_IN | CNL_UPSAMPLE_OUT_ADD        */
     /* Optional hand-over of the per-image maximum magnitude of a tensor between launches (cnl_conv3x3_winograd_f32 only; NULL =
-     * unused).  Both point to N floats, one per image.  The fp16-split Winograd kernel scales each image's input by a power of two
+     * unused).  Both point to N * cnl_absmax_stride() floats: image n's value sits at element n * cnl_absmax_stride() (32 floats = one 128-byte line
+     * per image since ABI v10, see cnl_absmax_stride() below; an array of N packed floats is OUT OF BOUNDS for n > 0).  The fp16-split Winograd kernel scales each image's input by a power of two
      * derived from max |x| of THAT image (an image's result never depends on its batch neighbours): with x_absmax it reads the
      * maxima from device memory instead of making its own pass over x.  A producer given y_absmax folds max |y| of everything it
-     * stores for image n into y_absmax[n] (atomic max on the bit pattern: zero the array on the stream before the producer
-     * runs); the fp16-split kernel honours it, the other kernels ignore it.  A maximum over a superset of the consumer's
-     * channels is a valid, slightly conservative bound.                                                                        */
+     * stores for image n into y_absmax[n * cnl_absmax_stride()] (atomic max on the bit pattern: zero the array on the stream before the producer
+     * runs); the fp16-split kernels honour it, and so does cnl_conv2d_nhwc_f32's CNL_UPSAMPLE_OUT_ADD epilogue (fp32 matrix cores; FPN Fuse: the 3x3 output
+     * conv behind it consumes the figure); the other fp32-matrix-core launches ignore it.  A maximum over a superset of the consumer's
+     * channels is a valid, slightly conservative bound.  WITHOUT x_absmax a launch of the fp16-split kernels takes at most 1024 images (4096 up
+     * to ABI v9: the private scratch of the own pass is strided like every maxima array now); more return CNL_E_UNSUPPORTED.
+     *                                                                        */
     const float* x_absmax;
     float* y_absmax;
     /* cnl_conv2d_nhwc_f32 only: device pointer to ONE float, max |w| of this layer's weights (e.g. computed once when the weights
@@ -225,8 +229,8 @@ int cnl_resize_bilinear_u8(const uint8_t* x, uint8_t* y, int32_t N, int32_t H_in
  * scaled two-way fp16 split [piece][21 groups of 8 k][64][8] and its power-of-two scale (csrc/stem_f16x2.hip: the default kernel
  * forms each fp32 product on the fp16 matrix cores, input scaled per workgroup patch; algo = CNL_ALGO_F32 selects the fp32
  * matrix-core kernel); cnl_stem_packed_weight_floats() sizes the buffer; bias: [64].
- * y_absmax (all three stem entry points, ABI v10): NULL, or N floats zeroed by the caller on the stream — the fp16-split kernel folds max |y| of
- * image n into y_absmax[n] (atomic max on the bit pattern; the values are post-ReLU), the hand-over the first Winograd layer takes as
+ * y_absmax (all three stem entry points, ABI v10): NULL, or N * cnl_absmax_stride() floats zeroed by the caller on the stream — the fp16-split kernel folds max |y| of
+ * image n into y_absmax[n * cnl_absmax_stride()] (atomic max on the bit pattern; the values are post-ReLU), the hand-over the first Winograd layer takes as
  * cnl_conv_params.x_absmax instead of a pass over the stem's output.  The fp32 kernel (CNL_ALGO_F32 without the fused pool) ignores it.
  */
 size_t cnl_stem_packed_weight_floats(void);

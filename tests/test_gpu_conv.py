@@ -674,6 +674,65 @@ def test_winograd9_matches_cpu_and_reports_absmax(case, variant):
     assert e9 <= 1.25 * e2 + 1e-7 * ref64.abs().max().item(), (e9, e2)
 
 
+@pytest.mark.parametrize("shape", [(1, 256, 4, 4, 128), (2, 512, 2, 2, 256), (3, 128, 19, 34, 64), (5, 64, 3, 5, 96)])
+def test_fuse_epilogue_reports_absmax(shape):
+    """The FPN Fuse launch (1x1 project -> nearest x2 -> + skip, CNL_UPSAMPLE_OUT_ADD; reference layers.py:160-174) folds max |y| per image into
+    y_absmax, so the 3x3 output conv behind it needs no pass of its own over the fused tensor: exact, also where a tile's rows span several
+    images; the output is unchanged by the report."""
+    N, Cin, H, W, Cout = shape
+    x, w, b = mk(N, Cin, H, W, Cout, 1, seed=H * W + Cout)
+    g = torch.Generator().manual_seed(5)
+    skip = torch.randn(N, Cout, 2 * H, 2 * W, generator=g) * torch.pow(10.0, torch.randint(-2, 3, (N, 1, 1, 1), generator=g).float())
+    y0 = run_conv(x, w, b, flags=CNL_UPSAMPLE_OUT_ADD, residual=skip)
+    y1, kern, ym = run_conv(x, w, b, flags=CNL_UPSAMPLE_OUT_ADD, residual=skip, hints=True)
+    assert kern == 2 and torch.equal(y0, y1)
+    assert torch.equal(ym, y1.abs().amax(dim=(1, 2, 3)))
+    torch.testing.assert_close(y1, ref_conv(x, w, b, flags=CNL_UPSAMPLE_OUT_ADD, residual=skip), rtol=RTOL, atol=ATOL)
+
+
+PACKED_CASES = [
+    # N, Cin, H, W, Cout, flags, residual — widths that 64-pixel block rows pad: the launch's images side by side in one virtual row, W + 2 columns each
+    (3, 32, 19, 34, 64, CNL_RELU, True),                # layer4 of a 608 x 1088 frame: 3 strips of 36 columns in 2 block rows (plain grid: 3)
+    (5, 64, 38, 68, 96, CNL_RELU, True),                # layer3: 5 x 70 columns in 6 block rows (10), couts 96 -> 128
+    (4, 32, 10, 136, 64, 0, False),                     # layer2's width: 9 block rows (12)
+    (3, 32, 9, 272, 64, CNL_RELU, False),               # layer1 / head width: 13 block rows (15)
+    (7, 32, 5, 14, 4, 0, False),                        # the narrowest strip (16 columns: a group of 8 tiles spans two images), Cout = 4
+    (9, 32, 6, 20, 64, CNL_RELU, True),                 # 22-column strips: block rows start anywhere inside an image
+    (33, 32, 4, 62, 64, CNL_RELU, False),               # 64-column strips: every block row is exactly one image + its padding columns
+]
+
+
+@pytest.mark.parametrize("variant", [9, 10, 11])
+@pytest.mark.parametrize("case", PACKED_CASES, ids=lambda c: "N{}c{}_{}x{}_o{}f{}r{}".format(*[int(v) for v in c]))
+def test_winograd_packed_rows_are_bit_identical_to_the_plain_grid(case, variant):
+    """Packed rows of the row-Winograd kernels (cnl_wino_packed_stride, winograd9.hip): images laid side by side in one virtual row so that maps
+    34 / 68 / 136 / 272 pixels wide (608 x 1088 frames, reference datasets/utils.py:29-33) fill the 64-pixel block rows.  Every output keeps its
+    chain of additions and its image's scale: bit-identical to the same kernel on the plain grid (FORCE + 32 + v), with images of very
+    different magnitude side by side in one block row; max |y| per image exact although a wave's tiles span two images; 1e-4 against the CPU."""
+    N, Cin, H, W, Cout, flags, use_res = case
+    g = torch.Generator().manual_seed(Cin + Cout + H + W)
+    x, w, b = mk(N, Cin, H, W, Cout, 3, seed=Cin + Cout + H + W)
+    x = x * torch.pow(10.0, torch.randint(-3, 3, (N, 1, 1, 1), generator=g).float())
+    res = torch.randn(N, Cout, H, W, generator=g) if use_res else None
+    packed, ym = run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + variant, want=5, ymax=True)
+    plain, ym0 = run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 32 + variant, want=5, ymax=True)
+    assert not torch.isnan(packed).any()
+    assert torch.equal(packed, plain)
+    assert torch.equal(ym, packed.abs().amax(dim=(1, 2, 3))) and torch.equal(ym0, ym)
+    ref = ref_conv(x, w, b, 1, flags, res)
+    for i in range(N):                                   # per image: its own magnitude sets the tolerance
+        sc = float(ref[i].abs().max())
+        assert float((packed[i] - ref[i]).abs().max()) <= 1e-4 * max(sc, 1.0), i
+    # the default plan takes these shapes into the row-Winograd class too (packed), whatever the batch: same bits for a shard
+    q = ConvParams()
+    q.N, q.H_in, q.W_in, q.Cin, q.Cout, q.KH, q.KW, q.stride, q.pad, q.ldx, q.ldy, q.flags, q.y = N, H, W, Cin, Cout, 3, 3, 1, 1, Cin, Cout, flags, 1 << 20
+    if H * W >= 19 * 34:                                 # (the tiny maps of this list stay where they were: not the row-Winograd class)
+        assert _lib.load().cnl_conv3x3_winograd_variant(ctypes.byref(q)) in (9, 10, 11)
+        auto = run_winograd(x, w, b, flags, res)
+        one = run_winograd(x[:1], w, b, flags, res[:1] if use_res else None)
+        assert torch.equal(auto, packed) and torch.equal(one, packed[:1])
+
+
 @pytest.mark.parametrize("variant", [9, 10, 11])
 def test_winograd9_many_items_per_workgroup_is_bit_identical_to_one_image_at_a_time(variant):
     """More work items than CUs (the chunk stream then runs on from one item into the next: patches, weights and the first V rows of
@@ -809,7 +868,10 @@ def test_winograd_dispatch_is_a_function_of_shape_and_algo_only():
         assert variant(N, 256, 128, 128, 256, CNL_ALGO_AUTO) == (11 if N == 1 else 9)
         assert variant(N, 256, 32, 32, 256, CNL_ALGO_AUTO) == (9 if N == 32 else 11)
         assert variant(N, 512, 16, 16, 512, CNL_ALGO_AUTO) == 10 and variant(N, 512, 16, 16, 256, CNL_ALGO_AUTO) == 11
-        assert variant(N, 512, 19, 34, 512, CNL_ALGO_AUTO) == 6
+        # the 19 x 34 / 38 x 68 maps of 608 x 1088 frames: the row-Winograd class since round 5 (packed rows), on the half-height items where 8-row
+        # items would pad 19 rows to 24 (rounds 1-4: the 2-D kernels, variant 6)
+        assert variant(N, 512, 19, 34, 512, CNL_ALGO_AUTO) == (10 if N == 32 else 11)
+        assert variant(N, 256, 38, 68, 256, CNL_ALGO_AUTO) == (11 if N == 1 else 9)
         for shp in ((256, 128, 128, 256), (256, 32, 32, 256), (128, 64, 64, 128), (64, 128, 128, 64), (512, 16, 16, 512)):
             assert variant(N, *shp, _lib.CNL_ALGO_LATENCY) == 11, shp
         assert variant(N, 24, 128, 128, 64, _lib.CNL_ALGO_LATENCY) == 2

@@ -192,7 +192,7 @@ __device__ __forceinline__ void run(const Args& a, char* smem) {
         }                                                                                                        \
         u_voff = (unsigned)((n0 + (lane & 31)) * 32 + hi * 16);                                                  \
         {                                                                                                        \
-            const float mx4_ = 4.f * a.xmax[n];                                                                  \
+            const float mx4_ = 4.f * a.xmax[n * AMS];                                                                  \
             S = 1.f;                                                                                             \
             if (mx4_ > 0.f && mx4_ < __builtin_inff()) {                                                         \
                 int e_;                                                                                          \
@@ -416,7 +416,7 @@ __device__ __forceinline__ void run(const Args& a, char* smem) {
         if (a.ymax) {          // max |y| of this item into its image's slot: one atomic per wave and item
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
-            if (lane == 0 && omax > 0.f) atomicMax(a.ymax + en, __float_as_uint(omax));
+            if (lane == 0) cnl::report_max(a.ymax + en * AMS, omax);
             omax = 0.f;
         }
         if (!more) break;
