@@ -92,6 +92,14 @@ __device__ __forceinline__ void report_max(unsigned* slot, float m) {      // pe
     if (m > 0.f && __float_as_uint(m) > peek_max(slot)) atomicMax(slot, __float_as_uint(m));
 }
 
+// The heatmap's sigmoid (reference centernet.py:205) in conv epilogues: 1 / (1 + 2^(-x log2 e)) on the hardware's v_exp_f32 and v_rcp_f32 (1 ulp each)
+// instead of expf + an IEEE divide (~40 instructions per value: 33-36 us of the 170-us heatmap conv at C1, profiles/r04_experiments.txt r6b).
+// Absolute error <= 3e-7 on [0, 1] (the argument's rounding: |x| 2^-24 ln 2 relative on the exponential, times its weight <= 1/4 in the
+// quotient), monotone in x; +-inf and the saturated ends give exactly 0 / 1.  The path's bar is 1e-4.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+
 // Maximum of a NON-NEGATIVE value over the wave / over each 32-lane half, in every lane: DPP inside the rows of 16 lanes, then four
 // v_readlane.  (A __shfl_xor butterfly computes its ds_bpermute lane addresses from the lane id; the compiler hoists those five or six
 // registers to kernel entry, where they stay live — or spill, every reload a vmcnt(0) — across a kernel's main loop.)

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) v[r] = fminf(fmaxf(v[r], lo), hi6);
             if (sigm) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+                for (int r = 0; r < 16; ++r) v[r] = cnl::fast_sigmoid(v[r]);
             }
             if constexpr (SUB) {
 #pragma unroll
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
             float o = v[i] + a.bias[col + i];
             if (a.res) o += a.res[(long)m * a.ldr + col + i];
             o = fminf(fmaxf(o, lo), hi6);
-            if (a.flags & CNL_SIGMOID) o = 1.0f / (1.0f + expf(-o));
+            if (a.flags & CNL_SIGMOID) o = cnl::fast_sigmoid(o);
             a.y[(long)m * a.ldy + col + i] = o;
             omax = fmaxf(omax, fabsf(o));
         }

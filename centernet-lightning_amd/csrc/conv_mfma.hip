@@ -64,7 +64,7 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, float bv, float lo
     for (int r = 0; r < 16; ++r) v[r] = fminf(fmaxf(v[r], lo), hi6);
     if (sigm) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+        for (int r = 0; r < 16; ++r) v[r] = cnl::fast_sigmoid(v[r]);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

@@ -104,7 +104,10 @@ typedef struct cnl_conv_params {
      * stores for image n into y_absmax[n * cnl_absmax_stride()] (atomic max on the bit pattern: zero the array on the stream before the producer
      * runs); the fp16-split kernels honour it, and so does cnl_conv2d_nhwc_f32's CNL_UPSAMPLE_OUT_ADD epilogue (fp32 matrix cores; FPN Fuse: the 3x3 output
      * conv behind it consumes the figure); the other fp32-matrix-core launches ignore it.  A maximum over a superset of the consumer's
-     * channels is a valid, slightly conservative bound.  WITHOUT x_absmax a launch of the fp16-split kernels takes at most 1024 images (4096 up
+     * channels is a valid, slightly conservative bound.  GUARANTEED RANGE of the split arithmetic: one scale per image means a value 2^-n below
+     * the image's maximum keeps min(22, 38 - n) significant bits — outputs whose inputs lie within 1e4 of the image maximum are at the fp32
+     * matrix core's error level, at 1e6 the error is 2-6e-5 of the LOCAL output magnitude (inside the path's 1e-4), beyond that pass
+     * CNL_ALGO_F32 (tests/test_gpu_conv.py::test_split_arithmetic_with_an_outlier_inside_one_image).  WITHOUT x_absmax a launch of the fp16-split kernels takes at most 1024 images (4096 up
      * to ABI v9: the private scratch of the own pass is strided like every maxima array now); more return CNL_E_UNSUPPORTED.
      *                                                                        */
     const float* x_absmax;
