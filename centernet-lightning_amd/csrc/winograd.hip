@@ -167,7 +167,7 @@ static int wino_choice(const cnl_conv_params* p) {
         // widths that are not a multiple of 64 (34, 68, 136, 272: the maps of 608 x 1088 frames): packed rows — the images of the launch side by
         // side in one virtual row, W + 2 columns each (cnl_wino_packed_stride, winograd9.hip).  The CLASS is chosen from the shape alone, with the
         // padding a long virtual row has ((W + 2) / W); whether a launch then packs (its N decides) cannot change a bit of the result.
-        const bool packable = upf == 1 && W % 2 == 0 && W >= 14 && W != 32 && W != 16 && W % 64 != 0;
+        const bool packable = W % 2 == 0 && W >= 14 && !(upf == 1 && (W == 32 || W == 16)) && W % 64 != 0;
         const int R9 = (H + 7) / 8 * 8, R10 = (H + 3) / 4 * 4;
         const long long wpad = packable ? (W + 2) : ((W * side + 63) / 64 * 64);
         const long long pad9 = (long long)R9 * wpad, pad10 = (long long)R10 * wpad;

@@ -408,10 +408,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 unsigned si_, px_, esi_, epx_;
                 W10_VDIVMOD(si_, px_, (unsigned)ix_, a.pk, a.m_pk);
                 const bool okc_ = ix_ >= 0 && (int)px_ < a.W && (int)si_ < a.Nimg;
-                st.cur.vcol = okc_ ? (unsigned)((((int)si_ * a.H * a.W + (int)px_) * a.ldx + q_ * 4) * 4) : OOB;
+                const int ush_ = up ? 1 : 0;       // a folded nearest-2x upsample: logical (row, column) -> stored (row >> 1, column >> 1)
+                st.cur.vcol = okc_ ? (unsigned)((((int)si_ * a.Hs * a.Ws + ((int)px_ >> ush_)) * a.ldx + q_ * 4) * 4) : OOB;
                 W10_VDIVMOD(esi_, epx_, (unsigned)ex_, a.pk, a.m_pk);
                 const bool oke_ = tid_ < 8 * PR && (unsigned)ey_ < (unsigned)a.H && (int)epx_ < a.W && (int)esi_ < a.Nimg;
-                st.cur.vext = oke_ ? (unsigned)(((((int)esi_ * a.H + ey_) * a.W + (int)epx_) * a.ldx + q_ * 4) * 4) : OOB;
+                st.cur.vext = oke_ ? (unsigned)(((((int)esi_ * a.Hs + (ey_ >> ush_)) * a.Ws + ((int)epx_ >> ush_)) * a.ldx + q_ * 4) * 4) : OOB;
             } else if (a.ipb > 1) {   // block row = ipb images of width 2^lw side by side (x0 = 0): column -> (sub-image, pixel)
                 const int si_ = ix_ >> a.lw, px_ = ix_ & (a.W - 1);
                 const bool okc_ = (unsigned)ix_ < 64u && cc.n * a.ipb + si_ < a.Nimg;

@@ -437,10 +437,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             unsigned si_, px_, esi_, epx_;                                                                       \
             W9_VDIVMOD(si_, px_, (unsigned)ix_, a.pk, a.m_pk);                                                   \
             const bool okc_ = ix_ >= 0 && (int)px_ < a.W && (int)si_ < a.Nimg;                                   \
-            (it_).vcol = okc_ ? (unsigned)((((int)si_ * a.H * a.W + (int)px_) * a.ldx + q_ * 4) * 4) : OOB;      \
+            const int ush_ = up ? 1 : 0;       /* a folded nearest-2x upsample: logical (row, column) -> stored (row >> 1, column >> 1) */ \
+            (it_).vcol = okc_ ? (unsigned)((((int)si_ * a.Hs * a.Ws + ((int)px_ >> ush_)) * a.ldx + q_ * 4) * 4) : OOB; \
             W9_VDIVMOD(esi_, epx_, (unsigned)ex_, a.pk, a.m_pk);                                                 \
             const bool oke_ = tid_ < 80 && (unsigned)ey_ < (unsigned)a.H && (int)epx_ < a.W && (int)esi_ < a.Nimg; \
-            (it_).vext = oke_ ? (unsigned)(((((int)esi_ * a.H + ey_) * a.W + (int)epx_) * a.ldx + q_ * 4) * 4) : OOB; \
+            (it_).vext = oke_ ? (unsigned)(((((int)esi_ * a.Hs + (ey_ >> ush_)) * a.Ws + ((int)epx_ >> ush_)) * a.ldx + q_ * 4) * 4) : OOB; \
         } else if (a.ipb > 1) {   /* block row = ipb images of width 2^lw side by side (x0 = 0): column -> (sub-image, pixel) */ \
             const int si_ = ix_ >> a.lw, px_ = ix_ & (a.W - 1);                                                  \
             const bool okc_ = (unsigned)ix_ < 64u && (c_).n * a.ipb + si_ < a.Nimg;                              \
@@ -832,10 +833,11 @@ bool cnl_wino9_eligible(const cnl_conv_params* p) {
 // result is bit-identical to the unpacked form (tests/test_gpu_conv.py), so — like the work-item shape — the choice may look at N.
 // Returns pk, or 0 where the plain block grid is at least as good (W a multiple of 64, the two / four-images-per-block forms of W = 32 / 16).
 int cnl_wino_packed_stride(const cnl_conv_params* p) {
-    if ((p->flags & CNL_UPSAMPLE_IN) || p->W_in % 2 || p->W_in < 14 || p->W_in == 32 || p->W_in == 16) return 0;
+    const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1, W = p->W_in * upf;       // (a folded nearest-2x upsample: the logical width)
+    if (W % 2 || W < 14 || (upf == 1 && (W == 32 || W == 16))) return 0;
     if (p->algo >= CNL_ALGO_FORCE + 32) return 0;          // tests: FORCE + 32 + v = variant v (9 / 10 / 11) on the plain block grid
-    const long long pk = p->W_in + 2;
-    const long long plain = (long long)p->N * ((p->W_in + 63) / 64), packed = ((long long)p->N * pk + 63) / 64;
+    const long long pk = W + 2;
+    const long long plain = (long long)p->N * ((W + 63) / 64), packed = ((long long)p->N * pk + 63) / 64;
     return packed < plain ? (int)pk : 0;
 }
 

@@ -699,6 +699,8 @@ PACKED_CASES = [
     (7, 32, 5, 14, 4, 0, False),                        # the narrowest strip (16 columns: a group of 8 tiles spans two images), Cout = 4
     (9, 32, 6, 20, 64, CNL_RELU, True),                 # 22-column strips: block rows start anywhere inside an image
     (33, 32, 4, 62, 64, CNL_RELU, False),               # 64-column strips: every block row is exactly one image + its padding columns
+    (5, 32, 9, 17, 64, CNL_RELU | CNL_UPSAMPLE_IN, False),     # behind a folded nearest-2x upsample: 18 x 34 logical pixels from 9 x 17 stored ones
+    (6, 64, 16, 16, 128, CNL_RELU | CNL_UPSAMPLE_IN, True),    # the 16 -> 32-pixel neck stage of 512 x 512 frames (34-column strips)
 ]
 
 
@@ -713,7 +715,8 @@ def test_winograd_packed_rows_are_bit_identical_to_the_plain_grid(case, variant)
     g = torch.Generator().manual_seed(Cin + Cout + H + W)
     x, w, b = mk(N, Cin, H, W, Cout, 3, seed=Cin + Cout + H + W)
     x = x * torch.pow(10.0, torch.randint(-3, 3, (N, 1, 1, 1), generator=g).float())
-    res = torch.randn(N, Cout, H, W, generator=g) if use_res else None
+    up = 2 if flags & CNL_UPSAMPLE_IN else 1
+    res = torch.randn(N, Cout, H * up, W * up, generator=g) if use_res else None
     packed, ym = run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + variant, want=5, ymax=True)
     plain, ym0 = run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 32 + variant, want=5, ymax=True)
     assert not torch.isnan(packed).any()
