@@ -321,10 +321,18 @@ class PackedWeights:
             self.head_blocks[name] = [L(m.conv_module, m.bn_module) for m in h.blocks()]
             self.head_out[name] = L(h.out_conv)
         self.fused_first = None
+        self._fused_groups = {}
         if all(len(b) >= 1 for b in self.head_blocks.values()) and len(self.head_names) > 1:
-            w = torch.cat([self.head_blocks[n][0].w for n in self.head_names], dim=0).contiguous()
-            b = torch.cat([self.head_blocks[n][0].b for n in self.head_names], dim=0).contiguous()
-            self.fused_first = _Layer(w, b)
+            self.fused_first = self.fused_group(self.head_names)
+
+    def fused_group(self, names):
+        """The first blocks of heads `names` as ONE layer, concatenated along Cout (built once per group)."""
+        key = tuple(names)
+        if key not in self._fused_groups:
+            w = torch.cat([self.head_blocks[n][0].w for n in key], dim=0).contiguous()
+            b = torch.cat([self.head_blocks[n][0].b for n in key], dim=0).contiguous()
+            self._fused_groups[key] = _Layer(w, b)
+        return self._fused_groups[key]
 
 
     def stale(self, model=None):
@@ -895,19 +903,33 @@ class Plan:
         # ---- heads ----
         self.head_features = {}
         first = {}
-        # the first blocks of all heads run as ONE launch writing one wide buffer — unless 32 images of that buffer (BASELINE's batch per
-        # GPU) would cross the kernels' 4 GiB addressing (C4: 32 x 152 x 272 x 768 floats = 4.06 GB): then they run per head, which costs
-        # two more launches and nothing else (a Winograd work item is one cout block either way) and lets such a batch stay in ONE plan
-        # instead of two sub-batches.  Decided per IMAGE, never by N: a shard and the full batch take the same launches.
-        if Wt.fused_first is not None and 32 * oh_ * ow_ * Wt.fused_first.cout * 4 <= ADDRESS_LIMIT:
-            tot = Wt.fused_first.cout
-            fb = self._buf(N, oh_, ow_, tot)
-            self._conv(Wt.fused_first, neck, nh, nw, nc, fb, tot, CNL_RELU | neck_up, what="heads.*.block_1 (fused)")
-            off = 0
+        # the first blocks of the heads run as ONE launch writing one wide buffer (same input: meta.py:46).  Where 32 images of that buffer
+        # (BASELINE's batch per GPU) would cross the kernels' 4 GiB addressing (C4: 32 x 152 x 272 x 768 floats = 4.06 GB against the engine's
+        # limit of 4.01) the heads are fused in GROUPS that fit, in order (C4: heatmap + box_2d = 512 couts in one launch, reid on its own) —
+        # decided per IMAGE, never by N: a shard and the full batch take the same launches.
+        if Wt.fused_first is not None:
+            groups, cur_g, cur_c = [], [], 0
             for name in Wt.head_names:
-                wdt = Wt.head_blocks[name][0].cout
-                first[name] = (fb, tot, off, wdt)
-                off += wdt
+                c = Wt.head_blocks[name][0].cout
+                if cur_g and 32 * oh_ * ow_ * (cur_c + c) * 4 > ADDRESS_LIMIT:
+                    groups.append(cur_g)
+                    cur_g, cur_c = [], 0
+                cur_g.append(name)
+                cur_c += c
+            groups.append(cur_g)
+            for grp in groups:
+                if len(grp) < 2:
+                    continue
+                layer = Wt.fused_group(grp)
+                tot = layer.cout
+                fb = self._buf(N, oh_, ow_, tot)
+                self._conv(layer, neck, nh, nw, nc, fb, tot, CNL_RELU | neck_up,
+                           what="heads.*.block_1 (fused)" if len(grp) == len(Wt.head_names) else f"heads.{'+'.join(grp)}.block_1 (fused)")
+                off = 0
+                for name in grp:
+                    wdt = Wt.head_blocks[name][0].cout
+                    first[name] = (fb, tot, off, wdt)
+                    off += wdt
         for name in Wt.head_names:
             blocks = Wt.head_blocks[name]
             if name in first:

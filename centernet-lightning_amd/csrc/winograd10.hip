@@ -722,6 +722,17 @@ static int wino10_launch(const cnl_conv_params* p, const void* u9, const float* 
     return cnl::check_launch("winograd10_kernel");
 }
 // cout32: 4-row x 64-pixel x 32-cout work items (twice the items of half the size: 16-pixel maps, one-image batches) instead of 64-cout ones
+int cnl_wino_images_per_launch(const cnl_conv_params* p);                                      // winograd9.hip: tensors of >= 4 GiB run in groups of images
+void cnl_wino_sub_batch(const cnl_conv_params* p, int n0, int n, cnl_conv_params* q, const float** xmax);
 int cnl_wino10_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, bool cout32, void* stream) {
-    return cout32 ? wino10_launch<1>(p, u9, isu, xmax, stream) : wino10_launch<2>(p, u9, isu, xmax, stream);
+    const int per = cnl_wino_images_per_launch(p);
+    CNL_REQUIRE(per > 0, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: one image of a tensor spans >= 4 GiB");
+    for (int n0 = 0; n0 < p->N; n0 += per) {
+        cnl_conv_params q;
+        const float* xm = xmax;
+        cnl_wino_sub_batch(p, n0, p->N - n0 < per ? p->N - n0 : per, &q, &xm);
+        const int rc = cout32 ? wino10_launch<1>(&q, u9, isu, xm, stream) : wino10_launch<2>(&q, u9, isu, xm, stream);
+        if (rc != CNL_OK) return rc;
+    }
+    return CNL_OK;
 }

@@ -841,8 +841,52 @@ int cnl_wino_packed_stride(const cnl_conv_params* p) {
     return packed < plain ? (int)pk : 0;
 }
 
+// The kernels address each tensor through 32-bit buffer offsets (< 4 GiB per launch).  A launch whose input, output or residual spans more —
+// the first blocks of three heads fused along Cout on 32 frames of 608 x 1088: 32 x 152 x 272 x 768 floats = 4.06 GB — runs as the fewest equal
+// groups of images that fit, one kernel launch each (images are independent and keep their own scale: the same bits as one launch).
+// Returns the images per launch (N when everything fits), 0 when a single image does not fit.
+int cnl_wino_images_per_launch(const cnl_conv_params* p) {
+    const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
+    const unsigned long long lim = 0xFFFFFF00ull - 4096ull * 4ull;      // (the span checks of the launchers keep a pixel of slack)
+    const unsigned long long xi = (unsigned long long)p->H_in * p->W_in * p->ldx * 4ull;
+    const unsigned long long yi = (unsigned long long)p->H_in * upf * p->W_in * upf * p->ldy * 4ull;
+    const unsigned long long ri = p->residual ? (unsigned long long)p->H_in * upf * p->W_in * upf * p->ldr * 4ull : 0ull;
+    const unsigned long long worst = xi > yi ? (xi > ri ? xi : ri) : (yi > ri ? yi : ri);
+    const unsigned long long nmax = lim / (worst + 4ull * (unsigned long long)(p->ldy > p->ldr ? p->ldy : p->ldr));
+    if (nmax == 0) return 0;
+    if ((unsigned long long)p->N <= nmax) return p->N;
+    const unsigned long long parts = ((unsigned long long)p->N + nmax - 1) / nmax;
+    return (int)(((unsigned long long)p->N + parts - 1) / parts);
+}
+// sub-batch [n0, n0 + n) of launch p: pointers moved to its first image (64-bit host arithmetic), per-image maxima with them
+void cnl_wino_sub_batch(const cnl_conv_params* p, int n0, int n, cnl_conv_params* q, const float** xmax) {
+    const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
+    *q = *p;
+    q->N = n;
+    q->x = p->x + (size_t)n0 * p->H_in * p->W_in * p->ldx;
+    q->y = p->y + (size_t)n0 * p->H_in * upf * p->W_in * upf * p->ldy;
+    if (p->residual) q->residual = p->residual + (size_t)n0 * p->H_in * upf * p->W_in * upf * p->ldr;
+    if (p->y_absmax) q->y_absmax = p->y_absmax + (size_t)n0 * AMS;
+    if (p->x_absmax) q->x_absmax = p->x_absmax + (size_t)n0 * AMS;
+    *xmax += (size_t)n0 * AMS;
+}
+
+static int wino9_launch_one(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream);
 // Launch (arguments already validated by cnl_conv3x3_winograd_f32); xmax = N per-image maxima of the input.
 int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream) {
+    const int per = cnl_wino_images_per_launch(p);
+    CNL_REQUIRE(per > 0, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: one image of a tensor spans >= 4 GiB");
+    if (per >= p->N) return wino9_launch_one(p, u9, isu, xmax, stream);
+    for (int n0 = 0; n0 < p->N; n0 += per) {
+        cnl_conv_params q;
+        const float* xm = xmax;
+        cnl_wino_sub_batch(p, n0, p->N - n0 < per ? p->N - n0 : per, &q, &xm);
+        const int rc = wino9_launch_one(&q, u9, isu, xm, stream);
+        if (rc != CNL_OK) return rc;
+    }
+    return CNL_OK;
+}
+static int wino9_launch_one(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream) {
     using namespace cnl_wino9;
     Args a;
     a.x = p->x; a.u9 = u9; a.xmax = xmax; a.isu = isu; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);

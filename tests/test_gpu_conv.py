@@ -946,3 +946,60 @@ def test_split_arithmetic_with_an_outlier_inside_one_image(kernel, factor, capsy
     if factor <= 1e4:
         assert e16 <= 2.0 * e32 + 1e-7, (e16, e32)
     assert e16 <= 1e-4, (e16, e32)
+
+
+def test_row_winograd_runs_a_tensor_beyond_4_gib_in_groups_of_images():
+    """A C-ABI caller's launch whose tensors cross the kernels' 32-bit buffer offsets — the first blocks of the three heads of the tracking
+    model fused along Cout on 34 frames of 608 x 1088: 34 x 152 x 272 x 768 floats = 4.32 GB > 4 GiB.  The row-Winograd launchers run it as
+    equal groups of images (cnl_wino_images_per_launch): bit-identical to each image alone, max |y| per image exact, nothing outside written —
+    and a head block READING a 256-channel slice of that tensor (pixel stride 768) takes the same route."""
+    lib = _lib.load()
+    N, Cin, H, W, Cout = 34, 64, 152, 272, 768
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(N, H, W, Cin, device="cuda", generator=g).clamp_min(0) * torch.pow(10.0, torch.randint(-2, 3, (N, 1, 1, 1), device="cuda", generator=g).float())
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    u = torch.empty((lib.cnl_winograd_weight_floats(Cin, Cout),), device="cuda")
+    _lib.check(lib.cnl_winograd_transform_weights_f32(w.data_ptr(), u.data_ptr(), Cin, Cout, _stream()))
+    y = torch.full((N * H * W * Cout + 1024,), float("nan"), device="cuda")
+    assert N * H * W * Cout * 4 > 1 << 32
+
+    def launch(x_, y_, n, cin, cout, ldx, ldy, u_, b_, xm, ym):
+        p = ConvParams()
+        p.x, p.w, p.bias, p.y = x_, u_.data_ptr(), b_.data_ptr(), y_
+        p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad = n, H, W, cin, cout, 3, 3, 1, 1
+        p.ldx, p.ldy, p.flags, p.algo = ldx, ldy, CNL_RELU, CNL_ALGO_AUTO
+        p.x_absmax, p.y_absmax = xm, ym
+        assert lib.cnl_conv3x3_winograd_variant(ctypes.byref(p)) in (9, 10, 11)
+        _lib.check(lib.cnl_conv3x3_winograd_f32(ctypes.byref(p), _stream()), "winograd")
+
+    ams = _lib.absmax_stride()
+    xm = _lib.absmax_pack(x.abs().amax(dim=(1, 2, 3)))
+    ym = _lib.absmax_buffer(N)
+    launch(x.data_ptr(), y.data_ptr(), N, Cin, Cout, Cin, Cout, u, b, xm.data_ptr(), ym.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.isnan(y[N * H * W * Cout:]).all()
+    yv = y[:N * H * W * Cout].view(N, H, W, Cout)
+    one = torch.empty((H, W, Cout), device="cuda")
+    ym1 = _lib.absmax_buffer(1)
+    for i in (0, 16, 17, 33):                                 # both sides of the group boundary
+        ym1.zero_()
+        launch(x[i].data_ptr(), one.data_ptr(), 1, Cin, Cout, Cin, Cout, u, b, xm.data_ptr() + 4 * ams * i, ym1.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(yv[i], one), i
+        assert float(_lib.absmax_values(ym)[i]) == float(one.max()) == float(_lib.absmax_values(ym1)[0]), i
+    # a head block reading channels [256, 512) of the wide tensor
+    w2 = torch.randn(256, 3, 3, 256, device="cuda", generator=g) * (2.0 / (256 * 9)) ** 0.5
+    b2 = torch.zeros(256, device="cuda")
+    u2 = torch.empty((lib.cnl_winograd_weight_floats(256, 256),), device="cuda")
+    _lib.check(lib.cnl_winograd_transform_weights_f32(w2.data_ptr(), u2.data_ptr(), 256, 256, _stream()))
+    z = torch.empty((N, H, W, 256), device="cuda")
+    zm = _lib.absmax_buffer(N)
+    launch(y.data_ptr() + 4 * 256, z.data_ptr(), N, 256, 256, Cout, 256, u2, b2, ym.data_ptr(), zm.data_ptr())
+    z1 = torch.empty((H, W, 256), device="cuda")
+    for i in (3, 33):
+        xi = yv[i, :, :, 256:512].contiguous()
+        ym1.zero_()
+        launch(xi.data_ptr(), z1.data_ptr(), 1, 256, 256, 256, 256, u2, b2, ym.data_ptr() + 4 * ams * i, ym1.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(z[i], z1), i
