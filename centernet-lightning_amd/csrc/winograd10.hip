@@ -340,7 +340,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((a.flags & CNL_RELU) ? 0 : (int)0xff800000u));      // ReLU floor or -inf
 
-    struct Coord { int n, y0, x0, n0; };
 #define W10_DIVMOD(q_, r_, b_, d_, m_)                                                                           \
     do {                                                                                                         \
         unsigned qq_ = __builtin_amdgcn_readfirstlane(__umulhi((b_), (m_)));                                     \
@@ -384,12 +383,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     int tr_n = 0;
 #endif
-    for (unsigned item = blockIdx.x; item < (unsigned)a.blocks; item += gridDim.x) {
-        W10_STAMP(0);
+    // Coordinates, per-thread addressing and ALL global requests of a work item (fourteen patch pieces of its chunks 0 / 1 into `keep`, the
+    // kernel-row 0 / 1 weight fragments of chunk 0, its image's maximum, its bias / weight scales).  Issued for the first item before the
+    // loop and for every later one INSIDE the previous item's epilogue (round 5: behind pass 1, when three of the four accumulator rows are
+    // dead), so that an item no longer starts by waiting a memory latency for its first patch (traced: 3.3-4.6 K of an item's 25-30 K
+    // cycles on the 64-channel layers, profiles/r04_w10_trace.txt).  `ok` false (no next item): every request reads out of range.
+    struct Coord { int n, y0, x0, n0; };
+    u32x4 keep[4][NSTG];
+    Coord cc;
+    float xmax_cur;
+    auto request = [&](const unsigned item_, const bool ok_item) __attribute__((always_inline)) {
         // ---- coordinates of the work item (scalars) and the per-thread addressing that follows from them ----
-        Coord cc;
         {
-            unsigned b_ = __builtin_amdgcn_readfirstlane(cnl::xcd_remap(item, (unsigned)a.blocks));
+            unsigned b_ = __builtin_amdgcn_readfirstlane(cnl::xcd_remap(item_, (unsigned)a.blocks));
             unsigned q_, nbi_, bxi_, byi_;
             W10_DIVMOD(q_, nbi_, b_, a.nb, a.m_nb); b_ = q_;
             W10_DIVMOD(q_, bxi_, b_, a.bx, a.m_bx); b_ = q_;
@@ -435,34 +441,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             W10_VDIVMOD(q_, r_, (unsigned)(cc.x0 + 2 * (lane_now() & 31)), a.pk, a.m_pk);
             img_lane = (int)q_;
         }
-        const float xmax_cur = W10_XMAX_OF(img_lane);          // requested now, used behind the patch requests (its wait is also a wait for
-                                                                // the previous item's stores)
+        xmax_cur = W10_XMAX_OF(img_lane);
         {   // this item's bias and inverse weight scales: one value per lane, written to LDS inside the first chunk (slice 30)
             const int co = cc.n0 + lane_now();
             st.bst = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (int)a.b_bytes, 0x00020000),
                                                                                     co < a.Cout ? (unsigned)co * 4u : OOB, 0, 0));
             st.ist = co < a.CoutP ? a.isu[co] : 0.f;
         }
-        // ---- prologue: patches 0 / 1 -> LDS, weight rows 0 / 1 of chunk 0, V rows 0 / 1 of chunk 0, the raw reads of row 2.  All fourteen
-        //      patch pieces are requested before the first is written (the fragment registers are still free: one memory latency);
-        //      the other workgroup of the CU computes meanwhile ----
-        {
-            u32x4 keep[4][NSTG];
+        // patches 0 / 1 (all fourteen pieces requested before the first is written: one memory latency) and the weight rows 0 / 1 of chunk 0
 #define W10_PLOAD_HALF(dst_, half_, cc_)                                                                         \
-            do {                                                                                                 \
-                pload<half_, 0>(st, a, cc_, up, true); pload<half_, 1>(st, a, cc_, up, true); pload<half_, 2>(st, a, cc_, up, true); \
-                if constexpr (half_ == 0) pload<0, 3>(st, a, cc_, up, true);                                     \
-                _Pragma("unroll") for (int i = 0; i < NSTG; ++i) keep[dst_][i] = st.stg[i];                      \
-            } while (0)
-            W10_PLOAD_HALF(0, 0, 0);
-            W10_PLOAD_HALF(1, 1, 0);
-            W10_PLOAD_HALF(2, 0, 1);
-            W10_PLOAD_HALF(3, 1, 1);
+        do {                                                                                                     \
+            pload<half_, 0>(st, a, cc_, up, ok_item); pload<half_, 1>(st, a, cc_, up, ok_item); pload<half_, 2>(st, a, cc_, up, ok_item); \
+            if constexpr (half_ == 0) pload<0, 3>(st, a, cc_, up, ok_item);                                      \
+            _Pragma("unroll") for (int i = 0; i < NSTG; ++i) keep[dst_][i] = st.stg[i];                          \
+        } while (0)
+        W10_PLOAD_HALF(0, 0, 0);
+        W10_PLOAD_HALF(1, 1, 0);
+        W10_PLOAD_HALF(2, 0, 1);
+        W10_PLOAD_HALF(3, 1, 1);
 #undef W10_PLOAD_HALF
 #pragma unroll
-            for (int i = 0; i < 2 * NBH; ++i) load_b<0>(st, a, 0, i, u_plane, u_wave, true);
+        for (int i = 0; i < 2 * NBH; ++i) load_b<0>(st, a, 0, i, u_plane, u_wave, ok_item);
 #pragma unroll
-            for (int i = 0; i < 2 * NBH; ++i) load_b<1>(st, a, 0, i, u_plane, u_wave, true);
+        for (int i = 0; i < 2 * NBH; ++i) load_b<1>(st, a, 0, i, u_plane, u_wave, ok_item);
+    };
+    unsigned item = blockIdx.x;
+    request(item, true);
+    while (true) {
+        W10_STAMP(0);
+        const Coord ci = cc;                // this item's coordinates (cc is overwritten with the next item's inside the epilogue)
+        // ---- prologue: patches 0 / 1 -> LDS, V rows 0 / 1 of chunk 0, the raw reads of row 2 ----
+        {
             W10_STAMP(1);
             {
                 int es_cur;
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int t_e = lane_e & 31, h_e = lane_e >> 5;
         const int g_e = NBH == 2 ? (wave & 1) : 0;
         const int piece_e = lane_e & 7;
-        const int cout_e = cc.n0 + g_e * 32 + piece_e * 4;            // this thread's four couts
+        const int cout_e = ci.n0 + g_e * 32 + piece_e * 4;            // this thread's four couts
         const bool cok_e = cout_e < a.Cout;
         const f32x4 bq = lds_f4(st.sB + (g_e * 32 + piece_e * 4) * 4);
         const f32x4 isu_e = lds_f4(st.sB + 256 + (g_e * 32 + piece_e * 4) * 4);
@@ -528,11 +537,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int rtile = (NBH == 2 ? 16 * (wave >> 1) + 8 * i : 8 * wave) + (lane_e >> 3);
             rslot[i] = rtile * 8 + (piece_e ^ (rtile & 7));
             const int si = a.ipb > 1 ? ((2 * rtile) >> a.lw) : 0;
-            rimg[i] = cc.n * a.ipb + si;
-            rpx[i] = a.ipb > 1 ? ((2 * rtile) & (a.W - 1)) : cc.x0 + 2 * rtile;
+            rimg[i] = ci.n * a.ipb + si;
+            rpx[i] = a.ipb > 1 ? ((2 * rtile) & (a.W - 1)) : ci.x0 + 2 * rtile;
             if (a.pk) {           // packed rows: the tile's virtual column -> (image, pixel); a strip's two padding columns (pixel >= W) are not stored
                 unsigned q_, r_;
-                W10_VDIVMOD(q_, r_, (unsigned)(cc.x0 + 2 * rtile), a.pk, a.m_pk);
+                W10_VDIVMOD(q_, r_, (unsigned)(ci.x0 + 2 * rtile), a.pk, a.m_pk);
                 rimg[i] = (int)q_; rpx[i] = (int)r_;
             }
             if (a.ipb > 1 || a.pk) {      // the tile's image is not the one this lane builds V for: its scale from its maximum
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < NI; ++i) omax2[i] = 0.f;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) yv0[i] = ((unsigned)((rimg[i] * a.H + cc.y0) * a.W + rpx[i]) * (unsigned)a.ldy + (unsigned)cout_e) * 4u;
+        for (int i = 0; i < NI; ++i) yv0[i] = ((unsigned)((rimg[i] * a.H + ci.y0) * a.W + rpx[i]) * (unsigned)a.ldy + (unsigned)cout_e) * 4u;
         const unsigned y_row = (unsigned)(a.W * a.ldy) * 4u;
         // what the images' max |y| slots hold so far: requested HERE, ahead of the item's stores, read behind the last pass (cnl::peek_max)
         unsigned yseen[NI];
@@ -561,6 +570,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 f32x4{A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};                                       \
         }
 #define W10_XWRITE(j_) do { W10_XWRITE2(j_, 0, 0); W10_XWRITE2(j_, 0, 2); if constexpr (NBH == 2) { W10_XWRITE2(j_, NBH - 1, 0); W10_XWRITE2(j_, NBH - 1, 2); } } while (0)
+        const unsigned next = item + gridDim.x;
+        const bool more = next < (unsigned)a.blocks;
+        f32x4 rvl[R - 2][NI][2];           // residual values of rows 2, 3 (RES)
         f32x2 iql[NI], iqh[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) { iql[i] = f32x2{iq[i][0], iq[i][1]}; iqh[i] = f32x2{iq[i][2], iq[i][3]}; }
@@ -570,7 +582,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const char* X = sX + (j & 1) * (X_BYTES / 2);
-            const int oy = cc.y0 + j;
+            const int oy = ci.y0 + j;
             const bool row_ok = oy < a.H && cok_e;
             unsigned yv[NI];
             bool ok[NI][2];
@@ -581,10 +593,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 yv[i] = yv0[i] + (unsigned)j * y_row;
                 ok[i][0] = row_ok && ox < a.W && rimg[i] < a.Nimg; ok[i][1] = row_ok && ox + 1 < a.W && rimg[i] < a.Nimg;
                 if constexpr (RES) {
-                    const unsigned rvo = ((unsigned)((rimg[i] * a.H + oy) * a.W + ox) * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
+                    if (j < 2) {
+                        const unsigned rvo = ((unsigned)((rimg[i] * a.H + oy) * a.W + ox) * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
 #pragma unroll
-                    for (int px = 0; px < 2; ++px)
-                        rv[i][px] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, ok[i][px] ? rvo : OOB, (unsigned)(px * a.ldr * 4)));
+                        for (int px = 0; px < 2; ++px)
+                            rv[i][px] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, ok[i][px] ? rvo : OOB, (unsigned)(px * a.ldr * 4)));
+                    } else {      // rows 2, 3: requested behind pass 1, AHEAD of the next item's requests (loads return in order)
+#pragma unroll
+                        for (int px = 0; px < 2; ++px) rv[i][px] = rvl[j - 2][i][px];
+                    }
                 }
             }
             f32x4 Y[NI][4];
@@ -624,6 +641,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             if (j + 1 < R) { W10_BARRIER(); }
             __builtin_amdgcn_sched_barrier(0);
+            if (j == 1) {
+                // three of the four accumulator rows are dead (row 3 went into the exchange region during this pass... row 2 during pass 0): the
+                // next item's requests go out here and fly during passes 2 and 3 — first the residual rows those passes add
+                if constexpr (RES) {
+#pragma unroll
+                    for (int jj = 2; jj < R; ++jj)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            const bool okr = ci.y0 + jj < a.H && cok_e && rimg[i] < a.Nimg;
+                            const unsigned rvo = ((unsigned)((rimg[i] * a.H + ci.y0 + jj) * a.W + rpx[i]) * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
+#pragma unroll
+                            for (int px = 0; px < 2; ++px)
+                                rvl[jj - 2][i][px] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, (okr && rpx[i] + px < a.W) ? rvo : OOB, (unsigned)(px * a.ldr * 4)));
+                        }
+                }
+                request(more ? next : item, more);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #undef W10_XWRITE
 #undef W10_XWRITE2
@@ -645,6 +680,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         ++tr_item;
         ++tr_n;
 #endif
+        if (!more) break;
+        item = next;
     }
 #ifdef W10_TRACE
     if (tid == 0) {
