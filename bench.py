@@ -85,11 +85,13 @@ KIND_NAMES = {"winograd_row4_f16x2": "cnl_wino10::winograd10_kernel (the row-Win
                                     "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
               "winograd_f32": "cnl_wino2::winograd2_kernel (Winograd F(2x2,3x3), fp32 v_mfma_f32_32x32x2_f32)",
               "direct_f16x2": "cnl_conv::conv_f16x2_kernel (direct implicit GEMM, fp16 matrix cores, scaled two-way split)",
-              "direct": "cnl_conv::conv_mfma_kernel (direct implicit GEMM, fp32 v_mfma_f32_32x32x2_f32)"}
+              "direct": "cnl_conv::conv_mfma_kernel (direct implicit GEMM, fp32 v_mfma_f32_32x32x2_f32)",
+              "fused_out_reduce": "cnl_fused::reduce_kernel (fixed-order sum of the per-32-channel partial sums of a 1x1 out_conv folded into the row-Winograd epilogue; HBM-bound)"}
 # executed matrix flops / direct-conv flops, and the peak they run against
 EXEC = {"winograd_row4_f16x2": (6.0 / 9.0 * 3.0, F16_MFMA_PEAK_TFLOPS), "winograd_f16x2": (16.0 / 36.0 * 3.0, F16_MFMA_PEAK_TFLOPS),
         "winograd_row_f16x2": (6.0 / 9.0 * 3.0, F16_MFMA_PEAK_TFLOPS),
-        "winograd_f32": (16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS), "direct_f16x2": (3.0, F16_MFMA_PEAK_TFLOPS), "direct": (1.0, FP32_MFMA_PEAK_TFLOPS)}
+        "winograd_f32": (16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS), "direct_f16x2": (3.0, F16_MFMA_PEAK_TFLOPS), "direct": (1.0, FP32_MFMA_PEAK_TFLOPS),
+        "fused_out_reduce": (1.0, FP32_MFMA_PEAK_TFLOPS)}
 
 
 def synthetic_weights_(model, seed=0):
@@ -266,7 +268,7 @@ def conv_kernel_profile(model, x, reps=3):
     plan = eng.plan_for(x, sigmoid=True)
     lib = plan.lib
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    convs = [L for L in plan.launches if L.fn in (lib.cnl_conv2d_nhwc_f32, lib.cnl_conv3x3_winograd_f32, lib.cnl_conv3x3_up2_nhwc_f32)]
+    convs = [L for L in plan.launches if L.fn in (lib.cnl_conv2d_nhwc_f32, lib.cnl_conv3x3_winograd_f32, lib.cnl_conv3x3_up2_nhwc_f32, lib.cnl_fused_out_reduce_f32)]
     acc = [0.0] * len(convs)
     for _ in range(reps):
         torch.cuda.synchronize()
@@ -297,6 +299,9 @@ def conv_kernel_profile(model, x, reps=3):
     rows = []
     for i, L in enumerate(convs):
         p = L.args
+        if L.fn is lib.cnl_fused_out_reduce_f32:        # second half of an out_conv folded into the 3x3 block before it: [part, blocks, M, C2, ...]
+            rows.append((L.what, 2.0 * p[2] * p[1] * 32 * p[3] * scale, acc[i] / reps * scale, "fused_out_reduce", (p[1] * p[2] * 16 + p[2] * p[3] * 4) * scale))
+            continue
         up_in = 2 if p.flags & 4 else 1
         ho = (p.H_in * up_in + 2 * p.pad - p.KH) // p.stride + 1
         wo = (p.W_in * up_in + 2 * p.pad - p.KW) // p.stride + 1

@@ -22,7 +22,7 @@ CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_LATENCY, CNL_ALGO_FORCE = 0, 
 CNL_WINO_F32, CNL_WINO_F16X2 = 2, 5
 
 CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4
-ABI_VERSION = 10         # CNL_ABI_VERSION of include/centernet_gfx950.h
+ABI_VERSION = 11         # CNL_ABI_VERSION of include/centernet_gfx950.h
 
 
 class ConvParams(Structure):
@@ -31,7 +31,8 @@ class ConvParams(Structure):
                 ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
                 ("ldx", c_int32), ("ldy", c_int32), ("ldr", c_int32), ("flags", c_uint32),
                 ("x_absmax", c_void_p), ("y_absmax", c_void_p), ("w_absmax", c_void_p), ("algo", c_uint32),
-                ("splitk", c_int32), ("splitk_scratch", c_void_p), ("splitk_scratch_bytes", c_size_t)]
+                ("splitk", c_int32), ("splitk_scratch", c_void_p), ("splitk_scratch_bytes", c_size_t),
+                ("fuse_w", c_void_p), ("fuse_part", c_void_p)]
 
 
 class DeconvParams(Structure):
@@ -56,6 +57,8 @@ _SIGNATURES = {
     "cnl_absmax_stride": (ctypes.c_int, []),
     "cnl_last_error": (c_size_t, [c_char_p, c_size_t]),
     "cnl_conv2d_nhwc_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
+    "cnl_fused_out_pack_weights_f32": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int32, ctypes.c_int32, c_void_p]),
+    "cnl_fused_out_reduce_f32": (ctypes.c_int, [c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, c_void_p, c_void_p, ctypes.c_int32, ctypes.c_uint32, c_void_p]),
     "cnl_conv2d_out_hw": (ctypes.c_int, [POINTER(ConvParams), POINTER(c_int32), POINTER(c_int32)]),
     "cnl_conv3x3_winograd_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
     "cnl_conv3x3_winograd_kernel": (ctypes.c_int, [POINTER(ConvParams)]),

@@ -41,6 +41,9 @@ class KernelOptions:
       stem_fused_pool  the 3x3/2 max-pool inside the stem kernel
       presplit_weights the direct convs' weights carry their fp16 split (CNL_W_SPLIT): the fp16-split direct kernel reads the pieces
                        instead of splitting every chunk's weights again — same bits out, -20..-35 % on the stride-2 3x3 convs
+      fuse_small_out   an out_conv with at most 4 output channels (box sizes; the heatmap of 1-2 class models) is folded into the epilogue of the
+                       3x3 block before it (cnl_conv_params.fuse_w: per-32-channel partial sums + a fixed-order reduce) instead of re-reading
+                       the block's 256-channel output (C1: 537 MB, 110 us)
       reuse_buffers    activation buffers share one arena by liveness; False keeps every intermediate (tests read them)
       latency          latency class for one-image batches (default off): every 3x3 / stride-1 layer the row-Winograd kernels can run
                        takes csrc/winograd10.hip's 4-row x 64-pixel x 32-cout work items (cnl_conv_params.algo = CNL_ALGO_LATENCY) — four times the
@@ -56,6 +59,7 @@ class KernelOptions:
     absmax_handover: bool = True
     stem_fused_pool: bool = True
     presplit_weights: bool = True
+    fuse_small_out: bool = True
     reuse_buffers: bool = True
     split_small: bool = False
     latency: bool = False
@@ -386,6 +390,22 @@ class _Launch:
         self.fn, self.args, self.what, self.flops, self.keep = fn, args, what, flops, keep
 
 
+class _ListSlot:
+    """`y` of a launch whose arguments are a plain list (patched per call like ConvParams.y of the output convs)."""
+    __slots__ = ("args", "index")
+
+    def __init__(self, args, index):
+        self.args, self.index = args, index
+
+    @property
+    def y(self):
+        return self.args[self.index]
+
+    @y.setter
+    def y(self, v):
+        self.args[self.index] = v
+
+
 class Plan:
     """Activation arena + launch list for one (N, H, W, sigmoid, options, stream) signature.  A Plan is SINGLE-STREAM: its arena, its
     absmax slots and the output pointers patched per call are private state; Engine keeps one plan per stream, so forwards on
@@ -422,7 +442,7 @@ class Plan:
 
         def pointers(L):
             if isinstance(L.args, (ConvParams, DeconvParams)):
-                return [(L.args, f) for f in (("x", "y", "residual", "splitk_scratch") if isinstance(L.args, ConvParams) else ("x", "y", "residual"))]
+                return [(L.args, f) for f in (("x", "y", "residual", "splitk_scratch", "fuse_part") if isinstance(L.args, ConvParams) else ("x", "y", "residual"))]
             if isinstance(L.args, list):
                 return [(L.args, i) for i in range(len(L.args))]
             return []
@@ -938,16 +958,52 @@ class Plan:
             else:
                 x, ldx, xoff, xc = neck, nc, 0, nc
                 rest, xh, xw, up = blocks, nh, nw, neck_up
+            p_last = None
             for bi, layer in enumerate(rest):
                 y = self._buf(N, oh_, ow_, layer.cout)
-                self._conv(layer, x, xh, xw, ldx, y, layer.cout, CNL_RELU | up, what=f"heads.{name}.block", x_off=xoff)
+                p_last, _, _ = self._conv(layer, x, xh, xw, ldx, y, layer.cout, CNL_RELU | up, what=f"heads.{name}.block", x_off=xoff)
                 x, ldx, xoff, xc, xh, xw, up = y, layer.cout, 0, layer.cout, oh_, ow_, 0
             self.head_features[name] = (x, ldx, xoff, xc, xh, xw, up)      # what out_conv reads (tests: feature-level parity gate)
             outl = Wt.head_out[name]
             flags = up | (CNL_SIGMOID if (name == "heatmap" and self.sigmoid) else 0)
+            # an out_conv of at most 4 channels behind a row-Winograd block: folded into that block's epilogue (partial sums per 32 channels)
+            # + a fixed-order reduce — decided from the layer shapes alone
+            if self._fold_small_out(p_last, outl, name, flags, oh_, ow_):
+                continue
             # output buffer is allocated fresh per call (ownership passes to the caller); patched in run()
             p, _, _ = self._conv(outl, x, xh, xw, ldx, x, outl.cout, flags, what=f"heads.{name}.out_conv", x_off=xoff)
             self.out_params[name] = (p, outl.cout)
+
+    def _fold_small_out(self, p_last, outl, name, flags, oh, ow):
+        if (p_last is None or not self.options.fuse_small_out or self.algo == CNL_ALGO_F32 or outl.kh != 1 or outl.kw != 1 or outl.cout > 4
+                or outl.stride != 1 or (flags & ~CNL_SIGMOID) or p_last.residual):
+            return False
+        L = self.launches[-1]
+        if L.args is not p_last or L.fn is not self.lib.cnl_conv3x3_winograd_f32 or p_last.Cout != p_last.ldy:
+            return False
+        nb = (p_last.Cout + 63) // 64 * 2
+        if nb * self.N * oh * ow * 16 > ADDRESS_LIMIT:
+            return False
+        fw = getattr(outl, "_fuse_w", None)
+        if fw is None:
+            with torch.cuda.device(outl.w.device):
+                fw = torch.empty(((p_last.Cout + 63) // 64 * 64, 4), device=outl.w.device, dtype=torch.float32)
+                _lib.check(self.lib.cnl_fused_out_pack_weights_f32(outl.w.data_ptr(), fw.data_ptr(), outl.cin, outl.cout,
+                                                                   ctypes.c_void_p(torch.cuda.current_stream(outl.w.device).cuda_stream)),
+                           "cnl_fused_out_pack_weights_f32")
+            outl._fuse_w = fw
+        p_last.fuse_w = fw.data_ptr()
+        if self.lib.cnl_conv3x3_winograd_variant(ctypes.byref(p_last)) != 9:        # the dispatcher keeps a folded launch on winograd9 — if it can run there
+            p_last.fuse_w = None
+            return False
+        part = self._buf(nb, self.N * oh, ow, 4)
+        p_last.fuse_part = part.data_ptr()
+        L.keep = tuple(L.keep) + (part, fw)
+        L.what += f" + {name}.out_conv partials"
+        args = [part.data_ptr(), nb, self.N * oh * ow, outl.cout, outl.b.data_ptr(), 0, outl.cout, flags]
+        self.launches.append(_Launch(self.lib.cnl_fused_out_reduce_f32, args, f"heads.{name}.out_conv (reduce of {nb} partials)", 0, keep=(part, outl)))
+        self.out_params[name] = (_ListSlot(args, 5), outl.cout)
+        return True
 
     def run(self, x, norm=None):
         """x: [N,3,H,W] fp32 on self.device, any strides — or, with norm = (mean255, inv_std255) ctypes float[3] arrays, uint8 frames

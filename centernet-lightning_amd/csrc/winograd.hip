@@ -152,11 +152,11 @@ static int wino_choice(const cnl_conv_params* p) {
     // (profiles/r04_winograd_variants.txt): layer1 22 -> 16 us, layer2 29 -> 16, layer3 46 -> 23, layer4 61 -> 38, 512 -> 256 @16x16 69 -> 36;
     // not behind a folded upsample (64 -> 512 first head blocks: 44 us on winograd9, 60 here).  The caller's option takes EVERY eligible layer there
     // (also those whose default is winograd5 / 6 or the fp32 kernel: other arithmetic); the default plan moves only winograd9's own layers (below).
-    if (p->algo == CNL_ALGO_LATENCY && upf == 1 && cnl_wino10_eligible(p)) return 11;
+    if (p->algo == CNL_ALGO_LATENCY && upf == 1 && cnl_wino10_eligible(p) && !p->fuse_w) return 11;
     // 16-pixel-wide maps (four images side by side in a block row): the half-height items of winograd10.hip give the chip twice the work
     // items of winograd9's and a second workgroup per CU to overlap with (long channel loops: what was measured) — 512 -> 512 @16x16 x 32: 83 us (winograd5: 90-93, winograd9: 97-107),
     // 512 -> 256: 61-65 us with 32-cout items (fp32 kernel: 89-92)
-    if (upf == 1 && W == 16 && p->Cin >= 256 && cnl_wino10_eligible(p)) return p->Cout <= 256 ? 11 : 10;
+    if (upf == 1 && W == 16 && p->Cin >= 256 && cnl_wino10_eligible(p) && !p->fuse_w) return p->Cout <= 256 ? 11 : 10;
     // row-Winograd (winograd9.hip): 8-row x 64-pixel x 64-cout work items.  Measured against kernels 2 / 5 / 6 on every 3x3 shape of the
     // three configurations (profiles/r03_winograd9_variants.txt): 0.5-0.8x their time wherever its blocks pad the map by less than ~1.5x
     // (maps at least ~44 pixels wide), channel loops from 32 up, with or without residual / folded upsample
@@ -177,6 +177,7 @@ static int wino_choice(const cnl_conv_params* p) {
             // per CU) — bit for bit the same output (tests/test_gpu_conv.py), so a shard and the full batch still agree exactly although
             // they may take different work-item shapes.  Measured (profiles/r04_small_batch_variants.txt), items of winograd9 -> us 9 / 11:
             // 8: 48 / 24, 16: 32 / 18, 32: 25 / 18, 64: 33 / 22, 128: 63 / 56 (head block), 37 / 30, 28 / 24; 256: 82 / 92 -> stays.
+            if (p->fuse_w) return 9;       // a folded 1x1 conv (cnl_conv_params.fuse_w): winograd9's epilogue has it, whatever the grid size
             const int pk = cnl_wino_packed_stride(p);
             const long long bx = pk ? ((long long)p->N * pk + 63) / 64 : (long long)((p->N + side - 1) / side) * ((W * side + 63) / 64);
             const long long items9 = bx * (R9 / 8) * (CoutP / 64);
@@ -225,6 +226,8 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                     (p->algo >= CNL_ALGO_FORCE + 32 + 9 && p->algo <= CNL_ALGO_FORCE + 32 + 11),
                 CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unknown algo %u (FORCE + 8, the F(4x4) kernel, was removed in ABI v10)", p->algo);
     const int choice = wino_choice(p);
+    CNL_REQUIRE(!p->fuse_w || (choice == 9 && p->fuse_part && !p->residual), CNL_E_UNSUPPORTED,
+                "cnl_conv3x3_winograd_f32: fuse_w needs a launch the row-Winograd kernel (variant 9) takes, fuse_part and no residual (this one: variant %d)", choice);
     const WeightLayout L(p->Cin, p->Cout);
     float* u = const_cast<float*>(p->w);
     if (choice == 5 || choice == 6 || choice == 7 || choice >= 9) {

@@ -64,6 +64,9 @@ struct Args {
     int blocks;
     unsigned x_bytes, u_bytes, y_bytes, r_bytes, b_bytes;
     unsigned flags;
+    const float* fw;                  // optional (cnl_conv_params.fuse_w / fuse_part): a following 1x1 conv of <= 4 channels folded into the epilogue:
+    float* fpart;                     //   fw [CoutP][4], fpart [CoutP / 32][N H W][4] partial sums per block of 32 couts
+    unsigned fp_bytes, fp_block;      //   bytes of fpart, bytes per block
 #ifdef W9_TRACE
     unsigned long long* trace;        // timing build: [item][32] s_memtime stamps of block 0 / thread 0 (16..23: inside the item's last MODE-0 chunk of parity 0)
 #endif
@@ -96,7 +99,7 @@ constexpr int ROW_BYTES = ROW_SLOTS * 16;   // 4224
 constexpr int P_SLOTS = 2688;               // PR * ROW_SLOTS = 2640 used (+ 48 slots that absorb the idle lanes of the last staging piece)
 constexpr int P_BYTES = P_SLOTS * 16;       // 43008 per buffer (two buffers)
 constexpr int X_BYTES = 65536;              // epilogue exchange: [4 blocks][4 positions][4 quads][64 lanes] x 16 B
-constexpr int B_BYTES = 512;                // the item's 64 bias values and 64 inverse weight scales (staged for the epilogue)
+constexpr int B_BYTES = 1536;               // the item's 64 bias values and 64 inverse weight scales (staged for the epilogue) + 64 rows of a folded 1x1 conv's weights
 constexpr int LDS_BYTES = 2 * P_BYTES + X_BYTES + B_BYTES;     // 152064: one workgroup per CU (the accumulators allow no more)
 constexpr int NSLICE = 144;                 // MFMAs per wave and chunk
 constexpr int JOB_SLICES = 14;              // one V fragment (28 VALU operations) is produced beside 14 MFMAs
@@ -184,6 +187,7 @@ struct State {
     unsigned long long* trp;   // timing build: this item's stamp row (block 0 / thread 0), else null
 #endif
     float bst, ist;          // this lane's bias / inverse weight scale of the item (cout n0 + lane), on their way to LDS
+    u32x4 fwst;              // FUSE: row n0 + lane of the folded 1x1 conv's weights, on its way to LDS
     char* sB;
 };
 
@@ -263,7 +267,7 @@ constexpr bool first_use(int S) {
         if (SEG_ROW[s / 6] - SEG_KY[s / 6] == yo && (s & 1) == nbh) return false;
     return true;
 }
-template <int S, int PAR, int MODE, bool FIRST>
+template <int S, int PAR, int MODE, bool FIRST, bool FUSE = false>
 __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave) {
     constexpr int seg = S / 6;
     constexpr int r = SEG_ROW[seg], ky = SEG_KY[seg];
@@ -333,25 +337,26 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
         sb[0] = st.bst;
         sb[64] = st.ist;
     }
+    if constexpr (FUSE && FIRST && S == 62) *reinterpret_cast<u32x4*>(st.sB + 512 + lane_now() * 16) = st.fwst;
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int PAR, int MODE, bool FIRST, int... S>
+template <int PAR, int MODE, bool FIRST, bool FUSE, int... S>
 __device__ __forceinline__ void chunk_impl(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave,
                                            std::integer_sequence<int, S...>) {
     __builtin_amdgcn_sched_barrier(0);
-    (slice<S, PAR, MODE, FIRST>(st, a, cn, up, u_plane, u_wave), ...);
+    (slice<S, PAR, MODE, FIRST, FUSE>(st, a, cn, up, u_plane, u_wave), ...);
 }
-template <int PAR, int MODE, bool FIRST = false>        // FIRST: the first chunk of an item (its accumulators start from zero)
+template <int PAR, int MODE, bool FIRST = false, bool FUSE = false>        // FIRST: the first chunk of an item (its accumulators start from zero)
 __device__ __forceinline__ void chunk(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave) {
-    chunk_impl<PAR, MODE, FIRST>(st, a, cn, up, u_plane, u_wave, std::make_integer_sequence<int, NSLICE>{});
+    chunk_impl<PAR, MODE, FIRST, FUSE>(st, a, cn, up, u_plane, u_wave, std::make_integer_sequence<int, NSLICE>{});
 }
 template <int... O>
 __device__ __forceinline__ void job_all(State& st, const int buf, const float S, std::integer_sequence<int, O...>) {
     (vop<O>(st, buf, S), ...);
 }
 
-template <bool RES>      // RES: the launch adds a residual
+template <bool RES, bool FUSE = false>      // RES: the launch adds a residual; FUSE: a following 1x1 conv of <= 4 channels is folded into the epilogue
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void winograd9_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem + 2 * P_BYTES;      // exchange region of the epilogue: two halves of 32 KB
@@ -558,13 +563,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             st.bst = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (int)a.b_bytes, 0x00020000),
                                                                                     co < a.Cout ? (unsigned)co * 4u : OOB, 0, 0));
             st.ist = a.isu[co];
+            if constexpr (FUSE) st.fwst = buf_load16(a.fw, (unsigned)a.CoutP * 16u, (unsigned)co * 16u, 0);
         }
         W9_STAMP(5);
 
         // the item's first chunk starts the accumulators from zero (first_use); CC = 2: that chunk is also the last but one
         int es_nxt;
         if (a.CC > 2) {
-            chunk<0, 0, true>(st, a, 0, up, u_plane, u_wave);
+            chunk<0, 0, true, FUSE>(st, a, 0, up, u_plane, u_wave);
             chunk<1, 0>(st, a, 1, up, u_plane, u_wave);
             for (int cn = 2; cn < a.CC - 2; cn += 2) {
                 chunk<0, 0>(st, a, cn, up, u_plane, u_wave);
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         } else {
             W9_SCALE_EXP(es_nxt, xmax_next);
             st.nxt.S = __builtin_ldexpf(1.f, es_nxt);
-            chunk<0, 1, true>(st, a, 0, up, u_plane, u_wave);
+            chunk<0, 1, true, FUSE>(st, a, 0, up, u_plane, u_wave);
         }
         chunk<1, 2>(st, a, a.CC - 1, up, u_plane, u_wave);
         W9_STAMP(6);
@@ -623,6 +629,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             } else {              // one image per block row: 1 / S from the exponent of the scale in use (S = 2^e exactly)
                 iq[i] = isu_e * __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(unsigned, st.cur.S));
             }
+        }
+        // the folded 1x1 conv: this thread's four couts x its (up to) four output channels, one row of fw per cout
+        f32x4 wq[4];
+        unsigned fv0[2];                 // byte offset of each tile's first pixel of row y0 in this thread's block of fpart
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wq[q] = lds_f4(st.sB + 512 + (g_e * 32 + piece_e * 4 + q) * 16);       // (staged in the item's first chunk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                fv0[i] = (unsigned)((cc_cur.n0 >> 5) + g_e) * a.fp_block + (unsigned)((rimg[i] * a.H + cc_cur.y0) * a.W + rpx[i]) * 16u;
         }
         float omax2[2] = {0.f, 0.f};
         unsigned yv0[2];                 // byte offset of each tile's first pixel in output row y0 (row j: + j rows)
@@ -704,6 +720,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (ok[i][1]) omax2[i] = fmaxf(omax2[i], fmaxf(fmaxf(fabsf(o1[0]), fabsf(o1[1])), fmaxf(fabsf(o1[2]), fabsf(o1[3]))));
                 buf_store16(o0, a.y, a.y_bytes, ok[i][0] ? yv[i] : OOB, 0);
                 buf_store16(o1, a.y, a.y_bytes, ok[i][1] ? yv[i] : OOB, (unsigned)(a.ldy * 4));
+                if constexpr (FUSE) {
+                    // d[c] = sum over this thread's four couts of out[co] * fw[co][c], then over the 8 lanes (pieces) of the tile: quad
+                    // neighbours, quad pairs, the two quads of the half row — a fixed tree, the same in every lane; lane piece 0 stores the
+                    // 32-cout partial sums of both pixels (16 bytes each)
+                    float e0[4], e1[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        e0[c] = __builtin_fmaf(o0[3], wq[3][c], __builtin_fmaf(o0[2], wq[2][c], __builtin_fmaf(o0[1], wq[1][c], o0[0] * wq[0][c])));
+                        e1[c] = __builtin_fmaf(o1[3], wq[3][c], __builtin_fmaf(o1[2], wq[2][c], __builtin_fmaf(o1[1], wq[1][c], o1[0] * wq[0][c])));
+                    }
+#define W9_DPP_OF(v_, ctrl_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v_)), (ctrl_), 0xF, 0xF, false))
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        e0[c] = e0[c] + W9_DPP_OF(e0[c], 0xB1); e1[c] = e1[c] + W9_DPP_OF(e1[c], 0xB1);        // quad_perm [1, 0, 3, 2]
+                        e0[c] = e0[c] + W9_DPP_OF(e0[c], 0x4E); e1[c] = e1[c] + W9_DPP_OF(e1[c], 0x4E);        // quad_perm [2, 3, 0, 1]
+                        e0[c] = e0[c] + W9_DPP_OF(e0[c], 0x141); e1[c] = e1[c] + W9_DPP_OF(e1[c], 0x141);      // row_half_mirror: the other quad of the 8 lanes
+                    }
+#undef W9_DPP_OF
+                    const f32x4 d0 = {e0[0], e0[1], e0[2], e0[3]}, d1 = {e1[0], e1[1], e1[2], e1[3]};
+                    const unsigned fv = fv0[i] + (unsigned)j * (unsigned)(a.W * 16);
+                    const bool st = piece_e == 0 && oy < a.H && rimg[i] < a.Nimg;      // (also for blocks of couts >= Cout: their weights are zero)
+                    buf_store16(d0, a.fpart, a.fp_bytes, (st && rpx[i] < a.W) ? fv : OOB, 0);
+                    buf_store16(d1, a.fpart, a.fp_bytes, (st && rpx[i] + 1 < a.W) ? fv : OOB, 16u);
+                }
             }
             if (j + 1 < R) { W9_BARRIER(); }
             __builtin_amdgcn_sched_barrier(0);
@@ -877,6 +917,7 @@ int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu,
     const int per = cnl_wino_images_per_launch(p);
     CNL_REQUIRE(per > 0, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: one image of a tensor spans >= 4 GiB");
     if (per >= p->N) return wino9_launch_one(p, u9, isu, xmax, stream);
+    CNL_REQUIRE(!p->fuse_w, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: fuse_w on a launch whose tensors span >= 4 GiB; split the batch");
     for (int n0 = 0; n0 < p->N; n0 += per) {
         cnl_conv_params q;
         const float* xm = xmax;
@@ -919,20 +960,30 @@ static int wino9_launch_one(const cnl_conv_params* p, const void* u9, const floa
                 CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb; a.b_bytes = (unsigned)p->Cout * 4u;
     a.flags = p->flags;
+    a.fw = p->fuse_w; a.fpart = p->fuse_w ? p->fuse_part : nullptr; a.fp_bytes = a.fp_block = 0;
+    if (a.fpart) {
+        const unsigned long long blk = Mo * 16ull, all = blk * (unsigned long long)(a.CoutP / 32);
+        CNL_REQUIRE(all < 0xFFFFFF00ull, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: fuse_part spans >= 4 GiB; split the batch");
+        a.fp_bytes = (unsigned)all; a.fp_block = (unsigned)blk;
+    }
 #ifdef W9_TRACE
     a.trace = g_w9_trace;
 #endif
     static cnl::DeviceOnce once;
     int n_cu = 0;                          // persistent workgroups: one per CU, walking the work items with stride gridDim.x
     static cnl::DeviceOnce once_res;
-    int rc = p->residual ? cnl::kernel_setup(once_res, reinterpret_cast<const void*>(&winograd9_kernel<true>), LDS_BYTES, &n_cu)
-                         : cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd9_kernel<false>), LDS_BYTES, &n_cu);
+    static cnl::DeviceOnce once_fuse;
+    CNL_REQUIRE(!(a.fpart && p->residual), CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: fuse_w with a residual");
+    int rc = a.fpart ? cnl::kernel_setup(once_fuse, reinterpret_cast<const void*>(&winograd9_kernel<false, true>), LDS_BYTES, &n_cu)
+             : p->residual ? cnl::kernel_setup(once_res, reinterpret_cast<const void*>(&winograd9_kernel<true>), LDS_BYTES, &n_cu)
+                           : cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd9_kernel<false>), LDS_BYTES, &n_cu);
     if (rc != CNL_OK) return rc;
 #ifdef W9_MAX_CUS      // experiment builds: the persistent grid on fewer CUs (is a power-bound launch any slower on 240 of 256?)
     if (n_cu > W9_MAX_CUS) n_cu = W9_MAX_CUS;
 #endif
     const unsigned grid = (unsigned)(blocks < (long long)n_cu ? blocks : (long long)n_cu);
-    if (p->residual) hipLaunchKernelGGL(winograd9_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    if (a.fpart) hipLaunchKernelGGL((winograd9_kernel<false, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    else if (p->residual) hipLaunchKernelGGL(winograd9_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(winograd9_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return cnl::check_launch("winograd9_kernel");
 }

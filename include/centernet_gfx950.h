@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 10   /* 10: per-image maxima arrays are strided (cnl_absmax_stride() = 32 floats: one cache line per image); the stem entry points take y_absmax; CNL_ALGO_LATENCY and the half-height row-Winograd kernel (csrc/winograd10.hip, variants 10 / 11); the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 11   /* 11: cnl_conv_params.fuse_w / fuse_part + cnl_fused_out_pack_weights_f32 / cnl_fused_out_reduce_f32 (a 1x1 conv of <= 4 channels folded into the 3x3 launch before it); the row-Winograd kernels take maps of any even width in packed rows and tensors of >= 4 GiB in groups of images; CNL_ALGO_FORCE + 32 + v; 10: per-image maxima arrays are strided (cnl_absmax_stride() = 32 floats: one cache line per image); the stem entry points take y_absmax; CNL_ALGO_LATENCY and the half-height row-Winograd kernel (csrc/winograd10.hip, variants 10 / 11); the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -127,8 +127,24 @@ typedef struct cnl_conv_params {
     int32_t splitk;
     float* splitk_scratch;
     size_t splitk_scratch_bytes;
+    /* cnl_conv3x3_winograd_f32 only, optional (NULL = off; ABI v11): a following 1x1 convolution with at most 4 output channels — the box-size
+     * head's out_conv behind its last 3x3 block (reference models/meta.py:24-30) — folded into THIS launch: besides y, the epilogue writes
+     * fuse_part[b][pixel][0..3] = sum over the 32 channels co of block b (co in [32 b, 32 b + 32)) of y[pixel][co] * fuse_w[co][0..3]
+     * (fp32, fixed order), for b < ceil(Cout / 64) * 2; cnl_fused_out_reduce_f32 then adds the blocks in order, adds the bias and applies the
+     * activation: the 1x1 conv never re-reads the 3x3 conv's output (C1: a 537 MB read, 110 us).  fuse_w: [ceil(Cout / 64) * 64][4] floats,
+     * rows >= Cout and columns >= the 1x1 conv's channel count zero (cnl_fused_out_pack_weights_f32); fuse_part: ceil(Cout / 64) * 2 *
+     * N * H * W * 4 floats.  Honoured by the row-Winograd kernels (cnl_conv3x3_winograd_variant 9 / 10 / 11: the dispatcher keeps such a
+     * launch there whatever its size); a launch that cannot take one of them fails with CNL_E_UNSUPPORTED.  Deterministic, batch-invariant. */
+    const float* fuse_w;
+    float* fuse_part;
 } cnl_conv_params;
 
+/* The 1x1 conv folded into a 3x3 launch (cnl_conv_params.fuse_w / fuse_part): w_ohwi [C2][Cout] (C2 <= 4) -> fuse_w [ceil(Cout/64)*64][4];
+ * and its second half: y[pixel][c] = act(bias[c] + sum_b part[b][pixel][c]), b in order, for M pixels (pixel stride ldy floats, c < C2;
+ * flags: CNL_SIGMOID | CNL_RELU).                                                                                                       */
+int cnl_fused_out_pack_weights_f32(const float* w_ohwi, float* fuse_w, int32_t Cout, int32_t C2, void* stream);
+int cnl_fused_out_reduce_f32(const float* part, int32_t nblocks, int64_t M, int32_t C2, const float* bias, float* y, int32_t ldy,
+                             uint32_t flags, void* stream);
 int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream);
 size_t cnl_conv2d_splitk_scratch_bytes(const cnl_conv_params* p);   /* for p->splitk slices; 0 when splitk <= 1 */
 

@@ -1003,3 +1003,67 @@ def test_row_winograd_runs_a_tensor_beyond_4_gib_in_groups_of_images():
         launch(xi.data_ptr(), z1.data_ptr(), 1, 256, 256, 256, 256, u2, b2, ym.data_ptr() + 4 * ams * i, ym1.data_ptr())
         torch.cuda.synchronize()
         assert torch.equal(z[i], z1), i
+
+
+@pytest.mark.parametrize("case", [(2, 64, 16, 64, 256, 4, False), (3, 32, 19, 34, 96, 2, True), (1, 256, 8, 128, 256, 1, True), (5, 32, 6, 20, 64, 3, False)],
+                         ids=lambda c: "N{}c{}_{}x{}_o{}c2_{}sig{}".format(*[int(v) for v in c]))
+def test_small_out_conv_folded_into_the_row_winograd_epilogue(case):
+    """cnl_conv_params.fuse_w / fuse_part (ABI v11): the 1x1 out_conv of at most 4 channels behind a head's last 3x3 block (reference
+    models/meta.py:24-30) leaves per-32-channel partial sums in the block's epilogue and cnl_fused_out_reduce_f32 adds them in order: the
+    block's own output is unchanged bit for bit; the folded conv is within fp32 rounding of a 1x1 conv of that output and within the path's
+    1e-4 of the CPU; deterministic; an image alone gives the same bits as inside a batch (packed rows included: widths 34 and 20)."""
+    lib = _lib.load()
+    N, Cin, H, W, Cout, C2, sig = case
+    x, w, b = mk(N, Cin, H, W, Cout, 3, seed=Cin + Cout + H)
+    g = torch.Generator().manual_seed(3)
+    x = x * torch.pow(10.0, torch.randint(-2, 3, (N, 1, 1, 1), generator=g).float())
+    w2 = torch.randn(C2, Cout, 1, 1, generator=g) * 0.05
+    b2 = torch.randn(C2, generator=g)
+    plain = run_winograd(x, w, b, CNL_RELU, algo=CNL_ALGO_FORCE + 9, want=5)
+
+    def folded(xs):
+        n = xs.shape[0]
+        xd = xs.permute(0, 2, 3, 1).contiguous().cuda()
+        wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+        u = torch.empty((lib.cnl_winograd_weight_floats(Cin, Cout),), device="cuda")
+        _lib.check(lib.cnl_winograd_transform_weights_f32(wd.data_ptr(), u.data_ptr(), Cin, Cout, _stream()))
+        bd, w2d, b2d = b.cuda(), w2.reshape(C2, Cout).contiguous().cuda(), b2.cuda()
+        CoutP = (Cout + 63) // 64 * 64
+        fw = torch.full((CoutP, 4), float("nan"), device="cuda")
+        _lib.check(lib.cnl_fused_out_pack_weights_f32(w2d.data_ptr(), fw.data_ptr(), Cout, C2, _stream()))
+        assert torch.equal(fw[:Cout, :C2].cpu(), w2.reshape(C2, Cout).t()) and float(fw[Cout:].abs().sum()) == 0 and float(fw[:, C2:].abs().sum()) == 0
+        nb = CoutP // 32
+        part = torch.full((nb, n * H * W, 4), float("nan"), device="cuda")
+        y = torch.full((n, H, W, Cout), float("nan"), device="cuda")
+        out = torch.full((n, H, W, C2), float("nan"), device="cuda")
+        p = ConvParams()
+        p.x, p.w, p.bias, p.y = xd.data_ptr(), u.data_ptr(), bd.data_ptr(), y.data_ptr()
+        p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad = n, H, W, Cin, Cout, 3, 3, 1, 1
+        p.ldx, p.ldy, p.flags, p.algo = Cin, Cout, CNL_RELU, CNL_ALGO_AUTO
+        p.fuse_w, p.fuse_part = fw.data_ptr(), part.data_ptr()
+        assert lib.cnl_conv3x3_winograd_variant(ctypes.byref(p)) == 9          # whatever the grid size
+        _lib.check(lib.cnl_conv3x3_winograd_f32(ctypes.byref(p), _stream()), "winograd + folded 1x1")
+        _lib.check(lib.cnl_fused_out_reduce_f32(part.data_ptr(), nb, n * H * W, C2, b2d.data_ptr(), out.data_ptr(), C2, CNL_SIGMOID if sig else 0, _stream()),
+                   "reduce")
+        torch.cuda.synchronize()
+        return y.cpu().permute(0, 3, 1, 2), out.cpu().permute(0, 3, 1, 2)
+
+    y, out = folded(x)
+    assert torch.equal(y, plain)
+    want = F.conv2d(y, w2, b2)
+    want = want.sigmoid() if sig else want
+    scale = max(1.0, float(want.abs().max()))
+    assert float((out - want).abs().max()) <= 4e-6 * scale                    # another summation order of the same fp32 products
+    ref = F.conv2d(ref_conv(x, w, b, 1, CNL_RELU), w2, b2)
+    ref = ref.sigmoid() if sig else ref
+    for i in range(N):
+        assert float((out[i] - ref[i]).abs().max()) <= 1e-4 * max(1.0, float(ref[i].abs().max())), i
+    y2, out2 = folded(x)
+    assert torch.equal(out, out2)
+    y1, out1 = folded(x[N - 1:])
+    assert torch.equal(out1[0], out[N - 1]) and torch.equal(y1[0], y[N - 1])
+    # a residual / a launch that is not the row-Winograd class cannot fold
+    p = ConvParams()
+    p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.ldx, p.ldy, p.algo = 1, 8, 8, 24, 64, 3, 3, 1, 1, 24, 64, CNL_ALGO_AUTO
+    p.x = p.w = p.bias = p.y = p.fuse_w = p.fuse_part = 1 << 20
+    assert lib.cnl_conv3x3_winograd_f32(ctypes.byref(p), _stream()) == _lib.CNL_E_UNSUPPORTED

@@ -346,8 +346,12 @@ def test_latency_class_matches_oracle(cfg, shape):
         torch.testing.assert_close(enc[name].cpu(), r, rtol=TOL, atol=TOL)
     plan = model._engine.plan_for(x.cuda(), sigmoid=False)
     lib = plan.lib
-    variants = [lib.cnl_conv3x3_winograd_variant(ctypes.byref(L.args)) for L in plan.launches if L.fn is lib.cnl_conv3x3_winograd_f32]
-    assert sum(v == 11 for v in variants) >= 20 and 9 not in variants[:-6], variants           # (the first head blocks behind a folded upsample stay on winograd9)
+    wino = [L for L in plan.launches if L.fn is lib.cnl_conv3x3_winograd_f32]
+    variants = [lib.cnl_conv3x3_winograd_variant(ctypes.byref(L.args)) for L in wino]
+    # every eligible layer is on the 4-row x 32-cout items; what stays on winograd9: launches behind a folded upsample (the neck stages and first
+    # head blocks of the simple neck) and the block that carries a folded out_conv (cnl_conv_params.fuse_w: winograd9's epilogue has it)
+    assert sum(v == 11 for v in variants) >= 20, variants
+    assert all(v == 11 or (v == 9 and ((L.args.flags & 4) or L.args.fuse_w)) for v, L in zip(variants, wino)), variants
     _, _, neck64, heads64 = ref_cpu.forward_float64(sd, x, sigmoid=False, return_intermediates="heads")
     nb, _, _, nc, nup = plan.neck_out
     neck = plan.tensor(nb)[..., :nc].permute(0, 3, 1, 2).cpu()

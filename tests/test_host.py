@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/centernet_gfx950.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.cnl_version() == _lib.ABI_VERSION == 10
+    assert lib.cnl_version() == _lib.ABI_VERSION == 11
 
 
 def test_abi_error_convention_without_gpu():
@@ -374,7 +374,7 @@ def test_absmax_arrays_are_one_cache_line_per_image():
     assert _lib.absmax_buffer(4, device="cpu").numel() == 128
 
 
-@pytest.mark.parametrize("src,kernels", [("winograd9.hip", 3), ("winograd10.hip", 4)])
+@pytest.mark.parametrize("src,kernels", [("winograd9.hip", 4), ("winograd10.hip", 4)])
 def test_winograd9_compiles_without_register_spills(src, kernels):
     """csrc/winograd9.hip sits at the edge of the register file (256 accumulator + 256 vector registers per lane): a spill inside its
     chunk loop comes back as a scratch load with a vmcnt(0) — a wait for every load in flight — and harmless-looking edits of the
