@@ -664,6 +664,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 iql[2] = {f32x2{iq[0][0], iq[0][1]}, f32x2{iq[1][0], iq[1][1]}}, iqh[2] = {f32x2{iq[0][2], iq[0][3]}, f32x2{iq[1][2], iq[1][3]}};
         const f32x2 bql = {bq[0], bq[1]}, bqh = {bq[2], bq[3]};
+        f32x4 rvn[2][2];                 // RES: the residual values of the next pass's row
+        if constexpr (RES) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool ok0 = cc_cur.y0 < a.H && cok_e && rimg[i] < a.Nimg;
+                const unsigned rvo = ((unsigned)((rimg[i] * a.H + cc_cur.y0) * a.W + rpx[i]) * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+                    rvn[i][px] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, (ok0 && rpx[i] + px < a.W) ? rvo : OOB, (unsigned)(px * a.ldr * 4)));
+            }
+        }
         W9_XWRITE(0);
         W9_BARRIER();
 #pragma unroll
@@ -680,10 +691,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 yv[i] = yv0[i] + (unsigned)j * y_row;
                 ok[i][0] = row_ok && ox < a.W && rimg[i] < a.Nimg; ok[i][1] = row_ok && ox + 1 < a.W && rimg[i] < a.Nimg;
                 if constexpr (RES) {
-                    const unsigned rvo = ((unsigned)((rimg[i] * a.H + oy) * a.W + ox) * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
+                    // the residual of THIS row was requested a pass ago (round 5: requested at the top of its own pass, every pass waited a memory
+                    // latency for it — layer1's conv2 launches 15-20 us behind their conv1 twins); the next row's goes out now
 #pragma unroll
-                    for (int px = 0; px < 2; ++px)
-                        rv[i][px] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, ok[i][px] ? rvo : OOB, (unsigned)(px * a.ldr * 4)));
+                    for (int px = 0; px < 2; ++px) rv[i][px] = rvn[i][px];
+                    if (j + 1 < R) {
+                        const bool okn = oy + 1 < a.H && cok_e && rimg[i] < a.Nimg;
+                        const unsigned rvo = ((unsigned)((rimg[i] * a.H + oy + 1) * a.W + ox) * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
+#pragma unroll
+                        for (int px = 0; px < 2; ++px)
+                            rvn[i][px] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, (okn && ox + px < a.W) ? rvo : OOB, (unsigned)(px * a.ldr * 4)));
+                    }
                 }
             }
             W9_STAMP(7 + (j & 7));
