@@ -299,7 +299,7 @@ __device__ __forceinline__ void job_all(ST& st, const int buf, std::integer_sequ
     (vop<O>(st, buf), ...);
 }
 
-template <bool RES, int NBH>      // RES: the launch adds a residual; NBH: 64- or 32-cout work items
+template <bool RES, int NBH, bool PK = false>      // RES: the launch adds a residual; NBH: 64- or 32-cout work items; PK: packed rows (winograd9.hip)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void winograd10_kernel(const Args a) {
     constexpr int BN = 32 * NBH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             asm volatile("" : "+v"(tid_));      // keeps the per-thread decode inside the item loop
             const int q_ = tid_ & 3, ix_ = cc.x0 - 1 + (tid_ >> 2);
             const int er_ = tid_ >> 3, ex_ = cc.x0 + 63 + ((tid_ >> 2) & 1), ey_ = cc.y0 - 1 + er_;
-            if (a.pk) {        // packed rows: virtual column -> (image, pixel of its strip); the strip's last two columns, a column before the
+            if constexpr (PK) { // packed rows: virtual column -> (image, pixel of its strip); the strip's last two columns, a column before the
                                // first strip or behind the last are the zero padding (out of range -> zeros)
                 unsigned si_, px_, esi_, epx_;
                 W10_VDIVMOD(si_, px_, (unsigned)ix_, a.pk, a.m_pk);
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             st.cur.u_voff = (unsigned)((cc.n0 + (tid_ & 31)) * 32 + ((tid_ >> 5) & 1) * 16);
         }
         int img_lane = cc.n * a.ipb + si_lane;                 // the image of this lane's tile (V production)
-        if (a.pk) {
+        if constexpr (PK) {
             unsigned q_, r_;
             W10_VDIVMOD(q_, r_, (unsigned)(cc.x0 + 2 * (lane_now() & 31)), a.pk, a.m_pk);
             img_lane = (int)q_;
@@ -539,12 +539,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int si = a.ipb > 1 ? ((2 * rtile) >> a.lw) : 0;
             rimg[i] = ci.n * a.ipb + si;
             rpx[i] = a.ipb > 1 ? ((2 * rtile) & (a.W - 1)) : ci.x0 + 2 * rtile;
-            if (a.pk) {           // packed rows: the tile's virtual column -> (image, pixel); a strip's two padding columns (pixel >= W) are not stored
+            if constexpr (PK) {   // packed rows: the tile's virtual column -> (image, pixel); a strip's two padding columns (pixel >= W) are not stored
                 unsigned q_, r_;
                 W10_VDIVMOD(q_, r_, (unsigned)(ci.x0 + 2 * rtile), a.pk, a.m_pk);
                 rimg[i] = (int)q_; rpx[i] = (int)r_;
             }
-            if (a.ipb > 1 || a.pk) {      // the tile's image is not the one this lane builds V for: its scale from its maximum
+            if (a.ipb > 1 || PK) {        // the tile's image is not the one this lane builds V for: its scale from its maximum
                 int es_i;
                 W10_SCALE_EXP(es_i, W10_XMAX_OF(rimg[i]));
                 iq[i] = isu_e * __builtin_ldexpf(1.f, -es_i);
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int img = __builtin_amdgcn_readfirstlane(rimg[i]);
-                if (a.pk) {    // ... or, in packed rows, in two neighbouring strips (pk >= 16): the first tile's image and the one behind it
+                if constexpr (PK) {    // ... or, in packed rows, in two neighbouring strips (pk >= 16): the first tile's image and the one behind it
                     const float m1 = cnl::wave_max_nonneg(rimg[i] != img ? omax2[i] : 0.f);
                     if (lane_e == 0 && img + 1 < a.Nimg) cnl::report_max(a.ymax + (img + 1) * AMS, m1);
                     omax2[i] = rimg[i] == img ? omax2[i] : 0.f;
@@ -750,11 +750,17 @@ static int wino10_launch(const cnl_conv_params* p, const void* u9, const float* 
 #endif
     static cnl::DeviceOnce once, once_res;
     int n_cu = 0;                          // persistent workgroups: two per CU, walking the work items with stride gridDim.x
-    int rc = p->residual ? cnl::kernel_setup(once_res, reinterpret_cast<const void*>(&winograd10_kernel<true, NBH>), LDS_BYTES, &n_cu)
-                         : cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd10_kernel<false, NBH>), LDS_BYTES, &n_cu);
+    static cnl::DeviceOnce once_pk, once_res_pk;
+    int rc = a.pk ? (p->residual ? cnl::kernel_setup(once_res_pk, reinterpret_cast<const void*>(&winograd10_kernel<true, NBH, true>), LDS_BYTES, &n_cu)
+                                 : cnl::kernel_setup(once_pk, reinterpret_cast<const void*>(&winograd10_kernel<false, NBH, true>), LDS_BYTES, &n_cu))
+                  : (p->residual ? cnl::kernel_setup(once_res, reinterpret_cast<const void*>(&winograd10_kernel<true, NBH>), LDS_BYTES, &n_cu)
+                                 : cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd10_kernel<false, NBH>), LDS_BYTES, &n_cu));
     if (rc != CNL_OK) return rc;
     const unsigned grid = (unsigned)(blocks < 2ll * n_cu ? blocks : 2ll * n_cu);
-    if (p->residual) hipLaunchKernelGGL((winograd10_kernel<true, NBH>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    if (a.pk) {
+        if (p->residual) hipLaunchKernelGGL((winograd10_kernel<true, NBH, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((winograd10_kernel<false, NBH, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    } else if (p->residual) hipLaunchKernelGGL((winograd10_kernel<true, NBH>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((winograd10_kernel<false, NBH>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
     return cnl::check_launch("winograd10_kernel");
 }

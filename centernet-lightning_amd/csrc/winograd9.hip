@@ -356,7 +356,10 @@ __device__ __forceinline__ void job_all(State& st, const int buf, const float S,
     (vop<O>(st, buf, S), ...);
 }
 
-template <bool RES, bool FUSE = false>      // RES: the launch adds a residual; FUSE: a following 1x1 conv of <= 4 channels is folded into the epilogue
+// RES: the launch adds a residual; FUSE: a following 1x1 conv of <= 4 channels is folded into the epilogue; PK: packed rows (cnl_wino_packed_stride).
+// Template parameters, not run-time branches: the plain instantiations are the code of round 4 (the packed-row index arithmetic as uniform
+// branches cost the unpacked launches of C1 1.5-2.3 us each: more scalar registers live across the chunk loop — profiles/r05_experiments.txt r5c)
+template <bool RES, bool FUSE = false, bool PK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void winograd9_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem + 2 * P_BYTES;      // exchange region of the epilogue: two halves of 32 KB
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("" : "+v"(tid_));      /* keeps the per-thread decode inside the item loop (hoisted, its values live across the main loop) */ \
         const int q_ = tid_ & 3, ix_ = (c_).x0 - 1 + (tid_ >> 2);                                                \
         const int er_ = tid_ >> 3, ex_ = (c_).x0 + 63 + ((tid_ >> 2) & 1), ey_ = (c_).y0 - 1 + er_;              \
-        if (a.pk) {        /* packed rows: virtual column -> (image, pixel of its strip); the strip's last two columns, a column before the */ \
+        if (PK) {          /* packed rows: virtual column -> (image, pixel of its strip); the strip's last two columns, a column before the */ \
                            /* first strip or behind the last are the zero padding (out of range -> zeros) */   \
             unsigned si_, px_, esi_, epx_;                                                                       \
             W9_VDIVMOD(si_, px_, (unsigned)ix_, a.pk, a.m_pk);                                                   \
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W9_IMG_LANE(out_, c_)                                                                                    \
     do {                                                                                                         \
         (out_) = (c_).n * a.ipb + si_lane;                                                                       \
-        if (a.pk) {                                                                                              \
+        if (PK) {                                                                                                \
             unsigned q_, r_;                                                                                     \
             W9_VDIVMOD(q_, r_, (unsigned)((c_).x0 + 2 * (lane_now() & 31)), a.pk, a.m_pk);                       \
             (out_) = (int)q_;                                                                                    \
@@ -617,12 +620,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int si = a.ipb > 1 ? ((2 * rtile[i]) >> a.lw) : 0;
             rimg[i] = cc_cur.n * a.ipb + si;
             rpx[i] = a.ipb > 1 ? ((2 * rtile[i]) & (a.W - 1)) : cc_cur.x0 + 2 * rtile[i];
-            if (a.pk) {           // packed rows: the tile's virtual column -> (image, pixel); a strip's two padding columns (pixel >= W) are not stored
+            if constexpr (PK) {   // packed rows: the tile's virtual column -> (image, pixel); a strip's two padding columns (pixel >= W) are not stored
                 unsigned q_, r_;
                 W9_VDIVMOD(q_, r_, (unsigned)(cc_cur.x0 + 2 * rtile[i]), a.pk, a.m_pk);
                 rimg[i] = (int)q_; rpx[i] = (int)r_;
             }
-            if (a.ipb > 1 || a.pk) {      // the tile's image is not the one this lane builds V for: its scale from its maximum
+            if (a.ipb > 1 || PK) {        // the tile's image is not the one this lane builds V for: its scale from its maximum
                 int es_i;
                 W9_SCALE_EXP(es_i, W9_XMAX_OF(rimg[i]));
                 iq[i] = isu_e * __builtin_ldexpf(1.f, -es_i);
@@ -772,7 +775,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int img = __builtin_amdgcn_readfirstlane(rimg[i]);
-                if (a.pk) {    // packed rows: the 8 tiles may lie in two neighbouring strips (pk >= 16): the first tile's image and the one behind it
+                if constexpr (PK) {    // packed rows: the 8 tiles may lie in two neighbouring strips (pk >= 16): the first tile's image and the one behind it
                     const float m1 = cnl::wave_max_nonneg(rimg[i] != img ? omax2[i] : 0.f);
                     if (lane_e == 0 && img + 1 < a.Nimg) cnl::report_max(a.ymax + (img + 1) * AMS, m1);
                     omax2[i] = rimg[i] == img ? omax2[i] : 0.f;
@@ -987,21 +990,27 @@ static int wino9_launch_one(const cnl_conv_params* p, const void* u9, const floa
 #ifdef W9_TRACE
     a.trace = g_w9_trace;
 #endif
-    static cnl::DeviceOnce once;
-    int n_cu = 0;                          // persistent workgroups: one per CU, walking the work items with stride gridDim.x
-    static cnl::DeviceOnce once_res;
-    static cnl::DeviceOnce once_fuse;
     CNL_REQUIRE(!(a.fpart && p->residual), CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: fuse_w with a residual");
-    int rc = a.fpart ? cnl::kernel_setup(once_fuse, reinterpret_cast<const void*>(&winograd9_kernel<false, true>), LDS_BYTES, &n_cu)
-             : p->residual ? cnl::kernel_setup(once_res, reinterpret_cast<const void*>(&winograd9_kernel<true>), LDS_BYTES, &n_cu)
-                           : cnl::kernel_setup(once, reinterpret_cast<const void*>(&winograd9_kernel<false>), LDS_BYTES, &n_cu);
+    // the six instantiations: (plain | residual | folded 1x1) x (plain grid | packed rows)
+    static cnl::DeviceOnce once[6];
+    const void* const fns[6] = {reinterpret_cast<const void*>(&winograd9_kernel<false, false, false>), reinterpret_cast<const void*>(&winograd9_kernel<true, false, false>),
+                                reinterpret_cast<const void*>(&winograd9_kernel<false, true, false>), reinterpret_cast<const void*>(&winograd9_kernel<false, false, true>),
+                                reinterpret_cast<const void*>(&winograd9_kernel<true, false, true>), reinterpret_cast<const void*>(&winograd9_kernel<false, true, true>)};
+    const int which = (a.fpart ? 2 : (p->residual ? 1 : 0)) + (a.pk ? 3 : 0);
+    int n_cu = 0;                          // persistent workgroups: one per CU, walking the work items with stride gridDim.x
+    int rc = cnl::kernel_setup(once[which], fns[which], LDS_BYTES, &n_cu);
     if (rc != CNL_OK) return rc;
 #ifdef W9_MAX_CUS      // experiment builds: the persistent grid on fewer CUs (is a power-bound launch any slower on 240 of 256?)
     if (n_cu > W9_MAX_CUS) n_cu = W9_MAX_CUS;
 #endif
     const unsigned grid = (unsigned)(blocks < (long long)n_cu ? blocks : (long long)n_cu);
-    if (a.fpart) hipLaunchKernelGGL((winograd9_kernel<false, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
-    else if (p->residual) hipLaunchKernelGGL(winograd9_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(winograd9_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+    switch (which) {
+    case 0: hipLaunchKernelGGL((winograd9_kernel<false, false, false>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    case 1: hipLaunchKernelGGL((winograd9_kernel<true, false, false>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL((winograd9_kernel<false, true, false>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    case 3: hipLaunchKernelGGL((winograd9_kernel<false, false, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    case 4: hipLaunchKernelGGL((winograd9_kernel<true, false, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL((winograd9_kernel<false, true, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    }
     return cnl::check_launch("winograd9_kernel");
 }
