@@ -17,6 +17,11 @@
 // The 16x16-pixel-block fp32 kernel this file used to hold, the exact three-way bf16 split (winograd3/4) and the two-waves-per-SIMD
 // form of 5 (winograd7) are measured-and-superseded variants: tools/experiments/ (`make -C csrc experiments`, algo = CNL_ALGO_FORCE + variant).
 #include "cnl_common.h"
+#if __has_include("build/w9_usage.h")
+#include "build/w9_usage.h"      // CNL_W9_VGPR_SPILLS: vector registers the compiler spilled in winograd9.hip's kernels (Makefile)
+#else
+#define CNL_W9_VGPR_SPILLS 0
+#endif
 
 namespace cnl_wino {
 
@@ -184,6 +189,9 @@ static int wino_choice(const cnl_conv_params* p) {
             if (items9 <= half_the_cus() && upf == 1 && cnl_wino10_eligible(p)) return 11;
             // maps whose height 8-row items pad by a sixth or more over 4-row items (19 rows: 24 vs 20): the half-height items
             if (upf == 1 && R9 * 100 >= R10 * 115 && cnl_wino10_eligible(p)) return p->Cout <= 256 ? 11 : 10;
+            // a winograd9 that the compiler could only build with spilled vector registers (scratch loads inside its chunk loop): its layers go
+            // to winograd10 — the same bits from 128 accumulators per lane (no folded upsample there: those launches keep winograd9)
+            if (CNL_W9_VGPR_SPILLS > 0 && upf == 1 && cnl_wino10_eligible(p)) return 10;
             return 9;
         }
     }

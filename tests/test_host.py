@@ -397,3 +397,17 @@ def test_winograd9_compiles_without_register_spills(src, kernels):
     if src == "winograd10.hip":
         occ = [int(l.split("Occupancy [waves/SIMD]:")[1].split()[0]) for l in r.stderr.splitlines() if "Occupancy [waves/SIMD]:" in l]
         assert occ == [2] * kernels, occ
+
+
+def test_makefile_hands_winograd9_spill_count_to_the_dispatcher():
+    """the product build records winograd9.hip's resource usage and generates build/w9_usage.h; winograd.hip reads
+    CNL_W9_VGPR_SPILLS from it as a compile-time constant and sends winograd9's layers to the bit-identical winograd10.hip when it is not zero
+    (a compiler that can only build the kernel with scratch traffic inside its chunk loop).  The shipped library was built with zero."""
+    csrc = os.path.join(ROOT, "centernet-lightning_amd", "csrc")
+    usage = os.path.join(csrc, "build", "w9_usage.h")
+    if not os.path.exists(usage):
+        pytest.skip("no build directory (library built elsewhere)")
+    text = open(usage).read()
+    assert "#define CNL_W9_VGPR_SPILLS 0" in text and "#define CNL_W9_KERNELS_CHECKED 6" in text
+    src = open(os.path.join(csrc, "winograd.hip")).read()
+    assert 'include "build/w9_usage.h"' in src and "CNL_W9_VGPR_SPILLS > 0" in src
