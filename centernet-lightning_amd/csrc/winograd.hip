@@ -72,6 +72,8 @@ int cnl_wino_packed_stride(const cnl_conv_params* p);                           
 bool cnl_wino10_eligible(const cnl_conv_params* p);                                // winograd10.hip (reads winograd9.hip's weights)
 int cnl_wino10_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, bool cout32, void* stream);
 #ifdef CNL_EXPERIMENTS
+bool cnl_wino12_eligible(const cnl_conv_params* p);                                // tools/experiments/winograd12.hip (round 5: Cin = 64, the epilogue rides in the next item's chunks)
+int cnl_wino12_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream);
 int cnl_wino1_launch(const cnl_conv_params* p, void* stream);                       // tools/experiments/winograd1.hip
 size_t cnl_wino3_weight_bytes(int Cin, int Cout);                                  // tools/experiments/winograd3.hip
 int cnl_wino3_transform_weights(const float* w_ohwi, void* u3, int Cin, int Cout, void* stream);
@@ -147,6 +149,11 @@ static int wino_choice(const cnl_conv_params* p) {
         if (v <= 2 || p->Cin % 16) return v == 1 ? 1 : 2;
         if (v == 9 && !cnl_wino9_eligible(p)) return 5;
         if ((v == 10 || v == 11) && !cnl_wino10_eligible(p)) return 5;
+#ifdef CNL_EXPERIMENTS
+        if (v == 12 && !cnl_wino12_eligible(p)) return cnl_wino9_eligible(p) ? 9 : 5;
+#else
+        if (v == 12) return cnl_wino9_eligible(p) ? 9 : 5;      // (variant 12 exists in experiment builds only)
+#endif
         if (v == 6 && p->Cout % 128) return 5;
         return v;
     }
@@ -208,7 +215,7 @@ extern "C" int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p) {
     CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: null params");
     CNL_REQUIRE(p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: non-positive dimension");
     const int c = wino_choice(p);
-    return (c == 5 || c == 6 || c == 7 || c == 9 || c == 10 || c == 11) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
+    return (c == 5 || c == 6 || c == 7 || c == 9 || c == 10 || c == 11 || c == 12) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
 }
 
 extern "C" int cnl_conv3x3_winograd_variant(const cnl_conv_params* p) {
@@ -230,8 +237,8 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 "cnl_conv3x3_winograd_f32: Cin %% 8 != 0 or bad pixel stride");
     CNL_REQUIRE(((uintptr_t)p->x & 15) == 0 && ((uintptr_t)p->w & 15) == 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unaligned x / u");
     CNL_REQUIRE(!p->residual || p->ldr >= p->Cout, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: ldr < Cout");
-    CNL_REQUIRE(p->algo <= CNL_ALGO_F32 || p->algo == CNL_ALGO_LATENCY || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 11 && p->algo != CNL_ALGO_FORCE + 8) ||
-                    (p->algo >= CNL_ALGO_FORCE + 32 + 9 && p->algo <= CNL_ALGO_FORCE + 32 + 11),
+    CNL_REQUIRE(p->algo <= CNL_ALGO_F32 || p->algo == CNL_ALGO_LATENCY || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 12 && p->algo != CNL_ALGO_FORCE + 8) ||
+                    (p->algo >= CNL_ALGO_FORCE + 32 + 9 && p->algo <= CNL_ALGO_FORCE + 32 + 12),
                 CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unknown algo %u (FORCE + 8, the F(4x4) kernel, was removed in ABI v10)", p->algo);
     const int choice = wino_choice(p);
     CNL_REQUIRE(!p->fuse_w || (choice == 9 && p->fuse_part && !p->residual), CNL_E_UNSUPPORTED,
@@ -250,6 +257,9 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 xmax = s5 + 16;
             }
             if (choice == 9) return cnl_wino9_launch(p, u + L.u9, u + L.s9, xmax, stream);
+#ifdef CNL_EXPERIMENTS
+            if (choice == 12) return cnl_wino12_launch(p, u + L.u9, u + L.s9, xmax, stream);
+#endif
             return cnl_wino10_launch(p, u + L.u9, u + L.s9, xmax, choice == 11, stream);
         }
 #ifdef CNL_EXPERIMENTS

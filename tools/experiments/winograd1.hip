@@ -36,7 +36,7 @@
 // (+ residual) (+ ReLU) and stores the 2x2 outputs NHWC with buffer stores (uniform part of the address in the SGPR
 // offset, 64 consecutive channels per 256 bytes).
 // (round 2: kept under experiments/ — superseded by winograd2.hip, bit-identical to it; built only by `make experiments`)
-#include "../cnl_common.h"
+#include "cnl_common.h"
 #include <cstdlib>
 
 namespace cnl_wino {

@@ -25,7 +25,7 @@
 //     ds_write_b64 per (item, position pair); hand-placed 6 VALU per MFMA slice.
 //   * only the input patch (18x18 px x 16 ch, double-buffered, LDS-DMA two chunks ahead) is shared: ONE barrier per chunk.
 //   * U is pre-split once per weight load (cnl_winograd_transform_weights_f32): [ci/16][position][piece][cout][16 ci] bf16.
-#include "../cnl_common.h"
+#include "cnl_common.h"
 #include <cstdlib>
 
 #pragma clang fp contract(off)

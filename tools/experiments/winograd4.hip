@@ -15,7 +15,7 @@
 //   every U and V element is still loaded / produced by exactly one wave (no duplicated streams); the only shared data is the
 //   input patch (double-buffered LDS-DMA, ONE barrier per chunk).
 // Weights: the pre-split layout of winograd3.hip.  Same call sites (reference models/meta.py:24-26, models/layers.py:72-77).
-#include "../cnl_common.h"
+#include "cnl_common.h"
 #include <cstdlib>
 
 #pragma clang fp contract(off)

@@ -10,7 +10,7 @@
 //   V of a position is produced and consumed by the same wave (private, single-buffered, program order), one (item, position) at
 //   a time: 4 patch reads, 8 fma + 4 add + 10 split operations, one ds_write2st64_b64; the patch is the only shared data (one
 //   barrier per chunk); the eight partial inverse-transform sums of a tile meet through LDS in the epilogue.
-#include "../cnl_common.h"
+#include "cnl_common.h"
 #include <cstdlib>
 
 #pragma clang fp contract(off)
