@@ -762,8 +762,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const f32x4 d0 = {e0[0], e0[1], e0[2], e0[3]}, d1 = {e1[0], e1[1], e1[2], e1[3]};
                     const unsigned fv = fv0[i] + (unsigned)j * (unsigned)(a.W * 16);
                     const bool st = piece_e == 0 && oy < a.H && rimg[i] < a.Nimg;      // (also for blocks of couts >= Cout: their weights are zero)
-                    buf_store16(d0, a.fpart, a.fp_bytes, (st && rpx[i] < a.W) ? fv : OOB, 0);
-                    buf_store16(d1, a.fpart, a.fp_bytes, (st && rpx[i] + 1 < a.W) ? fv : OOB, 16u);
+                    // (default cache policy, not nt: eight lanes of a wave fill a 128-byte line of fpart together with their neighbours' stores)
+                    {
+                        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.fpart, 0, (int)a.fp_bytes, 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d0), rs, (st && rpx[i] < a.W) ? fv : OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d1), rs, (st && rpx[i] + 1 < a.W) ? fv : OOB, 16, 0);
+                    }
                 }
             }
             if (j + 1 < R) { W9_BARRIER(); }
