@@ -1,9 +1,9 @@
 #!/bin/bash
 # Profiles of the bench command for one round: rocprofv3 kernel stats + PMC traffic (separate passes, MI355X_MICROARCH.md's recipe) per
 # configuration -> gpurun_out/$R/, one JSON per configuration that bench.py reads its `traffic` / `decode.kernels_profiled` figures from
-# (copy the results into profiles/ and commit them).   usage: R=r04 CFGS="c1 c2 c4" bash tools/profile_round.sh
+# (copy the results into profiles/ and commit them).   usage: R=r05 CFGS="c1 c2 c4" bash tools/profile_round.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${R:-r04}
+R=${R:-r05}
 mkdir -p gpurun_out/$R
 for c in ${CFGS:-c1 c2 c4}; do
   case $c in
