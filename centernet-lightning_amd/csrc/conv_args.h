@@ -72,6 +72,15 @@ __device__ __forceinline__ void buf_store(float v, float* base, unsigned bytes, 
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voffset, soffset, CNL_NT_STORES);
 }
+__device__ __forceinline__ f32x4 buf_load4(const float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
+}
+__device__ __forceinline__ void buf_store4(f32x4 v, float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rsrc, voffset, soffset, CNL_NT_STORES);
+}
 __device__ __forceinline__ f32x4 lds_read16(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
 // n / d for n < 2^31 with host-computed (magic, shift); shift == 0xFF encodes d == 1
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, unsigned shift) {

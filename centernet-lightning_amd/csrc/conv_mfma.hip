@@ -292,6 +292,90 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const float hi6 = (a.flags & CNL_RELU6) ? 6.f : __builtin_inff();
     const bool sigm = a.flags & CNL_SIGMOID;
     const bool full = (m0 + C::BM <= a.M) && (n0 + C::BN <= a.Cout);
+    // Fuse epilogue through LDS (round 5): in the MFMA's C layout a lane holds ONE cout of 16 pixels — 4-byte loads of the skip tensor and 4-byte
+    // stores, 64 of each per tile and 2x position, and one (n, oy, ox) decomposition per accumulator register.  Every wave turns its tiles
+    // through a private part of the (now idle) staging buffers instead: written as [pixel][32 couts] rows (16-byte slots XOR-swizzled by the
+    // pixel: conflict-free both ways), read back with 8 lanes per pixel — a lane then holds four consecutive couts: 16-byte loads and
+    // stores, every instruction 8 full 128-byte lines, a quarter of the memory instructions.  Same values, same order of additions.
+    bool fuse_x = false;
+    if constexpr (KS == 1 && !UP_IN) {
+        static_assert(TM * TN * 4096 * C::NW <= C::LDS_BYTES, "the wave-private transpose regions live in the staging buffers");
+        fuse_x = (a.flags & CNL_UPSAMPLE_OUT_ADD) && !(a.flags & CNL_I_SUBPIXEL) && a.Cout % 4 == 0 && a.ldy % 4 == 0 && a.ldr % 4 == 0 &&
+                 (((uintptr_t)a.y | (uintptr_t)a.res) & 15) == 0;
+    }
+    if (fuse_x) {
+        __syncthreads();                                               // every wave is done with the last chunk's operands
+        char* const T = smem + wave * (TM * TN * 4096);
+        const int cl = lane & 31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    *reinterpret_cast<float*>(T + (i * TN + j) * 4096 + p * 128 + (((cl >> 2) ^ (p & 7)) << 4) + (cl & 3) * 4) = acc[i][j][r];
+                }
+        const unsigned Wo2 = 2u * (unsigned)a.Wo;
+        const bool want_max = a.ymax != nullptr;
+        const unsigned img0 = fast_div((unsigned)m0, a.mg_hw, a.sh_hw);
+        float om0 = 0.f, om1 = 0.f;
+        const int q = lane & 7, pr = lane >> 3;
+        f32x4 bvj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const unsigned c = (unsigned)(n0 + (wn * TN + j) * 32 + 4 * q);
+            bvj[j] = buf_load4(a.bias, (unsigned)a.Cout * 4u, c < (unsigned)a.Cout ? c * 4u : OOB, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = pr + 8 * k;
+                const int m = m0 + (wm * TM + i) * 32 + p;
+                const bool row_ok = m < a.M;
+                const unsigned n = fast_div((unsigned)m, a.mg_hw, a.sh_hw);
+                const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
+                const unsigned oy = fast_div(rem, a.mg_w, a.sh_w);
+                const unsigned ox = rem - oy * (unsigned)a.Wo;
+                const unsigned pix = (n * 2u * (unsigned)a.Ho + 2u * oy) * Wo2 + 2u * ox;      // < 2^30: checked on the host (4 GiB rule)
+                float ov = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const unsigned c = (unsigned)(n0 + (wn * TN + j) * 32 + 4 * q);
+                    const bool ok = row_ok && c < (unsigned)a.Cout;
+                    const unsigned y_v = ok ? (pix * (unsigned)a.ldy + c) * 4u : OOB, r_v = ok ? (pix * (unsigned)a.ldr + c) * 4u : OOB;
+                    f32x4 rv[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) rv[d] = buf_load4(a.res, a.r_bytes, r_v, (((d >> 1) * Wo2 + (d & 1)) * (unsigned)a.ldr) * 4u);
+                    const f32x4 v = lds_read16(T + (i * TN + j) * 4096 + p * 128 + ((q ^ (p & 7)) << 4)) + bvj[j];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        f32x4 o = v + rv[d];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = fmaxf(o[e], lo);
+                            if (ok) ov = fmaxf(ov, fabsf(o[e]));
+                        }
+                        buf_store4(o, a.y, a.y_bytes, y_v, (((d >> 1) * Wo2 + (d & 1)) * (unsigned)a.ldy) * 4u);
+                    }
+                }
+                if (want_max && row_ok) {
+                    if (n == img0) om0 = fmaxf(om0, ov);
+                    else if (n == img0 + 1) om1 = fmaxf(om1, ov);
+                    else cnl::report_max(a.ymax + n * AMS, ov);
+                }
+            }
+        }
+        if (want_max) {
+            om0 = cnl::wave_max_nonneg(om0);
+            om1 = cnl::wave_max_nonneg(om1);
+            if (lane == 0) {
+                cnl::report_max(a.ymax + img0 * AMS, om0);
+                if (om1 > 0.f) cnl::report_max(a.ymax + (img0 + 1) * AMS, om1);
+            }
+        }
+    } else
     if (!(a.flags & (CNL_UPSAMPLE_OUT_ADD | CNL_I_SUBPIXEL))) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {

@@ -674,11 +674,12 @@ def test_winograd9_matches_cpu_and_reports_absmax(case, variant):
     assert e9 <= 1.25 * e2 + 1e-7 * ref64.abs().max().item(), (e9, e2)
 
 
-@pytest.mark.parametrize("shape", [(1, 256, 4, 4, 128), (2, 512, 2, 2, 256), (3, 128, 19, 34, 64), (5, 64, 3, 5, 96)])
+@pytest.mark.parametrize("shape", [(1, 256, 4, 4, 128), (2, 512, 2, 2, 256), (3, 128, 19, 34, 64), (5, 64, 3, 5, 96), (2, 64, 5, 6, 30), (2, 128, 40, 24, 64)])
 def test_fuse_epilogue_reports_absmax(shape):
     """The FPN Fuse launch (1x1 project -> nearest x2 -> + skip, CNL_UPSAMPLE_OUT_ADD; reference layers.py:160-174) folds max |y| per image into
     y_absmax, so the 3x3 output conv behind it needs no pass of its own over the fused tensor: exact, also where a tile's rows span several
-    images; the output is unchanged by the report."""
+    images; the output is unchanged by the report.  Cout % 4 == 0 runs on transposed accumulator tiles (16 bytes of four couts per lane), Cout = 30 on
+    the scalar epilogue."""
     N, Cin, H, W, Cout = shape
     x, w, b = mk(N, Cin, H, W, Cout, 1, seed=H * W + Cout)
     g = torch.Generator().manual_seed(5)
