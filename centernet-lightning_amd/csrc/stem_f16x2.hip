@@ -25,7 +25,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int TH = 16, TW = 32;                       // output tile (4 rows per wave)
+#ifndef S5_NW
+#define S5_NW 4       /* waves per workgroup (A/B build: make variant TAG=s5nw8 EXTRA=-DS5_NW=8) */
+#endif
+constexpr int TH = 16, TW = 32;                       // output tile
+constexpr int NW = S5_NW;                             // waves per workgroup; each owns RPW conv rows of the tile.  Round 5 measured 8 waves x 2 rows (the same
+constexpr int RPW = TH / NW;                          //   instructions per tile on twice the waves, 4 per SIMD, 102-117 registers): the stem WITHOUT the pool 294 -> 250 us,
+                                                      //   the stem + pool of the default plans 170 -> 175.6 (profiles/r05_experiments.txt r5i): 4 x 4 stays
+static_assert(NW == 4 || NW == 8, "the pooling epilogue is written for 4 or 2 conv rows per wave");
 constexpr int PR = 2 * TH + 5;                        // patch rows (37)
 constexpr int PC = 2 * TW + 5;                        // patch cols (69)
 constexpr int RS = 256;                               // patch row stride in floats: 207 used (+ 3 pad reads); 1 KB = 4 DMA instructions
@@ -35,7 +42,8 @@ constexpr int W_PIECE_BYTES = NG * 64 * 16;           // 21504: one piece (hi or
 constexpr int W_BYTES = 2 * W_PIECE_BYTES;            // 43008 = 42 x 1 KB
 constexpr int PATCH_BYTES = PR * RS * 4;              // 37888: the fp32 patch as staged, then its two fp16 planes (hi at 0, lo at PLANE_BYTES)
 constexpr int PLANE_BYTES = PR * RS * 2;              // 18944
-constexpr int SCAN_IT = (PR * (RS / 4) + 255) / 256;  // 10 float4 per thread
+constexpr int NT = 64 * NW;                           // threads per workgroup
+constexpr int SCAN_IT = (PR * (RS / 4) + NT - 1) / NT; // float4 per thread (5; NW = 4: 10)
 constexpr int LDS_BYTES = PATCH_BYTES + W_BYTES + 64; // 80960 -> 2 workgroups / CU
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
@@ -97,7 +105,7 @@ __device__ unsigned long long* s5_trace_ptr;
 #define S5_STAMP(i_) do {} while (0)
 #endif
 template <bool POOL, bool U8, bool FULL>
-__global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restrict__ x, long sn, int sc, int sh, int sw,
+__global__ __launch_bounds__(NT, NW / 2) void stem_f16x2_kernel(const void* __restrict__ x, long sn, int sc, int sh, int sw,
                                                             unsigned x_img_bytes, const void* __restrict__ w_split,
                                                             const float* __restrict__ scal, const float* __restrict__ bias,
                                                             float* __restrict__ y, unsigned* __restrict__ ymax, int N, int H, int W, int Ho, int Wo,
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* patch = reinterpret_cast<float*>(smem);
     char* wl = smem + PATCH_BYTES;
-    float* red = reinterpret_cast<float*>(smem + PATCH_BYTES + W_BYTES);      // [4] per-wave patch maxima
+    float* red = reinterpret_cast<float*>(smem + PATCH_BYTES + W_BYTES);      // [NW] per-wave patch maxima
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, hi = lane >> 5, px = lane & 31;
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
 #define S5_EXP 0        // timing builds (results wrong): 1 no patch DMA, 2 no weight DMA, 3 one K step, 4 no stores, 5 no patch scan, 6 / 7 border cells of the pooled map stored plainly / not at all
 #endif
     if (S5_EXP != 2)
-    for (int q = wave; q < W_BYTES / 1024; q += 4) dma16(w_split, (unsigned)W_BYTES, wl + q * 1024, (unsigned)(q * 1024 + lane * 16));
+    for (int q = wave; q < W_BYTES / 1024; q += NW) dma16(w_split, (unsigned)W_BYTES, wl + q * 1024, (unsigned)(q * 1024 + lane * 16));
     constexpr int ES = U8 ? 1 : 4;                                             // bytes per input element
     const char* xn = reinterpret_cast<const char*>(x) + (long)n * sn * ES;
     unsigned lane_off[4];
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
         const int ix = ix0 + col;
         lane_off[q] = (f < PC * 3 && (unsigned)ix < (unsigned)W) ? (unsigned)((c * sc + ix * sw) * ES) : OOB;
     }
-    for (int r = wave; r < (S5_EXP == 1 ? 0 : PR); r += 4) {
+    for (int r = wave; r < (S5_EXP == 1 ? 0 : PR); r += NW) {
         const int iy = iy0 + r;
         const bool row_ok = (unsigned)iy < (unsigned)H;                       // wave-uniform
         const unsigned row_off = (unsigned)(iy * sh * ES);
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
     float4 pv[SCAN_IT];
 #pragma unroll
     for (int it = 0; it < SCAN_IT; ++it) {
-        const int e = tid + it * 256;
+        const int e = tid + it * NT;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e < PR * (RS / 4) && (S5_EXP != 5 || it == 0)) {
             v = *reinterpret_cast<const float4*>(patch + e * 4);
@@ -187,12 +195,15 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) red[wave] = mx;
     __syncthreads();                                  // (every thread has read its part of the fp32 patch: the planes may overwrite it)
-    const float Sx = pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    float pmx = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) pmx = fmaxf(pmx, red[w]);
+    const float Sx = pow2_scale(pmx);
     const float inv = 1.f / (Sx * scal[0]);
     // ---- x S = hi + lo, ONCE per element: two fp16 planes over the patch ----
 #pragma unroll
     for (int it = 0; it < SCAN_IT; ++it) {
-        const int e = tid + it * 256;
+        const int e = tid + it * NT;
         if (e < PR * (RS / 4)) {
             unsigned h0, l0, h1, l1;
             split2(pv[it].x, pv[it].y, Sx, h0, l0);
@@ -204,16 +215,16 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
     __syncthreads();
     S5_STAMP(2);
 
-    f32x16 acc[4][2];
+    f32x16 acc[RPW][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RPW; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // lane's A base: output row (wave*4 + i), column px -> patch row 2*(wave*4+i) + ky, elements 6*px + 8q .. + 7 of each plane
-    const char* pa = smem + ((wave * 8) * RS + px * 6) * 2;
+    // lane's A base: output row (wave*RPW + i), column px -> patch row 2*(wave*RPW+i) + ky, elements 6*px + 8q .. + 7 of each plane
+    const char* pa = smem + ((wave * 2 * RPW) * RS + px * 6) * 2;
     const char* pb = wl + px * 16;                                // + piece * W_PIECE_BYTES + (g * 64 + 32 j) * 16
 #pragma unroll
     for (int s = 0; s < (S5_EXP == 3 ? 1 : STEPS); ++s) {
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RPW; ++i) {
             const unsigned* ph = reinterpret_cast<const unsigned*>(pa + ((2 * i) * RS + a_off) * 2);      // (4-byte aligned: 12 px + 16 q)
             const unsigned* pl = reinterpret_cast<const unsigned*>(pa + PLANE_BYTES + ((2 * i) * RS + a_off) * 2);
             unsigned h[4], l[4];
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
     }
 
 #ifdef S5_TRACE
-    asm volatile("s_nop 0" :: "v"(acc[3][1][15]), "v"(acc[0][0][0]));      // the stamp waits for the last MFMAs
+    asm volatile("s_nop 0" :: "v"(acc[RPW - 1][1][15]), "v"(acc[0][0][0]));      // the stamp waits for the last MFMAs
 #endif
     S5_STAMP(3);
     float omax = 0.f;                   // max of what this thread contributes to y (post-ReLU: >= 0)
@@ -268,8 +279,8 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
             const int co = j * 32 + px;
             const float bv = bias[co];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int oy = oy0 + wave * 4 + i;
+            for (int i = 0; i < RPW; ++i) {
+                const int oy = oy0 + wave * RPW + i;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -284,11 +295,13 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
     } else {
         // epilogue with the max-pool, in registers.  A lane holds, per conv row, the columns c0 .. c0+3 of four groups (c0 = 8g + 4hi):
         // pooled column 4g+2hi+1 = max of columns c0+1 .. c0+3 is lane-local, pooled column 4g+2hi = max(c0-1, c0, c0+1) takes c0-1
-        // from the other lane half (one xor-32 shuffle per group); a wave holds conv rows 4w .. 4w+3: pooled row 2w+1 (rows 4w+1 .. 4w+3)
-        // is wave-local, pooled row 2w = max(4w-1, 4w, 4w+1) takes the column-pooled row 4w-1 from the previous wave through LDS.
+        // from the other lane half (one xor-32 shuffle per group); a wave holds conv rows 4w .. 4w+3 (RPW = 4): pooled row 2w+1 (rows 4w+1 .. 4w+3)
+        // is wave-local, pooled row 2w = max(4w-1, 4w, 4w+1) takes the column-pooled row 4w-1 from the previous wave through LDS.  RPW = 2: a wave
+        // holds conv rows 2w, 2w+1 and owns pooled row w = max(2w-1, 2w, 2w+1), row 2w-1 again from the previous wave.
         // Pooled row 0 / column 0 (window continues in the tile above / left) and row 8 / column 16 (only the first row / column of the
         // window is in this tile) are merged across workgroups with atomic max; invalid conv positions (outside the image) count as 0.
-        float* X = reinterpret_cast<float*>(smem);                     // [j][wave][9][64 lanes]: column-pooled conv row 4w+3
+        float* X = reinterpret_cast<float*>(smem);                     // [j][wave][9][64 lanes]: column-pooled last conv row of the wave
+        static_assert(2 * NW * 9 * 64 * 4 <= PATCH_BYTES, "the hand-over rows live in the patch region");
         const int Hp = (Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1;        // MaxPool2d(3, 2, 1) output size
         const int rows_ok = Ho - oy0, cols_ok = Wo - ox0;              // conv rows / cols of the tile inside the image
         const int py0 = oy0 >> 1, px0 = ox0 >> 1;
@@ -314,20 +327,20 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
         for (int j = 0; j < 2; ++j) {
             const float bv = bias[j * 32 + px];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RPW; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[i][j][r] * inv + bv;
-                    const bool ok = FULL || (wave * 4 + i < rows_ok && (r & 3) + 8 * (r >> 2) + 4 * hi < cols_ok);
+                    const bool ok = FULL || (wave * RPW + i < rows_ok && (r & 3) + 8 * (r >> 2) + 4 * hi < cols_ok);
                     acc[i][j][r] = (ok && v > 0.f) ? v : 0.f;            // ReLU; never -0 or NaN
                     omax = fmaxf(omax, acc[i][j][r]);                  // (every valid conv value lies in some pooling window: max y = max of these)
                 }
             float in3[16], p3[9];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) in3[r] = acc[3][j][r];
+            for (int r = 0; r < 16; ++r) in3[r] = acc[RPW - 1][j][r];
             S5_COLPOOL(in3, p3);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) X[((j * 4 + wave) * 9 + k) * 64 + lane] = p3[k];
+            for (int k = 0; k < 9; ++k) X[((j * NW + wave) * 9 + k) * 64 + lane] = p3[k];
         }
         __syncthreads();
         float* const yimg = y + (size_t)n * Hp * Wp * 64;              // wave-uniform
@@ -337,20 +350,22 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
             float in_o[16], in_e[16], po[9], pe[9];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                in_o[r] = fmaxf(fmaxf(acc[1][j][r], acc[2][j][r]), acc[3][j][r]);
+                if constexpr (RPW == 4) in_o[r] = fmaxf(fmaxf(acc[1][j][r], acc[2][j][r]), acc[RPW - 1][j][r]);
                 in_e[r] = fmaxf(acc[0][j][r], acc[1][j][r]);
             }
-            S5_COLPOOL(in_o, po);
+            if constexpr (RPW == 4) S5_COLPOOL(in_o, po);
             S5_COLPOOL(in_e, pe);
             if (wave > 0) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) pe[k] = fmaxf(pe[k], X[((j * 4 + wave - 1) * 9 + k) * 64 + lane]);
+                for (int k = 0; k < 9; ++k) pe[k] = fmaxf(pe[k], X[((j * NW + wave - 1) * 9 + k) * 64 + lane]);
             }
-            // rows: 0 = pooled row 2w (even), 1 = pooled row 2w+1 (odd), 2 = pooled row 8 (wave 3 only: its conv row 15 alone)
+            // rows: 0 = the pooled row that takes the previous wave's last conv row (RPW = 4: 2w, RPW = 2: w), 1 = pooled row 2w+1 (RPW = 4 only),
+            // 2 = pooled row 8 (the last wave only: its conv row 15 alone)
 #pragma unroll
             for (int rw = 0; rw < 3; ++rw) {
-                if (rw == 2 && wave != 3) continue;
-                const int pr = rw == 2 ? 8 : 2 * wave + rw;
+                if (rw == 1 && RPW != 4) continue;
+                if (rw == 2 && wave != NW - 1) continue;
+                const int pr = rw == 2 ? 8 : (RPW == 4 ? 2 * wave + rw : wave);
                 const int gy = py0 + pr;
                 if (gy >= Hp) continue;
                 const bool row_border = pr == 0 || pr == 8;
@@ -360,8 +375,8 @@ __global__ __launch_bounds__(256, 2) void stem_f16x2_kernel(const void* __restri
                     // pooled column of the lane: pc = 4 (k & 3) + (k >> 2) + 2 hi; k == 8: column 16 (lane half 1 only)
                     const int pcu = k == 8 ? 14 : (4 * (k & 3) + (k >> 2));                 // the wave-uniform part
                     float m;
-                    if (rw == 2) m = X[((j * 4 + 3) * 9 + k) * 64 + lane];      // own column-pooled row 15
-                    else m = rw ? po[k] : pe[k];
+                    if (rw == 2) m = X[((j * NW + NW - 1) * 9 + k) * 64 + lane];      // own column-pooled row 15
+                    else m = (RPW == 4 && rw) ? po[k] : pe[k];
                     if (k == 8 && !hi) continue;
                     if ((!FULL || k == 8) && px0 + pcu + 2 * hi >= Wp) continue;
                     float* dst = yrow + pcu * 64 + lane_off;
@@ -483,7 +498,7 @@ int cnl_stem5_launch(const void* x, bool u8, const float* mean255, const float* 
         if (rcz != CNL_OK) return rcz;
     }
 #define S5_LAUNCH(P_, U_, F_)                                                                                                      \
-    hipLaunchKernelGGL((stem_f16x2_kernel<P_, U_, F_>), dim3(blocks), dim3(256), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes, \
+    hipLaunchKernelGGL((stem_f16x2_kernel<P_, U_, F_>), dim3(blocks), dim3(NT), LDS_BYTES, (hipStream_t)stream, x, sn, sc, sh, sw, img_bytes, \
                        (const void*)extra, extra + W_BYTES / 4, bias, y, reinterpret_cast<unsigned*>(y_absmax), N, H, W, Ho, Wo, tiles_x, tiles_y, nrm)
     switch (which) {
         case 0: S5_LAUNCH(false, false, false); break;

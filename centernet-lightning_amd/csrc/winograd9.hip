@@ -512,6 +512,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the first item's prologue (afterwards the chunk stream itself fetches ahead): patches 0 / 1, weights and first V rows of chunk 0
     {   // all four half-patches are requested before the first is written (the fragment registers are still free: one memory latency, not four)
         u32x4 keep[3][NSTG];
+        W9_STAMP(2);
         pload_all<0>(st, st.cur, a, 0, up, HalfA{});
 #pragma unroll
         for (int i = 0; i < NSTG; ++i) keep[0][i] = st.stg[i];
@@ -537,11 +538,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < 5; ++i) st.stg[i] = last[i];
     }
+    W9_STAMP(3);
 #pragma unroll
     for (int i = 0; i < 4; ++i) load_b<0>(st, a, st.cur.u_voff, 0, i, u_plane, u_wave);
 #pragma unroll
     for (int i = 0; i < 4; ++i) load_b<1>(st, a, st.cur.u_voff, 0, i, u_plane, u_wave);
     W9_BARRIER();
+    W9_STAMP(4);
     rread<0>(st, 0, 0); rread<1>(st, 0, 0); rread<2>(st, 0, 0); rread<3>(st, 0, 0);
     job_all(st, 0, st.cur.S, std::make_integer_sequence<int, 28>{});
     rread<0>(st, 0, 1); rread<1>(st, 0, 1); rread<2>(st, 0, 1); rread<3>(st, 0, 1);

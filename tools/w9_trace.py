@@ -37,6 +37,8 @@ for it in range(6):
     nm = {1: "top", 5: "setup+zero", 6: "chunks", 7: "ep.pre", 8: "p0", 9: "p1", 10: "p2", 11: "p3", 12: "p4", 13: "p5", 14: "p6", 15: "p7+end"}
     print(f"item {it:2d} start {int(r[1]-t[0][0]):7d} total {int(r[15]-r[1]):7d}: " + " ".join(f"{nm[order[i]]}={int(r[order[i]] - r[order[i-1]])}" for i in range(1, len(order))))
 
+r = t[0]
+print("prologue (block 0, cycles from the kernel's first stamp): requests start %d, patches in LDS %d, after the barrier %d, first loop top %d" % tuple(int(r[i] - r[0]) for i in (2, 3, 4, 1)))
 for it in range(1, 5):
     r = t[it]
     if int(r[16]):
