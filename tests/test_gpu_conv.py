@@ -646,6 +646,8 @@ W9_CASES = [
     (3, 32, 5, 7, 4, 0, False),                         # Cout = 4: one cout quad of one block
     (1, 64, 9, 130, 72, CNL_RELU, False),               # three blocks across, the last two pixels wide
     (2, 32, 6, 10, 64, CNL_RELU | CNL_UPSAMPLE_IN, False),
+    (2, 128, 12, 36, 128, CNL_RELU | CNL_UPSAMPLE_IN, False),   # folded upsample with a long channel loop (eight chunks), three items down, two across, two cout blocks
+    (3, 64, 64, 64, 64, CNL_UPSAMPLE_IN, False),        # the first head block's shape in small: 64 channels behind the upsample, 96 work items
     (1, 512, 16, 16, 512, CNL_RELU, True),              # 32 chunks
     (5, 64, 24, 72, 64, CNL_RELU, False),               # several items per workgroup never happen at this size; several images do
 ]
