@@ -22,7 +22,7 @@ CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_LATENCY, CNL_ALGO_FORCE = 0, 
 CNL_WINO_F32, CNL_WINO_F16X2 = 2, 5
 
 CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4
-ABI_VERSION = 11         # CNL_ABI_VERSION of include/centernet_gfx950.h
+ABI_VERSION = 12         # CNL_ABI_VERSION of include/centernet_gfx950.h
 
 
 class ConvParams(Structure):
@@ -32,7 +32,7 @@ class ConvParams(Structure):
                 ("ldx", c_int32), ("ldy", c_int32), ("ldr", c_int32), ("flags", c_uint32),
                 ("x_absmax", c_void_p), ("y_absmax", c_void_p), ("w_absmax", c_void_p), ("algo", c_uint32),
                 ("splitk", c_int32), ("splitk_scratch", c_void_p), ("splitk_scratch_bytes", c_size_t),
-                ("fuse_w", c_void_p), ("fuse_part", c_void_p)]
+                ("fuse_w", c_void_p), ("fuse_part", c_void_p), ("w_up", c_void_p)]
 
 
 class DeconvParams(Structure):
@@ -62,6 +62,8 @@ _SIGNATURES = {
     "cnl_conv2d_out_hw": (ctypes.c_int, [POINTER(ConvParams), POINTER(c_int32), POINTER(c_int32)]),
     "cnl_conv3x3_winograd_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
     "cnl_conv3x3_winograd_kernel": (ctypes.c_int, [POINTER(ConvParams)]),
+    "cnl_winograd_up_weight_floats": (c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    "cnl_winograd_transform_weights_up_f32": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int32, ctypes.c_int32, c_void_p]),
     "cnl_conv3x3_winograd_variant": (ctypes.c_int, [POINTER(ConvParams)]),
     "cnl_conv2d_kernel": (ctypes.c_int, [POINTER(ConvParams)]),
     "cnl_up2_weight_floats": (c_size_t, [ctypes.c_int32, ctypes.c_int32]),

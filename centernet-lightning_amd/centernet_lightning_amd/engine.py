@@ -49,6 +49,10 @@ class KernelOptions:
                        takes csrc/winograd10.hip's 4-row x 64-pixel x 32-cout work items (cnl_conv_params.algo = CNL_ALGO_LATENCY) — four times the
                        work items of winograd9's, two workgroups per CU.  (The default already does this for winograd9's own layers when a launch has
                        at most 128 work items — same bits; the option adds the layers whose default is another kernel.)
+      up_rows          a 3x3 conv the row-Winograd kernel runs behind a folded nearest-2x upsample (the first head blocks and the stages of the simple neck)
+                       gets the layer's ROW-PAIR weights (cnl_conv_params.w_up, ABI v12): the upsampled rows 2j and 2j+1 are one source row, so an output row
+                       meets two distinct input rows instead of three — 96 instead of 144 matrix instructions per 16-channel chunk; within fp32 rounding of
+                       the general form (False), batch-invariant
       split_small      latency mode for small batches (default off): launches whose output is too small to fill the chip (one image: the
                        16x16 .. 64x64 maps) run as direct convs with the reduction split over several workgroups per output tile and a
                        fixed-order reduce (cnl_conv_params.splitk).  The choice then depends on the batch size, so results are no longer
@@ -63,6 +67,7 @@ class KernelOptions:
     reuse_buffers: bool = True
     split_small: bool = False
     latency: bool = False
+    up_rows: bool = True
 
     @property
     def algo_id(self):
@@ -146,6 +151,25 @@ def _layer_up2(self):
     return self._up2
 
 
+def _layer_up_rows(self):
+    """The layer's row-pair weight sets for cnl_conv_params.w_up (cnl_winograd_transform_weights_up_f32), built on first use; None where the form does not
+    apply (Cin % 32 != 0, CPU tensors)."""
+    if getattr(self, "_up_rows", None) is None:
+        lib = _lib.load()
+        n = lib.cnl_winograd_up_weight_floats(self.cin, self.cout) if (self.w.is_cuda and self.kh == 3 and self.kw == 3 and self.stride == 1) else 0
+        if not n:
+            self._up_rows = False
+        else:
+            with torch.cuda.device(self.w.device):
+                buf = torch.empty((n,), device=self.w.device, dtype=torch.float32)
+                stream = ctypes.c_void_p(torch.cuda.current_stream(self.w.device).cuda_stream)
+                _lib.check(lib.cnl_winograd_transform_weights_up_f32(self.w.data_ptr(), buf.data_ptr(), self.cin, self.cout, stream),
+                           "cnl_winograd_transform_weights_up_f32")
+            self._up_rows = buf
+    return self._up_rows if self._up_rows is not False else None
+
+
+_Layer.up_rows = _layer_up_rows
 _Layer.split_w = _layer_split_w
 _Layer.wants_up2 = _layer_wants_up2
 _Layer.up2 = _layer_up2
@@ -657,6 +681,10 @@ class Plan:
         # below (C1: 8.93 -> 8.82 ms per forward); whether a layer takes one is the dispatcher's decision — asked, not re-derived here
         rowwino = (fn is self.lib.cnl_conv3x3_winograd_f32 and self.algo != CNL_ALGO_F32
                    and self.lib.cnl_conv3x3_winograd_variant(ctypes.byref(p)) in (9, 10, 11))
+        if rowwino and self.options.up_rows and (flags & CNL_UPSAMPLE_IN) and residual is None:
+            wu = layer.up_rows()                        # the row-pair form of the row-Winograd kernel: two kernel rows per output row behind the upsample
+            if wu is not None:
+                p.w_up = wu.data_ptr()
         if (self.options.up2 and (flags & CNL_UPSAMPLE_IN) and not (flags & ~(CNL_RELU | CNL_UPSAMPLE_IN)) and residual is None
                 and layer.wants_up2() and not rowwino):
             # short channel loop, many couts, conv on the nearest-2x upsampled input (the fused first head blocks behind the simple

@@ -67,6 +67,8 @@ size_t cnl_wino9_weight_bytes(int Cin, int Cout);                               
 size_t cnl_wino9_scalar_floats(int Cin, int Cout);
 int cnl_wino9_transform_weights(const float* w_ohwi, void* u9, float* isu, int Cin, int Cout, void* stream);
 bool cnl_wino9_eligible(const cnl_conv_params* p);
+size_t cnl_wino9_up_weight_bytes(int Cin, int Cout);                               // the row-pair weight sets of a conv behind a folded upsample (cnl_conv_params.w_up)
+int cnl_wino9_up_transform_weights(const float* w_ohwi, void* u9, float* isu, int Cin, int Cout, void* stream);
 int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream);
 int cnl_wino_packed_stride(const cnl_conv_params* p);                               // packed rows of the row kernels (winograd9.hip)
 bool cnl_wino10_eligible(const cnl_conv_params* p);                                // winograd10.hip (reads winograd9.hip's weights)
@@ -126,6 +128,18 @@ extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u,
     if (rc != CNL_OK) return rc;
     if (rc != CNL_OK || Cin % 32) return rc;
     return cnl_wino9_transform_weights(w_ohwi, u + L.u9, u + L.s9, Cin, Cout, stream);
+}
+
+extern "C" size_t cnl_winograd_up_weight_floats(int32_t Cin, int32_t Cout) {
+    const size_t b = cnl_wino9_up_weight_bytes(Cin, Cout);
+    return b ? b / 4 + cnl_wino9_scalar_floats(Cin, Cout) : 0;
+}
+extern "C" int cnl_winograd_transform_weights_up_f32(const float* w_ohwi, float* u_up, int32_t Cin, int32_t Cout, void* stream) {
+    CNL_REQUIRE(w_ohwi && u_up, CNL_E_BAD_ARG, "cnl_winograd_transform_weights_up_f32: null pointer");
+    CNL_REQUIRE(((uintptr_t)u_up & 15) == 0, CNL_E_BAD_ARG, "cnl_winograd_transform_weights_up_f32: u_up must be 16-byte aligned");
+    const size_t b = cnl_wino9_up_weight_bytes(Cin, Cout);
+    CNL_REQUIRE(b, CNL_E_UNSUPPORTED, "cnl_winograd_transform_weights_up_f32: Cin %% 32 != 0");
+    return cnl_wino9_up_transform_weights(w_ohwi, u_up, u_up + b / 4, Cin, Cout, stream);
 }
 
 // half the CUs of the current device (MI355X: 128) — the small-grid threshold of the row kernels; a process without a device (the CPU tests of

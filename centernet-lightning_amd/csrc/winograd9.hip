@@ -44,7 +44,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct Args {
     const float* x;
-    const void* u9;                   // pre-split, pre-scaled weights (fp16 pieces)
+    const void* u9;                   // pre-split, pre-scaled weights (fp16 pieces); UR launches: the four row-pair sets (weights9_up_kernel)
     const float* xmax;                // max |x| per image of this launch's input
     const float* isu;                 // [CoutP] 1 / S_u[co]
     unsigned* ymax;                   // optional: max |y| per image of this launch's output (atomic max on the bits)
@@ -171,7 +171,7 @@ struct Item {               // per-work-item addressing state (two live: the ite
 };
 struct State {
     f32x16 acc[R][2];        // [output row][cout half]: D[cout][tile]
-    u32x4 fb[3][2][2];       // weight fragments (A operand): [ky][cout half][piece], single-buffered
+    u32x4 fb[4][2][2];       // weight fragments (A operand): [ky (UR: weight set)][cout half][piece], single-buffered (set 3: UR only)
     u32x4 vf[4][2];          // V fragments (B operand): [(10 chunk + row) % 4][piece]
     f32x4 raw[4];            // patch reads of a job: pixel a quad 0, a quad 1, pixel b quad 0, b quad 1 (consumed by operations 0..7, refilled for the next job right after)
     float v[8];              // transform temporaries of the running job (V, then its residual in place)
@@ -218,20 +218,23 @@ __device__ __forceinline__ void rread(State& st, const int pbuf, const int row) 
     st.raw[I] = lds_f4(p);
 }
 // weight fragment i (cout half i >> 1, piece i & 1) of kernel row KY of chunk cc: global -> registers
-template <int KY>
+template <int KY, int NSET = 3>        // NSET: kernel rows (3) or row-pair weight sets (UR: 4) per (chunk, position)
 __device__ __forceinline__ void load_b(State& st, const Args& a, const unsigned u_voff, const int cc, const int i, const unsigned u_plane, const unsigned u_wave) {
     const int nbh = i >> 1, piece = i & 1;
-    const unsigned so = (unsigned)cc * (24u * u_plane) + u_wave + (unsigned)(KY * 2 + piece) * u_plane + (unsigned)nbh * 1024u;
+    const unsigned so = (unsigned)cc * ((unsigned)(8 * NSET) * u_plane) + u_wave + (unsigned)(KY * 2 + piece) * u_plane + (unsigned)nbh * 1024u;
     st.fb[KY][nbh][piece] = buf_load16<W9_AUX_U>(a.u9, a.u_bytes, u_voff, so);
 }
 // The patch of a chunk travels global -> staging registers -> LDS in two halves that share the registers: half A = rows 0..4 + the
 // piece with the two last pixel columns of all rows (stg[5]), half B = rows 5..9.  Piece I of half HALF of chunk cc of item `it`:
 // always issued (a branch around the load makes hipcc's wait counts conservative: vmcnt(0) at the next weight-fragment use); a row
 // outside the image reads out of range -> zeros, the convolution's padding.
-template <int HALF, int I>
+// UR: only the six DISTINCT patch rows travel — 0, 1, 3 in half A and 5, 7, 9 in half B (rows 2 / 4 / 6 / 8 repeat the row in front of them and are never read)
+constexpr int ur_row(int HALF, int I) { return HALF == 0 ? (I == 0 ? 0 : 2 * I - 1) : 5 + 2 * I; }
+template <int HALF, int I, bool UR = false>
 __device__ __forceinline__ void pload(State& st, const Item& it, const Args& a, const int cc, const bool up) {
+    if constexpr (UR && (I == 3 || I == 4)) return;
     if constexpr (I < 5) {
-        const int iy = __builtin_amdgcn_readfirstlane(it.y0m1) + 5 * HALF + I;     // (uniform by construction; the copies cur = nxt hide it from the
+        const int iy = __builtin_amdgcn_readfirstlane(it.y0m1) + (UR ? ur_row(HALF, I) : 5 * HALF + I);     // (uniform by construction; the copies cur = nxt hide it from the
         const bool ok = (unsigned)iy < (unsigned)a.H;                               //  compiler, which then wraps every load in a waterfall loop)
         const int sy = ok ? (up ? (iy >> 1) : iy) : 0;
         const unsigned so = __builtin_amdgcn_readfirstlane(it.img_base + (unsigned)sy * st.row_pitch + (unsigned)cc * 64u);
@@ -242,18 +245,19 @@ __device__ __forceinline__ void pload(State& st, const Item& it, const Args& a, 
     }
 }
 // ... staging register -> patch buffer `pbuf`
-template <int HALF, int I>
+template <int HALF, int I, bool UR = false>
 __device__ __forceinline__ void pwrite(State& st, const int pbuf) {
-    if constexpr (I < 5) *reinterpret_cast<u32x4*>(st.wb + pbuf * P_BYTES + (5 * HALF + I) * ROW_BYTES) = st.stg[I];
+    if constexpr (UR && (I == 3 || I == 4)) return;
+    if constexpr (I < 5) *reinterpret_cast<u32x4*>(st.wb + pbuf * P_BYTES + (UR ? ur_row(HALF, I) : 5 * HALF + I) * ROW_BYTES) = st.stg[I];
     else *reinterpret_cast<u32x4*>(st.wext + pbuf * P_BYTES) = st.stg[5];                        // (threads >= 80: into the slack slots)
 }
-template <int HALF, int... I>
+template <int HALF, bool UR, int... I>
 __device__ __forceinline__ void pload_all(State& st, const Item& it, const Args& a, const int cc, const bool up, std::integer_sequence<int, I...>) {
-    (pload<HALF, I>(st, it, a, cc, up), ...);
+    (pload<HALF, I, UR>(st, it, a, cc, up), ...);
 }
-template <int HALF, int... I>
+template <int HALF, bool UR, int... I>
 __device__ __forceinline__ void pwrite_all(State& st, const int pbuf, std::integer_sequence<int, I...>) {
-    (pwrite<HALF, I>(st, pbuf), ...);
+    (pwrite<HALF, I, UR>(st, pbuf), ...);
 }
 
 // One slice: MFMA S of the chunk with parity PAR, and what is issued beside it.  The chunk stream runs on across work items:
@@ -261,19 +265,30 @@ __device__ __forceinline__ void pwrite_all(State& st, const int pbuf, std::integ
 // NEXT item), 2 = the item's last (requests chunk 1 of the next item, loads the weights and builds the first two V rows of its chunk 0).
 // is slice S the first MFMA of a chunk into its accumulator block (output row, cout half)?  An item's first chunk starts those from
 // C = 0 instead of the kernel zeroing all 256 accumulator registers per item (256 v_accvgpr_write = 1 K cycles with nothing beside them)
-constexpr bool first_use(int S) {
+// UR ("upsampled rows": the launch folds a nearest-2x upsample into its patch gather AND has the row-pair weights, cnl_conv_params.w_up): y0 and H are even, so
+// the patch rows (1,2) (3,4) (5,6) (7,8) of an item are the same source row twice, and the three kernel rows of an output row meet only TWO distinct input rows:
+//   output row 2m   = row 2m   x g[0]          + row 2m+1 x (g[1] + g[2])         (rows 2m+1, 2m+2 identical)
+//   output row 2m+1 = row 2m+1 x (g[0] + g[1]) + row 2m+3 x g[2]                  (rows 2m+1, 2m+2 identical)
+// With the four pre-summed weight sets {g0, g0+g1, g1+g2, g2} (weights9_up_kernel) 16 of a chunk's 24 segments remain — 96 matrix instructions instead of 144:
+// a segment (r, ky) of an ODD patch row r takes set ky + 1, the (r, 0) segment of an EVEN row takes set 0, its (r, 1) and (r, 2) segments are left out (their
+// slices keep everything that is issued beside the MFMA).  Another order of the same fp32 products and two pre-summed weights: results within rounding of the
+// general form, not bit-identical to it — a function of the shape and of w_up being given, never of the batch.
+constexpr bool seg_skipped(int seg, bool UR) { return UR && (SEG_ROW[seg] & 1) == 0 && SEG_KY[seg] != 0; }
+constexpr int seg_wset(int seg, bool UR) { return !UR ? SEG_KY[seg] : ((SEG_ROW[seg] & 1) ? SEG_KY[seg] + 1 : 0); }
+constexpr bool first_use(int S, bool UR = false) {
     const int yo = SEG_ROW[S / 6] - SEG_KY[S / 6], nbh = S & 1;
     for (int s = 0; s < S; ++s)
-        if (SEG_ROW[s / 6] - SEG_KY[s / 6] == yo && (s & 1) == nbh) return false;
+        if (!seg_skipped(s / 6, UR) && SEG_ROW[s / 6] - SEG_KY[s / 6] == yo && (s & 1) == nbh) return false;
     return true;
 }
-template <int S, int PAR, int MODE, bool FIRST, bool FUSE = false>
+constexpr int UR_SET0_DEAD = 96;      // UR: first slice after the last use of weight set 0 (segment (6, 0)); sets 1 / 2 die where ky = 0 / 1 do, set 3 with the chunk
+template <int S, int PAR, int MODE, bool FIRST, bool FUSE = false, bool UR = false>
 __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave) {
     constexpr int seg = S / 6;
     constexpr int r = SEG_ROW[seg], ky = SEG_KY[seg];
     constexpr int term = (S % 6) / 2, nbh = S & 1;
     constexpr int ku = term == 1 ? 1 : 0, kv = term == 0 ? 1 : 0;         // terms: hi lo', lo hi', hi hi'
-    constexpr int vbuf = (r + 2 * PAR) & 3;
+    constexpr int vbuf = ((UR && r >= 2 && (r & 1) == 0 ? r - 1 : r) + 2 * PAR) & 3;      // UR: an even patch row IS the row in front of it — its segment reads that row's fragment
 #ifdef W9_TRACE
     if constexpr (PAR == 0 && MODE == 0 && !FIRST && (S == W9_P0 || S == W9_P1 || S == W9_P2 || S == W9_P3 || S == W9_P4 || S == W9_P5 || S == W9_P6 || S == W9_P7)) {
         constexpr int k = S == W9_P0 ? 16 : S == W9_P1 ? 17 : S == W9_P2 ? 18 : S == W9_P3 ? 19 : S == W9_P4 ? 20 : S == W9_P5 ? 21 : S == W9_P6 ? 22 : 23;
@@ -286,10 +301,13 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
         __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef W9_SKIP4     // timing build (wrong results): every fourth MFMA is left out — what 25 % fewer matrix instructions buy under the chip's power limit
-    if constexpr ((S & 3) != 3 || (FIRST && first_use(S))) {
+    if constexpr ((S & 3) != 3 || (FIRST && first_use(S, UR))) {
 #endif
-    if constexpr (FIRST && first_use(S)) st.acc[r - ky][nbh] = mfma16(st.fb[ky][nbh][ku], st.vf[vbuf][kv], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-    else st.acc[r - ky][nbh] = mfma16(st.fb[ky][nbh][ku], st.vf[vbuf][kv], st.acc[r - ky][nbh]);
+    constexpr int wset = seg_wset(seg, UR);
+    if constexpr (!seg_skipped(seg, UR)) {
+        if constexpr (FIRST && first_use(S, UR)) st.acc[r - ky][nbh] = mfma16(st.fb[wset][nbh][ku], st.vf[vbuf][kv], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+        else st.acc[r - ky][nbh] = mfma16(st.fb[wset][nbh][ku], st.vf[vbuf][kv], st.acc[r - ky][nbh]);
+    }
 #ifdef W9_SKIP4
     }
 #endif
@@ -300,35 +318,51 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
     if constexpr (S >= JOB0 && S < JOB0 + 10 * JOB_SLICES) {
         constexpr int j = (S - JOB0) / JOB_SLICES, k = (S - JOB0) % JOB_SLICES;
         constexpr int buf = j < 8 ? ((j + 2 + 2 * PAR) & 3) : ((j - 8 + 2 * (PAR ^ 1)) & 3);
-        const float Sj = (MODE == 2 && j >= 8) ? st.nxt.S : st.cur.S;
-        vop<2 * k>(st, buf, Sj);
-        vop<2 * k + 1>(st, buf, Sj);
+        constexpr int prow = j < 8 ? j + 2 : j - 8;                                  // the patch row this job's fragment belongs to
+        constexpr bool idle = UR && prow >= 2 && (prow & 1) == 0;                    // UR: rows 2, 4, 6, 8 have no fragment of their own (and no patch row in LDS)
+        if constexpr (!idle) {
+            const float Sj = (MODE == 2 && j >= 8) ? st.nxt.S : st.cur.S;
+            vop<2 * k>(st, buf, Sj);
+            vop<2 * k + 1>(st, buf, Sj);
+        }
         // raw reads of the next job (j + 1): rows 3..9 of this patch, then rows 0, 1, 2 of the next
         if constexpr (k >= 4 && k <= 7) {
             constexpr int jn = j + 1;
             constexpr int nrow = jn < 8 ? jn + 2 : jn - 8;
             constexpr int npb = jn < 8 ? PAR : (PAR ^ 1);
-            rread<k - 4>(st, npb, nrow);
+            constexpr bool nidle = UR && nrow >= 2 && (nrow & 1) == 0;
+            if constexpr (!nidle) rread<k - 4>(st, npb, nrow);
         }
     }
     // ---- weight fragments: kernel row 2 of THIS chunk (first used at slice 30), rows 0 / 1 of the next once this chunk is done with them ----
-    if constexpr (S < 4) load_b<2>(st, a, st.cur.u_voff, cn, S, u_plane, u_wave);
-    if constexpr (S >= KY0_DEAD && S < KY0_DEAD + 8 && (S - KY0_DEAD) % 2 == 0)
-        load_b<0>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - KY0_DEAD) / 2, u_plane, u_wave);
-    if constexpr (S >= KY1_DEAD && S < KY1_DEAD + 8 && (S - KY1_DEAD) % 2 == 0)
-        load_b<1>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - KY1_DEAD) / 2, u_plane, u_wave);
+    if constexpr (!UR) {
+        if constexpr (S < 4) load_b<2>(st, a, st.cur.u_voff, cn, S, u_plane, u_wave);
+        if constexpr (S >= KY0_DEAD && S < KY0_DEAD + 8 && (S - KY0_DEAD) % 2 == 0)
+            load_b<0>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - KY0_DEAD) / 2, u_plane, u_wave);
+        if constexpr (S >= KY1_DEAD && S < KY1_DEAD + 8 && (S - KY1_DEAD) % 2 == 0)
+            load_b<1>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - KY1_DEAD) / 2, u_plane, u_wave);
+    } else {
+        // UR: set 3 (g2: first used by segment (3, 2), slice 48) of THIS chunk; sets 0 / 1 / 2 of the next once this chunk is done with them
+        if constexpr (S < 4) load_b<3, 4>(st, a, st.cur.u_voff, cn, S, u_plane, u_wave);
+        if constexpr (S >= UR_SET0_DEAD && S < UR_SET0_DEAD + 8 && (S - UR_SET0_DEAD) % 2 == 0)
+            load_b<0, 4>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - UR_SET0_DEAD) / 2, u_plane, u_wave);
+        if constexpr (S >= KY0_DEAD && S < KY0_DEAD + 8 && (S - KY0_DEAD) % 2 == 0)
+            load_b<1, 4>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - KY0_DEAD) / 2, u_plane, u_wave);
+        if constexpr (S >= KY1_DEAD && S < KY1_DEAD + 8 && (S - KY1_DEAD) % 2 == 0)
+            load_b<2, 4>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - KY1_DEAD) / 2, u_plane, u_wave);
+    }
     // ---- patch of the chunk after next (of the next item in MODE 1 / 2), in two halves through the same staging registers:
     //   slices 28..36   half B of the NEXT chunk's patch (requested a chunk ago) -> the other buffer, rows 5..9 (first read a chunk from now)
     //   slices 38..58   request half A        99..109  half A -> this chunk's buffer (dead after the barrier)        111..127  request half B
-    if constexpr (S >= 28 && S <= 36 && (S - 28) % 2 == 0) pwrite<1, (S - 28) / 2>(st, PAR ^ 1);
+    if constexpr (S >= 28 && S <= 36 && (S - 28) % 2 == 0) pwrite<1, (S - 28) / 2, UR>(st, PAR ^ 1);
     if constexpr (S >= 38 && S <= 58 && (S - 38) % 4 == 0) {
-        if constexpr (MODE == 0) pload<0, (S - 38) / 4>(st, st.cur, a, cn + 2, up);
-        else pload<0, (S - 38) / 4>(st, st.nxt, a, MODE - 1, up);
+        if constexpr (MODE == 0) pload<0, (S - 38) / 4, UR>(st, st.cur, a, cn + 2, up);
+        else pload<0, (S - 38) / 4, UR>(st, st.nxt, a, MODE - 1, up);
     }
-    if constexpr (S >= 99 && S <= 109 && (S - 99) % 2 == 0) pwrite<0, (S - 99) / 2>(st, PAR);
+    if constexpr (S >= 99 && S <= 109 && (S - 99) % 2 == 0) pwrite<0, (S - 99) / 2, UR>(st, PAR);
     if constexpr (S >= 111 && S <= 127 && (S - 111) % 4 == 0) {
-        if constexpr (MODE == 0) pload<1, (S - 111) / 4>(st, st.cur, a, cn + 2, up);
-        else pload<1, (S - 111) / 4>(st, st.nxt, a, MODE - 1, up);
+        if constexpr (MODE == 0) pload<1, (S - 111) / 4, UR>(st, st.cur, a, cn + 2, up);
+        else pload<1, (S - 111) / 4, UR>(st, st.nxt, a, MODE - 1, up);
     }
     // ---- the item's bias / weight-scale values (requested at the top of the item) -> LDS for the epilogue; every wave writes the same 64
     //      values (no branch inside the chunk); two chunk barriers lie between this and the first read ----
@@ -341,15 +375,15 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int PAR, int MODE, bool FIRST, bool FUSE, int... S>
+template <int PAR, int MODE, bool FIRST, bool FUSE, bool UR, int... S>
 __device__ __forceinline__ void chunk_impl(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave,
                                            std::integer_sequence<int, S...>) {
     __builtin_amdgcn_sched_barrier(0);
-    (slice<S, PAR, MODE, FIRST, FUSE>(st, a, cn, up, u_plane, u_wave), ...);
+    (slice<S, PAR, MODE, FIRST, FUSE, UR>(st, a, cn, up, u_plane, u_wave), ...);
 }
-template <int PAR, int MODE, bool FIRST = false, bool FUSE = false>        // FIRST: the first chunk of an item (its accumulators start from zero)
+template <int PAR, int MODE, bool FIRST = false, bool FUSE = false, bool UR = false>        // FIRST: the first chunk of an item (its accumulators start from zero)
 __device__ __forceinline__ void chunk(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave) {
-    chunk_impl<PAR, MODE, FIRST, FUSE>(st, a, cn, up, u_plane, u_wave, std::make_integer_sequence<int, NSLICE>{});
+    chunk_impl<PAR, MODE, FIRST, FUSE, UR>(st, a, cn, up, u_plane, u_wave, std::make_integer_sequence<int, NSLICE>{});
 }
 template <int... O>
 __device__ __forceinline__ void job_all(State& st, const int buf, const float S, std::integer_sequence<int, O...>) {
@@ -359,7 +393,8 @@ __device__ __forceinline__ void job_all(State& st, const int buf, const float S,
 // RES: the launch adds a residual; FUSE: a following 1x1 conv of <= 4 channels is folded into the epilogue; PK: packed rows (cnl_wino_packed_stride).
 // Template parameters, not run-time branches: the plain instantiations are the code of round 4 (the packed-row index arithmetic as uniform
 // branches cost the unpacked launches of C1 1.5-2.3 us each: more scalar registers live across the chunk loop — profiles/r05_experiments.txt r5c)
-template <bool RES, bool FUSE = false, bool PK = false>
+// UR: folded nearest-2x upsample with the row-pair weight sets (see seg_skipped()): 96 matrix instructions per chunk.
+template <bool RES, bool FUSE = false, bool PK = false, bool UR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void winograd9_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem + 2 * P_BYTES;      // exchange region of the epilogue: two halves of 32 KB
@@ -368,9 +403,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = transform position p owned by this wave
     const int h = lane >> 5, t = lane & 31;
-    const bool up = a.flags & CNL_UPSAMPLE_IN;
+    const bool up = UR || (a.flags & CNL_UPSAMPLE_IN);
     const unsigned u_plane = (unsigned)(a.CoutP * 32);               // bytes per (chunk, position, ky, piece) plane of U
-    const unsigned u_wave = (unsigned)wave * 6u * u_plane;
+    const unsigned u_wave = (unsigned)wave * (UR ? 8u : 6u) * u_plane;
     typedef std::make_integer_sequence<int, 6> HalfA;      // rows 0..4 + the column piece
     typedef std::make_integer_sequence<int, 5> HalfB;      // rows 5..9
 
@@ -513,43 +548,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {   // all four half-patches are requested before the first is written (the fragment registers are still free: one memory latency, not four)
         u32x4 keep[3][NSTG];
         W9_STAMP(2);
-        pload_all<0>(st, st.cur, a, 0, up, HalfA{});
+        pload_all<0, UR>(st, st.cur, a, 0, up, HalfA{});
 #pragma unroll
         for (int i = 0; i < NSTG; ++i) keep[0][i] = st.stg[i];
-        pload_all<1>(st, st.cur, a, 0, up, HalfB{});
+        pload_all<1, UR>(st, st.cur, a, 0, up, HalfB{});
 #pragma unroll
         for (int i = 0; i < 5; ++i) keep[1][i] = st.stg[i];
-        pload_all<0>(st, st.cur, a, 1, up, HalfA{});
+        pload_all<0, UR>(st, st.cur, a, 1, up, HalfA{});
 #pragma unroll
         for (int i = 0; i < NSTG; ++i) keep[2][i] = st.stg[i];
-        pload_all<1>(st, st.cur, a, 1, up, HalfB{});       // (half B of patch 1 stays in the staging registers: chunk 0 writes it at slice 28)
+        pload_all<1, UR>(st, st.cur, a, 1, up, HalfB{});       // (half B of patch 1 stays in the staging registers: chunk 0 writes it at slice 28)
         u32x4 last[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) last[i] = st.stg[i];
 #pragma unroll
         for (int i = 0; i < NSTG; ++i) st.stg[i] = keep[0][i];
-        pwrite_all<0>(st, 0, HalfA{});
+        pwrite_all<0, UR>(st, 0, HalfA{});
 #pragma unroll
         for (int i = 0; i < 5; ++i) st.stg[i] = keep[1][i];
-        pwrite_all<1>(st, 0, HalfB{});
+        pwrite_all<1, UR>(st, 0, HalfB{});
 #pragma unroll
         for (int i = 0; i < NSTG; ++i) st.stg[i] = keep[2][i];
-        pwrite_all<0>(st, 1, HalfA{});
+        pwrite_all<0, UR>(st, 1, HalfA{});
 #pragma unroll
         for (int i = 0; i < 5; ++i) st.stg[i] = last[i];
     }
     W9_STAMP(3);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) load_b<0>(st, a, st.cur.u_voff, 0, i, u_plane, u_wave);
+    for (int i = 0; i < 4; ++i) load_b<0, UR ? 4 : 3>(st, a, st.cur.u_voff, 0, i, u_plane, u_wave);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) load_b<1>(st, a, st.cur.u_voff, 0, i, u_plane, u_wave);
+    for (int i = 0; i < 4; ++i) load_b<1, UR ? 4 : 3>(st, a, st.cur.u_voff, 0, i, u_plane, u_wave);
+    if constexpr (UR) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_b<2, 4>(st, a, st.cur.u_voff, 0, i, u_plane, u_wave);
+    }
     W9_BARRIER();
     W9_STAMP(4);
     rread<0>(st, 0, 0); rread<1>(st, 0, 0); rread<2>(st, 0, 0); rread<3>(st, 0, 0);
     job_all(st, 0, st.cur.S, std::make_integer_sequence<int, 28>{});
     rread<0>(st, 0, 1); rread<1>(st, 0, 1); rread<2>(st, 0, 1); rread<3>(st, 0, 1);
     job_all(st, 1, st.cur.S, std::make_integer_sequence<int, 28>{});
-    rread<0>(st, 0, 2); rread<1>(st, 0, 2); rread<2>(st, 0, 2); rread<3>(st, 0, 2);
+    if constexpr (!UR) { rread<0>(st, 0, 2); rread<1>(st, 0, 2); rread<2>(st, 0, 2); rread<3>(st, 0, 2); }      // (UR: row 2 has no job; job 1's reads go out inside the chunk)
     while (true) {
         W9_STAMP(1);
 #ifdef W9_TRACE
@@ -576,23 +615,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // the item's first chunk starts the accumulators from zero (first_use); CC = 2: that chunk is also the last but one
         int es_nxt;
         if (a.CC > 2) {
-            chunk<0, 0, true, FUSE>(st, a, 0, up, u_plane, u_wave);
-            chunk<1, 0>(st, a, 1, up, u_plane, u_wave);
+            chunk<0, 0, true, FUSE, UR>(st, a, 0, up, u_plane, u_wave);
+            chunk<1, 0, false, false, UR>(st, a, 1, up, u_plane, u_wave);
             for (int cn = 2; cn < a.CC - 2; cn += 2) {
-                chunk<0, 0>(st, a, cn, up, u_plane, u_wave);
-                chunk<1, 0>(st, a, cn + 1, up, u_plane, u_wave);
+                chunk<0, 0, false, false, UR>(st, a, cn, up, u_plane, u_wave);
+                chunk<1, 0, false, false, UR>(st, a, cn + 1, up, u_plane, u_wave);
             }
             // (the next item's maximum is first used HERE, behind the chunks: used at the top of the item it waits for its load, and with it
             //  for the previous item's stores)
             W9_SCALE_EXP(es_nxt, xmax_next);
             st.nxt.S = __builtin_ldexpf(1.f, es_nxt);
-            chunk<0, 1>(st, a, a.CC - 2, up, u_plane, u_wave);
+            chunk<0, 1, false, false, UR>(st, a, a.CC - 2, up, u_plane, u_wave);
         } else {
             W9_SCALE_EXP(es_nxt, xmax_next);
             st.nxt.S = __builtin_ldexpf(1.f, es_nxt);
-            chunk<0, 1, true, FUSE>(st, a, 0, up, u_plane, u_wave);
+            chunk<0, 1, true, FUSE, UR>(st, a, 0, up, u_plane, u_wave);
         }
-        chunk<1, 2>(st, a, a.CC - 1, up, u_plane, u_wave);
+        chunk<1, 2, false, false, UR>(st, a, a.CC - 1, up, u_plane, u_wave);
         W9_STAMP(6);
 
         // ---- epilogue: out0 = Y0 + Y1 + Y2, out1 = Y1 - Y2 - Y3; the four positions (waves) meet through LDS.  Pass j = output row j:
@@ -862,7 +901,78 @@ __global__ __launch_bounds__(256) void weights9_kernel(const float* __restrict__
     }
 }
 
+// The row-pair weight sets of a conv consumed behind a nearest-2x upsample (UR): per (co, ci) the kernel rows g[0], g[0] + g[1], g[1] + g[2], g[2] (pre-summed in fp32),
+// each transformed along x like weights9_kernel's, one power-of-two scale per output channel over all four sets:
+// [ci/16][p][set][piece][CoutP][16 ci] fp16, isu[co] = 1 / S_u[co].  One workgroup per output channel.
+__global__ __launch_bounds__(256) void weights9_up_kernel(const float* __restrict__ w, unsigned short* __restrict__ u9, float* __restrict__ isu,
+                                                          int Cin, int Cout, int CoutP) {
+    const int co = blockIdx.x;
+    __shared__ float wm[4];
+    float m = 0.f;
+    const auto rows = [&](int ci, float (&c)[4][3]) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float g0 = w[((long)co * 9 + 0 * 3 + kx) * Cin + ci], g1 = w[((long)co * 9 + 1 * 3 + kx) * Cin + ci], g2 = w[((long)co * 9 + 2 * 3 + kx) * Cin + ci];
+            c[0][kx] = g0; c[1][kx] = g0 + g1; c[2][kx] = g1 + g2; c[3][kx] = g2;
+        }
+    };
+    if (co < Cout)
+        for (int ci = threadIdx.x; ci < Cin; ci += 256) {
+            float c[4][3];
+            rows(ci, c);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float u1 = 0.5f * (c[s][0] + c[s][1] + c[s][2]), u2 = 0.5f * (c[s][0] - c[s][1] + c[s][2]);
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(c[s][0]), fabsf(c[s][2])), fmaxf(fabsf(u1), fabsf(u2))));
+            }
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    float Su = 1.f;
+    if (m > 0.f && m < __builtin_inff()) {
+        int e_;
+        (void)__builtin_frexpf(m, &e_);
+        e_ = 13 - e_;
+        Su = __builtin_ldexpf(1.f, e_ < -100 ? -100 : (e_ > 100 ? 100 : e_));
+    }
+    if (threadIdx.x == 0) isu[co] = 1.f / Su;
+    for (int ci = threadIdx.x; ci < Cin; ci += 256) {
+        const int cc = ci >> 4, c16 = ci & 15;
+        float c[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        if (co < Cout) rows(ci, c);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float uu[4] = {-c[s][0], 0.5f * (c[s][0] + c[s][1] + c[s][2]), 0.5f * (c[s][0] - c[s][1] + c[s][2]), c[s][2]};      // position 0 negated (as weights9_kernel)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float xs = uu[p] * Su;
+                const _Float16 hf = (_Float16)xs;
+                const _Float16 lf = (_Float16)(xs - (float)hf);
+                const long base = (((((long)cc * 4 + p) * 4 + s) * 2) * CoutP + co) * 16 + c16;
+                u9[base] = __builtin_bit_cast(unsigned short, hf);
+                u9[base + (long)CoutP * 16] = __builtin_bit_cast(unsigned short, lf);
+            }
+        }
+    }
+}
+
 }  // namespace cnl_wino9
+
+// the row-pair weight sets (UR launches): bytes of the pieces, floats of the per-cout scales behind them (cnl_winograd_up_weight_floats = both)
+size_t cnl_wino9_up_weight_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0 || Cin % 32) return 0;
+    const size_t CoutP = (size_t)((Cout + 63) / 64) * 64;
+    return (size_t)(Cin / 16) * 4 * 4 * 2 * CoutP * 32;
+}
+int cnl_wino9_up_transform_weights(const float* w_ohwi, void* u9, float* isu, int Cin, int Cout, void* stream) {
+    using namespace cnl_wino9;
+    const int CoutP = (Cout + 63) / 64 * 64;
+    hipLaunchKernelGGL(weights9_up_kernel, dim3((unsigned)CoutP), dim3(256), 0, (hipStream_t)stream, w_ohwi, (unsigned short*)u9, isu, Cin, Cout, CoutP);
+    return cnl::check_launch("weights9_up_kernel");
+}
 
 // bytes of this kernel's fp16-split weights (0 when it does not apply) and floats of the per-cout scales behind them
 size_t cnl_wino9_weight_bytes(int Cin, int Cout) {
@@ -940,6 +1050,10 @@ void cnl_wino_sub_batch(const cnl_conv_params* p, int n0, int n, cnl_conv_params
 }
 
 static int wino9_launch_one(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream);
+// can this launch take the row-pair form (UR)?  A folded upsample, the row-pair weights given, nothing the UR instantiations lack (residual, folded 1x1)
+bool cnl_wino9_up_rows(const cnl_conv_params* p) {
+    return (p->flags & CNL_UPSAMPLE_IN) && p->w_up && !p->residual && !p->fuse_w && ((uintptr_t)p->w_up & 15) == 0;
+}
 // Launch (arguments already validated by cnl_conv3x3_winograd_f32); xmax = N per-image maxima of the input.
 int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream) {
     const int per = cnl_wino_images_per_launch(p);
@@ -958,6 +1072,11 @@ int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu,
 static int wino9_launch_one(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream) {
     using namespace cnl_wino9;
     Args a;
+    const bool ur = cnl_wino9_up_rows(p);
+    if (ur) {               // the row-pair sets and their scales instead of the layer's three kernel rows
+        u9 = p->w_up;
+        isu = p->w_up + cnl_wino9_up_weight_bytes(p->Cin, p->Cout) / 4;
+    }
     a.x = p->x; a.u9 = u9; a.xmax = xmax; a.isu = isu; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
     a.bias = p->bias; a.res = p->residual; a.y = p->y;
     const int upf = (p->flags & CNL_UPSAMPLE_IN) ? 2 : 1;
@@ -980,7 +1099,7 @@ static int wino9_launch_one(const cnl_conv_params* p, const void* u9, const floa
     CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: grid too large");
     a.blocks = (int)blocks;
     const unsigned long long xb = (((unsigned long long)p->N * p->H_in * p->W_in - 1) * p->ldx + p->Cin) * 4ull;
-    const unsigned long long ub = (unsigned long long)cnl_wino9_weight_bytes(p->Cin, p->Cout);
+    const unsigned long long ub = (unsigned long long)(ur ? cnl_wino9_up_weight_bytes(p->Cin, p->Cout) : cnl_wino9_weight_bytes(p->Cin, p->Cout));
     const unsigned long long Mo = (unsigned long long)p->N * a.H * a.W;
     const unsigned long long yb = ((Mo - 1) * p->ldy + p->Cout) * 4ull;
     const unsigned long long rb = p->residual ? ((Mo - 1) * p->ldr + p->Cout) * 4ull : 0ull;
@@ -998,12 +1117,13 @@ static int wino9_launch_one(const cnl_conv_params* p, const void* u9, const floa
     a.trace = g_w9_trace;
 #endif
     CNL_REQUIRE(!(a.fpart && p->residual), CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: fuse_w with a residual");
-    // the six instantiations: (plain | residual | folded 1x1) x (plain grid | packed rows)
-    static cnl::DeviceOnce once[6];
-    const void* const fns[6] = {reinterpret_cast<const void*>(&winograd9_kernel<false, false, false>), reinterpret_cast<const void*>(&winograd9_kernel<true, false, false>),
+    // the eight instantiations: (plain | residual | folded 1x1) x (plain grid | packed rows) + the row-pair form behind a folded upsample x (plain grid | packed rows)
+    static cnl::DeviceOnce once[8];
+    const void* const fns[8] = {reinterpret_cast<const void*>(&winograd9_kernel<false, false, false>), reinterpret_cast<const void*>(&winograd9_kernel<true, false, false>),
                                 reinterpret_cast<const void*>(&winograd9_kernel<false, true, false>), reinterpret_cast<const void*>(&winograd9_kernel<false, false, true>),
-                                reinterpret_cast<const void*>(&winograd9_kernel<true, false, true>), reinterpret_cast<const void*>(&winograd9_kernel<false, true, true>)};
-    const int which = (a.fpart ? 2 : (p->residual ? 1 : 0)) + (a.pk ? 3 : 0);
+                                reinterpret_cast<const void*>(&winograd9_kernel<true, false, true>), reinterpret_cast<const void*>(&winograd9_kernel<false, true, true>),
+                                reinterpret_cast<const void*>(&winograd9_kernel<false, false, false, true>), reinterpret_cast<const void*>(&winograd9_kernel<false, false, true, true>)};
+    const int which = ur ? (a.pk ? 7 : 6) : (a.fpart ? 2 : (p->residual ? 1 : 0)) + (a.pk ? 3 : 0);
     int n_cu = 0;                          // persistent workgroups: one per CU, walking the work items with stride gridDim.x
     int rc = cnl::kernel_setup(once[which], fns[which], LDS_BYTES, &n_cu);
     if (rc != CNL_OK) return rc;
@@ -1017,7 +1137,9 @@ static int wino9_launch_one(const cnl_conv_params* p, const void* u9, const floa
     case 2: hipLaunchKernelGGL((winograd9_kernel<false, true, false>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
     case 3: hipLaunchKernelGGL((winograd9_kernel<false, false, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
     case 4: hipLaunchKernelGGL((winograd9_kernel<true, false, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
-    default: hipLaunchKernelGGL((winograd9_kernel<false, true, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    case 5: hipLaunchKernelGGL((winograd9_kernel<false, true, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    case 6: hipLaunchKernelGGL((winograd9_kernel<false, false, false, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL((winograd9_kernel<false, false, true, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
     }
     return cnl::check_launch("winograd9_kernel");
 }

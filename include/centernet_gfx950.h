@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 11   /* 11: cnl_conv_params.fuse_w / fuse_part + cnl_fused_out_pack_weights_f32 / cnl_fused_out_reduce_f32 (a 1x1 conv of <= 4 channels folded into the 3x3 launch before it); the row-Winograd kernels take maps of any even width in packed rows and tensors of >= 4 GiB in groups of images; CNL_ALGO_FORCE + 32 + v; 10: per-image maxima arrays are strided (cnl_absmax_stride() = 32 floats: one cache line per image); the stem entry points take y_absmax; CNL_ALGO_LATENCY and the half-height row-Winograd kernel (csrc/winograd10.hip, variants 10 / 11); the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 12   /* 12: cnl_conv_params.w_up + cnl_winograd_up_weight_floats / cnl_winograd_transform_weights_up_f32 (a 3x3 conv behind a folded nearest-2x upsample: pre-summed row-pair weights, two instead of three kernel rows per output row); 11: cnl_conv_params.fuse_w / fuse_part + cnl_fused_out_pack_weights_f32 / cnl_fused_out_reduce_f32 (a 1x1 conv of <= 4 channels folded into the 3x3 launch before it); the row-Winograd kernels take maps of any even width in packed rows and tensors of >= 4 GiB in groups of images; CNL_ALGO_FORCE + 32 + v; 10: per-image maxima arrays are strided (cnl_absmax_stride() = 32 floats: one cache line per image); the stem entry points take y_absmax; CNL_ALGO_LATENCY and the half-height row-Winograd kernel (csrc/winograd10.hip, variants 10 / 11); the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -137,6 +137,14 @@ typedef struct cnl_conv_params {
      * launch there whatever its size); a launch that cannot take one of them fails with CNL_E_UNSUPPORTED.  Deterministic, batch-invariant. */
     const float* fuse_w;
     float* fuse_part;
+    /* cnl_conv3x3_winograd_f32 with CNL_UPSAMPLE_IN only, optional (NULL = off; ABI v12): the ROW-PAIR weights of this layer
+     * (cnl_winograd_transform_weights_up_f32).  Behind a nearest-2x upsample (make_upsample + ConvBnAct: reference models/layers.py:99,72-77 — the first
+     * block of every head behind the simple neck, models/meta.py:24-26) the image rows 2j and 2j+1 are the same source row, so the three kernel rows of an
+     * output row meet two distinct input rows: out[2m] = row[2m-1] g0 + row[2m] (g1 + g2), out[2m+1] = row[2m] (g0 + g1) + row[2m+2] g2.  With the four
+     * pre-summed sets the row-Winograd kernel (variant 9) issues 96 instead of 144 matrix instructions per 16-channel chunk.  Results: within fp32
+     * rounding of the launch without w_up (another grouping of the same products), deterministic, batch-invariant — a function of the shape and of w_up
+     * being given.  Ignored (the general form runs) with a residual, with fuse_w, and by every other kernel.                                        */
+    const float* w_up;
 } cnl_conv_params;
 
 /* The 1x1 conv folded into a 3x3 launch (cnl_conv_params.fuse_w / fuse_part): w_ohwi [C2][Cout] (C2 <= 4) -> fuse_w [ceil(Cout/64)*64][4];
@@ -146,6 +154,10 @@ int cnl_fused_out_pack_weights_f32(const float* w_ohwi, float* fuse_w, int32_t C
 int cnl_fused_out_reduce_f32(const float* part, int32_t nblocks, int64_t M, int32_t C2, const float* bias, float* y, int32_t ldy,
                              uint32_t flags, void* stream);
 int cnl_conv2d_nhwc_f32(const cnl_conv_params* p, void* stream);
+/* The row-pair weights of cnl_conv_params.w_up: w_ohwi [Cout][3][3][Cin] (BatchNorm folded) -> u_up, cnl_winograd_up_weight_floats(Cin, Cout) floats
+ * (0: Cin % 32 != 0, no such form): [Cin/16][4 positions][4 sets g0, g0+g1, g1+g2, g2][2 fp16 pieces][ceil(Cout/64)*64][16] + one inverse scale per cout. */
+size_t cnl_winograd_up_weight_floats(int32_t Cin, int32_t Cout);
+int cnl_winograd_transform_weights_up_f32(const float* w_ohwi, float* u_up, int32_t Cin, int32_t Cout, void* stream);
 size_t cnl_conv2d_splitk_scratch_bytes(const cnl_conv_params* p);   /* for p->splitk slices; 0 when splitk <= 1 */
 
 /* Which kernel cnl_conv2d_nhwc_f32 takes for *p (a function of the hints, kernel size and flags only — never of the batch). */

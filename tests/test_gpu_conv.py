@@ -439,8 +439,9 @@ def test_maxpool_matches_cpu_bit_exact(shape):
 
 
 # ----------------------------------------------------------------------------- Winograd F(2x2,3x3) path
-def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None, algo=CNL_ALGO_AUTO, lib=None, want=None, ymax=False):
-    """`want`: assert that the dispatcher reports this kernel class (2 fp32 / 5 fp16-split)."""
+def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None, algo=CNL_ALGO_AUTO, lib=None, want=None, ymax=False, up_rows=False):
+    """`want`: assert that the dispatcher reports this kernel class (2 fp32 / 5 fp16-split).  up_rows: hand over the layer's row-pair weights
+    (cnl_conv_params.w_up: the row-Winograd kernel's form behind a folded upsample)."""
     lib = lib or _lib.load()
     N, Cin, Hs, Ws = x_nchw.shape
     upf = 2 if flags & CNL_UPSAMPLE_IN else 1
@@ -465,6 +466,11 @@ def run_winograd(x_nchw, w_oihw, bias, flags=0, residual=None, algo=CNL_ALGO_AUT
         xm = _lib.absmax_pack(x_nchw.abs().amax(dim=(1, 2, 3)).cuda())
         ym = _lib.absmax_buffer(N)
         p.x_absmax, p.y_absmax = xm.data_ptr(), ym.data_ptr()
+    if up_rows:
+        wu = torch.full((lib.cnl_winograd_up_weight_floats(Cin, Cout),), float("nan"), device="cuda")
+        assert wu.numel() > 0
+        _lib.check(lib.cnl_winograd_transform_weights_up_f32(wd.data_ptr(), wu.data_ptr(), Cin, Cout, _stream()))
+        p.w_up = wu.data_ptr()
     if want is not None:
         assert lib.cnl_conv3x3_winograd_kernel(ctypes.byref(p)) == want
     _lib.check(lib.cnl_conv3x3_winograd_f32(ctypes.byref(p), _stream()), "winograd")
@@ -691,6 +697,57 @@ def test_fuse_epilogue_reports_absmax(shape):
     assert kern == 2 and torch.equal(y0, y1)
     assert torch.equal(ym, y1.abs().amax(dim=(1, 2, 3)))
     torch.testing.assert_close(y1, ref_conv(x, w, b, flags=CNL_UPSAMPLE_OUT_ADD, residual=skip), rtol=RTOL, atol=ATOL)
+
+
+UP_ROWS_CASES = [
+    # N, Cin, Hs, Ws, Cout, flags — stored (low-resolution) size; the conv runs on the nearest-2x upsampled map
+    (2, 32, 6, 10, 64, CNL_RELU),                       # two chunks (the item's first chunk is also its last but one)
+    (2, 128, 12, 36, 128, CNL_RELU),                    # eight chunks, three items down, two across (ragged), two cout blocks
+    (3, 64, 64, 64, 64, 0),                             # the first head block's shape in small: 96 work items, no ReLU (signed outputs)
+    (2, 64, 20, 32, 96, CNL_RELU),                      # 40 rows = five items down, couts 96 -> 128
+    (5, 32, 9, 17, 64, CNL_RELU),                       # 18 x 34 logical pixels: packed rows (36-column strips), the last item's rows 16, 17 of 24
+    (6, 64, 16, 16, 128, CNL_RELU),                     # the 16 -> 32-pixel neck stage of 512 x 512 frames (packed)
+    (1, 64, 4, 32, 32, CNL_RELU),                       # one item, Cout = 32
+]
+
+
+@pytest.mark.parametrize("case", UP_ROWS_CASES, ids=lambda c: "N{}c{}_{}x{}_o{}f{}".format(*[int(v) for v in c]))
+def test_row_winograd_with_row_pair_weights_behind_a_folded_upsample(case):
+    """ABI v12, cnl_conv_params.w_up: behind a nearest-2x upsample (reference models/layers.py:99 + 72-77) image rows 2j and 2j + 1 are one source row, and the
+    row-Winograd kernel with the layer's pre-summed row-pair weights {g0, g0 + g1, g1 + g2, g2} issues two instead of three kernel rows per output row.
+    Against conv2d on the upsampled input (CPU fp32: the path's 1e-4 bar) and float64: error at or below 1.25 x the fp32 matrix core's (+ 1e-7 of the layer
+    maximum), max |y| exact; within rounding of the general form (w_up = NULL); a shard equals the full batch bit for bit (also across the packed-row
+    decision, which looks at N); a residual sends the launch to the general form (same bits as without w_up)."""
+    N, Cin, Hs, Ws, Cout, flags = case
+    flags |= CNL_UPSAMPLE_IN
+    g = torch.Generator().manual_seed(Cin + Hs * Ws + Cout)
+    x = torch.randn(N, Cin, Hs, Ws, generator=g) * torch.pow(10.0, torch.randint(-2, 3, (N, 1, 1, 1), generator=g).float())
+    if flags & CNL_RELU:
+        x = x.clamp_min(0)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (1.0 / (Cin * 9)) ** 0.5 * torch.pow(10.0, torch.randint(-1, 2, (Cout, 1, 1, 1), generator=g).float())
+    b = torch.randn(Cout, generator=g)
+    out, ym = run_winograd(x, w, b, flags, algo=CNL_ALGO_FORCE + 9, want=5, ymax=True, up_rows=True)
+    gen = run_winograd(x, w, b, flags, algo=CNL_ALGO_FORCE + 9, want=5)
+    ref = ref_conv(x, w, b, 1, flags)
+    scale = ref.abs().amax(dim=(1, 2, 3), keepdim=True)
+    assert ((out - ref).abs() / scale).max().item() < 1e-4
+    assert torch.equal(ym, out.abs().amax(dim=(1, 2, 3)))
+    ref64 = ref_conv(x.double(), w.double(), b.double(), 1, flags)
+    sc64 = ref64.abs().amax(dim=(1, 2, 3), keepdim=True)
+    e_up = ((out.double() - ref64).abs() / sc64).max().item()
+    e_gen = ((gen.double() - ref64).abs() / sc64).max().item()
+    e_f32 = ((run_winograd(x, w, b, flags, algo=CNL_ALGO_FORCE + 2).double() - ref64).abs() / sc64).max().item()
+    print(f"\n[row-pair weights] error / image max: {e_up:.3e} (general form {e_gen:.3e}, fp32 matrix cores {e_f32:.3e})")
+    assert e_up <= 1.25 * e_f32 + 1e-7, (e_up, e_f32)
+    assert ((out - gen).abs() / scale).max().item() < 2e-6
+    # batch invariance: every image alone, and the first two together
+    for n in range(min(N, 2)):
+        assert torch.equal(run_winograd(x[n:n + 1], w, b, flags, algo=CNL_ALGO_FORCE + 9, up_rows=True)[0], out[n])
+    if N > 2:
+        assert torch.equal(run_winograd(x[:2], w, b, flags, algo=CNL_ALGO_FORCE + 9, up_rows=True), out[:2])
+    # with a residual the general form runs: the same bits with and without w_up
+    res = torch.randn(N, Cout, 2 * Hs, 2 * Ws, generator=g)
+    assert torch.equal(run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 9, up_rows=True), run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 9))
 
 
 PACKED_CASES = [

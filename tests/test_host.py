@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/centernet_gfx950.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.cnl_version() == _lib.ABI_VERSION == 11
+    assert lib.cnl_version() == _lib.ABI_VERSION == 12
 
 
 def test_abi_error_convention_without_gpu():
@@ -374,7 +374,7 @@ def test_absmax_arrays_are_one_cache_line_per_image():
     assert _lib.absmax_buffer(4, device="cpu").numel() == 128
 
 
-@pytest.mark.parametrize("src,kernels", [("winograd9.hip", 7), ("winograd10.hip", 8)])
+@pytest.mark.parametrize("src,kernels", [("winograd9.hip", 10), ("winograd10.hip", 8)])
 def test_winograd9_compiles_without_register_spills(src, kernels):
     """csrc/winograd9.hip sits at the edge of the register file (256 accumulator + 256 vector registers per lane): a spill inside its
     chunk loop comes back as a scratch load with a vmcnt(0) — a wait for every load in flight — and harmless-looking edits of the
@@ -408,6 +408,6 @@ def test_makefile_hands_winograd9_spill_count_to_the_dispatcher():
     if not os.path.exists(usage):
         pytest.skip("no build directory (library built elsewhere)")
     text = open(usage).read()
-    assert "#define CNL_W9_VGPR_SPILLS 0" in text and "#define CNL_W9_KERNELS_CHECKED 6" in text
+    assert "#define CNL_W9_VGPR_SPILLS 0" in text and "#define CNL_W9_KERNELS_CHECKED 8" in text
     src = open(os.path.join(csrc, "winograd.hip")).read()
     assert 'include "build/w9_usage.h"' in src and "CNL_W9_VGPR_SPILLS > 0" in src
