@@ -257,7 +257,7 @@ def timed(model, x, tracking, k, warmup, steps, collator, barrier):
 
 def conv_kernel_profile(model, x, reps=3):
     """HIP-event timing of every conv launch of one forward (events on torch's current stream == the launch stream).
-    Returns per-launch rows (what, algorithmic flops, ms, kind, algorithmic bytes), scaled to the whole batch."""
+    Returns per-launch rows (what, algorithmic flops, ms, kind, algorithmic bytes, EXECUTED matrix flops), scaled to the whole batch."""
     import ctypes
     eng = model._engine
     model(x)                                            # make sure the plan exists
@@ -300,7 +300,8 @@ def conv_kernel_profile(model, x, reps=3):
     for i, L in enumerate(convs):
         p = L.args
         if L.fn is lib.cnl_fused_out_reduce_f32:        # second half of an out_conv folded into the 3x3 block before it: [part, blocks, M, C2, ...]
-            rows.append((L.what, 2.0 * p[2] * p[1] * 32 * p[3] * scale, acc[i] / reps * scale, "fused_out_reduce", (p[1] * p[2] * 16 + p[2] * p[3] * 4) * scale))
+            fl_r = 2.0 * p[2] * p[1] * 32 * p[3] * scale
+            rows.append((L.what, fl_r, acc[i] / reps * scale, "fused_out_reduce", (p[1] * p[2] * 16 + p[2] * p[3] * 4) * scale, fl_r))
             continue
         up_in = 2 if p.flags & 4 else 1
         ho = (p.H_in * up_in + 2 * p.pad - p.KH) // p.stride + 1
@@ -308,19 +309,23 @@ def conv_kernel_profile(model, x, reps=3):
         out_px = p.N * ho * wo * (4 if p.flags & 8 else 1)
         # algorithmic HBM bytes of a conv launch: input + weights + bias + output (+ residual), each touched once
         nbytes = 4 * (p.N * p.H_in * p.W_in * p.Cin + p.Cout * p.KH * p.KW * p.Cin + p.Cout + out_px * p.Cout + (out_px * p.Cout if p.residual else 0))
-        rows.append((L.what, L.flops * scale, acc[i] / reps * scale, kind(L), nbytes * scale))
+        kd = kind(L)
+        ratio = EXEC[kd][0]
+        if kd == "winograd_row_f16x2" and L.fn is lib.cnl_conv3x3_winograd_f32 and p.w_up and (p.flags & 4) and not p.residual and not p.fuse_w:
+            ratio *= 2.0 / 3.0                          # row-pair weights behind a folded upsample (cnl_conv_params.w_up): 96 of the 144 MFMAs per chunk are issued
+        rows.append((L.what, L.flops * scale, acc[i] / reps * scale, kd, nbytes * scale, L.flops * scale * ratio))
     return rows, plan
 
 
 def roofline_block(rows, config, B, H, W):
     agg = {}
-    for what, fl, ms, kd, nb in rows:
-        a = agg.setdefault(kd, [0, 0.0, 0.0, 0.0])
-        a[0] += 1; a[1] += ms; a[2] += fl; a[3] += nb
+    for what, fl, ms, kd, nb, fx in rows:
+        a = agg.setdefault(kd, [0, 0.0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += fl; a[3] += nb; a[4] += fx
     dom = max(agg, key=lambda k_: agg[k_][1])
-    n, ms, fl, nb = agg[dom]
+    n, ms, fl, nb, fx = agg[dom]
     ratio, peak = EXEC[dom]
-    exec_tf = fl * ratio / (ms * 1e-3) / 1e12
+    exec_tf = fx / (ms * 1e-3) / 1e12
     prof, prof_path = profiled(config, B, H, W)
     pks = {k_: v for k_, v in (prof or {}).get("kernels", {}).items() if dom in KIND_KERNEL and k_.startswith(KIND_KERNEL[dom]) and "hbm_MB_per_launch" in v}
     traffic = None
@@ -332,7 +337,8 @@ def roofline_block(rows, config, B, H, W):
                                     f"(all launches of the kernel in the profiled steps; rocprofv3 average duration there {us:.2f} us)")
     roof = {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": round(exec_tf, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(exec_tf / peak, 4),
-            "achieved_counts": f"EXECUTED matrix-core flops = direct-conv flops x {ratio:.4f} (Winograd multiplies x split terms); the algorithmic rate is effective_tflops",
+            "achieved_counts": f"EXECUTED matrix-core flops = direct-conv flops x {ratio:.4f} (Winograd multiplies x split terms; x {ratio * 2 / 3:.4f} for the launches behind a folded "
+                               f"upsample that run on row-pair weights, cnl_conv_params.w_up: 96 of 144 MFMAs per chunk) = {fx / fl:.4f} x over this kernel's launches; the algorithmic rate is effective_tflops",
             "effective_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
             "effective_frac_of_fp32_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3),
             "launches_per_step": n, "kernel_ms_per_step": round(ms, 3), "algorithmic_gflop_per_step": round(fl / 1e9, 2),
@@ -344,7 +350,7 @@ def roofline_block(rows, config, B, H, W):
             "sustained_clock_note": "power-limited DVFS: on the 256-channel head blocks this kernel holds 1.37-1.48 GHz of 2.4 under real data (GRBM_GUI_ACTIVE / duration, profiles/r04_winograd_variants.txt, r04_winograd9_skip4.txt): a denser schedule lowers the clock, 25 % fewer MFMAs buy 12.6 % (DESIGN.md 3.1); a loop of nothing but this MFMA on random fp16 operands sustains 1.84-1.90 PFLOP/s at 1.84-1.90 GHz (profiles/r04_mfma_order.txt), 0.74-0.76 of `peak`"}
     roof["other_kernels"] = {KIND_NAMES[k_].split(" (")[0]: {"launches_per_step": v[0], "kernel_ms_per_step": round(v[1], 3),
                                                             "effective_tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0,
-                                                            "executed_frac_of_its_peak": round(v[2] * EXEC[k_][0] / (v[1] * 1e-3) / 1e12 / EXEC[k_][1], 4) if v[1] else 0.0}
+                                                            "executed_frac_of_its_peak": round(v[4] / (v[1] * 1e-3) / 1e12 / EXEC[k_][1], 4) if v[1] else 0.0}
                              for k_, v in agg.items() if k_ != dom}
     conv_ms, conv_fl = sum(r[2] for r in rows), sum(r[1] for r in rows)
     stack = {"algorithmic_gflop_per_step": round(conv_fl / 1e9, 2), "kernel_ms_per_step": round(conv_ms, 3),
@@ -800,7 +806,7 @@ def main():
             result["collate_ms"] = round(collate_ms, 4)
             result["collate_note"] = "pack + all_gather_into_tensor + unpack run synchronously, median of 10 (inside `value` the gather runs on a side stream behind the next forward)"
         if args.layers:
-            for what, fl, ms, kd, _nb in rows:
+            for what, fl, ms, kd, _nb, _fx in rows:
                 print(f"{what:44s} {kd:16s} {fl / 1e9:10.2f} GFLOP {ms * 1e3:10.1f} us {fl / (ms * 1e-3) / 1e12 if ms else 0:8.1f} TF", file=sys.stderr)
         lap("roofline+decode")
         if world == 1:

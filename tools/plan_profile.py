@@ -29,7 +29,7 @@ def main():
     rows, plan = bench.conv_kernel_profile(model, x, reps=a.reps)
     tot = sum(r[2] for r in rows)
     print(f"{'launch':58s} {'kind':15s} {'us':>9s} {'TFLOP/s':>8s} {'GB/s alg':>9s} {'%':>5s}")
-    for what, fl, ms, kd, nb in rows:
+    for what, fl, ms, kd, nb, _fx in rows:
         print(f"{what[:58]:58s} {kd:15s} {ms * 1e3:9.1f} {fl / ms / 1e9 if ms else 0:8.1f} {nb / ms / 1e6 if ms else 0:9.0f} {100 * ms / tot:5.1f}")
     print(f"conv launches {len(rows)}: {tot:.3f} ms; all launches in the plan: {len(plan.launches)}")
 
