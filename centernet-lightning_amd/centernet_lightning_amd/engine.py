@@ -129,6 +129,7 @@ def _layer_split_w(self):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(self.w.device).cuda_stream)
                 _lib.check(lib.cnl_conv_split_weights_f32(self.w.data_ptr(), buf.data_ptr(), self.cin, self.cout, self.kh, self.kw, stream),
                            "cnl_conv_split_weights_f32")
+                torch.cuda.current_stream(self.w.device).synchronize()      # (as up_rows: one buffer for the plans of every stream)
             self._wsplit = buf
     return self._wsplit if self._wsplit is not False else None
 
@@ -165,6 +166,7 @@ def _layer_up_rows(self):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(self.w.device).cuda_stream)
                 _lib.check(lib.cnl_winograd_transform_weights_up_f32(self.w.data_ptr(), buf.data_ptr(), self.cin, self.cout, stream),
                            "cnl_winograd_transform_weights_up_f32")
+                torch.cuda.current_stream(self.w.device).synchronize()      # built once, on whichever stream's plan asks first; plans of other streams read it too
             self._up_rows = buf
     return self._up_rows if self._up_rows is not False else None
 
