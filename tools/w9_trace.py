@@ -11,17 +11,22 @@ from centernet_lightning_amd._lib import CNL_RELU, ConvParams
 lib = _lib.load()
 N, H, W, Cin, Cout = int(os.environ.get("W9N", "32")), int(sys.argv[2]) if len(sys.argv) > 2 else 128, int(sys.argv[2]) if len(sys.argv) > 2 else 128, int(sys.argv[1]) if len(sys.argv) > 1 else 256, int(sys.argv[3]) if len(sys.argv) > 3 else 256
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+UP = int(os.environ.get("W9UP", "0"))          # 1: the input is stored at H x W and upsampled 2x inside the launch (general form); 2: ... on row-pair weights (cnl_conv_params.w_up)
 x = torch.randn(N, H, W, Cin, device="cuda").clamp_min_(0)
 w = torch.randn(Cout, 3, 3, Cin, device="cuda") * (1.0 / (Cin * 9)) ** 0.5
 b = torch.randn(Cout, device="cuda")
-y = torch.empty(N, H, W, Cout, device="cuda")
+y = torch.empty(N, H * (2 if UP else 1), W * (2 if UP else 1), Cout, device="cuda")
 u = torch.empty(lib.cnl_winograd_weight_floats(Cin, Cout), device="cuda")
 _lib.check(lib.cnl_winograd_transform_weights_f32(w.data_ptr(), u.data_ptr(), Cin, Cout, stream))
 xm = _lib.absmax_pack(x.abs().amax(dim=(1, 2, 3))); ym = _lib.absmax_buffer(N)
 p = ConvParams()
 p.x, p.w, p.bias, p.y = x.data_ptr(), u.data_ptr(), b.data_ptr(), y.data_ptr()
 p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad = N, H, W, Cin, Cout, 3, 3, 1, 1
-p.ldx, p.ldy, p.ldr, p.flags, p.algo = Cin, Cout, Cout, CNL_RELU, 109
+p.ldx, p.ldy, p.ldr, p.flags, p.algo = Cin, Cout, Cout, CNL_RELU | (4 if UP else 0), 109
+if UP == 2:
+    wu = torch.empty(lib.cnl_winograd_up_weight_floats(Cin, Cout), device="cuda")
+    _lib.check(lib.cnl_winograd_transform_weights_up_f32(w.data_ptr(), wu.data_ptr(), Cin, Cout, stream))
+    p.w_up = wu.data_ptr()
 p.x_absmax, p.y_absmax = xm.data_ptr(), ym.data_ptr()
 tr = torch.zeros(64 * 32, dtype=torch.int64, device="cuda")
 lib.cnl_w9_set_trace.argtypes = [ctypes.c_void_p]
