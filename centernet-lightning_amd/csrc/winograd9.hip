@@ -375,15 +375,97 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- the COMPACT chunk of the row-pair form (UR): its 16 segments as 96 slices, six V jobs, seven patch pieces ------------------------------------------------------
+// (The first UR version kept the 144-slice schedule with 48 MFMA-less slices: 4 280 cycles per chunk against 3 072 of matrix issue — an empty slice still costs the ~20 cycles
+//  of what is issued beside it.)  Segments in issue order: (patch row r, kernel row ky); the V fragment is that of the ODD row (an even row r reads row r - 1's: the same
+//  source row), numbered 0..5 for rows 0, 1, 3, 5, 7, 9 and 6, 7 for rows 0, 1 of the NEXT chunk: buffer = (number + 2 PAR) & 3.  The set-0 segment of an even row LEADS its
+//  group, so that set 0 dies at slice 54 and is reloaded 42 slices before the next chunk needs it (sets 1 / 2: 30 / 28 slices; set 3 is loaded in the chunk that uses it).
+#ifndef W9_UR_COMPACT
+#define W9_UR_COMPACT 1
+#endif
+constexpr int NSLICE_UR = 96;
+constexpr int URS_ROW[16] = {0, 2, 1, 1, 4, 3, 3, 3, 6, 5, 5, 5, 7, 7, 7, 9};
+constexpr int URS_KY[16] = {0, 0, 0, 1, 0, 0, 1, 2, 0, 0, 1, 2, 0, 1, 2, 2};
+constexpr int urs_set(int seg) { return (URS_ROW[seg] & 1) ? URS_KY[seg] + 1 : 0; }
+constexpr int urs_frag(int seg) { const int r = URS_ROW[seg], ro = (r >= 2 && (r & 1) == 0) ? r - 1 : r; return (ro + 1) / 2; }
+constexpr bool urs_first_use(int S) {
+    const int yo = URS_ROW[S / 6] - URS_KY[S / 6], nbh = S & 1;
+    for (int s = 0; s < S; ++s)
+        if (URS_ROW[s / 6] - URS_KY[s / 6] == yo && (s & 1) == nbh) return false;
+    return true;
+}
+constexpr int UR_JOB0 = 2, UR_JOB_STRIDE = 16;        // job j: slices [2 + 16 j, 16 + 16 j): fragments 2..5 of this chunk (rows 3, 5, 7, 9), then 6, 7 (rows 0, 1 of the next)
+constexpr int UR_BARRIER = 44;                        // behind the last read of this chunk's patch (row 9: slices 38..41)
+constexpr int UR_SET0_LOAD = 54, UR_SET1_LOAD = 78, UR_SET2_LOAD = 86;
+template <int S, int PAR, int MODE, bool FIRST>
+__device__ __forceinline__ void slice_ur(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave) {
+    constexpr int seg = S / 6;
+    constexpr int r = URS_ROW[seg], ky = URS_KY[seg];
+    constexpr int term = (S % 6) / 2, nbh = S & 1;
+    constexpr int ku = term == 1 ? 1 : 0, kv = term == 0 ? 1 : 0;         // terms: hi lo', lo hi', hi hi'
+    constexpr int vbuf = (urs_frag(seg) + 2 * PAR) & 3, wset = urs_set(seg);
+    if constexpr (S == UR_BARRIER) {
+        W9_BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (FIRST && urs_first_use(S)) st.acc[r - ky][nbh] = mfma16(st.fb[wset][nbh][ku], st.vf[vbuf][kv], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+    else st.acc[r - ky][nbh] = mfma16(st.fb[wset][nbh][ku], st.vf[vbuf][kv], st.acc[r - ky][nbh]);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- V production ----
+    if constexpr (S >= UR_JOB0 && (S - UR_JOB0) % UR_JOB_STRIDE < 14) {
+        constexpr int j = (S - UR_JOB0) / UR_JOB_STRIDE, k = (S - UR_JOB0) % UR_JOB_STRIDE;
+        constexpr int buf = (j + 2 + 2 * PAR) & 3;
+        const float Sj = (MODE == 2 && j >= 4) ? st.nxt.S : st.cur.S;
+        vop<2 * k>(st, buf, Sj);
+        vop<2 * k + 1>(st, buf, Sj);
+        if constexpr (k >= 4 && k <= 7) {             // raw reads of the next job: rows 5, 7, 9 of this patch, rows 0, 1 of the next, and row 3 of the next for ITS job 0
+            constexpr int jn = j + 1;
+            constexpr int nrow = jn < 4 ? 2 * jn + 3 : (jn < 6 ? jn - 4 : 3);
+            constexpr int npb = jn < 4 ? PAR : (PAR ^ 1);
+            rread<k - 4>(st, npb, nrow);
+        }
+    }
+    // ---- weight fragments: set 3 of THIS chunk (first used at slice 42), sets 0 / 1 / 2 of the next once this chunk is done with them ----
+    if constexpr (S < 8 && S % 2 == 0) load_b<3, 4>(st, a, st.cur.u_voff, cn, S / 2, u_plane, u_wave);
+    if constexpr (S >= UR_SET0_LOAD && S < UR_SET0_LOAD + 8 && (S - UR_SET0_LOAD) % 2 == 0)
+        load_b<0, 4>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - UR_SET0_LOAD) / 2, u_plane, u_wave);
+    if constexpr (S >= UR_SET1_LOAD && S < UR_SET1_LOAD + 8 && (S - UR_SET1_LOAD) % 2 == 0)
+        load_b<1, 4>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - UR_SET1_LOAD) / 2, u_plane, u_wave);
+    if constexpr (S >= UR_SET2_LOAD && S < UR_SET2_LOAD + 8 && (S - UR_SET2_LOAD) % 2 == 0)
+        load_b<2, 4>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - UR_SET2_LOAD) / 2, u_plane, u_wave);
+    // ---- patch of the chunk after next, the six distinct rows in two halves through the staging registers:
+    //   10 / 12 / 14   rows 5, 7, 9 of the NEXT chunk's patch (requested a chunk ago) -> the other buffer
+    //   16 / 20 / 24 / 28   request rows 0, 1, 3 + the column piece        45 / 47 / 49 / 51   ... -> this chunk's buffer (dead behind the barrier)        62 / 66 / 70   request rows 5, 7, 9
+    if constexpr (S >= 10 && S <= 14 && S % 2 == 0) pwrite<1, (S - 10) / 2, true>(st, PAR ^ 1);
+    if constexpr ((S >= 16 && S <= 24 && S % 4 == 0) || S == 28) {
+        constexpr int I = S == 28 ? 5 : (S - 16) / 4;
+        if constexpr (MODE == 0) pload<0, I, true>(st, st.cur, a, cn + 2, up);
+        else pload<0, I, true>(st, st.nxt, a, MODE - 1, up);
+    }
+    if constexpr ((S >= 45 && S <= 49 && S % 2 == 1) || S == 51) pwrite<0, S == 51 ? 5 : (S - 45) / 2, true>(st, PAR);
+    if constexpr (S >= 62 && S <= 70 && (S - 62) % 4 == 0) {
+        if constexpr (MODE == 0) pload<1, (S - 62) / 4, true>(st, st.cur, a, cn + 2, up);
+        else pload<1, (S - 62) / 4, true>(st, st.nxt, a, MODE - 1, up);
+    }
+    // ---- the item's bias / weight-scale values -> LDS for the epilogue ----
+    if constexpr (FIRST && S == 32) {
+        float* sb = reinterpret_cast<float*>(st.sB) + lane_now();
+        sb[0] = st.bst;
+        sb[64] = st.ist;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int PAR, int MODE, bool FIRST, bool FUSE, bool UR, int... S>
 __device__ __forceinline__ void chunk_impl(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave,
                                            std::integer_sequence<int, S...>) {
     __builtin_amdgcn_sched_barrier(0);
-    (slice<S, PAR, MODE, FIRST, FUSE, UR>(st, a, cn, up, u_plane, u_wave), ...);
+    if constexpr (UR && W9_UR_COMPACT) (slice_ur<S, PAR, MODE, FIRST>(st, a, cn, up, u_plane, u_wave), ...);
+    else (slice<S, PAR, MODE, FIRST, FUSE, UR>(st, a, cn, up, u_plane, u_wave), ...);
 }
 template <int PAR, int MODE, bool FIRST = false, bool FUSE = false, bool UR = false>        // FIRST: the first chunk of an item (its accumulators start from zero)
 __device__ __forceinline__ void chunk(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave) {
-    chunk_impl<PAR, MODE, FIRST, FUSE, UR>(st, a, cn, up, u_plane, u_wave, std::make_integer_sequence<int, NSLICE>{});
+    chunk_impl<PAR, MODE, FIRST, FUSE, UR>(st, a, cn, up, u_plane, u_wave, std::make_integer_sequence<int, (UR && W9_UR_COMPACT) ? NSLICE_UR : NSLICE>{});
 }
 template <int... O>
 __device__ __forceinline__ void job_all(State& st, const int buf, const float S, std::integer_sequence<int, O...>) {
@@ -588,7 +670,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     job_all(st, 0, st.cur.S, std::make_integer_sequence<int, 28>{});
     rread<0>(st, 0, 1); rread<1>(st, 0, 1); rread<2>(st, 0, 1); rread<3>(st, 0, 1);
     job_all(st, 1, st.cur.S, std::make_integer_sequence<int, 28>{});
-    if constexpr (!UR) { rread<0>(st, 0, 2); rread<1>(st, 0, 2); rread<2>(st, 0, 2); rread<3>(st, 0, 2); }      // (UR: row 2 has no job; job 1's reads go out inside the chunk)
+    if constexpr (!UR) { rread<0>(st, 0, 2); rread<1>(st, 0, 2); rread<2>(st, 0, 2); rread<3>(st, 0, 2); }      // (UR: row 2 has no job ...)
+    else if constexpr (W9_UR_COMPACT) { rread<0>(st, 0, 3); rread<1>(st, 0, 3); rread<2>(st, 0, 3); rread<3>(st, 0, 3); }     // ... the compact chunk's job 0 builds row 3
     while (true) {
         W9_STAMP(1);
 #ifdef W9_TRACE
