@@ -434,18 +434,18 @@ __device__ __forceinline__ void slice_ur(State& st, const Args& a, const int cn,
     if constexpr (S >= UR_SET2_LOAD && S < UR_SET2_LOAD + 8 && (S - UR_SET2_LOAD) % 2 == 0)
         load_b<2, 4>(st, a, MODE == 2 ? st.nxt.u_voff : st.cur.u_voff, MODE == 2 ? 0 : cn + 1, (S - UR_SET2_LOAD) / 2, u_plane, u_wave);
     // ---- patch of the chunk after next, the six distinct rows in two halves through the staging registers:
-    //   10 / 12 / 14   rows 5, 7, 9 of the NEXT chunk's patch (requested a chunk ago) -> the other buffer
-    //   16 / 20 / 24 / 28   request rows 0, 1, 3 + the column piece        45 / 47 / 49 / 51   ... -> this chunk's buffer (dead behind the barrier)        62 / 66 / 70   request rows 5, 7, 9
-    if constexpr (S >= 10 && S <= 14 && S % 2 == 0) pwrite<1, (S - 10) / 2, true>(st, PAR ^ 1);
-    if constexpr ((S >= 16 && S <= 24 && S % 4 == 0) || S == 28) {
-        constexpr int I = S == 28 ? 5 : (S - 16) / 4;
+    //   1 / 3 / 5   rows 5, 7, 9 of the NEXT chunk's patch (requested 44 slices ago) -> the other buffer
+    //   7 / 9 / 11 / 13   request rows 0, 1, 3 + the column piece        45 / 47 / 49 / 51   ... -> this chunk's buffer (dead behind the barrier: 38 slices for the loads to land)        53 / 55 / 57   request rows 5, 7, 9
+    if constexpr (S >= 1 && S <= 5 && S % 2 == 1) pwrite<1, (S - 1) / 2, true>(st, PAR ^ 1);
+    if constexpr (S >= 7 && S <= 13 && S % 2 == 1) {
+        constexpr int I = S == 13 ? 5 : (S - 7) / 2;
         if constexpr (MODE == 0) pload<0, I, true>(st, st.cur, a, cn + 2, up);
         else pload<0, I, true>(st, st.nxt, a, MODE - 1, up);
     }
     if constexpr ((S >= 45 && S <= 49 && S % 2 == 1) || S == 51) pwrite<0, S == 51 ? 5 : (S - 45) / 2, true>(st, PAR);
-    if constexpr (S >= 62 && S <= 70 && (S - 62) % 4 == 0) {
-        if constexpr (MODE == 0) pload<1, (S - 62) / 4, true>(st, st.cur, a, cn + 2, up);
-        else pload<1, (S - 62) / 4, true>(st, st.nxt, a, MODE - 1, up);
+    if constexpr (S >= 53 && S <= 57 && S % 2 == 1) {
+        if constexpr (MODE == 0) pload<1, (S - 53) / 2, true>(st, st.cur, a, cn + 2, up);
+        else pload<1, (S - 53) / 2, true>(st, st.nxt, a, MODE - 1, up);
     }
     // ---- the item's bias / weight-scale values -> LDS for the epilogue ----
     if constexpr (FIRST && S == 32) {
