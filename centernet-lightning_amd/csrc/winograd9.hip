@@ -186,6 +186,7 @@ struct State {
 #ifdef W9_TRACE
     unsigned long long* trp;   // timing build: this item's stamp row (block 0 / thread 0), else null
 #endif
+    bool idle;               // UR: this wave's transform position is identically zero (wave 2)
     float bst, ist;          // this lane's bias / inverse weight scale of the item (cout n0 + lane), on their way to LDS
     u32x4 fwst;              // FUSE: row n0 + lane of the folded 1x1 conv's weights, on its way to LDS
     char* sB;
@@ -383,6 +384,9 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
 #ifndef W9_UR_COMPACT
 #define W9_UR_COMPACT 1
 #endif
+#ifndef W9_UR_SKIP_ZERO      /* the row-pair form's epilogue leaves the identically-zero transform position (wave 2) out of the exchange (A/B: 0) */
+#define W9_UR_SKIP_ZERO 1
+#endif
 constexpr int NSLICE_UR = 96;
 constexpr int URS_ROW[16] = {0, 2, 1, 1, 4, 3, 3, 3, 6, 5, 5, 5, 7, 7, 7, 9};
 constexpr int URS_KY[16] = {0, 0, 0, 1, 0, 0, 1, 2, 0, 0, 1, 2, 0, 1, 2, 2};
@@ -397,6 +401,8 @@ constexpr bool urs_first_use(int S) {
 constexpr int UR_JOB0 = 2, UR_JOB_STRIDE = 16;        // job j: slices [2 + 16 j, 16 + 16 j): fragments 2..5 of this chunk (rows 3, 5, 7, 9), then 6, 7 (rows 0, 1 of the next)
 constexpr int UR_BARRIER = 44;                        // behind the last read of this chunk's patch (row 9: slices 38..41)
 constexpr int UR_SET0_LOAD = 54, UR_SET1_LOAD = 78, UR_SET2_LOAD = 86;
+// (Tiles start on pixel pairs, so transform position 2 (d2 - d1) of an upsampled row is identically zero: wave 2 multiplies zeros.  Leaving its matrix work out needs a second code path per chunk —
+//  a wave-uniform branch around two unrolled chunk bodies: the 256 accumulators then live across a merge and the compiler spilled 2 300-2 700 registers; not kept.  The epilogue leaves position 2 out of the exchange.)
 template <int S, int PAR, int MODE, bool FIRST>
 __device__ __forceinline__ void slice_ur(State& st, const Args& a, const int cn, const bool up, const unsigned u_plane, const unsigned u_wave) {
     constexpr int seg = S / 6;
@@ -492,6 +498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     typedef std::make_integer_sequence<int, 5> HalfB;      // rows 5..9
 
     State st;
+    st.idle = UR && wave == 2;
     st.sB = smem + 2 * P_BYTES + X_BYTES;
     st.row_pitch = (unsigned)(a.Ws * a.ldx * 4);
     // V_p = d[offa] + sg d[offb] over the four pixels 2t-1 .. 2t+2 of a tile:  p = 0: -(d0 - d2) (its weights are stored negated), 1: d1 + d2,
@@ -783,6 +790,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // (MI355X_MICROARCH.md, LDS table) — eight in a row stall the wave behind the LDS queue (measured: 370 of a pass's 1200 cycles); two
         // per quarter of the arithmetic drain beside it
 #define W9_XWRITE2(j_, g_, q0_)                                                                                  \
+        if (!(UR && W9_UR_COMPACT && W9_UR_SKIP_ZERO) || !st.idle)          /* (the zero position has nothing to hand over) */ \
         _Pragma("unroll") for (int q = (q0_); q < (q0_) + 2; ++q) {                                              \
             const f32x16& A = st.acc[j_][g_];                                                                    \
             *reinterpret_cast<f32x4*>(sX + ((j_) & 1) * (X_BYTES / 2) + (((g_) * 4 + wave) * 256 + wslot0 + ((2 * q + h_e) ^ wsw)) * 16) = \
@@ -837,7 +845,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) Y[i][p] = lds_f4(X + ((g_e * 4 + p) * 256 + rslot[i]) * 16);
+                for (int p = 0; p < 4; ++p) {
+                    if constexpr (UR && W9_UR_COMPACT && W9_UR_SKIP_ZERO) {
+                        if (p == 2) { Y[i][p] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+                    }
+                    Y[i][p] = lds_f4(X + ((g_e * 4 + p) * 256 + rslot[i]) * 16);
+                }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 // packed fp32 arithmetic (no MFMA in flight here): two couts per instruction
