@@ -54,6 +54,7 @@ class DecodeParams(Structure):
 
 _SIGNATURES = {
     "cnl_version": (ctypes.c_int, []),
+    "cnl_sizeof_params": (c_size_t, [ctypes.c_int32]),
     "cnl_absmax_stride": (ctypes.c_int, []),
     "cnl_last_error": (c_size_t, [c_char_p, c_size_t]),
     "cnl_conv2d_nhwc_f32": (ctypes.c_int, [POINTER(ConvParams), c_void_p]),
@@ -157,6 +158,9 @@ def load():
     if lib.cnl_version() != ABI_VERSION:
         raise HipLibraryError(f"{path} has ABI version {lib.cnl_version()}, this binding expects {ABI_VERSION}: rebuild it "
                               "(__graft_entry__.build())")
+    for which, struct in enumerate((ConvParams, DecodeParams, DeconvParams)):       # the binding's struct layouts against the library's
+        if lib.cnl_sizeof_params(which) != ctypes.sizeof(struct):
+            raise HipLibraryError(f"{path}: sizeof({struct.__name__}) is {lib.cnl_sizeof_params(which)} in the library, {ctypes.sizeof(struct)} in this binding")
     _lib = lib
     return lib
 

@@ -34,6 +34,10 @@ int cu_count(int dev, int* n_cu) {
 
 extern "C" int cnl_version(void) { return CNL_ABI_VERSION; }
 extern "C" int cnl_absmax_stride(void) { return CNL_ABSMAX_STRIDE; }
+// sizeof of the parameter structs as THIS library was compiled (0 conv, 1 decode, 2 deconv): a binder checks its own struct layout against it
+extern "C" size_t cnl_sizeof_params(int32_t which) {
+    return which == 0 ? sizeof(cnl_conv_params) : which == 1 ? sizeof(cnl_decode_params) : which == 2 ? sizeof(cnl_deconv_params) : 0;
+}
 
 extern "C" size_t cnl_last_error(char* buf, size_t n) {
     const char* s = cnl::last_error_buf();

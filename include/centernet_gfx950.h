@@ -466,6 +466,9 @@ int cnl_track_apply_f32(const float* trk_emb, const float* trk_box, const float*
 int cnl_boxes_xyxy_to_xywh_f32(const float* boxes, float* out, int64_t n, void* stream);
 
 int cnl_version(void);
+/* sizeof(cnl_conv_params) / sizeof(cnl_decode_params) / sizeof(cnl_deconv_params) (which = 0 / 1 / 2; else 0) as the library was compiled — the structs grow at the end between ABI
+ * versions: a binder (ctypes, cgo, JNI ...) compares its own struct's size before the first call (ABI v12). */
+size_t cnl_sizeof_params(int32_t which);
 /* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
 size_t cnl_last_error(char* buf, size_t n);
 /*

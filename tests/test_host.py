@@ -29,6 +29,9 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/centernet_gfx950.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     assert lib.cnl_version() == _lib.ABI_VERSION == 12
+    # the binding's parameter structs have the size the library was compiled with (cnl_sizeof_params: conv, decode, deconv)
+    import ctypes as _ct
+    assert [lib.cnl_sizeof_params(i) for i in range(4)] == [_ct.sizeof(_lib.ConvParams), _ct.sizeof(_lib.DecodeParams), _ct.sizeof(_lib.DeconvParams), 0]
 
 
 def test_abi_error_convention_without_gpu():
