@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNL_ABI_VERSION 12   /* 12: cnl_conv_params.w_up + cnl_winograd_up_weight_floats / cnl_winograd_transform_weights_up_f32 (a 3x3 conv behind a folded nearest-2x upsample: pre-summed row-pair weights, two instead of three kernel rows per output row); 11: cnl_conv_params.fuse_w / fuse_part + cnl_fused_out_pack_weights_f32 / cnl_fused_out_reduce_f32 (a 1x1 conv of <= 4 channels folded into the 3x3 launch before it); the row-Winograd kernels take maps of any even width in packed rows and tensors of >= 4 GiB in groups of images; CNL_ALGO_FORCE + 32 + v; 10: per-image maxima arrays are strided (cnl_absmax_stride() = 32 floats: one cache line per image); the stem entry points take y_absmax; CNL_ALGO_LATENCY and the half-height row-Winograd kernel (csrc/winograd10.hip, variants 10 / 11); the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 12   /* 12: cnl_conv_params.w_up + cnl_winograd_up_weight_floats / cnl_winograd_transform_weights_up_f32 (a 3x3 conv behind a folded nearest-2x upsample: pre-summed row-pair weights, two instead of three kernel rows per output row), cnl_sizeof_params (a binder's struct-layout check); 11: cnl_conv_params.fuse_w / fuse_part + cnl_fused_out_pack_weights_f32 / cnl_fused_out_reduce_f32 (a 1x1 conv of <= 4 channels folded into the 3x3 launch before it); the row-Winograd kernels take maps of any even width in packed rows and tensors of >= 4 GiB in groups of images; CNL_ALGO_FORCE + 32 + v; 10: per-image maxima arrays are strided (cnl_absmax_stride() = 32 floats: one cache line per image); the stem entry points take y_absmax; CNL_ALGO_LATENCY and the half-height row-Winograd kernel (csrc/winograd10.hip, variants 10 / 11); the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
