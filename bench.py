@@ -21,7 +21,8 @@ the script launches those N ranks itself (`self_launch`) and exits non-zero if a
               The long 3x3 layers form every fp32 product on the fp16 matrix cores (scaled two-way fp16 split, three MFMAs per
               product, fp32 accumulation) as row-Winograd F(2,3) (`cnl_wino9` / `cnl_wino10`) or 2-D F(2x2,3x3) (`cnl_wino5/6`); peak =
               2.5 PFLOP/s dense fp16.  `achieved` counts the matrix-core flops
-              the kernel EXECUTES (direct-conv flops x 6/9 [row F(2,3)] or 16/36 [F(2x2)], x 3 for the split), so `frac` is an honest
+              the kernel EXECUTES, per launch (direct-conv flops x 6/9 [row F(2,3)] or 16/36 [F(2x2)], x 3 for the split; x 2/3 again for a row-Winograd
+              launch behind a folded upsample that runs on row-pair weights, cnl_conv_params.w_up: 96 of 144 MFMAs per chunk), so `frac` is an honest
               hardware fraction — Winograd trades executed flops for transform work, which is why `effective_tflops` (the same time
               against the direct-conv, i.e. algorithmic, flops) is reported beside it.  `traffic` is NOT measured in this run: it is
               the rocprofv3 PMC figure of the named profiles/ file (null where no profile of that configuration exists).
