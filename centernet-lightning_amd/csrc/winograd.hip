@@ -72,6 +72,11 @@ int cnl_wino9_up_transform_weights(const float* w_ohwi, void* u9, float* isu, in
 int cnl_wino9_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, void* stream);
 int cnl_wino_packed_stride(const cnl_conv_params* p);                               // packed rows of the row kernels (winograd9.hip)
 bool cnl_wino10_eligible(const cnl_conv_params* p);                                // winograd10.hip (reads winograd9.hip's weights)
+size_t cnl_wino13_weight_bytes(int Cin, int Cout);                                 // winograd13.hip: F(4,3) along x (weights of its own: six transform positions)
+size_t cnl_wino13_scalar_floats(int Cin, int Cout);
+int cnl_wino13_transform_weights(const float* w_ohwi, void* u13, float* isu, int Cin, int Cout, void* stream);
+bool cnl_wino13_eligible(const cnl_conv_params* p);
+int cnl_wino13_launch(const cnl_conv_params* p, const void* u13, const float* isu, const float* xmax, void* stream);
 int cnl_wino10_launch(const cnl_conv_params* p, const void* u9, const float* isu, const float* xmax, bool cout32, void* stream);
 #ifdef CNL_EXPERIMENTS
 bool cnl_wino12_eligible(const cnl_conv_params* p);                                // tools/experiments/winograd12.hip (round 5: Cin = 64, the epilogue rides in the next item's chunks)
@@ -87,14 +92,14 @@ static size_t cnl_wino3_weight_bytes(int, int) { return 0; }
 #endif
 
 // Layout of the transformed-weight buffer (floats): [fp32 U = [ci/8][16][CoutP][8]] [experiment builds: bf16 x 3 pieces]
-// [fp16 x 2 pieces of F(2x2)] [its scalars] [fp16 x 2 pieces of the row-Winograd kernel] [its per-cout scales]; the split copies exist
-// for Cin % 16 == 0 only.
+// [fp16 x 2 pieces of F(2x2)] [its scalars] [fp16 x 2 pieces of the row-Winograd kernel] [its per-cout scales] [fp16 x 2 pieces of the F(4,3) row
+// kernel] [its per-cout scales]; the split copies exist for Cin % 16 == 0 (rows: Cin % 32 == 0) only.
 static size_t wino_f32_floats(int Cin, int Cout) {
     const size_t CoutP = (size_t)((Cout + 63) / 64) * 64;
     return (size_t)(Cin / 8) * 16 * CoutP * 8;
 }
 struct WeightLayout {
-    size_t u3, u5, s5, u9, s9, total;     // float offsets
+    size_t u3, u5, s5, u9, s9, u13, s13, total;     // float offsets
     WeightLayout(int Cin, int Cout) {
         const bool split = Cin % 16 == 0;
         u3 = wino_f32_floats(Cin, Cout);
@@ -102,7 +107,9 @@ struct WeightLayout {
         s5 = u5 + cnl_wino5_weight_bytes(Cin, Cout) / 4;
         u9 = s5 + (split ? cnl_wino5_scalar_floats() : 0);
         s9 = u9 + cnl_wino9_weight_bytes(Cin, Cout) / 4;
-        total = s9 + cnl_wino9_scalar_floats(Cin, Cout);
+        u13 = s9 + cnl_wino9_scalar_floats(Cin, Cout);
+        s13 = u13 + cnl_wino13_weight_bytes(Cin, Cout) / 4;
+        total = s13 + cnl_wino13_scalar_floats(Cin, Cout);
     }
 };
 
@@ -127,7 +134,9 @@ extern "C" int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u,
     rc = cnl_wino5_transform_weights(w_ohwi, u, L.u3, u + L.u5, u + L.s5, Cin, Cout, stream);
     if (rc != CNL_OK) return rc;
     if (rc != CNL_OK || Cin % 32) return rc;
-    return cnl_wino9_transform_weights(w_ohwi, u + L.u9, u + L.s9, Cin, Cout, stream);
+    rc = cnl_wino9_transform_weights(w_ohwi, u + L.u9, u + L.s9, Cin, Cout, stream);
+    if (rc != CNL_OK) return rc;
+    return cnl_wino13_transform_weights(w_ohwi, u + L.u13, u + L.s13, Cin, Cout, stream);
 }
 
 extern "C" size_t cnl_winograd_up_weight_floats(int32_t Cin, int32_t Cout) {
@@ -163,6 +172,7 @@ static int wino_choice(const cnl_conv_params* p) {
         if (v <= 2 || p->Cin % 16) return v == 1 ? 1 : 2;
         if (v == 9 && !cnl_wino9_eligible(p)) return 5;
         if ((v == 10 || v == 11) && !cnl_wino10_eligible(p)) return 5;
+        if (v == 13 && !cnl_wino13_eligible(p)) return cnl_wino9_eligible(p) ? 9 : 5;
 #ifdef CNL_EXPERIMENTS
         if (v == 12 && !cnl_wino12_eligible(p)) return cnl_wino9_eligible(p) ? 9 : 5;
 #else
@@ -229,7 +239,7 @@ extern "C" int cnl_conv3x3_winograd_kernel(const cnl_conv_params* p) {
     CNL_REQUIRE(p, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: null params");
     CNL_REQUIRE(p->H_in > 0 && p->W_in > 0 && p->Cin > 0 && p->Cout > 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_kernel: non-positive dimension");
     const int c = wino_choice(p);
-    return (c == 5 || c == 6 || c == 7 || c == 9 || c == 10 || c == 11 || c == 12) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
+    return (c == 5 || c == 6 || c == 7 || c == 9 || c == 10 || c == 11 || c == 12 || c == 13) ? CNL_WINO_F16X2 : (c == 3 || c == 4) ? CNL_WINO_BF16X3 : CNL_WINO_F32;
 }
 
 extern "C" int cnl_conv3x3_winograd_variant(const cnl_conv_params* p) {
@@ -251,8 +261,8 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 "cnl_conv3x3_winograd_f32: Cin %% 8 != 0 or bad pixel stride");
     CNL_REQUIRE(((uintptr_t)p->x & 15) == 0 && ((uintptr_t)p->w & 15) == 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unaligned x / u");
     CNL_REQUIRE(!p->residual || p->ldr >= p->Cout, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: ldr < Cout");
-    CNL_REQUIRE(p->algo <= CNL_ALGO_F32 || p->algo == CNL_ALGO_LATENCY || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 12 && p->algo != CNL_ALGO_FORCE + 8) ||
-                    (p->algo >= CNL_ALGO_FORCE + 32 + 9 && p->algo <= CNL_ALGO_FORCE + 32 + 12),
+    CNL_REQUIRE(p->algo <= CNL_ALGO_F32 || p->algo == CNL_ALGO_LATENCY || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 13 && p->algo != CNL_ALGO_FORCE + 8) ||
+                    (p->algo >= CNL_ALGO_FORCE + 32 + 9 && p->algo <= CNL_ALGO_FORCE + 32 + 13),
                 CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unknown algo %u (FORCE + 8, the F(4x4) kernel, was removed in ABI v10)", p->algo);
     const int choice = wino_choice(p);
     CNL_REQUIRE(!p->fuse_w || (choice == 9 && p->fuse_part && !p->residual), CNL_E_UNSUPPORTED,
@@ -271,6 +281,7 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 xmax = s5 + 16;
             }
             if (choice == 9) return cnl_wino9_launch(p, u + L.u9, u + L.s9, xmax, stream);
+            if (choice == 13) return cnl_wino13_launch(p, u + L.u13, u + L.s13, xmax, stream);
 #ifdef CNL_EXPERIMENTS
             if (choice == 12) return cnl_wino12_launch(p, u + L.u9, u + L.s9, xmax, stream);
 #endif

@@ -1,0 +1,857 @@
+// winograd13.hip — 3x3 / stride-1 convolution as 1-D Winograd F(4,3) ALONG x with the three kernel rows folded into the reduction, every fp32
+// product formed on the FP16 matrix cores from scaled two-way splits (the arithmetic of winograd9.hip on a LARGER tile: VERDICT r5 #1).
+//
+//   out[y][4t + {0..3}] = A^T [ sum_{ky, ci} (G g[ky][.][ci]) (.) (B^T d[y + ky - 1][4t - 1 .. 4t + 4][ci]) ]
+//
+// SIX GEMMs (one per transform position) with K = 3 Cin per FOUR output pixels: 4.5 of the direct conv's 9 multiplies per output where F(2,3)
+// (winograd9.hip) needs 6 — 108 instead of 144 matrix instructions per 16-channel chunk and 512 outputs x 64 couts.  The reference call sites are
+// winograd9.hip's (GenericHead blocks, reference models/meta.py:21-30; ConvBnAct, models/layers.py:72-77).
+// Interpolation points {0, -1, 1, 1/2, -2, inf} (not the textbook {0, +-1, +-2}: the fp32 accumulation of the larger transform values is what
+// the error is made of — measured on the split arithmetic, tools/wino_f43_numerics.py: 1.0e-6 of the layer maximum against 1.8e-6, F(2,3): 3.7e-7):
+//   B^T = [ 1 -1.5 -2   1.5  1   0 ]      G = [   1      0      0   ]      A^T = [ 1  1  1  1    1   0 ]
+//         [ 0  1   -2.5 0.5  1   0 ]          [ -1/3    1/3   -1/3  ]            [ 0 -1  1  1/2 -2   0 ]
+//         [ 0 -1    0.5 2.5  1   0 ]          [  1/3    1/3    1/3  ]            [ 0  1  1  1/4  4   0 ]
+//         [ 0 -2   -1   2    1   0 ]          [ -16/15 -8/15  -4/15 ]            [ 0 -1  1  1/8 -8   1 ]
+//         [ 0  0.5 -1  -0.5  1   0 ]          [  1/15  -2/15   4/15 ]
+//         [ 0  1   -1.5 -2   1.5 1 ]          [   0      0      1   ]
+// Work item = 4 output rows x 128 pixels (32 tiles) x 64 couts of one image; 4 waves, one workgroup per CU.  Six positions on four waves: wave w
+// OWNS math position w + 1 (rows 1..4 of B^T: the four-tap positions, all on the pixels d1..d4 of a tile) for both cout halves, and SHARES position 0
+// (waves 0, 1) or 5 (waves 2, 3) with its neighbour, one cout half each: 128 + 64 = 192 accumulator registers per lane, 9 matrix instructions per
+// (input row, kernel row) segment (own: 3 split terms x 2 cout halves, shared: 3 terms), 12 segments = 108 per chunk.  The lane that transforms +
+// splits a V fragment feeds it to the MFMA (B operand: column = tile, k = 8 channels), as in winograd9.hip: V never goes through LDS; a wave reads the
+// FIVE pixels d1..d4 + d0 (or d5) of its tile once per patch row and builds both of its fragments from them.  The price of the larger tile:
+// 96 transform + split operations per patch row and wave (winograd10.hip: 28), i.e. 5.3 VALU beside each MFMA (1.9 there), and six patch rows per
+// four output rows.  Scaling rules as in winograd9.hip: weights per OUTPUT CHANNEL, activations per image (|V| <= 7 max |x|) — batch-invariant.
+// Structure (prologue requested inside the previous item's epilogue, one barrier per chunk, exchange region aliasing the patch buffers): winograd10.hip.
+#include "cnl_common.h"
+#include <utility>
+
+#pragma clang fp contract(off)
+
+namespace cnl_wino13 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct Args {
+    const float* x;
+    const void* u13;                  // pre-split, pre-scaled weights: [ci/16][position index 6][ky 3][piece 2][CoutP][16 ci] fp16 (weights13_kernel)
+    const float* xmax;                // max |x| per image of this launch's input
+    const float* isu;                 // [CoutP] 1 / S_u[co]
+    unsigned* ymax;                   // optional: max |y| per image of this launch's output (atomic max on the bits)
+    const float* bias;
+    const float* res;
+    float* y;
+    int N, H, W, Cin, Cout, CoutP;
+    int ldx, ldy, ldr;
+    int CC;                           // Cin / 16 (even)
+    int nb, bx, by;                   // blocks along cout (64), x (128 px), y (4 rows)
+    unsigned m_nb, m_bx, m_by;        // floor(2^32 / d) of the three
+    int Nimg;                         // images of the launch
+    int pk;                           // packed rows (0: off): the launch's images side by side in ONE virtual row, each in a strip of pk columns (W + its zero padding, a multiple of 4)
+    unsigned m_pk;
+    int blocks;
+    unsigned x_bytes, u_bytes, y_bytes, r_bytes, b_bytes;
+    unsigned flags;
+#ifdef W13_TRACE
+    unsigned long long* trace;        // timing build: [item][16] s_memtime stamps of block 0 / thread 0
+#endif
+};
+#ifdef W13_TRACE
+#define W13_STAMP(i_) do { if (blockIdx.x == 0 && tid == 0 && tr_item < 64) a.trace[tr_item * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W13_STAMP(i_) do {} while (0)
+#endif
+
+constexpr unsigned OOB = 0xFFFFFFF0u;
+constexpr int R = 4;                        // output rows per work item
+constexpr int PR = R + 2;                   // patch rows
+constexpr int TW = 32;                      // tiles (four pixels) per row of a work item: 128 output pixels
+constexpr int PXW = 4 * TW;                 // 128
+constexpr int BN = 64;                      // couts per work item
+constexpr int PXQ = TW + 1;                 // 33 pixels per phase plane of a patch row (columns x0-1 .. x0+128: column c -> plane c & 3, slot c >> 2)
+constexpr int QUAD_SLOTS = 4 * PXQ;         // 132 16-byte slots per (row, channel quad): [phase][33]
+constexpr int ROW_SLOTS = 4 * QUAD_SLOTS;   // 528 per patch row: [quad][phase][33]
+constexpr int ROW_BYTES = ROW_SLOTS * 16;   // 8448
+constexpr int P_SLOTS = PR * ROW_SLOTS + 64;      // 3232 (+ 64 slots that absorb the idle lanes of the column piece)
+constexpr int P_BYTES = P_SLOTS * 16;       // 51712 per buffer (two buffers)
+constexpr int X_HALF = 2 * 6 * 256 * 16;    // 49152: one exchange pass = [2 cout halves][6 positions][32 tiles][8 pieces] x 16 B
+constexpr int X_BYTES = 2 * X_HALF;         // two halves that alternate (one barrier per pass) — ALIASES the patch buffers
+constexpr int B_BYTES = 512;                // the item's 64 bias values and 64 inverse weight scales
+constexpr int LDS_BYTES = 2 * P_BYTES + B_BYTES;      // 103936: one workgroup per CU (192 accumulators)
+static_assert(2 * P_BYTES >= X_BYTES, "the exchange region fits into the two patch buffers");
+constexpr int NSLICE = 108;                 // MFMAs per wave and chunk
+constexpr int NSEG = 12;
+constexpr int SEG_ROW[NSEG] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+constexpr int SEG_KY[NSEG] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 1, 2, 2};
+constexpr int KY0_DEAD = 63, KY1_DEAD = 90;         // first slices after the last use of the ky = 0 / ky = 1 weight fragments
+constexpr int JOB0 = 9, JOB_SLICES = 18;            // job j (rows 2, 3, 4, 5 of this chunk, rows 0, 1 of the next): slices [9 + 18 j, 27 + 18 j), 96 operations in its first 16
+constexpr int JOB_OPS = 96, OPS_PER_SLICE = 6;
+constexpr int BARRIER_SLICE = 64;                   // behind the last read of this chunk's patch (row 5: slices 55..62), before the first of the next (73)
+constexpr int NSTG = 7;                             // staging registers: half A = rows 0..2 (two pieces each) + the column piece, half B = rows 3..5
+// the wave-dependent halves of the input transform (rows of B^T in the order own taps d1, d2, d3 [d4: 1] | shared taps d1..d4 [d0 / d5: 1])
+constexpr float OWN_C[4][3] = {{1.f, -2.5f, 0.5f}, {-1.f, 0.5f, 2.5f}, {-2.f, -1.f, 2.f}, {0.5f, -1.f, -0.5f}};
+constexpr float SH_C[2][4] = {{-1.5f, -2.f, 1.5f, 1.f}, {1.f, -1.5f, -2.f, 1.5f}};
+constexpr float V_BOUND = 7.f;                      // max over the rows of B^T of the sum of |coefficients|: |V| <= 7 max |x|
+
+__device__ __forceinline__ u32x4 buf_load16(const void* base, unsigned bytes, unsigned voffset, unsigned soffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    return (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
+}
+__device__ __forceinline__ void buf_store16(f32x4 v, float* base, unsigned bytes, unsigned voffset, unsigned soffset) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voffset, soffset, CNL_NT_STORES);
+}
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// the split of a channel pair (v0, v1), scaled by the power of two S:  hi = RN16(v S) packed, r = v S - hi exactly (winograd5.hip)
+__device__ __forceinline__ unsigned split_hi_lo(float v0, float S) {
+    unsigned pk;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(pk) : "v"(v0), "v"(S));
+    return pk;
+}
+__device__ __forceinline__ unsigned split_hi_hi(unsigned pk, float v1, float S) {
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(pk) : "v"(v1), "v"(S));
+    return pk;
+}
+__device__ __forceinline__ float split_res_lo(float v, float S, unsigned pk) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(S), "v"(pk));
+    return r;
+}
+__device__ __forceinline__ float split_res_hi(float v, float S, unsigned pk) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(S), "v"(pk));
+    return r;
+}
+__device__ __forceinline__ int lane_now() {
+    unsigned z = 0;
+    asm volatile("" : "+v"(z));
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+}
+__device__ __forceinline__ f32x4 lds_f4(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
+#define W13_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+struct Item {               // per-work-item addressing state
+    unsigned vcol[2], vext;  // source offsets: column part of the row pieces (pixel x0 - 1 + tid / 4 and 64 further; the row is a scalar offset), full offset of the column piece
+    unsigned u_voff;         // this lane's row of the weight planes
+    unsigned img_base;       // scalar: byte offset of image n
+    int y0m1;                // scalar: y0 - 1, first patch row
+    float S;                 // power-of-two scale of V for this item's image
+};
+struct State {
+    f32x16 acc[R][2];        // own position: [output row][cout half]: D[cout][tile]
+    f32x16 acs[R];           // shared position, this wave's cout half
+    u32x4 fb[3][2][2];       // own weight fragments (A operand): [ky][cout half][piece], single-buffered
+    u32x4 fs[3][2];          // shared position's: [ky][piece]
+    u32x4 vf[3][2];          // own V fragments (B operand): [row % 3][piece]
+    u32x4 vs[3][2];          // shared
+    f32x4 raw[5][2];         // patch reads of a job: pixels d1..d4 and d0 (waves 0, 1) / d5 (waves 2, 3), channel quads 2 h and 2 h + 1
+    float v[8], w[8];        // transform temporaries of the running job (V own / shared, then their residuals in place)
+    u32x4 stg[NSTG];         // patch pieces on their way global -> LDS
+    Item cur;
+    unsigned row_pitch;      // scalar: bytes per stored input row
+    const char* pa;          // LDS address of this lane's pixel d4 in patch buffer 0 (d1..d3: constant offsets, see rread) / of d0 | d5
+    const char* pe;
+    char* wb;                // LDS write address of piece (row 0, first half) in buffer 0, and of the column piece
+    char* wext;
+    float co[3], cs[4];      // wave-uniform transform coefficients
+    float bst, ist;          // this lane's bias / inverse weight scale of the item (cout n0 + lane), on their way to LDS
+    char* sB;
+};
+
+// VALU operation o (0..95) of the job that builds the V fragments `buf` of a patch row: own position (chain d4 + c2 d3 + c1 d2 + c0 d1), shared position
+// (chain e + c0 d1 + c1 d2 + c2 d3 + c3 d4, e = d0 or d5), then the two splits.  Element e = channel 8 h + e of the lane's tile: raw[.][e >> 2][e & 3].
+template <int O>
+__device__ __forceinline__ void vop(State& st, const int buf) {
+    const float S = st.cur.S;
+    if constexpr (O < 24) {
+        constexpr int step = O / 8, e = O % 8;
+        if constexpr (step == 0) st.v[e] = __builtin_fmaf(st.co[2], st.raw[2][e >> 2][e & 3], st.raw[3][e >> 2][e & 3]);
+        else st.v[e] = __builtin_fmaf(st.co[2 - step], st.raw[2 - step][e >> 2][e & 3], st.v[e]);
+    } else if constexpr (O < 56) {
+        constexpr int step = (O - 24) / 8, e = (O - 24) % 8;
+        if constexpr (step == 0) st.w[e] = __builtin_fmaf(st.cs[0], st.raw[0][e >> 2][e & 3], st.raw[4][e >> 2][e & 3]);
+        else st.w[e] = __builtin_fmaf(st.cs[step], st.raw[step][e >> 2][e & 3], st.w[e]);
+    } else {
+        constexpr bool sh = O >= 76;
+        constexpr int q = sh ? O - 76 : O - 56;
+        float (&t)[8] = sh ? st.w : st.v;
+        u32x4 (&f)[2] = sh ? st.vs[buf] : st.vf[buf];
+        if constexpr (q < 4) {
+            f[0][q] = split_hi_lo(t[2 * q], S);
+        } else if constexpr (q < 8) {
+            f[0][q - 4] = split_hi_hi(f[0][q - 4], t[2 * (q - 4) + 1], S);
+        } else if constexpr (q < 16) {
+            constexpr int e = q - 8;
+            t[e] = (e & 1) ? split_res_hi(t[e], S, f[0][e >> 1]) : split_res_lo(t[e], S, f[0][e >> 1]);
+        } else {
+            constexpr int j = q - 16;
+            f[1][j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t[2 * j], t[2 * j + 1]));
+            asm volatile("" : "+v"(f[1][j]));      // (pinned in its slice: see winograd9.hip)
+        }
+    }
+}
+// LDS read i (0..9) of patch row `row` of buffer `pbuf`: pixel i >> 1 (0..3: d1..d4, 4: d0 | d5), channel quad 2 h + (i & 1).
+// Column c of the patch (c = 0: x0 - 1) lives in plane c & 3, slot c >> 2: d1..d4 of tile t are planes 1, 2, 3, 0 at slots t, t, t, t + 1.
+template <int I>
+__device__ __forceinline__ void rread(State& st, const int pbuf, const int row) {
+    constexpr int px = I >> 1;
+    constexpr int off = px == 0 ? PXQ - 1 : (px == 1 ? 2 * PXQ - 1 : (px == 2 ? 3 * PXQ - 1 : 0));      // slots relative to d4 (plane 0, slot t + 1): d1..d3 = planes 1..3, slot t
+    const char* p = (px == 4 ? st.pe : st.pa) + pbuf * P_BYTES + row * ROW_BYTES + (off + (I & 1) * QUAD_SLOTS) * 16;
+    st.raw[px][I & 1] = lds_f4(p);
+}
+// weight fragment i of kernel row KY of chunk cc: i = 0..3 own (cout half i >> 1, piece i & 1), 4..5 shared (piece i & 1); `ok` false: nothing is fetched
+template <int KY>
+__device__ __forceinline__ void load_b(State& st, const Args& a, const int cc, const int i, const unsigned u_plane, const unsigned u_own, const unsigned u_sh, const bool ok) {
+    const int piece = i & 1;
+    const unsigned so = (unsigned)cc * (36u * u_plane) + (unsigned)(KY * 2 + piece) * u_plane;
+    if (i < 4) st.fb[KY][i >> 1][piece] = buf_load16(a.u13, a.u_bytes, ok ? st.cur.u_voff : OOB, so + u_own + (unsigned)(i >> 1) * 1024u);
+    else st.fs[KY][piece] = buf_load16(a.u13, a.u_bytes, ok ? st.cur.u_voff : OOB, so + u_sh);
+}
+// Patch piece I of half HALF of chunk cc: half 0 = rows 0..2 (pieces 0..5: row I >> 1, pixel half I & 1) + the column piece (6: the two last pixel
+// columns of all six rows), half 1 = rows 3..5.  Always issued (no branch: see winograd9.hip); a row outside the image — or `ok` false — reads out of range.
+template <int HALF, int I>
+__device__ __forceinline__ void pload(State& st, const Args& a, const int cc, const bool ok) {
+    if constexpr (I < 6) {
+        const int iy = __builtin_amdgcn_readfirstlane(st.cur.y0m1) + 3 * HALF + (I >> 1);
+        const bool okr = ok && (unsigned)iy < (unsigned)a.H;
+        const unsigned so = __builtin_amdgcn_readfirstlane(st.cur.img_base + (unsigned)(okr ? iy : 0) * st.row_pitch + (unsigned)cc * 64u);
+        st.stg[I] = buf_load16(a.x, a.x_bytes, okr ? st.cur.vcol[I & 1] : OOB, so);
+    } else {
+        static_assert(HALF == 0, "the column piece belongs to half A");
+        st.stg[6] = buf_load16(a.x, a.x_bytes, ok ? st.cur.vext : OOB, __builtin_amdgcn_readfirstlane(st.cur.img_base + (unsigned)cc * 64u));
+    }
+}
+template <int HALF, int I>
+__device__ __forceinline__ void pwrite(State& st, const int pbuf) {
+    if constexpr (I < 6) *reinterpret_cast<u32x4*>(st.wb + pbuf * P_BYTES + (3 * HALF + (I >> 1)) * ROW_BYTES + (I & 1) * 256) = st.stg[I];      // (64 pixels further: 16 slots)
+    else *reinterpret_cast<u32x4*>(st.wext + pbuf * P_BYTES) = st.stg[6];
+}
+
+// slice S = MFMA S of a chunk: segment S / 9 = (input row, kernel row), inside it term (S % 9) / 3 of the split and unit S % 3 (own cout half 0, own half 1, shared)
+constexpr bool first_use(int S) {      // is slice S the first MFMA of a chunk into its accumulator block (output row, unit)?
+    const int yo = SEG_ROW[S / 9] - SEG_KY[S / 9], u = S % 3;
+    for (int s = 0; s < S; ++s)
+        if (SEG_ROW[s / 9] - SEG_KY[s / 9] == yo && s % 3 == u) return false;
+    return true;
+}
+template <int S, int PAR, bool FIRST>
+__device__ __forceinline__ void slice(State& st, const Args& a, const int cn, const unsigned u_plane, const unsigned u_own, const unsigned u_sh, const bool has1, const bool has2) {
+    constexpr int seg = S / 9;
+    constexpr int r = SEG_ROW[seg], ky = SEG_KY[seg];
+    constexpr int term = (S % 9) / 3, unit = S % 3;
+    constexpr int ku = term == 1 ? 1 : 0, kv = term == 0 ? 1 : 0;         // terms: hi lo', lo hi', hi hi'
+    constexpr int vbuf = r % 3;
+    const f32x16 Z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (S == BARRIER_SLICE) {
+        // every wave is done reading this chunk's patch, and the next chunk's (written since the previous barrier) is complete
+        W13_BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (unit < 2) {
+        if constexpr (FIRST && first_use(S)) st.acc[r - ky][unit] = mfma16(st.fb[ky][unit][ku], st.vf[vbuf][kv], Z);
+        else st.acc[r - ky][unit] = mfma16(st.fb[ky][unit][ku], st.vf[vbuf][kv], st.acc[r - ky][unit]);
+    } else {
+        if constexpr (FIRST && first_use(S)) st.acs[r - ky] = mfma16(st.fs[ky][ku], st.vs[vbuf][kv], Z);
+        else st.acs[r - ky] = mfma16(st.fs[ky][ku], st.vs[vbuf][kv], st.acs[r - ky]);
+    }
+    __builtin_amdgcn_sched_barrier(0);       // the MFMA leads its slice
+    // ---- V production: G = position in the job stream (job 5 wraps into the next chunk's first slices) ----
+    constexpr int G = (S + NSLICE - JOB0) % NSLICE;
+    constexpr int j = G / JOB_SLICES, k = G % JOB_SLICES;
+    if constexpr (!(FIRST && S < JOB0) && k * OPS_PER_SLICE < JOB_OPS) {
+        constexpr int row = (j + 2) % 6;          // rows 2..5 of this chunk, then rows 0, 1 of the next
+        constexpr int buf = row % 3;
+        vop<k * OPS_PER_SLICE + 0>(st, buf); vop<k * OPS_PER_SLICE + 1>(st, buf); vop<k * OPS_PER_SLICE + 2>(st, buf);
+        vop<k * OPS_PER_SLICE + 3>(st, buf); vop<k * OPS_PER_SLICE + 4>(st, buf); vop<k * OPS_PER_SLICE + 5>(st, buf);
+    }
+    // raw reads of the NEXT job: its registers are free after operation 55 (slice k = 9) — ten reads in slices k = 10..17
+    if constexpr (!(FIRST && S < JOB0) && k >= 10) {
+        constexpr int jn = (j + 1) % 6;
+        constexpr int nrow = (jn + 2) % 6;
+        // the buffer of the chunk that row belongs to, seen from the slice the read is issued in: jobs 1..3 read this chunk's patch, jobs 4 / 5 the next
+        // chunk's; job 0 (row 2) is read in slices 1..8 of its own chunk (the running job 5 started in the chunk before)
+        constexpr int npb = (jn >= 1 && jn <= 3) ? PAR : (jn >= 4 ? (PAR ^ 1) : PAR);
+        static_assert(jn != 0 || S < JOB0, "job 0's reads are issued in its own chunk");
+        if constexpr (k == 10) { rread<0>(st, npb, nrow); rread<1>(st, npb, nrow); }
+        else if constexpr (k == 11) { rread<2>(st, npb, nrow); rread<3>(st, npb, nrow); }
+        else rread<k - 8>(st, npb, nrow);
+    }
+    // ---- weight fragments: kernel row 2 of THIS chunk (first used at slice 45), rows 0 / 1 of the next once this chunk is done with them ----
+    if constexpr (S < 6) load_b<2>(st, a, cn, S, u_plane, u_own, u_sh, true);
+    if constexpr (S > KY0_DEAD + 1 && S <= KY0_DEAD + 13 && (S - KY0_DEAD) % 2 == 1) load_b<0>(st, a, cn + 1, (S - KY0_DEAD - 3) / 2, u_plane, u_own, u_sh, has1);      // 66, 68, .. 76
+    if constexpr (S > KY1_DEAD && S <= KY1_DEAD + 11 && (S - KY1_DEAD) % 2 == 1) load_b<1>(st, a, cn + 1, (S - KY1_DEAD - 1) / 2, u_plane, u_own, u_sh, has1);          // 91, 93, .. 101
+    // ---- patch of chunk cn + 2, in two halves through the same staging registers:
+    //   slices 12..22   half B of the NEXT chunk's patch (requested a chunk ago) -> the other buffer, rows 3..5 (first read a chunk from now)
+    //   slices 24..48   request half A          65..77  half A -> this chunk's buffer (dead after the barrier)        78..98  request half B
+    if constexpr (!FIRST && S >= 12 && S <= 22 && (S - 12) % 2 == 0) pwrite<1, (S - 12) / 2>(st, PAR ^ 1);
+    if constexpr (S >= 24 && S <= 48 && (S - 24) % 4 == 0) pload<0, (S - 24) / 4>(st, a, cn + 2, has2);
+    if constexpr (S >= 65 && S <= 77 && (S - 65) % 2 == 0) pwrite<0, (S - 65) / 2>(st, PAR);
+    if constexpr (S >= 78 && S <= 98 && (S - 78) % 4 == 0) pload<1, (S - 78) / 4>(st, a, cn + 2, has2);
+    // ---- the item's bias / weight-scale values -> LDS for the epilogue (every wave writes the same 64 values; the region is not aliased) ----
+    if constexpr (FIRST && S == 50) {
+        float* sb = reinterpret_cast<float*>(st.sB) + lane_now();
+        sb[0] = st.bst;
+        sb[64] = st.ist;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int PAR, bool FIRST, int... S>
+__device__ __forceinline__ void chunk_impl(State& st, const Args& a, const int cn, const unsigned u_plane, const unsigned u_own, const unsigned u_sh, const bool has1, const bool has2,
+                                           std::integer_sequence<int, S...>) {
+    __builtin_amdgcn_sched_barrier(0);
+    (slice<S, PAR, FIRST>(st, a, cn, u_plane, u_own, u_sh, has1, has2), ...);
+}
+template <int PAR, bool FIRST = false>
+__device__ __forceinline__ void chunk(State& st, const Args& a, const int cn, const unsigned u_plane, const unsigned u_own, const unsigned u_sh) {
+    const bool has1 = cn + 1 < a.CC, has2 = cn + 2 < a.CC;
+    chunk_impl<PAR, FIRST>(st, a, cn, u_plane, u_own, u_sh, has1, has2, std::make_integer_sequence<int, NSLICE>{});
+}
+template <int... O>
+__device__ __forceinline__ void job_all(State& st, const int buf, std::integer_sequence<int, O...>) {
+    (vop<O>(st, buf), ...);
+}
+template <int... I>
+__device__ __forceinline__ void rread_all(State& st, const int pbuf, const int row, std::integer_sequence<int, I...>) {
+    (rread<I>(st, pbuf, row), ...);
+}
+
+template <bool RES, bool PK = false>      // RES: the launch adds a residual; PK: packed rows
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void winograd13_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;                    // exchange region of the epilogue (two halves of 48 KB): the patch buffers are dead by then
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // own position index = wave, shared position index = 4 + (wave >> 1), its cout half = wave & 1
+    const int h = lane >> 5, t = lane & 31;
+    const unsigned u_plane = (unsigned)(a.CoutP * 32);               // bytes per (chunk, position, ky, piece) plane of U
+    const unsigned u_own = (unsigned)wave * 6u * u_plane;
+    const unsigned u_sh = (unsigned)(4 + (wave >> 1)) * 6u * u_plane + (unsigned)(wave & 1) * 1024u;
+
+    State st;
+    st.sB = smem + 2 * P_BYTES;
+    st.row_pitch = (unsigned)(a.W * a.ldx * 4);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        st.co[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave == 0 ? OWN_C[0][i] : (wave == 1 ? OWN_C[1][i] : (wave == 2 ? OWN_C[2][i] : OWN_C[3][i])))));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st.cs[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave < 2 ? SH_C[0][i] : SH_C[1][i])));
+    // patch image [row][quad][phase][33 px] x 16 B: the lanes of a ds_read_b128 group (same h, 16 consecutive t) read consecutive slots of one plane
+    {
+        const int s1 = (2 * h) * QUAD_SLOTS + t + 1;                                    // d4 = column 4 t + 4: plane 0, slot t + 1 (the lowest address of d1..d4)
+        const int se = wave < 2 ? (2 * h) * QUAD_SLOTS + t : (2 * h) * QUAD_SLOTS + 1 * PXQ + t + 1;       // d0 = column 4 t: plane 0, slot t;  d5 = column 4 t + 5: plane 1, slot t + 1
+        st.pa = smem + s1 * 16;
+        st.pe = smem + se * 16;
+    }
+    // staging pieces: row piece (row i, half k) = (patch row i, column 64 k + tid / 4, channel quad tid % 4); the column piece = columns 128, 129 of all six rows (threads 0..47)
+    {
+        const int q = tid & 3, c = tid >> 2;
+        st.wb = smem + (q * QUAD_SLOTS + (c & 3) * PXQ + (c >> 2)) * 16;
+        const int er = tid >> 3, ec = PXW + ((tid >> 2) & 1);
+        st.wext = tid < 8 * PR ? smem + (er * ROW_SLOTS + q * QUAD_SLOTS + (ec & 3) * PXQ + (ec >> 2)) * 16 : smem + (PR * ROW_SLOTS + (tid & 63)) * 16;
+    }
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((a.flags & CNL_RELU) ? 0 : (int)0xff800000u));      // ReLU floor or -inf
+
+#define W13_DIVMOD(q_, r_, b_, d_, m_)                                                                           \
+    do {                                                                                                         \
+        unsigned qq_ = __builtin_amdgcn_readfirstlane(__umulhi((b_), (m_)));                                     \
+        unsigned rr_ = (b_) - qq_ * (unsigned)(d_);                                                              \
+        if (rr_ >= (unsigned)(d_)) { ++qq_; rr_ -= (unsigned)(d_); }                                             \
+        (q_) = qq_; (r_) = rr_;                                                                                  \
+    } while (0)
+    // the same per lane (packed rows: virtual column -> image, pixel)
+#define W13_VDIVMOD(q_, r_, b_, d_, m_)                                                                          \
+    do {                                                                                                         \
+        unsigned qq_ = __umulhi((b_), (m_));                                                                     \
+        unsigned rr_ = (b_) - qq_ * (unsigned)(d_);                                                              \
+        if (rr_ >= (unsigned)(d_)) { ++qq_; rr_ -= (unsigned)(d_); }                                             \
+        (q_) = qq_; (r_) = rr_;                                                                                  \
+    } while (0)
+    // max |x| of image img_; images past the end of the batch: 0 -> scale 1
+#define W13_XMAX_OF(img_) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                          \
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.xmax, 0, a.Nimg * 4 * AMS, 0x00020000), (unsigned)(img_) * (4u * AMS), 0, 0))
+    // power-of-two scale of V from the image's maximum: |V| <= 7 max |x|, 7 max |x| S in [2^13, 2^14); es_ = log2 S
+#define W13_SCALE_EXP(es_, xmax_)                                                                                \
+    do {                                                                                                         \
+        const float mxv_ = V_BOUND * (xmax_);                                                                    \
+        (es_) = 0;                                                                                               \
+        if (mxv_ > 0.f && mxv_ < __builtin_inff()) {                                                             \
+            int e_;                                                                                              \
+            (void)__builtin_frexpf(mxv_, &e_);            /* 2^(e-1) <= mxv < 2^e */                             \
+            e_ = 14 - e_;                                                                                        \
+            (es_) = e_ < -100 ? -100 : (e_ > 100 ? 100 : e_);                                                    \
+        }                                                                                                        \
+    } while (0)
+
+#ifdef W13_TRACE
+    int tr_item = 0;
+#endif
+    // Coordinates, per-thread addressing and ALL global requests of a work item (the 26 patch pieces of its chunks 0 / 1 into `keep`, the kernel-row
+    // 0 / 1 weight fragments of chunk 0, its image's maximum, its bias / weight scales).  Issued for the first item before the loop and for every later
+    // one INSIDE the previous item's epilogue (behind pass 1, when three of the four accumulator rows are dead): winograd10.hip.
+    struct Coord { int n, y0, x0, n0; };
+    u32x4 keep[4][NSTG];
+    Coord cc;
+    float xmax_cur;
+    auto request = [&](const unsigned item_, const bool ok_item) __attribute__((always_inline)) {
+        {
+            unsigned b_ = __builtin_amdgcn_readfirstlane(cnl::xcd_remap(item_, (unsigned)a.blocks));
+            unsigned q_, nbi_, bxi_, byi_;
+            W13_DIVMOD(q_, nbi_, b_, a.nb, a.m_nb); b_ = q_;
+            W13_DIVMOD(q_, bxi_, b_, a.bx, a.m_bx); b_ = q_;
+            W13_DIVMOD(q_, byi_, b_, a.by, a.m_by);
+            cc.n = (int)q_; cc.y0 = (int)byi_ * R; cc.x0 = (int)bxi_ * PXW; cc.n0 = (int)nbi_ * BN;
+        }
+        {
+            st.cur.y0m1 = cc.y0 - 1;
+            st.cur.img_base = (unsigned)(cc.n * a.H) * st.row_pitch;
+            int tid_ = tid;
+            asm volatile("" : "+v"(tid_));      // keeps the per-thread decode inside the item loop
+            const int q_ = tid_ & 3;
+            const int er_ = tid_ >> 3, ex_ = cc.x0 + PXW - 1 + ((tid_ >> 2) & 1), ey_ = cc.y0 - 1 + er_;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ix_ = cc.x0 - 1 + 64 * k + (tid_ >> 2);
+                if constexpr (PK) {   // packed rows: virtual column -> (image, pixel of its strip); the strip's padding columns, a column before the first strip or behind the last: zeros
+                    unsigned si_, px_;
+                    W13_VDIVMOD(si_, px_, (unsigned)ix_, a.pk, a.m_pk);
+                    const bool okc_ = ix_ >= 0 && (int)px_ < a.W && (int)si_ < a.Nimg;
+                    st.cur.vcol[k] = okc_ ? (unsigned)((((int)si_ * a.H * a.W + (int)px_) * a.ldx + q_ * 4) * 4) : OOB;
+                } else {
+                    st.cur.vcol[k] = (unsigned)ix_ < (unsigned)a.W ? (unsigned)((ix_ * a.ldx + q_ * 4) * 4) : OOB;
+                }
+            }
+            if constexpr (PK) {
+                unsigned esi_, epx_;
+                W13_VDIVMOD(esi_, epx_, (unsigned)ex_, a.pk, a.m_pk);
+                const bool oke_ = tid_ < 8 * PR && (unsigned)ey_ < (unsigned)a.H && (int)epx_ < a.W && (int)esi_ < a.Nimg;
+                st.cur.vext = oke_ ? (unsigned)(((((int)esi_ * a.H + ey_) * a.W + (int)epx_) * a.ldx + q_ * 4) * 4) : OOB;
+            } else {
+                const bool ok_ = tid_ < 8 * PR && (unsigned)ey_ < (unsigned)a.H && (unsigned)ex_ < (unsigned)a.W;
+                st.cur.vext = ok_ ? (unsigned)(((ey_ * a.W + ex_) * a.ldx + q_ * 4) * 4) : OOB;
+            }
+            st.cur.u_voff = (unsigned)((cc.n0 + (tid_ & 31)) * 32 + ((tid_ >> 5) & 1) * 16);
+        }
+        int img_lane = cc.n;                                   // the image of this lane's tile (V production)
+        if constexpr (PK) {
+            unsigned q_, r_;
+            W13_VDIVMOD(q_, r_, (unsigned)(cc.x0 + 4 * (lane_now() & 31)), a.pk, a.m_pk);
+            img_lane = (int)q_;
+        }
+        xmax_cur = W13_XMAX_OF(img_lane);
+        {   // this item's bias and inverse weight scales: one value per lane, written to LDS inside the first chunk (slice 50)
+            const int co = cc.n0 + lane_now();
+            st.bst = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (int)a.b_bytes, 0x00020000),
+                                                                                    co < a.Cout ? (unsigned)co * 4u : OOB, 0, 0));
+            st.ist = co < a.CoutP ? a.isu[co] : 0.f;
+        }
+        // patches 0 / 1 (all 26 pieces requested before the first is written: one memory latency) and the weight rows 0 / 1 of chunk 0
+#define W13_PLOAD_HALF(dst_, half_, cc_)                                                                         \
+        do {                                                                                                     \
+            pload<half_, 0>(st, a, cc_, ok_item); pload<half_, 1>(st, a, cc_, ok_item); pload<half_, 2>(st, a, cc_, ok_item); \
+            pload<half_, 3>(st, a, cc_, ok_item); pload<half_, 4>(st, a, cc_, ok_item); pload<half_, 5>(st, a, cc_, ok_item); \
+            if constexpr (half_ == 0) pload<0, 6>(st, a, cc_, ok_item);                                          \
+            _Pragma("unroll") for (int i = 0; i < NSTG; ++i) keep[dst_][i] = st.stg[i];                          \
+        } while (0)
+        W13_PLOAD_HALF(0, 0, 0);
+        W13_PLOAD_HALF(1, 1, 0);
+        W13_PLOAD_HALF(2, 0, 1);
+        W13_PLOAD_HALF(3, 1, 1);
+#undef W13_PLOAD_HALF
+#pragma unroll
+        for (int i = 0; i < 6; ++i) load_b<0>(st, a, 0, i, u_plane, u_own, u_sh, ok_item);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) load_b<1>(st, a, 0, i, u_plane, u_own, u_sh, ok_item);
+    };
+    unsigned item = blockIdx.x;
+    request(item, true);
+    while (true) {
+        W13_STAMP(0);
+        const Coord ci = cc;                // this item's coordinates (cc is overwritten with the next item's inside the epilogue)
+        // ---- prologue: patches 0 / 1 -> LDS, V rows 0 / 1 of chunk 0, the raw reads of row 2 ----
+        {
+            int es_cur;
+            W13_SCALE_EXP(es_cur, xmax_cur);
+            st.cur.S = __builtin_ldexpf(1.f, es_cur);
+        }
+        W13_BARRIER();                      // the previous item's last exchange pass has been read by every wave: the region is free
+        W13_STAMP(1);
+#define W13_PWRITE_HALF(src_, half_, pbuf_)                                                                      \
+        do {                                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < NSTG; ++i) st.stg[i] = keep[src_][i];                          \
+            pwrite<half_, 0>(st, pbuf_); pwrite<half_, 1>(st, pbuf_); pwrite<half_, 2>(st, pbuf_);               \
+            pwrite<half_, 3>(st, pbuf_); pwrite<half_, 4>(st, pbuf_); pwrite<half_, 5>(st, pbuf_);               \
+            if constexpr (half_ == 0) pwrite<0, 6>(st, pbuf_);                                                   \
+        } while (0)
+        W13_PWRITE_HALF(0, 0, 0);
+        W13_PWRITE_HALF(1, 1, 0);
+        W13_PWRITE_HALF(2, 0, 1);
+        W13_PWRITE_HALF(3, 1, 1);
+#undef W13_PWRITE_HALF
+        W13_BARRIER();
+        W13_STAMP(2);
+        typedef std::make_integer_sequence<int, 10> Reads;
+        typedef std::make_integer_sequence<int, JOB_OPS> Ops;
+        rread_all(st, 0, 0, Reads{});
+        job_all(st, 0, Ops{});
+        rread_all(st, 0, 1, Reads{});
+        job_all(st, 1, Ops{});
+        rread_all(st, 0, 2, Reads{});
+        W13_STAMP(3);
+        chunk<0, true>(st, a, 0, u_plane, u_own, u_sh);
+        W13_STAMP(4);
+        chunk<1, false>(st, a, 1, u_plane, u_own, u_sh);
+        W13_STAMP(5);
+        for (int cn = 2; cn < a.CC; cn += 2) {
+            chunk<0, false>(st, a, cn, u_plane, u_own, u_sh);
+            chunk<1, false>(st, a, cn + 1, u_plane, u_own, u_sh);
+        }
+        W13_STAMP(6);
+        W13_BARRIER();                      // every wave is done with the patch buffers: the exchange region may overwrite them
+        W13_STAMP(7);
+
+        // ---- epilogue, four passes (pass j = output row j): the six positions meet through LDS.  Every wave writes its three blocks of that row (own
+        // position: two cout halves; shared position: its half) into one half of the exchange region as [cout half][position][tile][16-byte piece = 4
+        // couts], pieces XOR-swizzled by the tile; wave w finishes cout half w & 1 of tiles 16 (w >> 1) .. + 15 for all six positions with
+        // thread = (tile, piece): the 8 lanes of a tile store one full 128-byte line of each of its four pixels.
+        //   o0 = Y0 + Y1 + Y2 + Y3 + Y4      o1 = -Y1 + Y2 + Y3 / 2 - 2 Y4      o2 = Y1 + Y2 + Y3 / 4 + 4 Y4      o3 = -Y1 + Y2 + Y3 / 8 - 8 Y4 + Y5
+        // (math positions; position INDEX i = math position i + 1 for i < 4, 4 = math position 0, 5 = math position 5) ----
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int t_e = lane_e & 31, h_e = lane_e >> 5;
+        const int g_e = wave & 1;
+        const int piece_e = lane_e & 7;
+        const int cout_e = ci.n0 + g_e * 32 + piece_e * 4;            // this thread's four couts
+        const bool cok_e = cout_e < a.Cout;
+        const f32x4 bq = lds_f4(st.sB + (g_e * 32 + piece_e * 4) * 4);
+        const f32x4 isu_e = lds_f4(st.sB + 256 + (g_e * 32 + piece_e * 4) * 4);
+        const int wslot0 = t_e * 8, wsw = t_e & 7;
+        const int sh_pos = 4 + (wave >> 1);
+        int rslot[2], rimg[2], rpx[2];
+        f32x4 iq[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rtile = 16 * (wave >> 1) + 8 * i + (lane_e >> 3);
+            rslot[i] = rtile * 8 + (piece_e ^ (rtile & 7));
+            rimg[i] = ci.n;
+            rpx[i] = ci.x0 + 4 * rtile;
+            if constexpr (PK) {   // packed rows: the tile's virtual column -> (image, pixel); a strip's padding columns (pixel >= W) are not stored
+                unsigned q_, r_;
+                W13_VDIVMOD(q_, r_, (unsigned)(ci.x0 + 4 * rtile), a.pk, a.m_pk);
+                rimg[i] = (int)q_; rpx[i] = (int)r_;
+                int es_i;             // the tile's image is not the one this lane builds V for: its scale from its maximum
+                W13_SCALE_EXP(es_i, W13_XMAX_OF(rimg[i]));
+                iq[i] = isu_e * __builtin_ldexpf(1.f, -es_i);
+            } else {              // 1 / S from the exponent of the scale in use (S = 2^e exactly)
+                iq[i] = isu_e * __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(unsigned, st.cur.S));
+            }
+        }
+        float omax2[2] = {0.f, 0.f};
+        unsigned yv0[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) yv0[i] = ((unsigned)((rimg[i] * a.H + ci.y0) * a.W + rpx[i]) * (unsigned)a.ldy + (unsigned)cout_e) * 4u;
+        const unsigned y_row = (unsigned)(a.W * a.ldy) * 4u;
+        // what the images' max |y| slots hold so far: requested HERE, ahead of the item's stores, read behind the last pass (cnl::peek_max)
+        unsigned yseen[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) yseen[i] = a.ymax ? cnl::peek_max(a.ymax + (rimg[i] < a.Nimg ? rimg[i] : 0) * AMS) : 0u;
+#define W13_XW(A_, pos_, g_, q_, j_)                                                                             \
+        *reinterpret_cast<f32x4*>(sX + ((j_) & 1) * X_HALF + (((g_) * 6 + (pos_)) * 256 + wslot0 + ((2 * (q_) + h_e) ^ wsw)) * 16) = \
+            f32x4{(A_)[4 * (q_)], (A_)[4 * (q_) + 1], (A_)[4 * (q_) + 2], (A_)[4 * (q_) + 3]}
+        // the twelve exchange writes of row j_ in four groups of three (two own + one shared), spread over the arithmetic of the pass before
+#define W13_XWRITE3(j_, k_)                                                                                      \
+        do {                                                                                                     \
+            W13_XW(st.acc[j_][0], wave, 0, (k_), j_);                                                            \
+            W13_XW(st.acc[j_][1], wave, 1, (k_), j_);                                                            \
+            W13_XW(st.acs[j_], sh_pos, g_e, (k_), j_);                                                           \
+        } while (0)
+        const unsigned next = item + gridDim.x;
+        const bool more = next < (unsigned)a.blocks;
+        f32x4 rvl[R - 2][2][4];            // residual values of rows 2, 3 (RES)
+        f32x2 iql[2], iqh[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { iql[i] = f32x2{iq[i][0], iq[i][1]}; iqh[i] = f32x2{iq[i][2], iq[i][3]}; }
+        const f32x2 bql = {bq[0], bq[1]}, bqh = {bq[2], bq[3]};
+        W13_XWRITE3(0, 0); W13_XWRITE3(0, 1); W13_XWRITE3(0, 2); W13_XWRITE3(0, 3);
+        W13_BARRIER();
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const char* X = sX + (j & 1) * X_HALF;
+            const int oy = ci.y0 + j;
+            const bool row_ok = oy < a.H && cok_e;
+            unsigned yv[2];
+            bool ok[2][4];
+            f32x4 rv[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ox = rpx[i];
+                yv[i] = yv0[i] + (unsigned)j * y_row;
+#pragma unroll
+                for (int px = 0; px < 4; ++px) ok[i][px] = row_ok && ox + px < a.W && rimg[i] < a.Nimg;
+                if constexpr (RES) {
+                    if (j < 2) {
+                        const unsigned rvo = ((unsigned)((rimg[i] * a.H + oy) * a.W + ox) * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
+#pragma unroll
+                        for (int px = 0; px < 4; ++px)
+                            rv[i][px] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, ok[i][px] ? rvo : OOB, (unsigned)(px * a.ldr * 4)));
+                    } else {      // rows 2, 3: requested behind pass 1, AHEAD of the next item's requests (loads return in order)
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) rv[i][px] = rvl[j - 2][i][px];
+                    }
+                }
+            }
+            W13_STAMP(8 + j);
+            f32x4 Y[2][6];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 6; ++p) Y[i][p] = lds_f4(X + ((g_e * 6 + p) * 256 + rslot[i]) * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                // One pixel at a time: its two cout pairs, its store, then the next pixel's arithmetic.  (All four pixels first and four 16-byte stores in a
+                // row — the shape of winograd9.hip's pass with two pixels — went wrong on the hardware: the stores queue, the fourth reads its data
+                // registers ~50 cycles after it was issued, and the VALU instruction that reused one of them two slots later won: one cout of pixel 3 in the
+                // last four lanes of every 16 held the next tile's sum.  A store's registers are therefore kept alive until the next pixel is done.)
+                f32x4 o[4];
+#define W13_Y2(p_, hh_) f32x2{Y[i][p_][2 * (hh_)], Y[i][p_][2 * (hh_) + 1]}
+                f32x2 s12[2], d12[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) { s12[hh] = W13_Y2(0, hh) + W13_Y2(1, hh); d12[hh] = W13_Y2(1, hh) - W13_Y2(0, hh); }      // math positions 1, 2
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const f32x2 m3 = W13_Y2(2, hh), m4 = W13_Y2(3, hh), m0 = W13_Y2(4, hh), m5 = W13_Y2(5, hh);
+                        const f32x2 sc = hh ? iqh[i] : iql[i], bb = hh ? bqh : bql;
+                        f32x2 y;
+                        if (px == 0) y = (m0 + s12[hh]) + (m3 + m4);
+                        else if (px == 1) y = d12[hh] + (0.5f * m3 - 2.f * m4);
+                        else if (px == 2) y = s12[hh] + (0.25f * m3 + 4.f * m4);
+                        else y = (d12[hh] + m5) + (0.125f * m3 - 8.f * m4);
+                        y = y * sc + bb;
+                        if constexpr (RES) y += f32x2{rv[i][px][2 * hh], rv[i][px][2 * hh + 1]};
+                        o[px][2 * hh] = fmaxf(y[0], lo); o[px][2 * hh + 1] = fmaxf(y[1], lo);
+                    }
+                    if (px > 0) asm volatile("" :: "v"(o[px - 1]));      // the previous pixel's store has read its registers by now
+                    buf_store16(o[px], a.y, a.y_bytes, ok[i][px] ? yv[i] : OOB, (unsigned)(px * a.ldy * 4));
+                    if (ok[i][px]) omax2[i] = fmaxf(omax2[i], fmaxf(fmaxf(fabsf(o[px][0]), fabsf(o[px][1])), fmaxf(fabsf(o[px][2]), fabsf(o[px][3]))));
+                    if (j + 1 < R && (px & 1)) { W13_XWRITE3(j + 1, 2 * i + (px >> 1)); }
+                }
+                asm volatile("" :: "v"(o[3]));
+#undef W13_Y2
+            }
+            if (j + 1 < R) { W13_BARRIER(); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j == 1) {
+                // three of the four accumulator rows are dead: the next item's requests go out here and fly during passes 2 and 3 — first the residual rows those passes add
+                if constexpr (RES) {
+#pragma unroll
+                    for (int jj = 2; jj < R; ++jj)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const bool okr = ci.y0 + jj < a.H && cok_e && rimg[i] < a.Nimg;
+                            const unsigned rvo = ((unsigned)((rimg[i] * a.H + ci.y0 + jj) * a.W + rpx[i]) * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
+#pragma unroll
+                            for (int px = 0; px < 4; ++px)
+                                rvl[jj - 2][i][px] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, (okr && rpx[i] + px < a.W) ? rvo : OOB, (unsigned)(px * a.ldr * 4)));
+                        }
+                }
+                request(more ? next : item, more);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef W13_XWRITE3
+#undef W13_XW
+        if (a.ymax) {          // max |y| of this item into its image's slot: the 8 tiles of an iteration lie in one image ...
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int img = __builtin_amdgcn_readfirstlane(rimg[i]);
+                if constexpr (PK) {    // ... or, in packed rows, in two neighbouring strips (pk >= 32): the first tile's image and the one behind it
+                    const float m1 = cnl::wave_max_nonneg(rimg[i] != img ? omax2[i] : 0.f);
+                    if (lane_e == 0 && img + 1 < a.Nimg) cnl::report_max(a.ymax + (img + 1) * AMS, m1);
+                    omax2[i] = rimg[i] == img ? omax2[i] : 0.f;
+                }
+                const float m = cnl::wave_max_nonneg(omax2[i]);
+                if (lane_e == 0 && img < a.Nimg) cnl::raise_max(a.ymax + img * AMS, m, (unsigned)__builtin_amdgcn_readfirstlane((int)yseen[i]));
+            }
+        }
+        W13_STAMP(12);
+#ifdef W13_TRACE
+        ++tr_item;
+#endif
+        if (!more) break;
+        item = next;
+    }
+#undef W13_DIVMOD
+#undef W13_VDIVMOD
+#undef W13_SCALE_EXP
+#undef W13_XMAX_OF
+}
+
+// fp32 OHWI 3x3 weights -> U_i[ky] = (G g[ky])_(math position of index i) per (co, ci) (formed in double, rounded once), scaled PER OUTPUT CHANNEL by
+// S_u[co] = 2^(13 - e) (max |U[co]| = m 2^e) and split into two fp16 pieces: [ci/16][position index][ky][piece][CoutP][16 ci]; isu[co] = 1 / S_u[co].
+// Position index -> math position: 0..3 -> 1..4, 4 -> 0, 5 -> 5.  One workgroup per output channel.
+__device__ __forceinline__ void u_of(const float g0, const float g1, const float g2, float (&u)[6]) {
+    const double a = g0, b = g1, c = g2;
+    u[0] = (float)((-a + b - c) / 3.0);
+    u[1] = (float)((a + b + c) / 3.0);
+    u[2] = (float)((-16.0 * a - 8.0 * b - 4.0 * c) / 15.0);
+    u[3] = (float)((a - 2.0 * b + 4.0 * c) / 15.0);
+    u[4] = g0;
+    u[5] = g2;
+}
+__global__ __launch_bounds__(256) void weights13_kernel(const float* __restrict__ w, unsigned short* __restrict__ u13, float* __restrict__ isu,
+                                                        int Cin, int Cout, int CoutP) {
+    const int co = blockIdx.x;
+    __shared__ float wm[4];
+    float m = 0.f;
+    if (co < Cout)
+        for (int ci = threadIdx.x; ci < Cin; ci += 256)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                float u[6];
+                u_of(w[((long)co * 9 + ky * 3 + 0) * Cin + ci], w[((long)co * 9 + ky * 3 + 1) * Cin + ci], w[((long)co * 9 + ky * 3 + 2) * Cin + ci], u);
+#pragma unroll
+                for (int p = 0; p < 6; ++p) m = fmaxf(m, fabsf(u[p]));
+            }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    float Su = 1.f;
+    if (m > 0.f && m < __builtin_inff()) {
+        int e_;
+        (void)__builtin_frexpf(m, &e_);
+        e_ = 13 - e_;
+        Su = __builtin_ldexpf(1.f, e_ < -100 ? -100 : (e_ > 100 ? 100 : e_));
+    }
+    if (threadIdx.x == 0) isu[co] = 1.f / Su;
+    for (int ci = threadIdx.x; ci < Cin; ci += 256) {
+        const int cc = ci >> 4, c16 = ci & 15;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            float u[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (co < Cout) u_of(w[((long)co * 9 + ky * 3 + 0) * Cin + ci], w[((long)co * 9 + ky * 3 + 1) * Cin + ci], w[((long)co * 9 + ky * 3 + 2) * Cin + ci], u);
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                const float xs = u[p] * Su;
+                const _Float16 hf = (_Float16)xs;
+                const _Float16 lf = (_Float16)(xs - (float)hf);
+                const long base = (((((long)cc * 6 + p) * 3 + ky) * 2) * CoutP + co) * 16 + c16;
+                u13[base] = __builtin_bit_cast(unsigned short, hf);
+                u13[base + (long)CoutP * 16] = __builtin_bit_cast(unsigned short, lf);
+            }
+        }
+    }
+}
+
+}  // namespace cnl_wino13
+
+#ifdef W13_TRACE
+static unsigned long long* g_w13_trace = nullptr;
+extern "C" void cnl_w13_set_trace(void* p) { g_w13_trace = (unsigned long long*)p; }
+#endif
+
+// bytes of this kernel's fp16-split weights (0 when it does not apply) and floats of the per-cout scales behind them
+size_t cnl_wino13_weight_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0 || Cin % 32) return 0;
+    const size_t CoutP = (size_t)((Cout + 63) / 64) * 64;
+    return (size_t)(Cin / 16) * 6 * 3 * 2 * CoutP * 32;
+}
+size_t cnl_wino13_scalar_floats(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0 || Cin % 32) return 0;
+    return (size_t)((Cout + 63) / 64) * 64;
+}
+int cnl_wino13_transform_weights(const float* w_ohwi, void* u13, float* isu, int Cin, int Cout, void* stream) {
+    using namespace cnl_wino13;
+    const int CoutP = (Cout + 63) / 64 * 64;
+    hipLaunchKernelGGL(weights13_kernel, dim3((unsigned)CoutP), dim3(256), 0, (hipStream_t)stream, w_ohwi, (unsigned short*)u13, isu, Cin, Cout, CoutP);
+    return cnl::check_launch("weights13_kernel");
+}
+// can this kernel run the layer at all?  (shape / alignment only; no folded upsample, no folded 1x1 conv)
+bool cnl_wino13_eligible(const cnl_conv_params* p) {
+    return p->Cin % 32 == 0 && p->Cin >= 32 && p->Cout % 4 == 0 && p->ldy % 4 == 0 && ((uintptr_t)p->y & 15) == 0 && !(p->flags & CNL_UPSAMPLE_IN) && !p->fuse_w &&
+           (!p->residual || (p->ldr % 4 == 0 && ((uintptr_t)p->residual & 15) == 0));
+}
+// Packed rows of the F(4,3) kernel: the launch's images side by side in one virtual row, image n in the strip [n pk, n pk + W) with pk = the next multiple
+// of 4 above W (the tiles are four pixels wide and strips start on tile boundaries; the columns behind an image are its right and the next image's left
+// zero padding).  Returns pk, or 0 where the plain block grid needs no more block rows (or W is odd).
+int cnl_wino13_packed_stride(const cnl_conv_params* p) {
+    const int W = p->W_in;
+    if (W % 2 || W < 28) return 0;       // (pk >= 32: the 8 tiles of an epilogue iteration lie in at most two strips)
+    if (p->algo >= CNL_ALGO_FORCE + 32) return 0;          // tests: FORCE + 32 + v = variant v on the plain block grid
+    const long long pk = W / 4 * 4 + 4;
+    const long long plain = (long long)p->N * ((W + 127) / 128), packed = ((long long)p->N * pk + 127) / 128;
+    return packed < plain ? (int)pk : 0;
+}
+
+int cnl_wino_images_per_launch(const cnl_conv_params* p);                                      // winograd9.hip: tensors of >= 4 GiB run in groups of images
+void cnl_wino_sub_batch(const cnl_conv_params* p, int n0, int n, cnl_conv_params* q, const float** xmax);
+static int wino13_launch_one(const cnl_conv_params* p, const void* u13, const float* isu, const float* xmax, void* stream) {
+    using namespace cnl_wino13;
+    Args a;
+    a.x = p->x; a.u13 = u13; a.xmax = xmax; a.isu = isu; a.ymax = reinterpret_cast<unsigned*>(p->y_absmax);
+    a.bias = p->bias; a.res = p->residual; a.y = p->y;
+    a.Nimg = p->N; a.H = p->H_in; a.W = p->W_in; a.Cin = p->Cin; a.Cout = p->Cout;
+    a.N = p->N;
+    a.pk = cnl_wino13_packed_stride(p);
+    a.m_pk = a.pk ? (unsigned)(0x100000000ull / (unsigned)a.pk) : 0u;
+    if (a.pk) a.N = 1;
+    a.CoutP = (p->Cout + 63) / 64 * 64;
+    a.ldx = p->ldx; a.ldy = p->ldy; a.ldr = p->ldr;
+    a.CC = p->Cin / 16;
+    a.nb = a.CoutP / BN; a.bx = a.pk ? (int)(((long long)p->N * a.pk + PXW - 1) / PXW) : (a.W + PXW - 1) / PXW; a.by = (a.H + R - 1) / R;
+    const auto magic = [](int d) { return d == 1 ? 0xFFFFFFFFu : (unsigned)(0x100000000ull / (unsigned)d); };
+    a.m_nb = magic(a.nb); a.m_bx = magic(a.bx); a.m_by = magic(a.by);
+    const long long blocks = (long long)a.N * a.by * a.bx * a.nb;
+    CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: grid too large");
+    a.blocks = (int)blocks;
+    const unsigned long long xb = (((unsigned long long)p->N * p->H_in * p->W_in - 1) * p->ldx + p->Cin) * 4ull;
+    const unsigned long long ub = (unsigned long long)cnl_wino13_weight_bytes(p->Cin, p->Cout);
+    const unsigned long long Mo = (unsigned long long)p->N * a.H * a.W;
+    const unsigned long long yb = ((Mo - 1) * p->ldy + p->Cout) * 4ull;
+    const unsigned long long rb = p->residual ? ((Mo - 1) * p->ldr + p->Cout) * 4ull : 0ull;
+    CNL_REQUIRE(xb < 0xFFFFFF00ull && ub < 0xFFFFFF00ull && yb + 16ull * p->ldy < 0xFFFFFF00ull && rb + 16ull * (p->residual ? p->ldr : 0) < 0xFFFFFF00ull,
+                CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: tensor spans >= 4 GiB; split the batch");
+    a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb; a.r_bytes = (unsigned)rb; a.b_bytes = (unsigned)p->Cout * 4u;
+    a.flags = p->flags;
+#ifdef W13_TRACE
+    a.trace = g_w13_trace;
+#endif
+    static cnl::DeviceOnce once[4];
+    const void* const fns[4] = {reinterpret_cast<const void*>(&winograd13_kernel<false, false>), reinterpret_cast<const void*>(&winograd13_kernel<true, false>),
+                                reinterpret_cast<const void*>(&winograd13_kernel<false, true>), reinterpret_cast<const void*>(&winograd13_kernel<true, true>)};
+    const int which = (p->residual ? 1 : 0) + (a.pk ? 2 : 0);
+    int n_cu = 0;                          // persistent workgroups: one per CU, walking the work items with stride gridDim.x
+    const int rc = cnl::kernel_setup(once[which], fns[which], LDS_BYTES, &n_cu);
+    if (rc != CNL_OK) return rc;
+    const unsigned grid = (unsigned)(blocks < (long long)n_cu ? blocks : (long long)n_cu);
+    switch (which) {
+    case 0: hipLaunchKernelGGL((winograd13_kernel<false, false>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    case 1: hipLaunchKernelGGL((winograd13_kernel<true, false>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL((winograd13_kernel<false, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL((winograd13_kernel<true, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a); break;
+    }
+    return cnl::check_launch("winograd13_kernel");
+}
+// Launch (arguments already validated by cnl_conv3x3_winograd_f32); u13 / isu: this kernel's weight pieces and per-cout scales; xmax = N per-image maxima of the input.
+int cnl_wino13_launch(const cnl_conv_params* p, const void* u13, const float* isu, const float* xmax, void* stream) {
+    const int per = cnl_wino_images_per_launch(p);
+    CNL_REQUIRE(per > 0, CNL_E_UNSUPPORTED, "cnl_conv3x3_winograd_f32: one image of a tensor spans >= 4 GiB");
+    for (int n0 = 0; n0 < p->N; n0 += per) {
+        cnl_conv_params q;
+        const float* xm = xmax;
+        cnl_wino_sub_batch(p, n0, p->N - n0 < per ? p->N - n0 : per, &q, &xm);
+        const int rc = wino13_launch_one(&q, u13, isu, xm, stream);
+        if (rc != CNL_OK) return rc;
+    }
+    return CNL_OK;
+}
