@@ -27,9 +27,10 @@ the script launches those N ranks itself (`self_launch`) and exits non-zero if a
               against the direct-conv, i.e. algorithmic, flops) is reported beside it.  `traffic` is NOT measured in this run: it is
               the rocprofv3 PMC figure of the named profiles/ file (null where no profile of that configuration exists).
   variants  = the same job in the other arithmetic classes of the plan (KernelOptions.algo; in-process, short runs):
-              f32 = fp32 matrix cores only.
+              f32 = fp32 matrix cores only; f43 = "auto" with KernelOptions(f43=True): the 256-channel head blocks on the F(4,3) row kernel
+              (csrc/winograd13.hip, CNL_ALGO_F43: 2.4-3.2 x the fp32 matrix core's rounding error — an opt-in class, see `accuracy`).
   accuracy  = max |feature - float64 oracle| / max |float64 oracle| at the neck output and at each head's last 256-channel block
-              output (what out_conv reads), for auto / f32 and for the CPU fp32 oracle itself, on 2 images of the bench shape.
+              output (what out_conv reads), for auto / f32 / f43 and for the CPU fp32 oracle itself, on 2 images of the bench shape.
               (The post-sigmoid heatmap hides feature error by ~3 orders of magnitude; it is reported too.)  Backbone / ConvBnAct
               parity is "unpinned" by the reference itself (torchvision / vision_toolbox absent): the oracle is this repo's restatement.
   decode    = decode p50 on the forward's own outputs: bytes that must move, GB/s, fraction of 8 TB/s; with a separate sigmoid pass
@@ -66,7 +67,7 @@ HBM_PEAK_GBPS = 8000.0            # same guide: HBM3E spec peak (6.29 TB/s measu
 PROFILE_JSON = {("simple", 32, 512, 512): "profiles/r05_profile_c1.json", ("fpn", 64, 512, 512): "profiles/r05_profile_c2.json",
                 ("tracking", 32, 608, 1088): "profiles/r05_profile_c4.json"}
 # kernel-name PREFIX in the profile JSON (template variants of one kernel — with / without a residual — are combined, weighted by calls)
-KIND_KERNEL = {"winograd_row_f16x2": "cnl_wino9::winograd9_kernel", "winograd_row4_f16x2": "cnl_wino10::winograd10_kernel",
+KIND_KERNEL = {"winograd_row_f16x2": "cnl_wino9::winograd9_kernel", "winograd_row4_f16x2": "cnl_wino10::winograd10_kernel", "winograd_row_f43_f16x2": "cnl_wino13::winograd13_kernel",
                "winograd_f16x2": "cnl_wino5::winograd5_kernel", "winograd_f32": "cnl_wino2::winograd2_kernel"}
 
 
@@ -84,15 +85,17 @@ KIND_NAMES = {"winograd_row4_f16x2": "cnl_wino10::winograd10_kernel (the row-Win
               "winograd_row_f16x2": "cnl_wino9::winograd9_kernel (1-D Winograd F(2,3) along x, the three kernel rows in the reduction: 6 of the direct conv's 9 multiplies "
                                     "per output; fp32 operands scaled per image / per output channel by a power of two and split into 2 fp16 pieces, "
                                     "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
+              "winograd_row_f43_f16x2": "cnl_wino13::winograd13_kernel (1-D Winograd F(4,3) along x, the three kernel rows in the reduction: 4.5 of the direct conv's 9 multiplies "
+                                        "per output, the same split arithmetic; the opt-in class KernelOptions(f43=True) / CNL_ALGO_F43)",
               "winograd_f32": "cnl_wino2::winograd2_kernel (Winograd F(2x2,3x3), fp32 v_mfma_f32_32x32x2_f32)",
               "direct_f16x2": "cnl_conv::conv_f16x2_kernel (direct implicit GEMM, fp16 matrix cores, scaled two-way split)",
               "direct": "cnl_conv::conv_mfma_kernel (direct implicit GEMM, fp32 v_mfma_f32_32x32x2_f32)",
               "fused_out_reduce": "cnl_fused::reduce_kernel (fixed-order sum of the per-32-channel partial sums of a 1x1 out_conv folded into the row-Winograd epilogue; HBM-bound)"}
 # executed matrix flops / direct-conv flops, and the peak they run against
 EXEC = {"winograd_row4_f16x2": (6.0 / 9.0 * 3.0, F16_MFMA_PEAK_TFLOPS), "winograd_f16x2": (16.0 / 36.0 * 3.0, F16_MFMA_PEAK_TFLOPS),
-        "winograd_row_f16x2": (6.0 / 9.0 * 3.0, F16_MFMA_PEAK_TFLOPS),
+        "winograd_row_f16x2": (6.0 / 9.0 * 3.0, F16_MFMA_PEAK_TFLOPS), "winograd_row_f43_f16x2": (4.5 / 9.0 * 3.0, F16_MFMA_PEAK_TFLOPS),
         "winograd_f32": (16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS), "direct_f16x2": (3.0, F16_MFMA_PEAK_TFLOPS), "direct": (1.0, FP32_MFMA_PEAK_TFLOPS),
-        "fused_out_reduce": (1.0, FP32_MFMA_PEAK_TFLOPS)}
+        "fused_out_reduce": (0.0, FP32_MFMA_PEAK_TFLOPS)}      # (the reduce only adds partial sums: no matrix flops — reported against the HBM peak below; the folded 1x1 conv's multiplies run in winograd9's epilogue on the vector ALUs)
 
 
 def synthetic_weights_(model, seed=0):
@@ -295,14 +298,16 @@ def conv_kernel_profile(model, x, reps=3):
             return "direct_f16x2" if lib.cnl_conv3x3_up2_kernel(ctypes.byref(L.args)) == 5 else "direct"
         if L.fn is not lib.cnl_conv3x3_winograd_f32:
             return "direct_f16x2" if lib.cnl_conv2d_kernel(ctypes.byref(L.args)) == 5 else "direct"
-        return {5: "winograd_f16x2", 6: "winograd_f16x2", 9: "winograd_row_f16x2", 10: "winograd_row4_f16x2", 11: "winograd_row4_f16x2"}.get(lib.cnl_conv3x3_winograd_variant(ctypes.byref(L.args)), "winograd_f32")
+        return {5: "winograd_f16x2", 6: "winograd_f16x2", 9: "winograd_row_f16x2", 10: "winograd_row4_f16x2", 11: "winograd_row4_f16x2", 13: "winograd_row_f43_f16x2"}.get(lib.cnl_conv3x3_winograd_variant(ctypes.byref(L.args)), "winograd_f32")
 
     rows = []
     for i, L in enumerate(convs):
         p = L.args
         if L.fn is lib.cnl_fused_out_reduce_f32:        # second half of an out_conv folded into the 3x3 block before it: [part, blocks, M, C2, ...]
+            # HBM-bound: it reads the [blocks][M][4] partial sums and writes [M][C2]; its "flops" are the folded 1x1 conv's ALGORITHMIC flops (counted once, here,
+            # for the conv stack's total) and it executes no matrix instruction
             fl_r = 2.0 * p[2] * p[1] * 32 * p[3] * scale
-            rows.append((L.what, fl_r, acc[i] / reps * scale, "fused_out_reduce", (p[1] * p[2] * 16 + p[2] * p[3] * 4) * scale, fl_r))
+            rows.append((L.what, fl_r, acc[i] / reps * scale, "fused_out_reduce", (p[1] * p[2] * 16 + p[2] * p[3] * 4) * scale, 0.0))
             continue
         up_in = 2 if p.flags & 4 else 1
         ho = (p.H_in * up_in + 2 * p.pad - p.KH) // p.stride + 1
@@ -349,10 +354,14 @@ def roofline_block(rows, config, B, H, W):
             "traffic_source": (traffic[1] + " — rocprofv3 PMC of an earlier run of this command, not measured here") if traffic else
                               "no PMC profile of this kernel / configuration committed yet (see profiles/)",
             "sustained_clock_note": "power-limited DVFS: on the 256-channel head blocks this kernel holds 1.37-1.48 GHz of 2.4 under real data (GRBM_GUI_ACTIVE / duration, profiles/r04_winograd_variants.txt, r04_winograd9_skip4.txt): a denser schedule lowers the clock, 25 % fewer MFMAs buy 12.6 % (DESIGN.md 3.1); a loop of nothing but this MFMA on random fp16 operands sustains 1.84-1.90 PFLOP/s at 1.84-1.90 GHz (profiles/r04_mfma_order.txt), 0.74-0.76 of `peak`"}
-    roof["other_kernels"] = {KIND_NAMES[k_].split(" (")[0]: {"launches_per_step": v[0], "kernel_ms_per_step": round(v[1], 3),
-                                                            "effective_tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0,
-                                                            "executed_frac_of_its_peak": round(v[4] / (v[1] * 1e-3) / 1e12 / EXEC[k_][1], 4) if v[1] else 0.0}
-                             for k_, v in agg.items() if k_ != dom}
+    def other(k_, v):
+        if k_ == "fused_out_reduce":      # HBM-bound: bytes / s against the HBM peak, no executed matrix flops
+            gbps = v[3] / (v[1] * 1e-3) / 1e9 if v[1] else 0.0
+            return {"launches_per_step": v[0], "kernel_ms_per_step": round(v[1], 3), "bound": "hbm", "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4),
+                    "executed_matrix_flops": 0}
+        return {"launches_per_step": v[0], "kernel_ms_per_step": round(v[1], 3), "effective_tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0,
+                "executed_frac_of_its_peak": round(v[4] / (v[1] * 1e-3) / 1e12 / EXEC[k_][1], 4) if v[1] else 0.0}
+    roof["other_kernels"] = {KIND_NAMES[k_].split(" (")[0]: other(k_, v) for k_, v in agg.items() if k_ != dom}
     conv_ms, conv_fl = sum(r[2] for r in rows), sum(r[1] for r in rows)
     stack = {"algorithmic_gflop_per_step": round(conv_fl / 1e9, 2), "kernel_ms_per_step": round(conv_ms, 3),
              "effective_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
@@ -434,7 +443,10 @@ def feature_errors(config, x2, algo):
     """max |feature - float64 oracle| / max |float64 oracle| at the neck output and each head's last-block output + the heatmap."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref_cpu
-    model = build_model(config, algo=algo, reuse_buffers=False) if algo != "cpu" else build_model(config)
+    if algo == "f43":        # the opt-in F(4,3) class (KernelOptions.f43): AUTO's plan with the 256-channel head blocks on csrc/winograd13.hip
+        model = build_model(config, algo="auto", f43=True, reuse_buffers=False)
+    else:
+        model = build_model(config, algo=algo, reuse_buffers=False) if algo != "cpu" else build_model(config)
     sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
     key = (config, tuple(x2.shape), float(x2.double().sum()))          # the float64 oracle once per (weights recipe, input): the same for every class
     if key not in _REF64:
@@ -814,11 +826,11 @@ def main():
             sync = torch.cuda.synchronize
             if not args.no_variants:
                 result["variants"] = {}
-                for algo in ("f32",):
+                for algo in ("f32", "f43"):
                     if algo == args.algo:
                         continue
                     try:
-                        m2 = build_model(args.config, algo=algo)
+                        m2 = build_model(args.config, algo="auto", f43=True) if algo == "f43" else build_model(args.config, algo=algo)
                         st = min(max(args.steps // 2, 3), 20)
                         el = timed(m2, x, tracking, args.k, min(args.warmup, 3), st, cl.Collator(), sync)
                         with torch.no_grad():
@@ -891,7 +903,7 @@ def main():
             if not args.no_accuracy:
                 x2 = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(4242))
                 try:
-                    acc = {a: feature_errors(args.config, x2, a) for a in ("auto", "f32", "cpu")}
+                    acc = {a: feature_errors(args.config, x2, a) for a in ("auto", "f32", "f43", "cpu")}
                     result["accuracy"] = {"max_err_over_max_ref_vs_float64_oracle": acc, "tolerance": 1e-4,
                                           "sample": f"2 images of the bench shape, same weights; 'cpu' = the CPU fp32 oracle's own distance from float64",
                                           "parity_note": "backbone + ConvBnAct parity is unpinned by the reference (torchvision / vision_toolbox absent): the oracle is this repo's restatement; "

@@ -18,11 +18,11 @@ CNL_RELU6 = 1 << 4
 CNL_W_SPLIT = 1 << 5          # cnl_conv_params.w is a cnl_conv_split_weights_f32 buffer (fp32 weights + their fp16 split)
 
 # cnl_conv_params.algo: the arithmetic class a launch may use (include/centernet_gfx950.h)
-CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_LATENCY, CNL_ALGO_FORCE = 0, 1, 2, 4, 100
+CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_LATENCY, CNL_ALGO_F43, CNL_ALGO_FORCE = 0, 1, 2, 4, 5, 100
 CNL_WINO_F32, CNL_WINO_F16X2 = 2, 5
 
 CNL_E_BAD_ARG, CNL_E_UNSUPPORTED, CNL_E_WORKSPACE, CNL_E_HIP = -1, -2, -3, -4
-ABI_VERSION = 12         # CNL_ABI_VERSION of include/centernet_gfx950.h
+ABI_VERSION = 13         # CNL_ABI_VERSION of include/centernet_gfx950.h
 
 
 class ConvParams(Structure):

@@ -53,6 +53,9 @@ class KernelOptions:
                        gets the layer's ROW-PAIR weights (cnl_conv_params.w_up, ABI v12): the upsampled rows 2j and 2j+1 are one source row, so an output row
                        meets two distinct input rows instead of three — 96 instead of 144 matrix instructions per 16-channel chunk; within fp32 rounding of
                        the general form (False), batch-invariant
+      f43              opt-in arithmetic class (default off): 3x3 / stride-1 layers with Cin >= 128 on maps that 4-row x 128-pixel work items tile
+                       well (the 256 -> 256 head blocks) run as 1-D Winograd F(4,3) along x (csrc/winograd13.hip, cnl_conv_params.algo = CNL_ALGO_F43): 25 % fewer
+                       matrix instructions, 2.4-3.2 x the fp32 matrix core's rounding error (inside the path's 1e-4 by two orders of magnitude, above "auto"'s promise)
       split_small      latency mode for small batches (default off): launches whose output is too small to fill the chip (one image: the
                        16x16 .. 64x64 maps) run as direct convs with the reduction split over several workgroups per output tile and a
                        fixed-order reduce (cnl_conv_params.splitk).  The choice then depends on the batch size, so results are no longer
@@ -68,6 +71,7 @@ class KernelOptions:
     split_small: bool = False
     latency: bool = False
     up_rows: bool = True
+    f43: bool = False
 
     @property
     def algo_id(self):
@@ -679,6 +683,8 @@ class Plan:
             what += " [winograd]"
             if self.options.latency and self.algo in (CNL_ALGO_AUTO, CNL_ALGO_F2):
                 p.algo = CNL_ALGO_LATENCY
+            elif self.options.f43 and self.algo in (CNL_ALGO_AUTO, CNL_ALGO_F2):
+                p.algo = CNL_ALGO_F43
         # the row-Winograd kernels (winograd9.hip / winograd10.hip) fold the upsample into their patch gather and beat the sub-pixel phases
         # below (C1: 8.93 -> 8.82 ms per forward); whether a layer takes one is the dispatcher's decision — asked, not re-derived here
         rowwino = (fn is self.lib.cnl_conv3x3_winograd_f32 and self.algo != CNL_ALGO_F32
@@ -1011,6 +1017,11 @@ class Plan:
         L = self.launches[-1]
         if L.args is not p_last or L.fn is not self.lib.cnl_conv3x3_winograd_f32 or p_last.Cout != p_last.ldy:
             return False
+        # only winograd9's epilogue has the fold, and the dispatcher keeps a launch that carries fuse_w there: a block whose own choice is the small work
+        # items of variant 11 — the latency class, or a launch of at most half the CUs' worth of items (one image: 63 us on 9 against 56 on 11,
+        # profiles/r04_small_batch_variants.txt) — keeps them, and its out_conv stays a launch (the fold saves a tiny re-read there)
+        if self.options.latency or self.lib.cnl_conv3x3_winograd_variant(ctypes.byref(p_last)) != 9:
+            return False
         nb = (p_last.Cout + 63) // 64 * 2
         if nb * self.N * oh * ow * 16 > ADDRESS_LIMIT:
             return False
@@ -1021,6 +1032,7 @@ class Plan:
                 _lib.check(self.lib.cnl_fused_out_pack_weights_f32(outl.w.data_ptr(), fw.data_ptr(), outl.cin, outl.cout,
                                                                    ctypes.c_void_p(torch.cuda.current_stream(outl.w.device).cuda_stream)),
                            "cnl_fused_out_pack_weights_f32")
+                torch.cuda.current_stream(outl.w.device).synchronize()      # (as up_rows / split_w: built once, read by the plans of every stream — ADVICE r5)
             outl._fuse_w = fw
         p_last.fuse_w = fw.data_ptr()
         if self.lib.cnl_conv3x3_winograd_variant(ctypes.byref(p_last)) != 9:        # the dispatcher keeps a folded launch on winograd9 — if it can run there

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void stem_zero_borders_kernel(float* __restric
 using namespace cnl_stem5;
 
 #ifdef S5_TRACE
-extern "C" int cnl_stem5_set_trace(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(s5_trace_ptr), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+extern "C" __attribute__((visibility("default"))) int cnl_stem5_set_trace(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(s5_trace_ptr), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
 #endif
 // floats appended to the fp32 packed weights: the two fp16 pieces + 4 scalars
 size_t cnl_stem5_extra_floats() { return (size_t)W_BYTES / 4 + 4; }

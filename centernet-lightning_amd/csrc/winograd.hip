@@ -17,7 +17,9 @@
 // The 16x16-pixel-block fp32 kernel this file used to hold, the exact three-way bf16 split (winograd3/4) and the two-waves-per-SIMD
 // form of 5 (winograd7) are measured-and-superseded variants: tools/experiments/ (`make -C csrc experiments`, algo = CNL_ALGO_FORCE + variant).
 #include "cnl_common.h"
-#if __has_include("build/w9_usage.h")
+#ifdef CNL_W9_VGPR_SPILLS_OVERRIDE      /* `make variant`: the spill count of THAT build's winograd9.hip */
+#define CNL_W9_VGPR_SPILLS CNL_W9_VGPR_SPILLS_OVERRIDE
+#elif __has_include("build/w9_usage.h")
 #include "build/w9_usage.h"      // CNL_W9_VGPR_SPILLS: vector registers the compiler spilled in winograd9.hip's kernels (Makefile)
 #else
 #define CNL_W9_VGPR_SPILLS 0
@@ -193,6 +195,13 @@ static int wino_choice(const cnl_conv_params* p) {
     // items of winograd9's and a second workgroup per CU to overlap with (long channel loops: what was measured) — 512 -> 512 @16x16 x 32: 83 us (winograd5: 90-93, winograd9: 97-107),
     // 512 -> 256: 61-65 us with 32-cout items (fp32 kernel: 89-92)
     if (upf == 1 && W == 16 && p->Cin >= 256 && cnl_wino10_eligible(p) && !p->fuse_w) return p->Cout <= 256 ? 11 : 10;
+    // the F(4,3) class (CNL_ALGO_F43, winograd13.hip): long channel loops on maps that 4-row x 128-pixel items (packed rows included) pad by at most 1.35 x —
+    // the head blocks of 512 x 512 and 608 x 1088 frames.  A function of the shape alone (the padding a long virtual row has, as below).
+    if (p->algo == CNL_ALGO_F43 && p->Cin >= 128 && cnl_wino13_eligible(p)) {
+        const bool packable13 = W % 2 == 0 && W >= 28 && W % 128 != 0;
+        const long long wpad13 = packable13 ? (W / 4 * 4 + 4) : ((W + 127) / 128 * 128);
+        if ((long long)((H + 3) / 4 * 4) * wpad13 * 100 <= area * 135) return 13;
+    }
     // row-Winograd (winograd9.hip): 8-row x 64-pixel x 64-cout work items.  Measured against kernels 2 / 5 / 6 on every 3x3 shape of the
     // three configurations (profiles/r03_winograd9_variants.txt): 0.5-0.8x their time wherever its blocks pad the map by less than ~1.5x
     // (maps at least ~44 pixels wide), channel loops from 32 up, with or without residual / folded upsample
@@ -261,7 +270,7 @@ extern "C" int cnl_conv3x3_winograd_f32(const cnl_conv_params* p, void* stream) 
                 "cnl_conv3x3_winograd_f32: Cin %% 8 != 0 or bad pixel stride");
     CNL_REQUIRE(((uintptr_t)p->x & 15) == 0 && ((uintptr_t)p->w & 15) == 0, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unaligned x / u");
     CNL_REQUIRE(!p->residual || p->ldr >= p->Cout, CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: ldr < Cout");
-    CNL_REQUIRE(p->algo <= CNL_ALGO_F32 || p->algo == CNL_ALGO_LATENCY || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 13 && p->algo != CNL_ALGO_FORCE + 8) ||
+    CNL_REQUIRE(p->algo <= CNL_ALGO_F32 || p->algo == CNL_ALGO_LATENCY || p->algo == CNL_ALGO_F43 || (p->algo >= CNL_ALGO_FORCE && p->algo <= CNL_ALGO_FORCE + 13 && p->algo != CNL_ALGO_FORCE + 8) ||
                     (p->algo >= CNL_ALGO_FORCE + 32 + 9 && p->algo <= CNL_ALGO_FORCE + 32 + 13),
                 CNL_E_BAD_ARG, "cnl_conv3x3_winograd_f32: unknown algo %u (FORCE + 8, the F(4x4) kernel, was removed in ABI v10)", p->algo);
     const int choice = wino_choice(p);

@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 #ifdef W10_TRACE
 static unsigned long long* g_w10_trace = nullptr;
-extern "C" void cnl_w10_set_trace(void* p) { g_w10_trace = (unsigned long long*)p; }
+extern "C" __attribute__((visibility("default"))) void cnl_w10_set_trace(void* p) { g_w10_trace = (unsigned long long*)p; }
 #endif
 // can this kernel run the layer at all?  (the conditions of winograd9.hip: it reads that kernel's weights)
 bool cnl_wino9_eligible(const cnl_conv_params* p);

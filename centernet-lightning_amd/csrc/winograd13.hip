@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int co = cc.n0 + lane_now();
             st.bst = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (int)a.b_bytes, 0x00020000),
                                                                                     co < a.Cout ? (unsigned)co * 4u : OOB, 0, 0));
-            st.ist = co < a.CoutP ? a.isu[co] : 0.f;
+            st.ist = a.isu[co];        // (co < CoutP always: a select on the loaded value is a vmcnt wait here — behind the previous item's stores)
         }
         // patches 0 / 1 (all 26 pieces requested before the first is written: one memory latency) and the weight rows 0 / 1 of chunk 0
 #define W13_PLOAD_HALF(dst_, half_, cc_)                                                                         \
@@ -474,6 +474,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     request(item, true);
     while (true) {
         W13_STAMP(0);
+#ifdef W13_TRACE
+        if (blockIdx.x == 0 && tid == 0 && tr_item < 64) a.trace[tr_item * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+#endif
         const Coord ci = cc;                // this item's coordinates (cc is overwritten with the next item's inside the epilogue)
         // ---- prologue: patches 0 / 1 -> LDS, V rows 0 / 1 of chunk 0, the raw reads of row 2 ----
         {
@@ -684,6 +687,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         W13_STAMP(12);
 #ifdef W13_TRACE
+        if (blockIdx.x == 0 && tid == 0 && tr_item < 64) a.trace[tr_item * 16 + 14] = __builtin_amdgcn_s_memrealtime();
         ++tr_item;
 #endif
         if (!more) break;
@@ -757,7 +761,7 @@ __global__ __launch_bounds__(256) void weights13_kernel(const float* __restrict_
 
 #ifdef W13_TRACE
 static unsigned long long* g_w13_trace = nullptr;
-extern "C" void cnl_w13_set_trace(void* p) { g_w13_trace = (unsigned long long*)p; }
+extern "C" __attribute__((visibility("default"))) void cnl_w13_set_trace(void* p) { g_w13_trace = (unsigned long long*)p; }
 #endif
 
 // bytes of this kernel's fp16-split weights (0 when it does not apply) and floats of the per-cout scales behind them

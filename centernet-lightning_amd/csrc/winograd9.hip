@@ -899,12 +899,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W9_DPP_OF
                     const f32x4 d0 = {e0[0], e0[1], e0[2], e0[3]}, d1 = {e1[0], e1[1], e1[2], e1[3]};
                     const unsigned fv = fv0[i] + (unsigned)j * (unsigned)(a.W * 16);
-                    const bool st = piece_e == 0 && oy < a.H && rimg[i] < a.Nimg;      // (also for blocks of couts >= Cout: their weights are zero)
+                    const bool do_store = piece_e == 0 && oy < a.H && rimg[i] < a.Nimg;      // (also for blocks of couts >= Cout: their weights are zero)
                     // (default cache policy, not nt: eight lanes of a wave fill a 128-byte line of fpart together with their neighbours' stores)
                     {
                         const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.fpart, 0, (int)a.fp_bytes, 0x00020000);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d0), rs, (st && rpx[i] < a.W) ? fv : OOB, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d1), rs, (st && rpx[i] + 1 < a.W) ? fv : OOB, 16, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d0), rs, (do_store && rpx[i] < a.W) ? fv : OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d1), rs, (do_store && rpx[i] + 1 < a.W) ? fv : OOB, 16, 0);
                     }
                 }
             }
@@ -1090,7 +1090,7 @@ int cnl_wino9_transform_weights(const float* w_ohwi, void* u9, float* isu, int C
 
 #ifdef W9_TRACE
 static unsigned long long* g_w9_trace = nullptr;
-extern "C" void cnl_w9_set_trace(void* p) { g_w9_trace = (unsigned long long*)p; }
+extern "C" __attribute__((visibility("default"))) void cnl_w9_set_trace(void* p) { g_w9_trace = (unsigned long long*)p; }
 #endif
 // can this kernel run the layer at all?  (shape / alignment only)
 bool cnl_wino9_eligible(const cnl_conv_params* p) {

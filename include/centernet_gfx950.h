@@ -26,8 +26,12 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the entry points declared in this header are its whole dynamic symbol table. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
-#define CNL_ABI_VERSION 12   /* 12: cnl_conv_params.w_up + cnl_winograd_up_weight_floats / cnl_winograd_transform_weights_up_f32 (a 3x3 conv behind a folded nearest-2x upsample: pre-summed row-pair weights, two instead of three kernel rows per output row), cnl_sizeof_params (a binder's struct-layout check); 11: cnl_conv_params.fuse_w / fuse_part + cnl_fused_out_pack_weights_f32 / cnl_fused_out_reduce_f32 (a 1x1 conv of <= 4 channels folded into the 3x3 launch before it); the row-Winograd kernels take maps of any even width in packed rows and tensors of >= 4 GiB in groups of images; CNL_ALGO_FORCE + 32 + v; 10: per-image maxima arrays are strided (cnl_absmax_stride() = 32 floats: one cache line per image); the stem entry points take y_absmax; CNL_ALGO_LATENCY and the half-height row-Winograd kernel (csrc/winograd10.hip, variants 10 / 11); the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
+#define CNL_ABI_VERSION 13   /* 13: CNL_ALGO_F43 + kernel variant 13 (csrc/winograd13.hip: 1-D Winograd F(4,3) along x on the fp16-split arithmetic; its weight pieces are a new tail of the transformed-weight buffer, so cnl_winograd_weight_floats grows for Cin % 32 == 0); 12: cnl_conv_params.w_up + cnl_winograd_up_weight_floats / cnl_winograd_transform_weights_up_f32 (a 3x3 conv behind a folded nearest-2x upsample: pre-summed row-pair weights, two instead of three kernel rows per output row), cnl_sizeof_params (a binder's struct-layout check); 11: cnl_conv_params.fuse_w / fuse_part + cnl_fused_out_pack_weights_f32 / cnl_fused_out_reduce_f32 (a 1x1 conv of <= 4 channels folded into the 3x3 launch before it); the row-Winograd kernels take maps of any even width in packed rows and tensors of >= 4 GiB in groups of images; CNL_ALGO_FORCE + 32 + v; 10: per-image maxima arrays are strided (cnl_absmax_stride() = 32 floats: one cache line per image); the stem entry points take y_absmax; CNL_ALGO_LATENCY and the half-height row-Winograd kernel (csrc/winograd10.hip, variants 10 / 11); the F(4x4,3x3) split kernel is gone (CNL_ALGO_F4, CNL_WINO_F16X2_F4, cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32 removed: slower than the row-Winograd default at 4x its rounding error); 9: CNL_W_SPLIT + cnl_conv_split_weight_floats / cnl_conv_split_weights_f32 (pre-split weights for the fp16-split direct convs); 8: cnl_track_frame_f32 / cnl_track_frame_bytes (one self-describing record per frame, writable straight into mapped host memory), cnl_host_alloc / cnl_host_free; 7: the F(4x4) weight copy is an optional tail of the transformed-weight buffer (cnl_winograd_f4_weight_floats, cnl_winograd_transform_weights_f4_f32), cnl_conv3x3_winograd_variant, row-Winograd kernel behind CNL_WINO_F16X2; 6: cnl_conv_params.splitk / splitk_scratch (reduction split for small grids), cnl_fuse_sum_nhwc_f32; 5: cnl_conv_params.algo (arithmetic class per launch instead of process-wide environment switches), Winograd F(4x4,3x3) kernel, cnl_stem_conv7x7_f32 takes algo, uint8 stem + resize entry points; 4: cnl_conv_params.w_absmax, cnl_conv2d_kernel, cnl_absmax_per_image_f32 (fp16-split direct conv); 3: cnl_conv_params carries x_absmax / y_absmax (tensor-maximum hand-over between conv launches); 2: stem packed weights are [154][64] (cnl_stem_packed_weight_floats), neck-option / tracker / format entry points */
 
 enum {
     CNL_OK = 0,
@@ -48,7 +52,12 @@ enum {
  *   CNL_ALGO_LATENCY  cnl_conv3x3_winograd_f32 only: AUTO's arithmetic on small work items (csrc/winograd10.hip: 4 rows x 64 pixels x 32 couts, two
  *                  workgroups per CU) wherever the row-Winograd kernels apply — for one-image batches, where the default's 8-row x 64-cout items leave
  *                  most CUs idle (a 256 -> 256 conv on a 32 x 32 map: 46 -> 23 us).  Same bits as AUTO wherever AUTO takes a row-Winograd kernel.
- *   CNL_ALGO_FORCE + v  tests / A-B measurements: pin kernel variant v (2, 5, 6, 9, 10, 11; 1, 3, 4, 7 in `make experiments` builds) wherever
+ *   CNL_ALGO_F43   cnl_conv3x3_winograd_f32 only (ABI v13): AUTO's choices, except that a 3x3 / stride-1 layer with Cin >= 128 whose map the 4-row x 128-pixel
+ *                  items of csrc/winograd13.hip tile well (padding <= 1.35 x; packed rows included) runs as 1-D Winograd F(4,3) along x — 108 instead of
+ *                  144 matrix instructions per 16-channel chunk, the same split arithmetic, interpolation points {0, -1, 1, 1/2, -2, inf}.  The larger tile's
+ *                  transforms amplify rounding: error against float64 2.4-3.2 x the fp32 matrix core's (tests/test_gpu_conv.py pins <= 4 x), inside the
+ *                  path's 1e-4 by two orders of magnitude but above AUTO's promise — hence a class of its own, never what AUTO takes.  Batch-invariant.
+ *   CNL_ALGO_FORCE + v  tests / A-B measurements: pin kernel variant v (2, 5, 6, 9, 10, 11, 13; 1, 3, 4, 7 in `make experiments` builds) wherever
  *                  it can run at all.
  */
 enum {
@@ -56,6 +65,7 @@ enum {
     CNL_ALGO_F2 = 1,
     CNL_ALGO_F32 = 2,                /* (3 was CNL_ALGO_F4 until ABI v9: rejected now) */
     CNL_ALGO_LATENCY = 4,
+    CNL_ALGO_F43 = 5,
     CNL_ALGO_FORCE = 100
 };
 
@@ -133,8 +143,10 @@ typedef struct cnl_conv_params {
      * (fp32, fixed order), for b < ceil(Cout / 64) * 2; cnl_fused_out_reduce_f32 then adds the blocks in order, adds the bias and applies the
      * activation: the 1x1 conv never re-reads the 3x3 conv's output (C1: a 537 MB read, 110 us).  fuse_w: [ceil(Cout / 64) * 64][4] floats,
      * rows >= Cout and columns >= the 1x1 conv's channel count zero (cnl_fused_out_pack_weights_f32); fuse_part: ceil(Cout / 64) * 2 *
-     * N * H * W * 4 floats.  Honoured by the row-Winograd kernels (cnl_conv3x3_winograd_variant 9 / 10 / 11: the dispatcher keeps such a
-     * launch there whatever its size); a launch that cannot take one of them fails with CNL_E_UNSUPPORTED.  Deterministic, batch-invariant. */
+     * N * H * W * 4 floats.  Implemented by ONE kernel: the row-Winograd variant 9 (csrc/winograd9.hip).  The dispatcher keeps a launch that
+     * carries fuse_w on variant 9 wherever its AUTO / LATENCY / F43 choice would have been another ROW kernel (10 / 11 / 13), but a shape it routes elsewhere
+     * (e.g. N = 32, 16 x 16, 512 -> 512: variant 5) fails with CNL_E_UNSUPPORTED — a caller must check cnl_conv3x3_winograd_variant(p) == 9 WITH fuse_w set
+     * before relying on the fold (engine.py does).  Deterministic, batch-invariant. */
     const float* fuse_w;
     float* fuse_part;
     /* cnl_conv3x3_winograd_f32 with CNL_UPSAMPLE_IN only, optional (NULL = off; ABI v12): the ROW-PAIR weights of this layer
@@ -230,7 +242,8 @@ int cnl_conv3x3_winograd_variant(const cnl_conv_params* p);           /* the ker
                                                                          in the reduction: 2/3 of the direct conv's multiplies], 10 / 11 winograd10
                                                                          [the same on 4-row x 64- / 32-cout items: bit for bit winograd9's
                                                                          output — the class never depends on N, but a launch of at most
-                                                                         128 winograd9 items takes 11]; < 0: error code */
+                                                                         128 winograd9 items takes 11], 13 winograd13 [F(4,3) along x: 1/2 of the
+                                                                         direct conv's multiplies; CNL_ALGO_F43 / FORCE + 13 only]; < 0: error code */
 size_t cnl_winograd_weight_floats(int32_t Cin, int32_t Cout);        /* elements of the transformed weight buffer */
 int cnl_winograd_transform_weights_f32(const float* w_ohwi, float* u, int32_t Cin, int32_t Cout, void* stream);
 /*
@@ -480,6 +493,9 @@ int cnl_host_alloc(size_t bytes, void** ptr);
 int cnl_host_free(void* ptr);
 
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

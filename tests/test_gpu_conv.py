@@ -682,6 +682,78 @@ def test_winograd9_matches_cpu_and_reports_absmax(case, variant):
     assert e9 <= 1.25 * e2 + 1e-7 * ref64.abs().max().item(), (e9, e2)
 
 
+W13_CASES = [
+    # N, Cin, H, W, Cout, flags, residual — winograd13.hip (F(4,3) along x): 4-row x 128-pixel x 64-cout work items, six transform positions on four waves
+    (1, 32, 4, 128, 64, 0, False),                      # one work item, two chunks
+    (1, 32, 8, 64, 64, CNL_RELU, True),                 # half-empty block row, residual
+    (2, 64, 16, 128, 64, CNL_RELU, False),
+    (1, 256, 32, 32, 256, CNL_RELU, True),              # four cout blocks, sixteen chunks
+    (2, 64, 19, 34, 96, CNL_RELU, True),                # ragged rows / columns / couts
+    (3, 32, 5, 7, 4, 0, False),                         # Cout = 4: one cout quad of one block; seven pixels: the second tile is three wide
+    (1, 64, 9, 130, 72, CNL_RELU, False),               # two blocks across, the second two pixels wide
+    (1, 128, 6, 256, 128, CNL_RELU, True),              # two full blocks across, 1.5 items down
+    (6, 32, 6, 60, 64, CNL_RELU, True),                 # packed rows: 64-column strips, two images per block row
+    (9, 64, 5, 30, 32, 0, False),                       # packed rows: 32-column strips, four images per block row (a wave's tiles span two images)
+    (5, 32, 8, 68, 64, CNL_RELU, False),                # packed rows: 72-column strips — block rows start anywhere inside an image (the 38 x 68 maps of 608 x 1088 frames)
+]
+
+
+@pytest.mark.parametrize("case", W13_CASES, ids=lambda c: "N{}c{}_{}x{}_o{}f{}r{}".format(*[int(v) for v in c]))
+def test_winograd13_f43_row_kernel(case):
+    """winograd13.hip (F(4,3) along x, 108 instead of 144 matrix instructions per chunk) forced on shapes that exercise its edges: the
+    path's 1e-4 bar against conv2d on the CPU; error against float64 within 4 x the fp32 matrix-core kernel's (+ 1e-7 of the layer maximum) — the larger
+    tile's transforms amplify rounding: measured 2.4-3.2 x, which is why the class is opt-in (CNL_ALGO_FORCE + 13) and not what AUTO takes; max |y| per
+    image handed over exactly; every image alone == inside the batch, bit for bit (one scale per image, packed rows or not); packed rows == the plain
+    block grid, bit for bit; deterministic."""
+    N, Cin, H, W, Cout, flags, use_res = case
+    g = torch.Generator().manual_seed(Cin + Cout + H + W)
+    x, w, b = mk(N, Cin, H, W, Cout, 3, seed=Cin + Cout + H + W)
+    if N > 1:
+        x = x * torch.pow(10.0, torch.randint(-2, 3, (N, 1, 1, 1), generator=g).float())
+    res = torch.randn(N, Cout, H, W, generator=g) if use_res else None
+    lib = _lib.load()
+    q = ConvParams()
+    q.N, q.H_in, q.W_in, q.Cin, q.Cout, q.KH, q.KW, q.stride, q.pad, q.ldx, q.ldy, q.flags, q.y, q.algo = N, H, W, Cin, Cout, 3, 3, 1, 1, Cin, Cout, flags, 1 << 20, CNL_ALGO_FORCE + 13
+    assert lib.cnl_conv3x3_winograd_variant(ctypes.byref(q)) == 13
+    out, ym = run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 13, want=5, ymax=True)
+    assert not torch.isnan(out).any()
+    ref = ref_conv(x, w, b, 1, flags, res)
+    ref64 = ref_conv(x.double(), w.double(), b.double(), 1, flags, res.double() if use_res else None)
+    o2 = run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 2)
+    for i in range(N):                                   # per image: its own magnitude sets the tolerance
+        sc = float(ref64[i].abs().max())
+        assert float((out[i] - ref[i]).abs().max()) <= 1e-4 * max(sc, 1.0), i
+        e13 = float((out[i].double() - ref64[i]).abs().max())
+        e2 = float((o2[i].double() - ref64[i]).abs().max())
+        assert e13 <= 4.0 * e2 + 1e-7 * sc, (i, e13, e2, sc)
+    assert torch.equal(ym, out.abs().amax(dim=(1, 2, 3)))
+    assert torch.equal(out, run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 13))
+    assert torch.equal(out, run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 32 + 13))           # the plain block grid
+    for i in sorted({0, N // 2, N - 1}):
+        assert torch.equal(out[i:i + 1], run_winograd(x[i:i + 1], w, b, flags, res[i:i + 1] if use_res else None, algo=CNL_ALGO_FORCE + 13)), i
+
+
+def test_winograd13_many_items_per_workgroup_and_fallback():
+    """More work items than CUs (the next item's patches and weights are requested inside the previous item's epilogue): bit for bit what each image
+    gives alone, images of very different magnitude behind each other in one workgroup.  A launch the kernel cannot take (folded upsample) falls back to
+    the F(2,3) row kernel."""
+    g = torch.Generator().manual_seed(23)
+    N = 10
+    x = torch.randn(N, 64, 64, 128, generator=g).clamp_min(0) * torch.pow(10.0, torch.randint(-3, 3, (N, 1, 1, 1), generator=g).float())
+    w = torch.randn(128, 64, 3, 3, generator=g) * (2.0 / (64 * 9)) ** 0.5
+    b = torch.randn(128, generator=g)
+    res = torch.randn(N, 128, 64, 128, generator=g)
+    full, ym = run_winograd(x, w, b, CNL_RELU, res, algo=CNL_ALGO_FORCE + 13, want=5, ymax=True)      # 10 * 16 * 1 * 2 = 320 items on 256 CUs
+    torch.testing.assert_close(full, ref_conv(x, w, b, 1, CNL_RELU, res), rtol=RTOL, atol=ATOL * 100)
+    for i in (0, 4, 9):
+        assert torch.equal(full[i:i + 1], run_winograd(x[i:i + 1], w, b, CNL_RELU, res[i:i + 1], algo=CNL_ALGO_FORCE + 13)), i
+    assert torch.equal(ym, full.abs().amax(dim=(1, 2, 3)))
+    q = ConvParams()
+    q.N, q.H_in, q.W_in, q.Cin, q.Cout, q.KH, q.KW, q.stride, q.pad, q.ldx, q.ldy, q.y = 2, 32, 32, 64, 64, 3, 3, 1, 1, 64, 64, 1 << 20
+    q.flags, q.algo = CNL_RELU | CNL_UPSAMPLE_IN, CNL_ALGO_FORCE + 13
+    assert _lib.load().cnl_conv3x3_winograd_variant(ctypes.byref(q)) == 9
+
+
 @pytest.mark.parametrize("shape", [(1, 256, 4, 4, 128), (2, 512, 2, 2, 256), (3, 128, 19, 34, 64), (5, 64, 3, 5, 96), (2, 64, 5, 6, 30), (2, 128, 40, 24, 64)])
 def test_fuse_epilogue_reports_absmax(shape):
     """The FPN Fuse launch (1x1 project -> nearest x2 -> + skip, CNL_UPSAMPLE_OUT_ADD; reference layers.py:160-174) folds max |y| per image into

@@ -12,7 +12,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "centernet-lightning_amd", "csrc")
-ASM_KERNELS = ["winograd5.hip", "winograd6.hip", "winograd9.hip", "winograd10.hip"]      # (tools/experiments/winograd3,4,7.hip: python tools/mfma_hazard_audit.py <path>)
+ASM_KERNELS = ["winograd5.hip", "winograd6.hip", "winograd9.hip", "winograd10.hip", "winograd13.hip"]      # (tools/experiments/winograd3,4,7.hip: python tools/mfma_hazard_audit.py <path>)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-mllvm",
          "-pragma-unroll-threshold=4000000", "-fno-slp-vectorize", "-S", "--cuda-device-only"]      # = csrc/Makefile's for these files
 
