@@ -28,7 +28,7 @@ the script launches those N ranks itself (`self_launch`) and exits non-zero if a
               the rocprofv3 PMC figure of the named profiles/ file (null where no profile of that configuration exists).
   variants  = the same job in the other arithmetic classes of the plan (KernelOptions.algo; in-process, short runs):
               f32 = fp32 matrix cores only; f43 = "auto" with KernelOptions(f43=True): the 256-channel head blocks on the F(4,3) row kernel
-              (csrc/winograd13.hip, CNL_ALGO_F43: 2.4-3.2 x the fp32 matrix core's rounding error — an opt-in class, see `accuracy`).
+              (csrc/winograd13.hip, CNL_ALGO_F43: 2.4-4.6 x the fp32 matrix core's rounding error — an opt-in class, see `accuracy`).
   accuracy  = max |feature - float64 oracle| / max |float64 oracle| at the neck output and at each head's last 256-channel block
               output (what out_conv reads), for auto / f32 / f43 and for the CPU fp32 oracle itself, on 2 images of the bench shape.
               (The post-sigmoid heatmap hides feature error by ~3 orders of magnitude; it is reported too.)  Backbone / ConvBnAct

@@ -21,7 +21,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_LATENCY, CNL_RELU, CNL_RELU6, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD, CNL_W_SPLIT,
+from ._lib import (CNL_ALGO_AUTO, CNL_ALGO_F2, CNL_ALGO_F32, CNL_ALGO_F43, CNL_ALGO_LATENCY, CNL_RELU, CNL_RELU6, CNL_SIGMOID, CNL_UPSAMPLE_IN, CNL_UPSAMPLE_OUT_ADD, CNL_W_SPLIT,
                    CNL_WINO_F16X2, ConvParams, DeconvParams)
 
 BN_EPS_DEFAULT = 1e-5
@@ -55,7 +55,7 @@ class KernelOptions:
                        the general form (False), batch-invariant
       f43              opt-in arithmetic class (default off): 3x3 / stride-1 layers with Cin >= 128 on maps that 4-row x 128-pixel work items tile
                        well (the 256 -> 256 head blocks) run as 1-D Winograd F(4,3) along x (csrc/winograd13.hip, cnl_conv_params.algo = CNL_ALGO_F43): 25 % fewer
-                       matrix instructions, 2.4-3.2 x the fp32 matrix core's rounding error (inside the path's 1e-4 by two orders of magnitude, above "auto"'s promise)
+                       matrix instructions, 2.4-4.6 x the fp32 matrix core's rounding error (inside the path's 1e-4 by two orders of magnitude, above "auto"'s promise)
       split_small      latency mode for small batches (default off): launches whose output is too small to fill the chip (one image: the
                        16x16 .. 64x64 maps) run as direct convs with the reduction split over several workgroups per output tile and a
                        fixed-order reduce (cnl_conv_params.splitk).  The choice then depends on the batch size, so results are no longer
