@@ -197,7 +197,7 @@ static int wino_choice(const cnl_conv_params* p) {
     if (upf == 1 && W == 16 && p->Cin >= 256 && cnl_wino10_eligible(p) && !p->fuse_w) return p->Cout <= 256 ? 11 : 10;
     // the F(4,3) class (CNL_ALGO_F43, winograd13.hip): long channel loops on maps that 4-row x 128-pixel items (packed rows included) pad by at most 1.35 x —
     // the head blocks of 512 x 512 and 608 x 1088 frames.  A function of the shape alone (the padding a long virtual row has, as below).
-    if (p->algo == CNL_ALGO_F43 && p->Cin >= 128 && cnl_wino13_eligible(p)) {
+    if (p->algo == CNL_ALGO_F43 && p->Cin >= 128 && W >= 128 && cnl_wino13_eligible(p)) {      // (narrower maps, packed: measured slower than the F(2,3) kernels — C1 with layer2 / layer3 on this kernel 7.48 -> 8.52 ms)
         const bool packable13 = W % 2 == 0 && W >= 28 && W % 128 != 0;
         const long long wpad13 = packable13 ? (W / 4 * 4 + 4) : ((W + 127) / 128 * 128);
         if ((long long)((H + 3) / 4 * 4) * wpad13 * 100 <= area * 135) return 13;

@@ -52,7 +52,7 @@ enum {
  *   CNL_ALGO_LATENCY  cnl_conv3x3_winograd_f32 only: AUTO's arithmetic on small work items (csrc/winograd10.hip: 4 rows x 64 pixels x 32 couts, two
  *                  workgroups per CU) wherever the row-Winograd kernels apply — for one-image batches, where the default's 8-row x 64-cout items leave
  *                  most CUs idle (a 256 -> 256 conv on a 32 x 32 map: 46 -> 23 us).  Same bits as AUTO wherever AUTO takes a row-Winograd kernel.
- *   CNL_ALGO_F43   cnl_conv3x3_winograd_f32 only (ABI v13): AUTO's choices, except that a 3x3 / stride-1 layer with Cin >= 128 whose map the 4-row x 128-pixel
+ *   CNL_ALGO_F43   cnl_conv3x3_winograd_f32 only (ABI v13): AUTO's choices, except that a 3x3 / stride-1 layer with Cin >= 128 on a map at least 128 pixels wide that the 4-row x 128-pixel
  *                  items of csrc/winograd13.hip tile well (padding <= 1.35 x; packed rows included) runs as 1-D Winograd F(4,3) along x — 108 instead of
  *                  144 matrix instructions per 16-channel chunk, the same split arithmetic, interpolation points {0, -1, 1, 1/2, -2, inf}.  The larger tile's
  *                  transforms amplify rounding: error against float64 2.4-4.6 x the fp32 matrix core's (tests/test_gpu_conv.py pins <= 6 x), inside the
