@@ -52,12 +52,20 @@ struct PeakArgs {
     int tiles_x, strips;
     float* ws_score;
     int* ws_label;
+    unsigned* slab_ctr;      // per-image arrival counters of stage 2's slab blocks (stride SLAB_STRIDE_U32 words): zeroed here, by the call that uses them
 };
+constexpr int SLAB_CAND_MAX = 1024;                       // candidates the slabs of one image hand to the merging block: S * k <= 1024
+constexpr int SLAB_STRIDE_U32 = 16 + 2 * SLAB_CAND_MAX;   // per image: 64 bytes (the counter) + 1024 (key, ~index) pairs
+__device__ __forceinline__ void zero_slab_counters(const PeakArgs& a) {
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < a.N; i += blockDim.x) a.slab_ctr[(size_t)i * SLAB_STRIDE_U32] = 0u;
+}
 
 // ---- stage 1, channel-minor layout (sc == 1) ----
 template <int VEC, int P>
 __global__ __launch_bounds__(256) void peaks_cminor_kernel(const PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    zero_slab_counters(a);
     float* red_v = reinterpret_cast<float*>(smem);                  // [R][PXB][CG]
     int* red_c = reinterpret_cast<int*>(red_v + a.R * a.PXB * a.CG);
 
@@ -185,6 +193,7 @@ template <int P, int PK8_R>
 __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q) {
     const PeakArgs& a = q.p;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    zero_slab_counters(a);
     unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);       // [PK8_R][TW]
     int b = (int)cnl::xcd_remap(blockIdx.x, gridDim.x);
     const int bx = b % a.tiles_x; b /= a.tiles_x;
@@ -298,6 +307,7 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
 // ---- stage 1, generic strides (lanes along x, loop over classes) ----
 template <int P, int R>
 __global__ __launch_bounds__(256) void peaks_generic_kernel(const PeakArgs a) {
+    zero_slab_counters(a);
     int b = (int)cnl::xcd_remap(blockIdx.x, gridDim.x);
     const int bx = b % a.tiles_x; b /= a.tiles_x;
     const int by = b % a.strips;
@@ -392,6 +402,8 @@ struct TopkArgs {
     const float* box; long bsn, bsc, bsh, bsw;
     const float* reid; long rsn, rsc, rsh, rsw;
     int HW, W, H, E, k, KP;       // KP = next pow2 >= k
+    int S, SL;                    // slabs per image (1: the whole image in one workgroup) and pixels per slab (the last one may be shorter)
+    unsigned* slab;               // S > 1: per image [arrival counter, 64 bytes][S * k (key, ~index) pairs] (SLAB_STRIDE_U32 words apart)
     int keys_in_lds;              // HW * 4 bytes of dynamic LDS hold the image's score keys (read from memory ONCE)
     int normalize, box_log;
     float mult, stride;
@@ -456,11 +468,20 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     __shared__ unsigned long long cand[1024 + 8];
     __shared__ unsigned sh_prefix, sh_need, sh_count;
 
-    const int n = blockIdx.x;
+    // Stage 2 on S workgroups per image (VERDICT r5 #2b; S = 1: everything below is the round-2 kernel).  Slab s selects the top k of ITS pixels — the
+    // image's top k is among the S * k slab winners — and hands them over as (key, ~global index) pairs; the workgroup that arrives last (an arrival counter in
+    // the caller's workspace, zeroed by stage 1 of this call) ranks the S * k <= 1024 pairs and gathers.  The pairs are distinct and the rank is by value:
+    // the same canonical order (score desc, index asc) whatever the slab count and whoever arrives last — deterministic.
+    const int n = blockIdx.x / a.S, slab_i = blockIdx.x - n * a.S;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const float* sc = a.ws_score + (long)n * a.HW;
-    const int KCH = (a.HW + TK_THREADS - 1) / TK_THREADS, KST = KCH | 1;      // indices per thread, LDS row pitch (odd)
+    const int lo = slab_i * a.SL;                            // first pixel of the slab; every index below is slab-local until it enters a pair
+    const int HWs = min(a.SL, a.HW - lo);
+    const int ks = min(a.k, HWs);
+    int KPs = a.KP;                                          // next power of two >= ks (the radix path's sort width)
+    while ((KPs >> 1) >= ks && KPs > 2) KPs >>= 1;
+    const float* sc = a.ws_score + (long)n * a.HW + lo;      // (re-pointed at the image's first pixel before the gathers)
+    const int KCH = (HWs + TK_THREADS - 1) / TK_THREADS, KST = KCH | 1;      // indices per thread, LDS row pitch (odd)
 
     // --- phase A: the keys go to LDS (when they fit: the only pass over memory) and every thread keeps the maximum of the keys it read.
     // PRUNING BOUND: the m-th largest of a wave's 64 thread maxima, m = ceil(k / 16), has m elements at or above it; the minimum of that
@@ -483,10 +504,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     if (in_regs) {
         float v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = tid + j * TK_THREADS < a.HW ? sc[tid + j * TK_THREADS] : 0.f;
+        for (int j = 0; j < 16; ++j) v[j] = tid + j * TK_THREADS < HWs ? sc[tid + j * TK_THREADS] : 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            if (tid + j * TK_THREADS < a.HW) {
+            if (tid + j * TK_THREADS < HWs) {
                 kreg[j] = score_key(v[j]);
                 tmax = tmax > kreg[j] ? tmax : kreg[j];
             }
@@ -494,14 +515,14 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     }
     const bool kch_pow2 = (KCH & (KCH - 1)) == 0;            // then i / KCH, i % KCH are a shift and a mask
     const int kch_sh = 31 - __builtin_clz((unsigned)KCH);
-    for (int i = tid; !in_regs && i < a.HW; i += 16 * TK_THREADS) {      // sixteen independent loads in flight per thread, then the bookkeeping
+    for (int i = tid; !in_regs && i < HWs; i += 16 * TK_THREADS) {      // sixteen independent loads in flight per thread, then the bookkeeping
         float v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = i + j * TK_THREADS < a.HW ? sc[i + j * TK_THREADS] : 0.f;
+        for (int j = 0; j < 16; ++j) v[j] = i + j * TK_THREADS < HWs ? sc[i + j * TK_THREADS] : 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int ii = i + j * TK_THREADS;
-            if (ii < a.HW) {
+            if (ii < HWs) {
                 const unsigned key = score_key(v[j]);
                 if (klds) {
                     const int own = kch_pow2 ? (ii >> kch_sh) : ii / KCH;
@@ -532,7 +553,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
             }
         }
 #undef TK_EXCH
-        const unsigned vm = __shfl(v, (a.k + TK_THREADS / 64 - 1) / (TK_THREADS / 64) - 1);
+        const unsigned vm = __shfl(v, (ks + TK_THREADS / 64 - 1) / (TK_THREADS / 64) - 1);
         if (lane == 0) wave_tot[wave] = vm;
         TK_STAMP(10);
     }
@@ -545,7 +566,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     {
         // compaction of the elements >= T_lo into cand[] — in ANY order: the winners are placed by rank of the (key, ~index) pair below.
         // Thread t owns the contiguous index range [t*KCH, (t+1)*KCH); one LDS atomic per wave and round reserves the wave's slots.
-        const int j0 = tid * KCH, j1 = min(j0 + KCH, a.HW);
+        const int j0 = tid * KCH, j1 = min(j0 + KCH, HWs);
         const bool strided = !in_regs && KCH <= 64;          // up to 64 x 1024 pixels: thread t takes indices t + 1024 c again (coalesced; the
                                                              // scores are L2-resident by now) — the compaction needs no index order
         if (in_regs || strided) {
@@ -553,15 +574,15 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
             if (in_regs) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
-                    if (tid + j * TK_THREADS < a.HW && kreg[j] >= Tlo) qual |= 1ull << j;
+                    if (tid + j * TK_THREADS < HWs && kreg[j] >= Tlo) qual |= 1ull << j;
             }
             for (int c0 = 0; strided && c0 < KCH; c0 += 8) {             // eight independent loads at a time
                 float vv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vv[j] = tid + (c0 + j) * TK_THREADS < a.HW ? sc[tid + (c0 + j) * TK_THREADS] : 0.f;
+                for (int j = 0; j < 8; ++j) vv[j] = tid + (c0 + j) * TK_THREADS < HWs ? sc[tid + (c0 + j) * TK_THREADS] : 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (tid + (c0 + j) * TK_THREADS < a.HW && score_key(vv[j]) >= Tlo) qual |= 1ull << (c0 + j);
+                    if (tid + (c0 + j) * TK_THREADS < HWs && score_key(vv[j]) >= Tlo) qual |= 1ull << (c0 + j);
             }
             for (;;) {                                       // most threads own no candidate at all: 1-3 rounds per wave
                 const bool has = qual != 0ull;
@@ -585,7 +606,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                         idx = (unsigned)(tid + c * TK_THREADS);
                         key = score_key(sc[idx]);
                     }
-                    if (pos < (unsigned)FAST_CAP) cand[pos] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - idx);
+                    if (pos < (unsigned)FAST_CAP) cand[pos] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - ((unsigned)lo + idx));
                 }
             }
         } else {                                             // maps beyond the LDS budget: plain per-element reservation
@@ -593,7 +614,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                 const unsigned key = klds ? lds_keys[tid * KST + (i - j0)] : score_key(sc[i]);
                 if (key >= Tlo) {
                     const unsigned pos = atomicAdd(&sh_count, 1u);
-                    if (pos < (unsigned)FAST_CAP) cand[pos] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+                    if (pos < (unsigned)FAST_CAP) cand[pos] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(lo + i));
                 }
             }
         }
@@ -624,7 +645,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                 if (psh > 0) rank += (unsigned)__shfl_xor((int)rank, 1);
                 if (psh > 1) rank += (unsigned)__shfl_xor((int)rank, 2);
                 if (psh > 2) rank += (unsigned)__shfl_xor((int)rank, 4);
-                if (part == 0 && c < (int)total && rank < (unsigned)a.k) win[rank] = mine;
+                if (part == 0 && c < (int)total && rank < (unsigned)ks) win[rank] = mine;
             }
             __syncthreads();
             TK_STAMP(3);
@@ -634,7 +655,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     if (!fast) {
     // --- radix select: key T of the k-th largest element, digits of 12 / 10 / 10 bits from the top.  (A 12-bit first digit
     // spreads sigmoid scores, which share 1-2 exponents, over 16x more bins than an 8-bit one: far less LDS-atomic contention.) ---
-    unsigned prefix = 0, mask = 0, need = (unsigned)a.k;
+    unsigned prefix = 0, mask = 0, need = (unsigned)ks;
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
         const int bits = pass == 0 ? 12 : 10;
@@ -647,12 +668,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
             // keys live in LDS as [thread][KST] (thread t owns indices t*KCH .. t*KCH+KCH-1; the odd row pitch KST keeps both this
             // loop and the ordered compaction below free of bank conflicts)
             for (int j = 0; j < KCH; ++j) {
-                if (tid * KCH + j >= a.HW) break;
+                if (tid * KCH + j >= HWs) break;
                 const unsigned key = lds_keys[tid * KST + j];
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (unsigned)(nbins - 1)], 1u);
             }
         } else {
-            for (int i = tid; i < a.HW; i += TK_THREADS) {          // maps too large for LDS: every pass streams the scores (L2-resident)
+            for (int i = tid; i < HWs; i += TK_THREADS) {          // maps too large for LDS: every pass streams the scores (L2-resident)
                 const unsigned key = score_key(sc[i]);
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (unsigned)(nbins - 1)], 1u);
             }
@@ -699,7 +720,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
 
     // --- ordered compaction: thread t owns the contiguous index range [t*CH, (t+1)*CH); counts packed (gt << 16 | eq) ---
     const int CH = KCH;
-    const int i0 = tid * CH, i1 = min(i0 + CH, a.HW);
+    const int i0 = tid * CH, i1 = min(i0 + CH, HWs);
     unsigned cnt = 0;
     for (int i = i0; i < i1; ++i) {
         const unsigned key = klds ? lds_keys[tid * KST + (i - i0)] : score_key(sc[i]);
@@ -709,7 +730,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     // CH <= 2^24 / 1024 elements per thread may overflow 16 bits in general; totals are bounded by HW <= 2^24, so scan the
     // two counters separately when HW > 65535, packed otherwise (the common case)
     unsigned pos_gt, pos_eq, total_gt;
-    if (a.HW <= 65535) {
+    if (HWs <= 65535) {
         const unsigned inc = wave_incl_scan(cnt, lane);
         if (lane == 63) wave_tot[wave] = inc;
         __syncthreads();
@@ -738,11 +759,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         pos_eq = be + ie - e;
         total_gt = tg;
     }
-    for (int i = tid; i < a.KP; i += TK_THREADS) cand[i] = 0ull;   // padding sorts last
+    for (int i = tid; i < KPs; i += TK_THREADS) cand[i] = 0ull;   // padding sorts last
     __syncthreads();
     for (int i = i0; i < i1; ++i) {
         const unsigned key = klds ? lds_keys[tid * KST + (i - i0)] : score_key(sc[i]);
-        const unsigned long long comp = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+        const unsigned long long comp = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(lo + i));
         if (key > T) {
             cand[pos_gt++] = comp;
         } else if (key == T) {
@@ -752,13 +773,53 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     }
     __syncthreads();
 
-    block_sort_desc(cand, a.KP, tid);                        // descending by (key, ~index)
+    block_sort_desc(cand, KPs, tid);                        // descending by (key, ~index)
     }   // !fast
 
     TK_STAMP(5);
+    const unsigned long long* winners = fast ? win : cand;
+    if (a.S > 1) {
+        // hand the slab's winners over (zero pairs pad a slab shorter than k: they rank last), then arrive
+        unsigned* img = a.slab + (size_t)n * SLAB_STRIDE_U32;
+        unsigned long long* list = reinterpret_cast<unsigned long long*>(img + 16);
+        // (agent-scope ATOMIC stores and loads: they are performed at the device's coherence point, so no L2 write-back / invalidate is needed — a release
+        //  fence at agent scope writes back EVERY dirty line of the XCD's L2, the heatmap's producer's output included: decode 47 -> 90 us when it was tried.
+        //  The pairs only have to be PERFORMED before the arrival: the workgroup-scope fence waits for the stores' acknowledgements.)
+        if (tid < a.k) __hip_atomic_store(&list[slab_i * a.k + tid], tid < ks ? winners[tid] : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (tid == 0) sh_count = __hip_atomic_fetch_add(img, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (sh_count != (unsigned)(a.S - 1)) return;         // (uniform: every thread reads the same word)
+        __syncthreads();                                     // every thread is done with `win` / `cand` of its own slab
+        const unsigned total = (unsigned)(a.S * a.k);        // <= SLAB_CAND_MAX
+        for (int i = tid; i < FAST_CAP + 8; i += TK_THREADS)
+            cand[i] = i < (int)total ? __hip_atomic_load(&list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        __syncthreads();
+        int psh = 0;
+        while (psh < 3 && (total << (psh + 1)) <= (unsigned)TK_THREADS) ++psh;
+        const int c = tid >> psh, part = tid & ((1 << psh) - 1);
+        const unsigned long long mine = c < (int)total ? cand[c] : ~0ull;
+        unsigned rank = 0;
+        for (unsigned j = (unsigned)part * 8u; j < total; j += 8u << psh) {
+            unsigned long long o[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = cand[j + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rank += o[q] > mine ? 1u : 0u;
+        }
+        if (psh > 0) rank += (unsigned)__shfl_xor((int)rank, 1);
+        if (psh > 1) rank += (unsigned)__shfl_xor((int)rank, 2);
+        if (psh > 2) rank += (unsigned)__shfl_xor((int)rank, 4);
+        // (zero pairs tie with each other — rank >= the number of real pairs >= k: never among the first k)
+        if (part == 0 && c < (int)total && mine != 0ull && rank < (unsigned)a.k) win[rank] = mine;
+        __syncthreads();
+        winners = win;
+    }
+    sc = a.ws_score + (long)n * a.HW;                        // (global indices from here on)
     // --- gathers + box decode for the k winners ---
     if (tid < a.k) {
-        const unsigned long long comp = (fast ? win : cand)[tid];
+        const unsigned long long comp = winners[tid];
         const int idx = (int)(0xFFFFFFFFu - (unsigned)(comp & 0xFFFFFFFFull));
         const long o = (long)n * a.k + tid;
         a.scores[o] = sc[idx];
@@ -772,7 +833,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         // embeddings: k*E elements, E-contiguous per detection (one coalesced row when reid is NHWC)
         for (int t = tid; t < a.k * a.E; t += TK_THREADS) {
             const int d = t / a.E, e = t - d * a.E;
-            const unsigned long long comp = (fast ? win : cand)[d];
+            const unsigned long long comp = winners[d];
             const int idx = (int)(0xFFFFFFFFu - (unsigned)(comp & 0xFFFFFFFFull));
             const int yi = idx / a.W, xi = idx - yi * a.W;
             a.emb[((long)n * a.k + d) * a.E + e] =
@@ -829,9 +890,22 @@ extern "C" int cnl_debug_topk_stamps(unsigned long long* out) {
 }
 #endif
 
+// workspace: [score plane N*H*W f32][label plane N*H*W i32][pad to 256][per image: arrival counter (64 bytes) + up to 1024 (key, ~index) pairs of stage 2's slabs]
+static size_t decode_planes_bytes(int32_t N, int32_t H, int32_t W) { return ((size_t)N * H * W * 8 + 255) / 256 * 256; }
 extern "C" size_t cnl_decode_workspace_bytes(int32_t N, int32_t H, int32_t W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)N * H * W * 8 + 256;
+    return decode_planes_bytes(N, H, W) + 256 + (size_t)N * SLAB_STRIDE_U32 * 4;
+}
+// Slabs per image of stage 2 — a function of the map size and k alone: maps of at least 8192 pixels are split 4-fold, of at least 32768 pixels 8-fold, as far
+// as S * k <= 1024 pairs allow (k = 300 on the 152 x 272 maps of 608 x 1088 frames: 3).
+static int decode_slabs(int HW, int k) {
+#ifdef CNL_DECODE_SLABS      /* A/B builds (make variant EXTRA=-DCNL_DECODE_SLABS=1): a fixed slab count where it is possible at all */
+    { const int f = CNL_DECODE_SLABS; return (f > 1 && HW >= 2048 * f && f * k <= SLAB_CAND_MAX) ? f : 1; }
+#endif
+    const int by_size = HW >= 32768 ? 8 : (HW >= 8192 ? 4 : 1);
+    const int by_k = SLAB_CAND_MAX / k;
+    const int S = by_size < by_k ? by_size : by_k;
+    return S < 1 ? 1 : S;
 }
 
 extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
@@ -859,6 +933,7 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
     a.N = p->N; a.C = p->C; a.H = p->H; a.W = p->W;
     a.ws_score = (float*)p->workspace;
     a.ws_label = (int*)((char*)p->workspace + (size_t)p->N * HW * 4);
+    a.slab_ctr = (unsigned*)((char*)p->workspace + decode_planes_bytes(p->N, p->H, p->W));
 
     int rc;
     const bool cminor = p->heat_sc == 1;
@@ -930,6 +1005,9 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
     t.box = p->box; t.bsn = p->box_sn; t.bsc = p->box_sc; t.bsh = p->box_sh; t.bsw = p->box_sw;
     t.reid = p->reid; t.rsn = p->reid_sn; t.rsc = p->reid_sc; t.rsh = p->reid_sh; t.rsw = p->reid_sw;
     t.HW = HW; t.W = p->W; t.H = p->H; t.E = p->reid ? p->E : 0; t.k = p->k;
+    t.S = decode_slabs(HW, p->k);
+    t.SL = (HW + t.S - 1) / t.S;
+    t.slab = a.slab_ctr;
     int kp = 2;
     while (kp < p->k) kp <<= 1;
     t.KP = kp;
@@ -937,13 +1015,14 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
     t.scores = p->scores; t.indices = (long long*)p->indices; t.labels = (long long*)p->labels; t.boxes = p->boxes;
     t.emb = p->emb;
     // 40 KB of static LDS + the keys: one workgroup per CU either way (1024 threads)
-    const size_t kst = (size_t)(((HW + TK_THREADS - 1) / TK_THREADS) | 1);
+    const size_t kst = (size_t)(((t.SL + TK_THREADS - 1) / TK_THREADS) | 1);
     t.keys_in_lds = kst * TK_THREADS * 4 <= 96 * 1024;
     const size_t key_bytes = t.keys_in_lds ? kst * TK_THREADS * 4 : 0;
     static cnl::DeviceOnce once;
     rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&topk_kernel), 96 * 1024);
     if (rc != CNL_OK) return rc;
-    hipLaunchKernelGGL(topk_kernel, dim3(p->N), dim3(TK_THREADS), key_bytes, s, t);
+    CNL_REQUIRE((long long)p->N * t.S < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_decode_f32: grid too large");
+    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)(p->N * t.S)), dim3(TK_THREADS), key_bytes, s, t);
     return cnl::check_launch("topk_kernel");
 }
 

@@ -113,6 +113,35 @@ def test_decode_quantised_scores_many_ties():
         _check(_np(hip_decode.decode(h, b, None, 60, 3)), ref)
 
 
+@pytest.mark.parametrize("shape,k", [((2, 4, 128, 128), 100), ((2, 3, 96, 96), 100), ((1, 2, 152, 272), 300), ((2, 2, 200, 200), 120), ((1, 4, 128, 128), 400)])
+@pytest.mark.parametrize("kind", ["random", "quantised", "plateau_rows", "all_equal", "one_slab_only"])
+def test_decode_topk_on_several_workgroups_per_image(shape, k, kind):
+    """Stage 2 runs on 1 / 3 / 4 / 8 workgroups per image (maps of >= 8192 pixels, S * k <= 1024: VERDICT r5 #2b): every slab's winners are merged by
+    the workgroup that arrives last.  Bit-exact against the oracle (scores, indices in canonical order, labels, boxes) where ties straddle slab
+    boundaries, where a slab holds none of the winners, where whole rows are plateaus (the radix-select path inside a slab) and where everything is
+    equal; three runs give identical bytes (the arrival order is not in the result)."""
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(H * W + k)
+    if kind == "random":
+        heat = torch.rand(N, C, H, W, generator=g)
+    elif kind == "quantised":
+        heat = (torch.rand(N, C, H, W, generator=g) * 16).floor() / 16
+    elif kind == "plateau_rows":
+        heat = torch.rand(N, C, H, 1, generator=g).expand(N, C, H, W).contiguous()      # every row constant: every pixel of a row-maximum row survives the pool... in x
+        heat = (heat * 8).floor() / 8
+    elif kind == "all_equal":
+        heat = torch.full((N, C, H, W), 0.25)
+    else:
+        heat = torch.rand(N, C, H, W, generator=g) * 0.01
+        heat[:, :, H - 20:H - 4, :] += 0.5                                                  # all winners in the last slab
+    box = torch.rand(N, 4, H, W, generator=g) * 7
+    ref = decode_ref.decode_detections(heat.numpy(), box.numpy(), k, 3)
+    outs = [_np(hip_decode.decode(_layouts(heat)[1], _layouts(box)[1], None, k, 3)) for _ in range(3)]
+    _check(outs[0], ref)
+    for o in outs[1:]:
+        assert all((o[key] == outs[0][key]).all() for key in outs[0])
+
+
 def test_decode_full_size_properties():
     """BASELINE C1 size (32x80x128x128): properties that need no oracle run — sortedness, peak-ness, top-k-ness."""
     N, C, H, W, k = 32, 80, 128, 128, 100
