@@ -52,20 +52,12 @@ struct PeakArgs {
     int tiles_x, strips;
     float* ws_score;
     int* ws_label;
-    unsigned* slab_ctr;      // per-image arrival counters of stage 2's slab blocks (stride SLAB_STRIDE_U32 words): zeroed here, by the call that uses them
 };
-constexpr int SLAB_CAND_MAX = 1024;                       // candidates the slabs of one image hand to the merging block: S * k <= 1024
-constexpr int SLAB_STRIDE_U32 = 16 + 2 * SLAB_CAND_MAX;   // per image: 64 bytes (the counter) + 1024 (key, ~index) pairs
-__device__ __forceinline__ void zero_slab_counters(const PeakArgs& a) {
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < a.N; i += blockDim.x) a.slab_ctr[(size_t)i * SLAB_STRIDE_U32] = 0u;
-}
 
 // ---- stage 1, channel-minor layout (sc == 1) ----
 template <int VEC, int P>
 __global__ __launch_bounds__(256) void peaks_cminor_kernel(const PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    zero_slab_counters(a);
     float* red_v = reinterpret_cast<float*>(smem);                  // [R][PXB][CG]
     int* red_c = reinterpret_cast<int*>(red_v + a.R * a.PXB * a.CG);
 
@@ -193,7 +185,6 @@ template <int P, int PK8_R>
 __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q) {
     const PeakArgs& a = q.p;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    zero_slab_counters(a);
     unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);       // [PK8_R][TW]
     int b = (int)cnl::xcd_remap(blockIdx.x, gridDim.x);
     const int bx = b % a.tiles_x; b /= a.tiles_x;
@@ -307,7 +298,6 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
 // ---- stage 1, generic strides (lanes along x, loop over classes) ----
 template <int P, int R>
 __global__ __launch_bounds__(256) void peaks_generic_kernel(const PeakArgs a) {
-    zero_slab_counters(a);
     int b = (int)cnl::xcd_remap(blockIdx.x, gridDim.x);
     const int bx = b % a.tiles_x; b /= a.tiles_x;
     const int by = b % a.strips;
@@ -402,9 +392,8 @@ struct TopkArgs {
     const float* box; long bsn, bsc, bsh, bsw;
     const float* reid; long rsn, rsc, rsh, rsw;
     int HW, W, H, E, k, KP;       // KP = next pow2 >= k
-    int S, SL;                    // slabs per image (1: the whole image in one workgroup) and pixels per slab (the last one may be shorter)
-    unsigned* slab;               // S > 1: per image [arrival counter, 64 bytes][S * k (key, ~index) pairs] (SLAB_STRIDE_U32 words apart)
     int keys_in_lds;              // HW * 4 bytes of dynamic LDS hold the image's score keys (read from memory ONCE)
+    int keys16_in_lds;            // ... or, where those do not fit, HW * 2 bytes hold their upper halves (the compaction's prefilter)
     int normalize, box_log;
     float mult, stride;
     float* scores; long long* indices; long long* labels; float* boxes; float* emb;
@@ -468,20 +457,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     __shared__ unsigned long long cand[1024 + 8];
     __shared__ unsigned sh_prefix, sh_need, sh_count;
 
-    // Stage 2 on S workgroups per image (VERDICT r5 #2b; S = 1: everything below is the round-2 kernel).  Slab s selects the top k of ITS pixels — the
-    // image's top k is among the S * k slab winners — and hands them over as (key, ~global index) pairs; the workgroup that arrives last (an arrival counter in
-    // the caller's workspace, zeroed by stage 1 of this call) ranks the S * k <= 1024 pairs and gathers.  The pairs are distinct and the rank is by value:
-    // the same canonical order (score desc, index asc) whatever the slab count and whoever arrives last — deterministic.
-    const int n = blockIdx.x / a.S, slab_i = blockIdx.x - n * a.S;
+    const int n = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int lo = slab_i * a.SL;                            // first pixel of the slab; every index below is slab-local until it enters a pair
-    const int HWs = min(a.SL, a.HW - lo);
-    const int ks = min(a.k, HWs);
-    int KPs = a.KP;                                          // next power of two >= ks (the radix path's sort width)
-    while ((KPs >> 1) >= ks && KPs > 2) KPs >>= 1;
-    const float* sc = a.ws_score + (long)n * a.HW + lo;      // (re-pointed at the image's first pixel before the gathers)
-    const int KCH = (HWs + TK_THREADS - 1) / TK_THREADS, KST = KCH | 1;      // indices per thread, LDS row pitch (odd)
+    const float* sc = a.ws_score + (long)n * a.HW;
+    const int KCH = (a.HW + TK_THREADS - 1) / TK_THREADS;      // indices per thread
 
     // --- phase A: the keys go to LDS (when they fit: the only pass over memory) and every thread keeps the maximum of the keys it read.
     // PRUNING BOUND: the m-th largest of a wave's 64 thread maxima, m = ceil(k / 16), has m elements at or above it; the minimum of that
@@ -498,36 +478,37 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     // index arithmetic; the fallback re-reads the scores from memory.  Larger maps: keys in LDS ([owner thread][odd pitch]) when they fit.
     const bool in_regs = KCH <= 16;
     const bool klds = a.keys_in_lds && !in_regs;
+    // Maps whose 32-bit keys do not fit the LDS budget (the 152 x 272 maps of 608 x 1088 frames: 165 KB) keep the UPPER HALVES of the keys there (round 6):
+    // key >> 16 >= bound >> 16 is a superset test, so the second pass over the scores — six rounds of dependent loads, 12 of the kernel's 17 K compaction
+    // cycles at that size — becomes 41 two-byte LDS reads per thread; the few elements that pass are re-read and tested exactly.
+    const bool k16 = a.keys16_in_lds && !in_regs && !klds;
+    unsigned short* lds_k16 = reinterpret_cast<unsigned short*>(lds_keys);
     unsigned kreg[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) kreg[j] = 0u;
     if (in_regs) {
         float v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = tid + j * TK_THREADS < HWs ? sc[tid + j * TK_THREADS] : 0.f;
+        for (int j = 0; j < 16; ++j) v[j] = tid + j * TK_THREADS < a.HW ? sc[tid + j * TK_THREADS] : 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            if (tid + j * TK_THREADS < HWs) {
+            if (tid + j * TK_THREADS < a.HW) {
                 kreg[j] = score_key(v[j]);
                 tmax = tmax > kreg[j] ? tmax : kreg[j];
             }
         }
     }
-    const bool kch_pow2 = (KCH & (KCH - 1)) == 0;            // then i / KCH, i % KCH are a shift and a mask
-    const int kch_sh = 31 - __builtin_clz((unsigned)KCH);
-    for (int i = tid; !in_regs && i < HWs; i += 16 * TK_THREADS) {      // sixteen independent loads in flight per thread, then the bookkeeping
+    for (int i = tid; !in_regs && i < a.HW; i += 16 * TK_THREADS) {      // sixteen independent loads in flight per thread, then the bookkeeping
         float v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = i + j * TK_THREADS < HWs ? sc[i + j * TK_THREADS] : 0.f;
+        for (int j = 0; j < 16; ++j) v[j] = i + j * TK_THREADS < a.HW ? sc[i + j * TK_THREADS] : 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int ii = i + j * TK_THREADS;
-            if (ii < HWs) {
+            if (ii < a.HW) {
                 const unsigned key = score_key(v[j]);
-                if (klds) {
-                    const int own = kch_pow2 ? (ii >> kch_sh) : ii / KCH;
-                    lds_keys[own * KST + (ii - own * KCH)] = key;
-                }
+                if (klds) lds_keys[ii] = key;             // identity layout: consecutive lanes, consecutive words (round 6: the [owner][odd pitch] image cost a division per key)
+                if (k16) lds_k16[ii] = (unsigned short)(key >> 16);
                 tmax = tmax > key ? tmax : key;
             }
         }
@@ -553,7 +534,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
             }
         }
 #undef TK_EXCH
-        const unsigned vm = __shfl(v, (ks + TK_THREADS / 64 - 1) / (TK_THREADS / 64) - 1);
+        const unsigned vm = __shfl(v, (a.k + TK_THREADS / 64 - 1) / (TK_THREADS / 64) - 1);
         if (lane == 0) wave_tot[wave] = vm;
         TK_STAMP(10);
     }
@@ -562,11 +543,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     unsigned Tlo = wave_tot[0];
 #pragma unroll
     for (int w = 1; w < TK_THREADS / 64; ++w) Tlo = Tlo < wave_tot[w] ? Tlo : wave_tot[w];
-    bool fast = false;
+    bool fast = false, sort_path = false;
     {
         // compaction of the elements >= T_lo into cand[] — in ANY order: the winners are placed by rank of the (key, ~index) pair below.
         // Thread t owns the contiguous index range [t*KCH, (t+1)*KCH); one LDS atomic per wave and round reserves the wave's slots.
-        const int j0 = tid * KCH, j1 = min(j0 + KCH, HWs);
+        const int j0 = tid * KCH, j1 = min(j0 + KCH, a.HW);
         const bool strided = !in_regs && KCH <= 64;          // up to 64 x 1024 pixels: thread t takes indices t + 1024 c again (coalesced; the
                                                              // scores are L2-resident by now) — the compaction needs no index order
         if (in_regs || strided) {
@@ -574,47 +555,62 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
             if (in_regs) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
-                    if (tid + j * TK_THREADS < HWs && kreg[j] >= Tlo) qual |= 1ull << j;
+                    if (tid + j * TK_THREADS < a.HW && kreg[j] >= Tlo) qual |= 1ull << j;
             }
             for (int c0 = 0; strided && c0 < KCH; c0 += 8) {             // eight independent loads at a time
+                if (klds) {          // the keys are in LDS (this thread wrote exactly these words): no second pass over memory (round 6: the 41 K-pixel maps of 608 x 1088 frames)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (tid + (c0 + j) * TK_THREADS < a.HW && lds_keys[tid + (c0 + j) * TK_THREADS] >= Tlo) qual |= 1ull << (c0 + j);
+                    continue;
+                }
+                if (k16) {           // upper halves only: a superset (exact test below, on the re-read score)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (tid + (c0 + j) * TK_THREADS < a.HW && lds_k16[tid + (c0 + j) * TK_THREADS] >= (unsigned short)(Tlo >> 16)) qual |= 1ull << (c0 + j);
+                    continue;
+                }
                 float vv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vv[j] = tid + (c0 + j) * TK_THREADS < HWs ? sc[tid + (c0 + j) * TK_THREADS] : 0.f;
+                for (int j = 0; j < 8; ++j) vv[j] = tid + (c0 + j) * TK_THREADS < a.HW ? sc[tid + (c0 + j) * TK_THREADS] : 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (tid + (c0 + j) * TK_THREADS < HWs && score_key(vv[j]) >= Tlo) qual |= 1ull << (c0 + j);
+                    if (tid + (c0 + j) * TK_THREADS < a.HW && score_key(vv[j]) >= Tlo) qual |= 1ull << (c0 + j);
             }
             for (;;) {                                       // most threads own no candidate at all: 1-3 rounds per wave
-                const bool has = qual != 0ull;
+                if (__ballot(qual != 0ull) == 0ull) break;
+                bool has = qual != 0ull;
+                unsigned key = 0u, idx = 0u;
+                if (has) {
+                    const int c = __builtin_ctzll(qual);
+                    qual &= qual - 1;
+                    idx = (unsigned)(tid + c * TK_THREADS);
+                    if (in_regs) {
+                        key = kreg[0];
+#pragma unroll
+                        for (int j = 1; j < 16; ++j) key = c == j ? kreg[j] : key;
+                    } else {
+                        key = klds ? lds_keys[idx] : score_key(sc[idx]);
+                        has = key >= Tlo;                    // (k16: the upper halves let a few elements below the bound through)
+                    }
+                }
                 const unsigned long long bal = __ballot(has);
-                if (bal == 0ull) break;
+                if (bal == 0ull) continue;
                 const int leader = __builtin_ctzll(bal);
                 unsigned base = 0u;
                 if (lane == leader) base = atomicAdd(&sh_count, (unsigned)__builtin_popcountll(bal));
                 base = (unsigned)__shfl((int)base, leader);
                 if (has) {
-                    const int c = __builtin_ctzll(qual);
-                    qual &= qual - 1;
                     const unsigned pos = base + (unsigned)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
-                    unsigned key, idx;
-                    if (in_regs) {
-                        key = kreg[0];
-#pragma unroll
-                        for (int j = 1; j < 16; ++j) key = c == j ? kreg[j] : key;
-                        idx = (unsigned)(tid + c * TK_THREADS);
-                    } else {
-                        idx = (unsigned)(tid + c * TK_THREADS);
-                        key = score_key(sc[idx]);
-                    }
-                    if (pos < (unsigned)FAST_CAP) cand[pos] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - ((unsigned)lo + idx));
+                    if (pos < (unsigned)FAST_CAP) cand[pos] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - idx);
                 }
             }
         } else {                                             // maps beyond the LDS budget: plain per-element reservation
             for (int i = j0; i < j1; ++i) {
-                const unsigned key = klds ? lds_keys[tid * KST + (i - j0)] : score_key(sc[i]);
+                const unsigned key = klds ? lds_keys[tid * KCH + (i - j0)] : score_key(sc[i]);
                 if (key >= Tlo) {
                     const unsigned pos = atomicAdd(&sh_count, 1u);
-                    if (pos < (unsigned)FAST_CAP) cand[pos] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(lo + i));
+                    if (pos < (unsigned)FAST_CAP) cand[pos] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
                 }
             }
         }
@@ -629,10 +625,17 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
             // rank of a candidate = how many candidates are greater ((key, ~index) pairs are distinct): the k winners land in canonical
             // order (score desc, index asc) without a sort.  All lanes read the same 16 bytes (two candidates): LDS broadcasts.
             // 1 .. 8 neighbouring lanes share a candidate (1024 threads, at most 1024 candidates) and scan interleaved slices of the array.
+            // More than 512 candidates (k = 300 on the large maps: 400-650): every lane then scans the whole array — 16 waves x n 8-byte LDS reads, 30-32 K cycles at
+            // n = 569-623 (tools/topk_trace.py; 12 K at n = 419, where two lanes share a candidate) — while a bitonic sort of the zero-padded 1024 (wave shuffles
+            // below distance 64) takes 26 K whatever n; the winners are then the first k of `cand` itself.  The pairs are distinct: both give the same order.
+            // (At n <= 512 the rank wins: a 512-wide sort measured 18.5 K against 12 K, and C1's 158-309 candidates went from 10.4 to 14.5 us.)
+            sort_path = total > 512u;
             int psh = 0;
             while (psh < 3 && (total << (psh + 1)) <= (unsigned)TK_THREADS) ++psh;
             const int c = tid >> psh, part = tid & ((1 << psh) - 1);
-            {
+            if (sort_path) {
+                block_sort_desc(cand, 1024, tid);
+            } else {
                 const unsigned long long mine = c < (int)total ? cand[c] : ~0ull;
                 unsigned rank = 0;
                 for (unsigned j = (unsigned)part * 8u; j < total; j += 8u << psh) {
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                 if (psh > 0) rank += (unsigned)__shfl_xor((int)rank, 1);
                 if (psh > 1) rank += (unsigned)__shfl_xor((int)rank, 2);
                 if (psh > 2) rank += (unsigned)__shfl_xor((int)rank, 4);
-                if (part == 0 && c < (int)total && rank < (unsigned)ks) win[rank] = mine;
+                if (part == 0 && c < (int)total && rank < (unsigned)a.k) win[rank] = mine;
             }
             __syncthreads();
             TK_STAMP(3);
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     if (!fast) {
     // --- radix select: key T of the k-th largest element, digits of 12 / 10 / 10 bits from the top.  (A 12-bit first digit
     // spreads sigmoid scores, which share 1-2 exponents, over 16x more bins than an 8-bit one: far less LDS-atomic contention.) ---
-    unsigned prefix = 0, mask = 0, need = (unsigned)ks;
+    unsigned prefix = 0, mask = 0, need = (unsigned)a.k;
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
         const int bits = pass == 0 ? 12 : 10;
@@ -665,15 +668,14 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         for (int i = tid; i < nbins; i += TK_THREADS) hist[i] = 0;
         __syncthreads();
         if (klds) {
-            // keys live in LDS as [thread][KST] (thread t owns indices t*KCH .. t*KCH+KCH-1; the odd row pitch KST keeps both this
-            // loop and the ordered compaction below free of bank conflicts)
-            for (int j = 0; j < KCH; ++j) {
-                if (tid * KCH + j >= HWs) break;
-                const unsigned key = lds_keys[tid * KST + j];
+            // keys live in LDS in index order (lds_keys[i] = key of pixel i): this pass needs no order and strides over them conflict-free; the ordered
+            // compaction below reads thread t's contiguous range t*KCH .. (2-way and worse bank conflicts when KCH is even: the fallback path only)
+            for (int i = tid; i < a.HW; i += TK_THREADS) {
+                const unsigned key = lds_keys[i];
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (unsigned)(nbins - 1)], 1u);
             }
         } else {
-            for (int i = tid; i < HWs; i += TK_THREADS) {          // maps too large for LDS: every pass streams the scores (L2-resident)
+            for (int i = tid; i < a.HW; i += TK_THREADS) {          // maps too large for LDS: every pass streams the scores (L2-resident)
                 const unsigned key = score_key(sc[i]);
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (unsigned)(nbins - 1)], 1u);
             }
@@ -720,17 +722,17 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
 
     // --- ordered compaction: thread t owns the contiguous index range [t*CH, (t+1)*CH); counts packed (gt << 16 | eq) ---
     const int CH = KCH;
-    const int i0 = tid * CH, i1 = min(i0 + CH, HWs);
+    const int i0 = tid * CH, i1 = min(i0 + CH, a.HW);
     unsigned cnt = 0;
     for (int i = i0; i < i1; ++i) {
-        const unsigned key = klds ? lds_keys[tid * KST + (i - i0)] : score_key(sc[i]);
+        const unsigned key = klds ? lds_keys[tid * KCH + (i - i0)] : score_key(sc[i]);
         cnt += key > T ? 0x10000u : 0u;
         cnt += key == T ? 1u : 0u;
     }
     // CH <= 2^24 / 1024 elements per thread may overflow 16 bits in general; totals are bounded by HW <= 2^24, so scan the
     // two counters separately when HW > 65535, packed otherwise (the common case)
     unsigned pos_gt, pos_eq, total_gt;
-    if (HWs <= 65535) {
+    if (a.HW <= 65535) {
         const unsigned inc = wave_incl_scan(cnt, lane);
         if (lane == 63) wave_tot[wave] = inc;
         __syncthreads();
@@ -759,11 +761,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         pos_eq = be + ie - e;
         total_gt = tg;
     }
-    for (int i = tid; i < KPs; i += TK_THREADS) cand[i] = 0ull;   // padding sorts last
+    for (int i = tid; i < a.KP; i += TK_THREADS) cand[i] = 0ull;   // padding sorts last
     __syncthreads();
     for (int i = i0; i < i1; ++i) {
-        const unsigned key = klds ? lds_keys[tid * KST + (i - i0)] : score_key(sc[i]);
-        const unsigned long long comp = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(lo + i));
+        const unsigned key = klds ? lds_keys[tid * KCH + (i - i0)] : score_key(sc[i]);
+        const unsigned long long comp = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
         if (key > T) {
             cand[pos_gt++] = comp;
         } else if (key == T) {
@@ -773,51 +775,15 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     }
     __syncthreads();
 
-    block_sort_desc(cand, KPs, tid);                        // descending by (key, ~index)
+    block_sort_desc(cand, a.KP, tid);                        // descending by (key, ~index)
     }   // !fast
 
     TK_STAMP(5);
-    const unsigned long long* winners = fast ? win : cand;
-    if (a.S > 1) {
-        // hand the slab's winners over (zero pairs pad a slab shorter than k: they rank last), then arrive
-        unsigned* img = a.slab + (size_t)n * SLAB_STRIDE_U32;
-        unsigned long long* list = reinterpret_cast<unsigned long long*>(img + 16);
-        // (agent-scope ATOMIC stores and loads: they are performed at the device's coherence point, so no L2 write-back / invalidate is needed — a release
-        //  fence at agent scope writes back EVERY dirty line of the XCD's L2, the heatmap's producer's output included: decode 47 -> 90 us when it was tried.
-        //  The pairs only have to be PERFORMED before the arrival: the workgroup-scope fence waits for the stores' acknowledgements.)
-        if (tid < a.k) __hip_atomic_store(&list[slab_i * a.k + tid], tid < ks ? winners[tid] : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        if (tid == 0) sh_count = __hip_atomic_fetch_add(img, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (sh_count != (unsigned)(a.S - 1)) return;         // (uniform: every thread reads the same word)
-        __syncthreads();                                     // every thread is done with `win` / `cand` of its own slab
-        const unsigned total = (unsigned)(a.S * a.k);        // <= SLAB_CAND_MAX
-        for (int i = tid; i < FAST_CAP + 8; i += TK_THREADS)
-            cand[i] = i < (int)total ? __hip_atomic_load(&list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        __syncthreads();
-        int psh = 0;
-        while (psh < 3 && (total << (psh + 1)) <= (unsigned)TK_THREADS) ++psh;
-        const int c = tid >> psh, part = tid & ((1 << psh) - 1);
-        const unsigned long long mine = c < (int)total ? cand[c] : ~0ull;
-        unsigned rank = 0;
-        for (unsigned j = (unsigned)part * 8u; j < total; j += 8u << psh) {
-            unsigned long long o[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) o[q] = cand[j + q];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rank += o[q] > mine ? 1u : 0u;
-        }
-        if (psh > 0) rank += (unsigned)__shfl_xor((int)rank, 1);
-        if (psh > 1) rank += (unsigned)__shfl_xor((int)rank, 2);
-        if (psh > 2) rank += (unsigned)__shfl_xor((int)rank, 4);
-        // (zero pairs tie with each other — rank >= the number of real pairs >= k: never among the first k)
-        if (part == 0 && c < (int)total && mine != 0ull && rank < (unsigned)a.k) win[rank] = mine;
-        __syncthreads();
-        winners = win;
-    }
-    sc = a.ws_score + (long)n * a.HW;                        // (global indices from here on)
     // --- gathers + box decode for the k winners ---
+    const unsigned long long* winners = (fast && !sort_path) ? win : cand;
+    // the winners' offsets into the embedding map, once per detection (the gather below had two integer divisions per ELEMENT: 13 K cycles at k = 300, E = 64);
+    // `hist` is free on both paths by now — but `win` aliases its first k * 8 bytes: the offsets live behind them
+    long* ebase = reinterpret_cast<long*>(hist) + 1024;
     if (tid < a.k) {
         const unsigned long long comp = winners[tid];
         const int idx = (int)(0xFFFFFFFFu - (unsigned)(comp & 0xFFFFFFFFull));
@@ -828,16 +794,16 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         const int yi = idx / a.W, xi = idx - yi * a.W;
         decode_box(a.box + (long)n * a.bsn + (long)yi * a.bsh + (long)xi * a.bsw, a.bsc, xi, yi, a.W, a.H, a.normalize,
                    a.box_log, a.mult, a.stride, a.boxes + o * 4);
+        if (a.reid && a.emb) ebase[tid] = (long)n * a.rsn + (long)yi * a.rsh + (long)xi * a.rsw;
     }
     if (a.reid && a.emb) {
         // embeddings: k*E elements, E-contiguous per detection (one coalesced row when reid is NHWC)
+        __syncthreads();
+        const bool e_pow2 = (a.E & (a.E - 1)) == 0;
+        const int e_sh = 31 - __builtin_clz((unsigned)a.E);
         for (int t = tid; t < a.k * a.E; t += TK_THREADS) {
-            const int d = t / a.E, e = t - d * a.E;
-            const unsigned long long comp = winners[d];
-            const int idx = (int)(0xFFFFFFFFu - (unsigned)(comp & 0xFFFFFFFFull));
-            const int yi = idx / a.W, xi = idx - yi * a.W;
-            a.emb[((long)n * a.k + d) * a.E + e] =
-                a.reid[(long)n * a.rsn + (long)e * a.rsc + (long)yi * a.rsh + (long)xi * a.rsw];
+            const int d = e_pow2 ? (t >> e_sh) : t / a.E, e = t - d * a.E;
+            a.emb[((long)n * a.k + d) * a.E + e] = a.reid[ebase[d] + (long)e * a.rsc];
         }
     }
     TK_STAMP(6);
@@ -885,27 +851,14 @@ int launch_cminor(const PeakArgs& a, int P, size_t lds, unsigned blocks, hipStre
 using namespace cnl_decode;
 
 #ifdef TK_TIMING
-extern "C" int cnl_debug_topk_stamps(unsigned long long* out) {
+extern "C" __attribute__((visibility("default"))) int cnl_debug_topk_stamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(cnl_decode::tk_stamps), sizeof(unsigned long long) * 64 * 16) == hipSuccess ? 0 : 1;
 }
 #endif
 
-// workspace: [score plane N*H*W f32][label plane N*H*W i32][pad to 256][per image: arrival counter (64 bytes) + up to 1024 (key, ~index) pairs of stage 2's slabs]
-static size_t decode_planes_bytes(int32_t N, int32_t H, int32_t W) { return ((size_t)N * H * W * 8 + 255) / 256 * 256; }
 extern "C" size_t cnl_decode_workspace_bytes(int32_t N, int32_t H, int32_t W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
-    return decode_planes_bytes(N, H, W) + 256 + (size_t)N * SLAB_STRIDE_U32 * 4;
-}
-// Slabs per image of stage 2 — a function of the map size and k alone: maps of at least 8192 pixels are split 4-fold, of at least 32768 pixels 8-fold, as far
-// as S * k <= 1024 pairs allow (k = 300 on the 152 x 272 maps of 608 x 1088 frames: 3).
-static int decode_slabs(int HW, int k) {
-#ifdef CNL_DECODE_SLABS      /* A/B builds (make variant EXTRA=-DCNL_DECODE_SLABS=1): a fixed slab count where it is possible at all */
-    { const int f = CNL_DECODE_SLABS; return (f > 1 && HW >= 2048 * f && f * k <= SLAB_CAND_MAX) ? f : 1; }
-#endif
-    const int by_size = HW >= 32768 ? 8 : (HW >= 8192 ? 4 : 1);
-    const int by_k = SLAB_CAND_MAX / k;
-    const int S = by_size < by_k ? by_size : by_k;
-    return S < 1 ? 1 : S;
+    return (size_t)N * H * W * 8 + 256;
 }
 
 extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
@@ -933,7 +886,6 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
     a.N = p->N; a.C = p->C; a.H = p->H; a.W = p->W;
     a.ws_score = (float*)p->workspace;
     a.ws_label = (int*)((char*)p->workspace + (size_t)p->N * HW * 4);
-    a.slab_ctr = (unsigned*)((char*)p->workspace + decode_planes_bytes(p->N, p->H, p->W));
 
     int rc;
     const bool cminor = p->heat_sc == 1;
@@ -1005,9 +957,6 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
     t.box = p->box; t.bsn = p->box_sn; t.bsc = p->box_sc; t.bsh = p->box_sh; t.bsw = p->box_sw;
     t.reid = p->reid; t.rsn = p->reid_sn; t.rsc = p->reid_sc; t.rsh = p->reid_sh; t.rsw = p->reid_sw;
     t.HW = HW; t.W = p->W; t.H = p->H; t.E = p->reid ? p->E : 0; t.k = p->k;
-    t.S = decode_slabs(HW, p->k);
-    t.SL = (HW + t.S - 1) / t.S;
-    t.slab = a.slab_ctr;
     int kp = 2;
     while (kp < p->k) kp <<= 1;
     t.KP = kp;
@@ -1015,14 +964,14 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
     t.scores = p->scores; t.indices = (long long*)p->indices; t.labels = (long long*)p->labels; t.boxes = p->boxes;
     t.emb = p->emb;
     // 40 KB of static LDS + the keys: one workgroup per CU either way (1024 threads)
-    const size_t kst = (size_t)(((t.SL + TK_THREADS - 1) / TK_THREADS) | 1);
-    t.keys_in_lds = kst * TK_THREADS * 4 <= 96 * 1024;
-    const size_t key_bytes = t.keys_in_lds ? kst * TK_THREADS * 4 : 0;
+    const size_t key_words = (size_t)((HW + TK_THREADS - 1) / TK_THREADS) * TK_THREADS;
+    t.keys_in_lds = key_words * 4 <= 96 * 1024;
+    t.keys16_in_lds = !t.keys_in_lds && key_words * 2 <= 96 * 1024;
+    const size_t key_bytes = t.keys_in_lds ? key_words * 4 : (t.keys16_in_lds ? key_words * 2 : 0);
     static cnl::DeviceOnce once;
     rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&topk_kernel), 96 * 1024);
     if (rc != CNL_OK) return rc;
-    CNL_REQUIRE((long long)p->N * t.S < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_decode_f32: grid too large");
-    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)(p->N * t.S)), dim3(TK_THREADS), key_bytes, s, t);
+    hipLaunchKernelGGL(topk_kernel, dim3(p->N), dim3(TK_THREADS), key_bytes, s, t);
     return cnl::check_launch("topk_kernel");
 }
 

@@ -313,12 +313,6 @@ int cnl_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, int32_t H, in
  * heat/box/reid element (n,c,y,x) at n*s_n + c*s_c + y*s_h + x*s_w (elements): any NCHW or NHWC view.
  * Outputs: scores [N,k] f32, indices [N,k] i64 (flat y*W+x), labels [N,k] i64, boxes [N,k,4] f32,
  * emb [N,k,E] f32 (may be null when reid is null).
- * Two launches: the streaming pass (score + label per pixel into `workspace`), then the per-image top-k — on 1, 3, 4 or 8 workgroups per image (a
- * function of H * W and k: ABI v13): each takes the k best of its slab of the map, hands them over through `workspace`, and the workgroup that arrives
- * last at the image's arrival counter (it lives in `workspace` too and is zeroed by the first launch of the SAME call: no state survives a call, none is
- * expected before it) ranks the slabs' winners and gathers.  (score desc, index asc) pairs are distinct and ranked by value: the result does not depend
- * on which workgroup arrives last.  The workspace is written by the call and may be reused or freed once the call's work on `stream` is done; two calls
- * that run CONCURRENTLY (different streams) need different workspaces.
  */
 typedef struct cnl_decode_params {
     const float* heat; int64_t heat_sn, heat_sc, heat_sh, heat_sw;

@@ -115,11 +115,11 @@ def test_decode_quantised_scores_many_ties():
 
 @pytest.mark.parametrize("shape,k", [((2, 4, 128, 128), 100), ((2, 3, 96, 96), 100), ((1, 2, 152, 272), 300), ((2, 2, 200, 200), 120), ((1, 4, 128, 128), 400)])
 @pytest.mark.parametrize("kind", ["random", "quantised", "plateau_rows", "all_equal", "one_slab_only"])
-def test_decode_topk_on_several_workgroups_per_image(shape, k, kind):
-    """Stage 2 runs on 1 / 3 / 4 / 8 workgroups per image (maps of >= 8192 pixels, S * k <= 1024: VERDICT r5 #2b): every slab's winners are merged by
-    the workgroup that arrives last.  Bit-exact against the oracle (scores, indices in canonical order, labels, boxes) where ties straddle slab
-    boundaries, where a slab holds none of the winners, where whole rows are plateaus (the radix-select path inside a slab) and where everything is
-    equal; three runs give identical bytes (the arrival order is not in the result)."""
+def test_decode_topk_on_large_maps_with_ties(shape, k, kind):
+    """Maps of 9 K - 41 K pixels (keys in registers / in LDS) with the tie structures that stress the selection: quantised scores, whole rows that are
+    plateaus (the radix-select path), everything equal, all winners in the last rows.  Bit-exact against the oracle (scores, indices in canonical
+    order, labels, boxes); three runs give identical bytes.  (Written for round 6's experiment r6b — the top-k on several workgroups per image, merged by
+    the last arriver: bit-exact on these cases too, but slower, profiles/r06_experiments.txt — and kept for the kernel that stayed.)"""
     N, C, H, W = shape
     g = torch.Generator().manual_seed(H * W + k)
     if kind == "random":
