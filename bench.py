@@ -78,6 +78,12 @@ def profiled(config, B, H, W):
     return json.load(open(os.path.join(ROOT, path))), path
 
 
+def profile_matches_sources(prof):
+    """Was the committed profile taken from the kernel sources of this tree?  (meta.sources_sha16, written by tools/profile_round.sh; profiles of rounds 1-5 carry none: None.)"""
+    want = (prof or {}).get("meta", {}).get("sources_sha16")
+    return None if want is None else (want == sources_sha16())
+
+
 CONFIGS = {"simple": "resnet34_simple.yaml", "fpn": "resnet34_fpn.yaml", "tracking": "tracking_resnet34_fpn.yaml"}
 KIND_NAMES = {"winograd_row4_f16x2": "cnl_wino10::winograd10_kernel (the row-Winograd arithmetic of cnl_wino9 on 4-row x 64-pixel x 64-cout work items, two "
                                      "workgroups per CU)",
@@ -141,6 +147,10 @@ def setup_distributed(gpus):
     if world != gpus:                    # (a plain `bench.py --gpus N` never gets here: main() starts the ranks itself, `self_launch`)
         raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}")
     backend = os.environ.get("CNL_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > 1 and torch.cuda.is_available() and torch.cuda.device_count() < world:
+        # RCCL needs one device per rank; two ranks on one GPU end in an abort deep inside the communicator set-up
+        raise SystemExit(f"bench.py --gpus {gpus}: {torch.cuda.device_count()} GPU(s) visible to rank {rank} — the RCCL (nccl) backend needs one device per rank; "
+                         f"for a functional run of the N > 1 flow on fewer devices set CNL_BENCH_BACKEND=gloo (its line says so: collective.backend)")
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
     if world > 1:
@@ -208,6 +218,8 @@ def stub_main(args, rank, world):
     elapsed = timed(model, x, False, args.k, args.warmup, args.steps, collator, barrier)
     out = run_steps(model, x, False, args.k, 1, collator)
     ok = tuple(out.shape) == (world * args.batch, args.k, 6) and all(bool((out[q * args.batch:(q + 1) * args.batch] == q).all()) for q in range(world))
+    coll = collective_info("cpu")
+    par = parallelism_text(world)
     if world > 1:
         elapsed = max_over_ranks(elapsed, "cpu")
         dist.barrier()
@@ -219,7 +231,57 @@ def stub_main(args, rank, world):
                           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "STUB (CNL_BENCH_STUB=1: launcher / collate self-test without a GPU — NOT a measurement)",
-                          "config": {"workload": "stub", "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"batch-shard x{world}"}}), flush=True)
+                          "collective": coll,
+                          "config": {"workload": "stub", "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": par}}), flush=True)
+
+
+def collective_info(device):
+    """What the communicator of THIS run was (the N > 1 line must prove an RCCL run, not assert it): backend, RCCL version, the world size the
+    process group reports, and every rank's device — ordinal, name and PCI bus id, all-gathered — so that "8 ranks on 8 distinct devices" is a field of the line.
+    Every rank calls this (it is a collective); world size 1: no process group, no collective."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world_size": 1, "note": "one rank: no process group, collate is a no-op (reference eval/coco.py:11-13)"}
+    backend = dist.get_backend()
+    mine = {"rank": dist.get_rank(), "device": None, "pci_bus_id": None, "name": None, "host": os.uname().nodename, "pid": os.getpid()}
+    if torch.cuda.is_available():
+        d = torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(d)
+        mine.update(device=d, name=pr.name, pci_bus_id=getattr(pr, "pci_bus_id", None) if not hasattr(pr, "pci_domain_id") else f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}")
+        if isinstance(mine["pci_bus_id"], int):
+            mine["pci_bus_id"] = f"{mine['pci_bus_id']:02x}"
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:          # noqa: BLE001 — reported, never fatal
+            ver = repr(e)
+    ids = [(e["host"], e["pci_bus_id"] if e["pci_bus_id"] is not None else e["device"]) for e in everyone]
+    return {"backend": backend, "rccl_version": ver, "world_size": dist.get_world_size(), "devices": everyone,
+            "distinct_devices": len(set(ids)) if all(i[1] is not None for i in ids) else 0,
+            "note": "backend 'nccl' IS RCCL on ROCm (collectives over xGMI between the GPUs of one node); 'gloo' = a functional run through the host, never a measurement of the collective"}
+
+
+def parallelism_text(world):
+    if world <= 1:
+        return "batch-shard x1"
+    backend = dist.get_backend() if dist.is_initialized() else "none"
+    how = "RCCL all-gather of detections over xGMI" if backend == "nccl" else f"{backend} all-gather of detections through the host (FUNCTIONAL run, not RCCL)"
+    return f"batch-shard x{world} + {how} (side stream, one step behind)"
+
+
+def sources_sha16():
+    """First 16 hex digits of the SHA-256 over csrc/*.hip, csrc/*.h and include/*.h (sorted by name): what a committed profile was taken from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "centernet-lightning_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "centernet-lightning_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def max_over_ranks(elapsed, device):
@@ -353,6 +415,7 @@ def roofline_block(rows, config, B, H, W):
             "traffic": traffic[0] if traffic else None,
             "traffic_source": (traffic[1] + " — rocprofv3 PMC of an earlier run of this command, not measured here") if traffic else
                               "no PMC profile of this kernel / configuration committed yet (see profiles/)",
+            "profile_matches_sources": profile_matches_sources(prof),
             "sustained_clock_note": "power-limited DVFS: on the 256-channel head blocks this kernel holds 1.37-1.48 GHz of 2.4 under real data (GRBM_GUI_ACTIVE / duration, profiles/r04_winograd_variants.txt, r04_winograd9_skip4.txt): a denser schedule lowers the clock, 25 % fewer MFMAs buy 12.6 % (DESIGN.md 3.1); a loop of nothing but this MFMA on random fp16 operands sustains 1.84-1.90 PFLOP/s at 1.84-1.90 GHz (profiles/r04_mfma_order.txt), 0.74-0.76 of `peak`"}
     def other(k_, v):
         if k_ == "fused_out_reduce":      # HBM-bound: bytes / s against the HBM peak, no executed matrix flops
@@ -405,7 +468,7 @@ def decode_profiled(config, B, H, W):
     prof, path = profiled(config, B, H, W)
     if not prof:
         return None
-    out = {"source": f"{path} — rocprofv3 kernel-trace / PMC of an earlier run of this command, not measured by this run"}
+    out = {"source": f"{path} — rocprofv3 kernel-trace / PMC of an earlier run of this command, not measured by this run", "profile_matches_sources": profile_matches_sources(prof)}
     for name, k in prof["kernels"].items():
         if name.startswith("cnl_decode::"):
             out[name] = {f: k[f] for f in ("avg_us", "hbm_MB_per_launch", "calls") if f in k}
@@ -713,7 +776,7 @@ def short_line(spec, rank=0, world=1, barrier=None, steps=10, warmup=3):
     roof, stack = roofline_block(rows, config, B, H, W)
     eng = model._engine
     line = {"config": {"workload": f"BASELINE {spec['name']}: ResNet34 + {config} neck, {B} img/GPU x {H}x{W}, k={k}", "global_batch": world * B, "per_gpu_batch": B,
-                       "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of detections (side stream, one step behind)" if world > 1 else "")},
+                       "parallelism": parallelism_text(world)},
             "value": round(job_throughput(B, world, steps, el), 2), "unit": "images/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 3),
             "roofline": {kk: roof[kk] for kk in ("kernel", "achieved", "peak", "frac", "effective_tflops", "launches_per_step", "kernel_ms_per_step", "avg_launch_us",
@@ -786,6 +849,7 @@ def main():
     if world > 1:
         elapsed = max_over_ranks(elapsed, "cuda")
         collate_ms = collate_alone_ms(model, x, tracking, args.k, collator, barrier)
+    coll = collective_info("cuda")          # (a collective at world > 1: every rank)
 
     if rank == 0:
         with torch.no_grad():
@@ -799,7 +863,9 @@ def main():
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "timed_region_s": round(elapsed, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "collective": coll,
             "dtype": "f32",
             "dtype_note": "fp32 in / fp32 accumulate / fp32 out; where it pays, each fp32 product is formed on the fp16 matrix cores from a two-way fp16 split of "
                           "both (power-of-two scaled) operands (3 cross terms); KernelOptions.algo = " + args.algo + " (auto: every kernel's error at or below the fp32 MFMA's; "
@@ -807,7 +873,7 @@ def main():
             "data": "synthetic (seeded rand images; random-init weights of the named architecture)",
             "config": {"workload": f"BASELINE C{'1' if args.config == 'simple' else ('4' if tracking else '2/3')}: ResNet34 + {args.config} neck, "
                                    f"{B} img/GPU x {H}x{W}, heads {'2+4+reid64' if tracking else '80+4'} (w256), k={args.k}, nms 3",
-                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of detections (side stream, one step behind)" if world > 1 else "")},
+                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": parallelism_text(world)},
             "roofline": roof,
             "conv_stack": stack,
             "decode": dec,
@@ -887,9 +953,20 @@ def main():
     # the other BASELINE configurations: EVERY rank takes part (at N > 1 these are C3 and C4, the two configurations defined on 8 GPUs)
     if not args.no_also:
         lines = []
+        if args.steps < 200:
+            # the main line's job once more over 200 steps (the driver's --steps 20 makes `value` a 150-ms sample; this is the same job as a 1.5-s one)
+            el200 = timed(model, x, tracking, args.k, 0, 200, collator, barrier)
+            if world > 1:
+                el200 = max_over_ranks(el200, "cuda")
+            if rank == 0:
+                lines.append({"config": {"workload": "the main line's job again, 200 steps (no further warm-up)", "global_batch": world * B, "per_gpu_batch": B, "parallelism": parallelism_text(world)},
+                              "value": round(job_throughput(B, world, 200, el200), 2), "unit": "images/s", "n_gpus": world, "steps": 200, "warmup": 0,
+                              "ms_per_step": round(el200 / 200 * 1e3, 3), "timed_region_s": round(el200, 4)})
         for spec in also_workloads(world, args.config, B, H, W):
             try:
-                lines.append(short_line(spec, rank, world, barrier))
+                ln = short_line(spec, rank, world, barrier)
+                if ln is not None or world == 1:
+                    lines.append(ln)
             except Exception as e:
                 if world > 1:
                     raise                                   # a rank that drops out of a collective would hang the others: fail the job loudly

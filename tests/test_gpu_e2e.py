@@ -33,23 +33,36 @@ def build(cfg_name, mutate=None, **options):
     return model.cuda(), sd
 
 
-def compare_detections(dets, ref, k, indices=None):
+def compare_detections(dets, indices, ref_heat, ref_box, k, ref_reid=None):
+    """End-to-end detections against the oracle's, EVERY rank pinned (VERDICT r5 #4b; rounds 3-5 pinned only the ranks whose neighbouring oracle scores lie
+    more than GAP apart — 80-90 % of them).  Two fp32 summation orders may legitimately swap detections whose scores differ by less than the conv
+    round-off, and the k-th may trade places with the (k+1)-th; so the oracle decodes k + 64 candidates from ITS maps and, rank by rank, the GPU's detection
+    must BE one of them — same pixel — whose oracle score lies within GAP of the oracle's score at that rank; labels, boxes and embeddings are then compared
+    through that matching.  Returns the mask of ranks where GPU and oracle agree on the pixel outright."""
     s, l, b = dets["scores"].cpu().numpy(), dets["labels"].cpu().numpy(), dets["bboxes"].cpu().numpy()
+    gi = indices.cpu().numpy()
+    N, HW = s.shape[0], ref_heat.shape[2] * ref_heat.shape[3]
+    ref = decode_ref.decode_detections(ref_heat, ref_box, k, 3, reid=ref_reid)
+    ext = decode_ref.decode_detections(ref_heat, ref_box, min(HW, k + 64), 3, reid=ref_reid)
     np.testing.assert_allclose(s, ref["scores"], rtol=TOL, atol=TOL)
-    # Across two different fp32 summation orders a rank is only well-defined where the oracle's neighbouring scores
-    # are further apart than the conv round-off (observed ~3e-7); everywhere else positions may legitimately swap.
-    gap_prev = np.abs(np.diff(ref["scores"], axis=1, prepend=np.inf))
-    gap_next = np.abs(np.diff(ref["scores"], axis=1, append=-np.inf))
-    safe = (gap_prev > GAP) & (gap_next > GAP)
-    safe[:, -1] = False                       # the k-th may swap with the (k+1)-th
-    # the share of the top-k ranks this comparison actually pins end to end (the rest is pinned on identical bytes only: Level A below)
-    print(f"compare_detections: safe fraction {safe.mean():.3f} of {safe.size} ranks (gap > {GAP:g} on both sides)")
-    assert safe.mean() >= 0.8, safe.mean()
-    assert np.array_equal(l[safe], ref["labels"][safe])
-    if indices is not None:                   # top-k indices bit-exact
-        assert np.array_equal(indices.cpu().numpy()[safe], ref["indices"][safe])
-    np.testing.assert_allclose(b[safe], ref["boxes"][safe], rtol=TOL, atol=TOL * 4)     # boxes are in pixels (x stride 4)
-    return safe
+    same = gi == ref["indices"]
+    pinned = 0
+    for n in range(N):
+        assert len(set(gi[n].tolist())) == k                                     # k distinct pixels
+        where = {int(ix): j for j, ix in enumerate(ext["indices"][n])}
+        for r in range(k):
+            j = where.get(int(gi[n, r]))
+            assert j is not None, f"image {n} rank {r}: pixel {gi[n, r]} is not among the oracle's first {len(where)} candidates"
+            assert abs(float(ext["scores"][n, j]) - float(ref["scores"][n, r])) <= GAP, (n, r, j, float(ext["scores"][n, j]), float(ref["scores"][n, r]))
+            assert l[n, r] == ext["labels"][n, j], (n, r)
+            np.testing.assert_allclose(b[n, r], ext["boxes"][n, j], rtol=TOL, atol=TOL * 4)      # boxes are in pixels (x stride 4)
+            if ref_reid is not None:
+                np.testing.assert_allclose(dets["embeddings"][n, r].cpu().numpy(), ext["embeddings"][n, j], rtol=TOL, atol=TOL)
+            pinned += 1
+    print(f"compare_detections: safe fraction {pinned / (N * k):.3f} of {N * k} ranks (tolerance-aware matching: every rank pinned); "
+          f"identical pixel at the same rank: {same.mean():.3f}")
+    assert pinned == N * k
+    return same
 
 
 @pytest.mark.parametrize("cfg,shape", [("resnet34_simple.yaml", (2, 3, 128, 160)), ("resnet34_fpn.yaml", (2, 3, 160, 128)),
@@ -75,12 +88,10 @@ def test_forward_and_decode_match_cpu_oracle(cfg, shape):
     k = 50
     if model.task == "tracking":
         dets = model.gather_tracking2d(out, num_detections=k)
-        ref = decode_ref.decode_detections(ref_sig["heatmap"].numpy(), ref_sig["box_2d"].numpy(), k, 3, reid=ref_sig["reid"].numpy())
     else:
         dets = model.gather_detection2d(out, num_detections=k)
-        ref = decode_ref.decode_detections(ref_sig["heatmap"].numpy(), ref_sig["box_2d"].numpy(), k, 3)
     idx = cl.decode.decode(heat, box, None, k, 3, stride=model.output_stride)["indices"]
-    safe = compare_detections(dets, ref, k, idx)
+    compare_detections(dets, idx, ref_sig["heatmap"].numpy(), ref_sig["box_2d"].numpy(), k, ref_sig["reid"].numpy() if model.task == "tracking" else None)
     # Level A on the GPU's own tensors: indices bit-exact against the oracle decode of the same bytes
     refA = decode_ref.decode_detections(heat.cpu().numpy(), box.cpu().numpy(), k, 3,
                                         reid=out[2].cpu().numpy() if model.task == "tracking" else None)
@@ -90,7 +101,6 @@ def test_forward_and_decode_match_cpu_oracle(cfg, shape):
     assert np.array_equal(dets["bboxes"].cpu().numpy().view(np.uint32), refA["boxes"].view(np.uint32))
     if model.task == "tracking":
         assert np.array_equal(dets["embeddings"].cpu().numpy(), refA["embeddings"])
-        np.testing.assert_allclose(dets["embeddings"].cpu().numpy()[safe], ref["embeddings"][safe], rtol=TOL, atol=TOL)
 
 
 def test_c0_config_512(request):
@@ -104,7 +114,8 @@ def test_c0_config_512(request):
     torch.testing.assert_close(box.cpu(), ref["box_2d"], rtol=TOL, atol=TOL)
     dets = model.gather_detection2d(heat, box)
     assert tuple(dets["bboxes"].shape) == (1, 100, 4) and dets["labels"].dtype == torch.int64
-    compare_detections(dets, decode_ref.decode_detections(ref["heatmap"].numpy(), ref["box_2d"].numpy(), 100, 3), 100)
+    idx = cl.decode.decode(heat, box, None, 100, 3, stride=model.output_stride)["indices"]
+    compare_detections(dets, idx, ref["heatmap"].numpy(), ref["box_2d"].numpy(), 100)
 
 
 def test_batch_shard_equals_full_batch():

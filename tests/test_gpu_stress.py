@@ -107,3 +107,126 @@ def test_deconv_random_shapes_exact(seed):
         p.ldx, p.ldy, p.flags = C, C, CNL_RELU
         _lib.check(lib.cnl_deconv2x_nhwc_f32(ctypes.byref(p), None))
         assert torch.equal(y.cpu().permute(0, 3, 1, 2), ref), (seed, K, C, N, H, W)
+
+
+# ----------------------------------------------------------------------------- the row-Winograd family on random shapes (VERDICT r5 #4a)
+def _row_shape(rnd):
+    """N 1-9, even widths 6..300 (with the special widths of the block grid: 16, 32 — images side by side —, 34, 68 — packed rows —, 64, 128), heights 1-40,
+    Cin % 32 == 0, Cout % 4 == 0; kept small enough that one case is ~10 ms of CPU reference."""
+    N = rnd.randint(1, 9)
+    W = rnd.choice([16, 32, 34, 68, 64, 128, 2 * rnd.randint(3, 150), 2 * rnd.randint(3, 40), 2 * rnd.randint(3, 40)])
+    H = rnd.randint(1, 40)
+    Cin = rnd.choice([32, 32, 64, 64, 96, 128, 256, 512])
+    Cout = rnd.choice([4, 8, 32, 60, 64, 68, 96, 128, 160, 256])
+    while N * H * W * (Cin + Cout) > 6_000_000:      # (bounded work: shrink the batch, then the height)
+        if N > 1:
+            N -= 1
+        else:
+            H = max(1, H // 2)
+    return N, Cin, H, W, Cout
+
+
+def _real_case(N, Cin, H, W, Cout, g, res_hw=None):
+    x = torch.randn(N, Cin, H, W, generator=g).clamp_min(0) * torch.pow(10.0, torch.randint(-3, 3, (N, 1, 1, 1), generator=g).float())
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, Cout, *res_hw, generator=g) if res_hw else None
+    return x, w, b, res
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_row_winograd_family_random_shapes_bit_identity(seed):
+    """Variants 9 / 10 / 11 are ONE arithmetic chain per accumulator on different work items, packed rows are the same chain on another block grid, and every
+    image carries its own scale: on seeded random shapes (ragged heights, the special widths, residual / folded-upsample flags, images of 10^-3 .. 10^2 side by
+    side) all of these give the same BITS — variant vs variant, packed vs plain grid, an image alone vs inside the batch — and stay within 1e-4 of the CPU."""
+    from centernet_lightning_amd._lib import CNL_ALGO_FORCE
+    rnd = random.Random(4000 + seed)
+    g = torch.Generator().manual_seed(400 + seed)
+    for _ in range(7):
+        N, Cin, H, W, Cout = _row_shape(rnd)
+        mode = rnd.choice(["plain", "relu", "res", "up_in", "up_in_relu"])
+        flags = (CNL_RELU if mode in ("relu", "res", "up_in_relu") else 0) | (CNL_UPSAMPLE_IN if mode.startswith("up_in") else 0)
+        up = 2 if flags & CNL_UPSAMPLE_IN else 1
+        Hs, Ws = (max(1, H // 2), max(3, W // 2)) if up == 2 else (H, W)
+        x, w, b, res = _real_case(N, Cin, Hs, Ws, Cout, g, (Hs * up, Ws * up) if mode == "res" else None)
+        tag = (seed, N, Cin, Hs, Ws, Cout, mode)
+        o9 = run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 9, want=5)
+        assert not torch.isnan(o9).any(), tag
+        for v in (10, 11):
+            assert torch.equal(o9, run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + v)), (tag, v)
+        for v in (9, 10, 11):
+            assert torch.equal(o9, run_winograd(x, w, b, flags, res, algo=CNL_ALGO_FORCE + 32 + v)), (tag, "plain grid", v)
+        i = rnd.randrange(N)
+        one = run_winograd(x[i:i + 1], w, b, flags, res[i:i + 1] if res is not None else None, algo=CNL_ALGO_FORCE + 9)
+        assert torch.equal(o9[i:i + 1], one), (tag, "image alone", i)
+        ref = ref_conv(x, w, b, 1, flags, res)
+        for n in range(N):
+            sc = max(1.0, float(ref[n].abs().max()))
+            assert float((o9[n] - ref[n]).abs().max()) <= 1e-4 * sc, (tag, n)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_row_pair_and_folded_forms_random_shapes_within_their_bounds(seed):
+    """The two default forms that are 'within rounding', not bit-identical, of the general one, on seeded random shapes instead of a handful of
+    hand-picked ones: the row-pair weights behind a folded upsample (cnl_conv_params.w_up) stay < 2e-6 of the image maximum from the general form, a folded
+    out_conv of <= 4 channels (fuse_w) <= 4e-6 from a 1x1 conv of the block's (bit-identical) output; both deterministic and batch-invariant."""
+    import test_gpu_conv as tc
+    from centernet_lightning_amd import _lib
+    from centernet_lightning_amd._lib import CNL_ALGO_FORCE, ConvParams
+    rnd = random.Random(5000 + seed)
+    g = torch.Generator().manual_seed(500 + seed)
+    lib = _lib.load()
+    for _ in range(4):
+        N, Cin, H, W, Cout = _row_shape(rnd)
+        Hs, Ws = max(1, H // 2), max(3, W // 2)
+        x, w, b, _ = _real_case(N, Cin, Hs, Ws, Cout, g)
+        flags = CNL_UPSAMPLE_IN | (CNL_RELU if rnd.random() < 0.5 else 0)
+        gen = run_winograd(x, w, b, flags, algo=CNL_ALGO_FORCE + 9)
+        rp = run_winograd(x, w, b, flags, algo=CNL_ALGO_FORCE + 9, up_rows=True)
+        for n in range(N):
+            sc = max(float(gen[n].abs().max()), 1e-30)
+            assert float((rp[n] - gen[n]).abs().max()) <= 2e-6 * sc, (seed, N, Cin, Hs, Ws, Cout, n)
+        assert torch.equal(rp, run_winograd(x, w, b, flags, algo=CNL_ALGO_FORCE + 9, up_rows=True))
+        i = rnd.randrange(N)
+        assert torch.equal(rp[i:i + 1], run_winograd(x[i:i + 1], w, b, flags, algo=CNL_ALGO_FORCE + 9, up_rows=True))
+    for _ in range(4):
+        N, Cin, H, W, Cout = _row_shape(rnd)
+        C2 = rnd.randint(1, 4)
+        x, w, b, _ = _real_case(N, Cin, H, W, Cout, g)
+        w2 = torch.randn(C2, Cout, 1, 1, generator=g) * 0.05
+        b2 = torch.randn(C2, generator=g)
+        plain = run_winograd(x, w, b, CNL_RELU, algo=CNL_ALGO_FORCE + 9)
+
+        def folded(xs):
+            n = xs.shape[0]
+            xd = xs.permute(0, 2, 3, 1).contiguous().cuda()
+            wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+            u = torch.empty((lib.cnl_winograd_weight_floats(Cin, Cout),), device="cuda")
+            _lib.check(lib.cnl_winograd_transform_weights_f32(wd.data_ptr(), u.data_ptr(), Cin, Cout, tc._stream()))
+            bd, w2d, b2d = b.cuda(), w2.reshape(C2, Cout).contiguous().cuda(), b2.cuda()
+            CoutP = (Cout + 63) // 64 * 64
+            fw = torch.full((CoutP, 4), float("nan"), device="cuda")
+            _lib.check(lib.cnl_fused_out_pack_weights_f32(w2d.data_ptr(), fw.data_ptr(), Cout, C2, tc._stream()))
+            nb = CoutP // 32
+            part = torch.full((nb, n * H * W, 4), float("nan"), device="cuda")
+            y = torch.full((n, H, W, Cout), float("nan"), device="cuda")
+            out = torch.full((n, H, W, C2), float("nan"), device="cuda")
+            p = ConvParams()
+            p.x, p.w, p.bias, p.y = xd.data_ptr(), u.data_ptr(), bd.data_ptr(), y.data_ptr()
+            p.N, p.H_in, p.W_in, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad = n, H, W, Cin, Cout, 3, 3, 1, 1
+            p.ldx, p.ldy, p.flags, p.algo = Cin, Cout, CNL_RELU, CNL_ALGO_FORCE + 9
+            p.fuse_w, p.fuse_part = fw.data_ptr(), part.data_ptr()
+            _lib.check(lib.cnl_conv3x3_winograd_f32(ctypes.byref(p), tc._stream()), "winograd + folded 1x1")
+            _lib.check(lib.cnl_fused_out_reduce_f32(part.data_ptr(), nb, n * H * W, C2, b2d.data_ptr(), out.data_ptr(), C2, 0, tc._stream()), "reduce")
+            torch.cuda.synchronize()
+            return y.cpu().permute(0, 3, 1, 2), out.cpu().permute(0, 3, 1, 2)
+
+        y, out = folded(x)
+        tag = (seed, N, Cin, H, W, Cout, C2)
+        assert torch.equal(y, plain), tag
+        want = F.conv2d(y, w2, b2)
+        for n in range(N):
+            assert float((out[n] - want[n]).abs().max()) <= 4e-6 * max(1.0, float(want[n].abs().max())), (tag, n)
+        i = rnd.randrange(N)
+        y1, out1 = folded(x[i:i + 1])
+        assert torch.equal(out1[0], out[i]) and torch.equal(y1[0], y[i]), (tag, i)

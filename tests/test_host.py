@@ -343,6 +343,10 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 64 and line["data"].startswith("STUB")
     assert line["value"] > 0 and abs(line["value"] - 64 * 2 / (line["ms_per_step"] * 2e-3)) / line["value"] < 0.01
+    # the line proves which collective ran: backend, the world size the process group reports, one entry per rank — and says so in `parallelism`
+    coll = line["collective"]
+    assert coll["backend"] == "gloo" and coll["world_size"] == 2 and [d["rank"] for d in coll["devices"]] == [0, 1] and coll["rccl_version"] is None
+    assert "gloo" in line["config"]["parallelism"] and "FUNCTIONAL" in line["config"]["parallelism"] and "RCCL all-gather of detections over" not in line["config"]["parallelism"]
 
 
 def test_bench_self_launch_reports_a_failed_rank():

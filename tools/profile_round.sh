@@ -19,7 +19,8 @@ for c in ${CFGS:-c1 c2 c4}; do
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o r -- $CMD > /dev/null 2>&1
   python tools/rocpd_summary.py stats $O/stats > gpurun_out/$R/${R}_kernel_stats_$c.csv
   python tools/rocpd_summary.py pmc $O/fetch $O/write > gpurun_out/$R/${R}_pmc_traffic_$c.txt
-  python tools/rocpd_summary.py json $O/stats $O/fetch $O/write gpurun_out/$R/${R}_profile_$c.json "command=$CMD" config=$c
+  SHA=$(python -c "import bench; print(bench.sources_sha16())")
+  python tools/rocpd_summary.py json $O/stats $O/fetch $O/write gpurun_out/$R/${R}_profile_$c.json "command=$CMD" config=$c sources_sha16=$SHA
   timeout 300 python tools/plan_profile.py $P > gpurun_out/$R/${R}_plan_per_launch_$c.txt 2>&1
   tail -1 $O/bench_stats.json | cut -c1-200 > gpurun_out/$R/${R}_bench_profiled_$c.head
   rm -rf $O/stats $O/fetch $O/write
