@@ -56,7 +56,13 @@ class KernelOptions:
       f43              opt-in arithmetic class (default off): 3x3 / stride-1 layers with Cin >= 128 on maps that 4-row x 128-pixel work items tile
                        well (the 256 -> 256 head blocks) run as 1-D Winograd F(4,3) along x (csrc/winograd13.hip, cnl_conv_params.algo = CNL_ALGO_F43): 25 % fewer
                        matrix instructions, 2.4-4.6 x the fp32 matrix core's rounding error (inside the path's 1e-4 by two orders of magnitude, above "auto"'s promise)
-      split_small      latency mode for small batches (default off): launches whose output is too small to fill the chip (one image: the
+      check_range      debug guard for the split arithmetic's input range (default off; VERDICT r5 #4c): one power-of-two scale per image means a value 2^-n below the
+                       image's maximum keeps min(22, 38 - n) significant bits — regions whose magnitudes lie 10^6 below the image maximum are at 2-6e-5 of THEIR magnitude,
+                       10^7 breaks the path's 1e-4, and nothing in the kernels notices.  With the option every fp16-split launch's input is inspected before it runs
+                       (per image: the maximum over all channels of each 8 x 8-pixel tile; the smallest non-zero tile maximum against the image maximum) and a
+                       SplitRangeError names the launch when the ratio exceeds 10^5 — the caller then uses algo="f32" for that model.  A full extra pass per launch
+                       and a host synchronisation: a diagnostic, not a production setting
+ for small batches (default off): launches whose output is too small to fill the chip (one image: the
                        16x16 .. 64x64 maps) run as direct convs with the reduction split over several workgroups per output tile and a
                        fixed-order reduce (cnl_conv_params.splitk).  The choice then depends on the batch size, so results are no longer
                        bit-identical between a shard and the full batch (they stay within the fp32-grade error bars)."""
@@ -72,6 +78,7 @@ class KernelOptions:
     latency: bool = False
     up_rows: bool = True
     f43: bool = False
+    check_range: bool = False
 
     @property
     def algo_id(self):
@@ -410,6 +417,23 @@ class _VBuf:
 
     def data_ptr(self):
         return self.real if self.real is not None else self.vbase
+
+
+class SplitRangeError(RuntimeError):
+    """KernelOptions(check_range=True): an input of a fp16-split launch spans more than SPLIT_RANGE_LIMIT between an image's maximum and its weakest 8 x 8 tile."""
+
+
+SPLIT_RANGE_LIMIT = 1e5
+
+
+def split_range_ratio(x_nhwc):
+    """Per image of an NHWC activation tensor: max |x| over the image / the smallest NON-ZERO maximum of an 8 x 8-pixel tile (over all channels) — how far below
+    the image's one power-of-two scale the weakest populated region sits (1.0 for an all-zero image: exact zeros stay exact)."""
+    a = x_nhwc.abs().amax(dim=3)                                       # [N, H, W]: per pixel, over channels
+    tiles = torch.nn.functional.max_pool2d(a[:, None], 8, 8, ceil_mode=True).flatten(1)
+    top = tiles.amax(dim=1)
+    weakest = torch.where(tiles > 0, tiles, torch.full_like(tiles, float("inf"))).amin(dim=1)
+    return torch.where(top > 0, top / weakest, torch.ones_like(top))
 
 
 class _Launch:
@@ -1063,10 +1087,40 @@ class Plan:
         if self.absmax is not None:
             self.absmax.zero_()                                # the producers fold max |y| into these with atomic max
         for L in self.launches:
+            if self.options.check_range:
+                self._check_split_range(L)
             rc = self.launch(L, x, stream)
             if rc != 0:
                 _lib.check(rc, L.what)
         return OrderedDict((k, v.permute(0, 3, 1, 2)) for k, v in outs.items())
+
+    def input_view(self, p):
+        """The [N, H_in, W_in, Cin] view (pixel stride ldx) of a conv launch's input inside the plan's arena."""
+        off = (p.x - self.arena.data_ptr()) // 4
+        assert 0 <= off < self.arena.numel(), "not an arena buffer"
+        return self.arena.as_strided((p.N, p.H_in, p.W_in, p.Cin), (p.H_in * p.W_in * p.ldx, p.W_in * p.ldx, p.ldx, 1), self.arena.storage_offset() + off)
+
+    def _check_split_range(self, L):
+        """KernelOptions(check_range=True): inspect the input of a launch that scales it per image for the fp16 split (the producer launches of this forward have
+        been enqueued on the same stream, so the buffer holds THIS forward's activations when the reductions below run)."""
+        p = L.args
+        if not isinstance(p, ConvParams) or not p.x_absmax:
+            return
+        lib = self.lib
+        if L.fn is lib.cnl_conv3x3_winograd_f32:
+            split = lib.cnl_conv3x3_winograd_kernel(ctypes.byref(p)) == CNL_WINO_F16X2
+        elif L.fn is lib.cnl_conv2d_nhwc_f32:
+            split = lib.cnl_conv2d_kernel(ctypes.byref(p)) == 5
+        else:
+            split = L.fn is lib.cnl_conv3x3_up2_nhwc_f32
+        if not split:
+            return
+        ratio = split_range_ratio(self.input_view(p))
+        worst = float(ratio.max())
+        if worst > SPLIT_RANGE_LIMIT:
+            n = int(ratio.argmax())
+            raise SplitRangeError(f"{L.what}: image {n} of the batch holds a populated 8 x 8 tile {worst:.3g} x below the image's maximum (limit {SPLIT_RANGE_LIMIT:g}): "
+                                  f"the fp16-split kernels scale an image by ONE power of two — use KernelOptions(algo='f32') for inputs like this (include/centernet_gfx950.h, x_absmax)")
 
     def launch(self, L, x, stream):
         """Issue ONE launch of the plan (x: the forward's input, read by the stem only).  Returns the C ABI's return code."""

@@ -609,3 +609,36 @@ def test_bench_contract_one_json_line():
     r = d["roofline"]
     assert r["bound"] in ("mfma", "hbm") and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["decode"]["gpu_ms"] > 0 and set(d["latency_ms_N1"]) >= {"default", "split_small"}
+
+
+def test_check_range_guard_for_the_split_arithmetic():
+    """KernelOptions(check_range=True) (VERDICT r5 #4c): every fp16-split launch's input is inspected before it runs — per image, the weakest populated 8 x 8 tile
+    against the image maximum — and a SplitRangeError names the launch beyond 10^5; the statistic itself on crafted tensors; a normal forward passes with the
+    guard on and gives the same bytes as without it; an activation map with a region 10^7 below its maximum (forced through a hook on the plan's first
+    split launch) is refused instead of silently losing the path's 1e-4."""
+    from centernet_lightning_amd import engine as E
+    x = torch.ones(3, 16, 24, 8, device="cuda")
+    x[1, :8, :8] = 1e-6                                  # one tile a million times below the rest
+    x[2] = 0                                             # an all-zero image: exact, ratio 1
+    x[2, 0, 0, 0] = 5.0
+    r = E.split_range_ratio(x).cpu()
+    assert float(r[0]) == 1.0 and abs(float(r[1]) - 1e6) / 1e6 < 1e-5 and float(r[2]) == 1.0
+    model, sd = build("resnet34_simple.yaml")
+    xi = recipes.images(99, (2, 3, 128, 128)).cuda()
+    plain = [t.clone() for t in model(xi)]
+    model.set_kernel_options(check_range=True)
+    guarded = model(xi)
+    assert all(torch.equal(a, b) for a, b in zip(plain, guarded))
+    plan = model._engine.plan_for(xi, sigmoid=True)
+    L = next(l for l in plan.launches if isinstance(l.args, E.ConvParams) and l.args.x_absmax and l.fn is plan.lib.cnl_conv3x3_winograd_f32)
+    prev = plan._check_split_range
+
+    def check(launch):
+        if launch is L:
+            xs = plan.input_view(L.args)
+            xs[0, : L.args.H_in // 2] *= 1e-7              # the upper half of image 0's activations: 10^7 below the rest
+        return prev(launch)
+    plan._check_split_range = check
+    with pytest.raises(E.SplitRangeError, match="below the image's maximum"):
+        model(xi)
+    plan._check_split_range = prev
