@@ -1041,10 +1041,11 @@ class Plan:
         L = self.launches[-1]
         if L.args is not p_last or L.fn is not self.lib.cnl_conv3x3_winograd_f32 or p_last.Cout != p_last.ldy:
             return False
-        # only winograd9's epilogue has the fold, and the dispatcher keeps a launch that carries fuse_w there: a block whose own choice is the small work
-        # items of variant 11 — the latency class, or a launch of at most half the CUs' worth of items (one image: 63 us on 9 against 56 on 11,
-        # profiles/r04_small_batch_variants.txt) — keeps them, and its out_conv stays a launch (the fold saves a tiny re-read there)
-        if self.options.latency or self.lib.cnl_conv3x3_winograd_variant(ctypes.byref(p_last)) != 9:
+        # only winograd9's epilogue has the fold, and the dispatcher keeps a launch that carries fuse_w there.  The latency class (an explicit per-model option)
+        # keeps its small work items instead and its out_conv stays a launch.  The DEFAULT plan folds whatever the grid size: the folded conv is
+        # another summation order of the same products, so the choice must not look at N — a one-image shard and the full batch agree bit for bit
+        # (tests/test_gpu_e2e.py::test_full_size_properties) — at the price of variant 9 instead of 11 on the last head block of a small batch (63 against 56 us at N = 1)
+        if self.options.latency:
             return False
         nb = (p_last.Cout + 63) // 64 * 2
         if nb * self.N * oh * ow * 16 > ADDRESS_LIMIT:
