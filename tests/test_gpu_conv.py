@@ -1019,7 +1019,7 @@ def _local_error(out, ref64, mask):
 
 
 @pytest.mark.parametrize("factor", [1e3, 1e4, 1e6])
-@pytest.mark.parametrize("kernel", ["winograd9", "winograd10", "winograd5", "conv_f16x2", "stem"])
+@pytest.mark.parametrize("kernel", ["winograd9", "winograd10", "winograd13", "winograd5", "conv_f16x2", "stem"])
 def test_split_arithmetic_with_an_outlier_inside_one_image(kernel, factor, capsys):
     """VERDICT r4 #5.  The fp16-split kernels scale an image's activations by ONE power of two taken from the image's maximum (the stem: from
     its workgroup's patch), so a value far below that maximum loses the low piece of its split to fp16 subnormals: with the maximum at
@@ -1069,14 +1069,27 @@ def test_split_arithmetic_with_an_outlier_inside_one_image(kernel, factor, capsy
             e16 = _local_error(out, ref, mask)
             e32 = _local_error(run_conv(x, w, b, stride=2), ref, mask)
         else:
-            v = {"winograd9": 9, "winograd10": 10, "winograd5": 5}[kernel]
-            e16 = _local_error(run_winograd(x, w, b, algo=CNL_ALGO_FORCE + v, want=5), ref, mask)
+            v = {"winograd9": 9, "winograd10": 10, "winograd5": 5, "winograd13": 13}[kernel]
+            out = run_winograd(x, w, b, algo=CNL_ALGO_FORCE + v, want=5)
+            if kernel == "winograd13":
+                # F(4,3): a pixel enters ALL transform positions of its four-pixel tile(s), also those of outputs whose 3 x 3 window does not contain it — it
+                # cancels there exactly in exact arithmetic and to 2^-22 of ITS magnitude in the split arithmetic (F(2,3) has no such position: every input
+                # of a tile is in the window of every output it reaches).  The outputs of the outlier's tiles are therefore measured separately: their error
+                # grows with the outlier (another reason why the class is opt-in), everything outside them behaves like the other kernels.
+                tile = mask.clone()
+                mask[:, :, oy - 1:oy + 2, max(0, ox - 5):ox + 6] = False
+                tile &= ~mask
+                leak = _local_error(out, ref, tile)
+                with capsys.disabled():
+                    print(f"\n[outlier x{factor:g}] winograd13, outputs of the outlier's tiles outside its 3 x 3 window: error / local max = {leak:.3e} = {leak / factor:.2e} x the factor")
+                assert leak <= 4e-7 * factor
+            e16 = _local_error(out, ref, mask)
             e32 = _local_error(run_winograd(x, w, b, algo=CNL_ALGO_FORCE + 2), ref, mask)
     with capsys.disabled():
         print(f"\n[outlier x{factor:g}] {kernel}: error / local max = {e16:.3e} (fp32 matrix cores: {e32:.3e}, ratio {e16 / e32:.2f})")
     assert e32 < 2e-6
-    if factor <= 1e4:
-        assert e16 <= 2.0 * e32 + 1e-7, (e16, e32)
+    if factor <= 1e4:      # (winograd13, the opt-in F(4,3) class: its larger transforms sit at 2.4-4.6 x the fp32 matrix core's error with or without an outlier — the admission gate of VERDICT r5 #1)
+        assert e16 <= (6.0 if kernel == "winograd13" else 2.0) * e32 + 1e-7, (e16, e32)
     assert e16 <= 1e-4, (e16, e32)
 
 
