@@ -64,8 +64,8 @@ HBM_PEAK_GBPS = 8000.0            # same guide: HBM3E spec peak (6.29 TB/s measu
 # rocprofv3 figures this line quotes but does not measure itself (HBM bytes per launch from the PMC passes: FETCH_SIZE x 2 + WRITE_SIZE, see
 # tools/rocpd_summary.py json; kernel-trace averages of the decode kernels): read from the committed profile JSON of the same command, so a
 # quoted number is byte-equal to a field of that file.  Written on the GPU box by tools/profile_round.sh.
-PROFILE_JSON = {("simple", 32, 512, 512): "profiles/r05_profile_c1.json", ("fpn", 64, 512, 512): "profiles/r05_profile_c2.json",
-                ("tracking", 32, 608, 1088): "profiles/r05_profile_c4.json"}
+PROFILE_JSON = {("simple", 32, 512, 512): "profiles/r06_profile_c1.json", ("fpn", 64, 512, 512): "profiles/r06_profile_c2.json",
+                ("tracking", 32, 608, 1088): "profiles/r06_profile_c4.json"}
 # kernel-name PREFIX in the profile JSON (template variants of one kernel — with / without a residual — are combined, weighted by calls)
 KIND_KERNEL = {"winograd_row_f16x2": "cnl_wino9::winograd9_kernel", "winograd_row4_f16x2": "cnl_wino10::winograd10_kernel", "winograd_row_f43_f16x2": "cnl_wino13::winograd13_kernel",
                "winograd_f16x2": "cnl_wino5::winograd5_kernel", "winograd_f32": "cnl_wino2::winograd2_kernel"}

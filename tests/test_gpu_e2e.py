@@ -4,6 +4,7 @@
 Level A (decode on identical tensors): bit-exact — test_gpu_decode.py.
 Level B (this file): conv accumulation order differs from oneDNN, so logits / scores / boxes must agree within
 rtol = atol = 1e-4 and top-k indices wherever the oracle's neighbouring score gap exceeds that tolerance."""
+import ctypes
 import os
 
 import numpy as np
@@ -642,3 +643,26 @@ def test_check_range_guard_for_the_split_arithmetic():
     with pytest.raises(E.SplitRangeError, match="below the image's maximum"):
         model(xi)
     plan._check_split_range = prev
+
+
+def test_odd_width_input_runs_the_2d_winograd_kernels_end_to_end():
+    """since round 5 no launch of the default C1 / C2 / C4 plans takes the 2-D F(2x2,3x3) split kernels (csrc/winograd5.hip / winograd6.hip) — they
+    remain what AUTO takes on maps of ODD width with long channel loops, where the row kernels' two-pixel tiles do not apply.  Inputs are multiples of 32
+    (reference docs/implementation.md:52), so such maps appear in layer4 of frames whose width is an odd multiple of 32: a 160 x 224 frame gives 5 x 7 maps at
+    512 channels.  The plan must route them there, and forward + decode must match the CPU oracle like every other shape."""
+    model, sd = build("resnet34_simple.yaml")
+    x = recipes.images(77, (2, 3, 160, 224))
+    ref = ref_cpu.forward(sd, x, sigmoid=True)
+    xd = x.cuda()
+    heat, box = model(xd)
+    assert tuple(heat.shape) == tuple(ref["heatmap"].shape)
+    torch.testing.assert_close(heat.cpu(), ref["heatmap"], rtol=TOL, atol=TOL)
+    torch.testing.assert_close(box.cpu(), ref["box_2d"], rtol=TOL, atol=TOL)
+    plan = model._engine.plan_for(xd, sigmoid=True)
+    lib = plan.lib
+    variants = [lib.cnl_conv3x3_winograd_variant(ctypes.byref(L.args)) for L in plan.launches if L.fn is lib.cnl_conv3x3_winograd_f32]
+    assert any(v in (5, 6) for v in variants), variants
+    k = 40
+    dets = model.gather_detection2d((heat, box), num_detections=k)
+    idx = cl.decode.decode(heat, box, None, k, 3, stride=model.output_stride)["indices"]
+    compare_detections(dets, idx, ref["heatmap"].numpy(), ref["box_2d"].numpy(), k)
