@@ -400,7 +400,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     u32x4 keep[4][NSTG];
     Coord cc;
     float xmax_cur;
-    auto request = [&](const unsigned item_, const bool ok_item) __attribute__((always_inline)) {
+    // In FOUR parts, one behind each epilogue pass (round 6, second step): issued in one burst behind pass 1 the 40 requests — 152 KB per CU, every CU at the same
+    // moment — stalled the wave at issue for 5-7 K cycles (tools/w13_trace.py); a quarter at a time they drain while the next pass runs.
+    auto request = [&](const unsigned item_, const bool ok_item, const int part) __attribute__((always_inline)) {
+        if (part == 0) {
         {
             unsigned b_ = __builtin_amdgcn_readfirstlane(cnl::xcd_remap(item_, (unsigned)a.blocks));
             unsigned q_, nbi_, bxi_, byi_;
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                                                     co < a.Cout ? (unsigned)co * 4u : OOB, 0, 0));
             st.ist = a.isu[co];        // (co < CoutP always: a select on the loaded value is a vmcnt wait here — behind the previous item's stores)
         }
+        }
         // patches 0 / 1 (all 26 pieces requested before the first is written: one memory latency) and the weight rows 0 / 1 of chunk 0
 #define W13_PLOAD_HALF(dst_, half_, cc_)                                                                         \
         do {                                                                                                     \
@@ -460,18 +464,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (half_ == 0) pload<0, 6>(st, a, cc_, ok_item);                                          \
             _Pragma("unroll") for (int i = 0; i < NSTG; ++i) keep[dst_][i] = st.stg[i];                          \
         } while (0)
-        W13_PLOAD_HALF(0, 0, 0);
-        W13_PLOAD_HALF(1, 1, 0);
-        W13_PLOAD_HALF(2, 0, 1);
-        W13_PLOAD_HALF(3, 1, 1);
+        if (part == 0) W13_PLOAD_HALF(0, 0, 0);
+        if (part == 1) W13_PLOAD_HALF(1, 1, 0);
+        if (part == 2) {
+            W13_PLOAD_HALF(2, 0, 1);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) load_b<0>(st, a, 0, i, u_plane, u_own, u_sh, ok_item);
+        }
+        if (part == 3) {
+            W13_PLOAD_HALF(3, 1, 1);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) load_b<1>(st, a, 0, i, u_plane, u_own, u_sh, ok_item);
+        }
 #undef W13_PLOAD_HALF
-#pragma unroll
-        for (int i = 0; i < 6; ++i) load_b<0>(st, a, 0, i, u_plane, u_own, u_sh, ok_item);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) load_b<1>(st, a, 0, i, u_plane, u_own, u_sh, ok_item);
     };
     unsigned item = blockIdx.x;
-    request(item, true);
+    request(item, true, 0); request(item, true, 1); request(item, true, 2); request(item, true, 3);
     while (true) {
         W13_STAMP(0);
 #ifdef W13_TRACE
@@ -577,7 +585,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         } while (0)
         const unsigned next = item + gridDim.x;
         const bool more = next < (unsigned)a.blocks;
-        f32x4 rvl[R - 2][2][4];            // residual values of rows 2, 3 (RES)
+        f32x4 rvl[R][2][4];                // residual values (RES): rows 0, 1 requested before the first pass, rows 2, 3 behind it — always AHEAD of the next item's requests (loads return in order)
+        auto res_rows = [&](const int j0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int jj = j0; jj < j0 + 2; ++jj)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bool okr = ci.y0 + jj < a.H && cok_e && rimg[i] < a.Nimg;
+                    const unsigned rvo = ((unsigned)((rimg[i] * a.H + ci.y0 + jj) * a.W + rpx[i]) * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
+#pragma unroll
+                    for (int px = 0; px < 4; ++px)
+                        rvl[jj][i][px] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, (okr && rpx[i] + px < a.W) ? rvo : OOB, (unsigned)(px * a.ldr * 4)));
+                }
+        };
+        if constexpr (RES) res_rows(0);
         f32x2 iql[2], iqh[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) { iql[i] = f32x2{iq[i][0], iq[i][1]}; iqh[i] = f32x2{iq[i][2], iq[i][3]}; }
@@ -599,15 +620,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int px = 0; px < 4; ++px) ok[i][px] = row_ok && ox + px < a.W && rimg[i] < a.Nimg;
                 if constexpr (RES) {
-                    if (j < 2) {
-                        const unsigned rvo = ((unsigned)((rimg[i] * a.H + oy) * a.W + ox) * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
 #pragma unroll
-                        for (int px = 0; px < 4; ++px)
-                            rv[i][px] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, ok[i][px] ? rvo : OOB, (unsigned)(px * a.ldr * 4)));
-                    } else {      // rows 2, 3: requested behind pass 1, AHEAD of the next item's requests (loads return in order)
-#pragma unroll
-                        for (int px = 0; px < 4; ++px) rv[i][px] = rvl[j - 2][i][px];
-                    }
+                    for (int px = 0; px < 4; ++px) rv[i][px] = rvl[j][i][px];
                 }
             }
             W13_STAMP(8 + j);
@@ -652,21 +666,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             if (j + 1 < R) { W13_BARRIER(); }
             __builtin_amdgcn_sched_barrier(0);
-            if (j == 1) {
-                // three of the four accumulator rows are dead: the next item's requests go out here and fly during passes 2 and 3 — first the residual rows those passes add
-                if constexpr (RES) {
-#pragma unroll
-                    for (int jj = 2; jj < R; ++jj)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            const bool okr = ci.y0 + jj < a.H && cok_e && rimg[i] < a.Nimg;
-                            const unsigned rvo = ((unsigned)((rimg[i] * a.H + ci.y0 + jj) * a.W + rpx[i]) * (unsigned)a.ldr + (unsigned)cout_e) * 4u;
-#pragma unroll
-                            for (int px = 0; px < 4; ++px)
-                                rvl[jj - 2][i][px] = __builtin_bit_cast(f32x4, buf_load16(a.res, a.r_bytes, (okr && rpx[i] + px < a.W) ? rvo : OOB, (unsigned)(px * a.ldr * 4)));
-                        }
-                }
-                request(more ? next : item, more);
+            if (j == 0) {
+                if constexpr (RES) res_rows(2);
+            }
+            {   // the next item's requests, a quarter behind each pass (the first one overwrites st.cur / cc: this item's epilogue reads neither any more)
+                request(more ? next : item, more, j);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
