@@ -141,6 +141,8 @@ struct Item {               // per-work-item addressing state
     unsigned u_voff;         // this lane's row of the weight planes
     unsigned img_base;       // scalar: byte offset of image n
     int y0m1;                // scalar: y0 - 1, first patch row
+    unsigned row_so;         // scalar: img_base + (y0 - 1) * row_pitch (wraps for y0 = 0: that row is masked out)
+    unsigned rows_ok;        // scalar: bit r = patch row r lies inside the image
     float S;                 // power-of-two scale of V for this item's image
 };
 struct State {
@@ -168,6 +170,9 @@ struct State {
 // (chain e + c0 d1 + c1 d2 + c2 d3 + c3 d4, e = d0 or d5), then the two splits.  Element e = channel 8 h + e of the lane's tile: raw[.][e >> 2][e & 3].
 template <int O>
 __device__ __forceinline__ void vop(State& st, const int buf) {
+#ifdef W13_TIMING_SKIP       /* timing builds (WRONG results): 1 = without the shared position's transform + split (what handing those fragments over through LDS could save at most), 2 = without any V production */
+    if constexpr (W13_TIMING_SKIP == 2 || (O >= 24 && O < 56) || O >= 76) return;
+#endif
     const float S = st.cur.S;
     if constexpr (O < 24) {
         constexpr int step = O / 8, e = O % 8;
@@ -198,8 +203,12 @@ __device__ __forceinline__ void vop(State& st, const int buf) {
 }
 // LDS read i (0..9) of patch row `row` of buffer `pbuf`: pixel i >> 1 (0..3: d1..d4, 4: d0 | d5), channel quad 2 h + (i & 1).
 // Column c of the patch (c = 0: x0 - 1) lives in plane c & 3, slot c >> 2: d1..d4 of tile t are planes 1, 2, 3, 0 at slots t, t, t, t + 1.
-template <int I>
+// Issue order: pixels d1, d2, d0 | d5, d3, d4 — the job's first operations read d3 and d4, and a wait for the LAST request covers the earlier ones (in-order return):
+// one s_waitcnt per job instead of four.
+constexpr int RREAD_PX[5] = {0, 1, 4, 2, 3};
+template <int J>
 __device__ __forceinline__ void rread(State& st, const int pbuf, const int row) {
+    constexpr int I = J == 8 ? 7 : (J == 9 ? 6 : 2 * RREAD_PX[J >> 1] + (J & 1));      // (d4's second quad before its first: operation 0 reads quad 0)
     constexpr int px = I >> 1;
     constexpr int off = px == 0 ? PXQ - 1 : (px == 1 ? 2 * PXQ - 1 : (px == 2 ? 3 * PXQ - 1 : 0));      // slots relative to d4 (plane 0, slot t + 1): d1..d3 = planes 1..3, slot t
     const char* p = (px == 4 ? st.pe : st.pa) + pbuf * P_BYTES + row * ROW_BYTES + (off + (I & 1) * QUAD_SLOTS) * 16;
@@ -215,13 +224,16 @@ __device__ __forceinline__ void load_b(State& st, const Args& a, const int cc, c
 }
 // Patch piece I of half HALF of chunk cc: half 0 = rows 0..2 (pieces 0..5: row I >> 1, pixel half I & 1) + the column piece (6: the two last pixel
 // columns of all six rows), half 1 = rows 3..5.  Always issued (no branch: see winograd9.hip); a row outside the image — or `ok` false — reads out of range.
+// (round 6: the address of a piece is  row_so + row * row_pitch + 64 cc  with row_so = img_base + (y0 - 1) row_pitch computed once per item, and a row outside the image —
+//  or a chunk past the item's last — is one bit of the item's `rows_ok` mask: 2 + 2 scalar instructions and a select per load where the first version spent 7 + 1;
+//  the scalar offset of an invalid row may point anywhere: the range check is on the vector offset)
 template <int HALF, int I>
 __device__ __forceinline__ void pload(State& st, const Args& a, const int cc, const bool ok) {
     if constexpr (I < 6) {
-        const int iy = __builtin_amdgcn_readfirstlane(st.cur.y0m1) + 3 * HALF + (I >> 1);
-        const bool okr = ok && (unsigned)iy < (unsigned)a.H;
-        const unsigned so = __builtin_amdgcn_readfirstlane(st.cur.img_base + (unsigned)(okr ? iy : 0) * st.row_pitch + (unsigned)cc * 64u);
-        st.stg[I] = buf_load16(a.x, a.x_bytes, okr ? st.cur.vcol[I & 1] : OOB, so);
+        constexpr int row = 3 * HALF + (I >> 1);
+        const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)st.cur.rows_ok) & (0u - (unsigned)ok);      // (no ternary around the readfirstlane: it becomes a branch)
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)st.cur.row_so) + (unsigned)row * st.row_pitch + (unsigned)cc * 64u;
+        st.stg[I] = buf_load16(a.x, a.x_bytes, (mask >> row) & 1u ? st.cur.vcol[I & 1] : OOB, so);
     } else {
         static_assert(HALF == 0, "the column piece belongs to half A");
         st.stg[6] = buf_load16(a.x, a.x_bytes, ok ? st.cur.vext : OOB, __builtin_amdgcn_readfirstlane(st.cur.img_base + (unsigned)cc * 64u));
@@ -289,9 +301,9 @@ __device__ __forceinline__ void slice(State& st, const Args& a, const int cn, co
     // ---- patch of chunk cn + 2, in two halves through the same staging registers:
     //   slices 12..22   half B of the NEXT chunk's patch (requested a chunk ago) -> the other buffer, rows 3..5 (first read a chunk from now)
     //   slices 24..48   request half A          65..77  half A -> this chunk's buffer (dead after the barrier)        78..98  request half B
-    if constexpr (!FIRST && S >= 12 && S <= 22 && (S - 12) % 2 == 0) pwrite<1, (S - 12) / 2>(st, PAR ^ 1);
+    if constexpr (!FIRST && S >= 12 && S <= 22 && (S - 12) % 2 == 0) pwrite<1, 5 - (S - 12) / 2>(st, PAR ^ 1);      // (the piece requested LAST first: its wait covers the others)
     if constexpr (S >= 24 && S <= 48 && (S - 24) % 4 == 0) pload<0, (S - 24) / 4>(st, a, cn + 2, has2);
-    if constexpr (S >= 65 && S <= 77 && (S - 65) % 2 == 0) pwrite<0, (S - 65) / 2>(st, PAR);
+    if constexpr (S >= 65 && S <= 77 && (S - 65) % 2 == 0) pwrite<0, 6 - (S - 65) / 2>(st, PAR);
     if constexpr (S >= 78 && S <= 98 && (S - 78) % 4 == 0) pload<1, (S - 78) / 4>(st, a, cn + 2, has2);
     // ---- the item's bias / weight-scale values -> LDS for the epilogue (every wave writes the same 64 values; the region is not aliased) ----
     if constexpr (FIRST && S == 50) {
@@ -415,6 +427,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         {
             st.cur.y0m1 = cc.y0 - 1;
             st.cur.img_base = (unsigned)(cc.n * a.H) * st.row_pitch;
+            st.cur.row_so = st.cur.img_base + (unsigned)(cc.y0 - 1) * st.row_pitch;
+            {
+                unsigned m = 0;
+#pragma unroll
+                for (int r = 0; r < PR; ++r) m |= ((unsigned)(cc.y0 - 1 + r) < (unsigned)a.H ? 1u : 0u) << r;
+                st.cur.rows_ok = m;
+            }
             int tid_ = tid;
             asm volatile("" : "+v"(tid_));      // keeps the per-thread decode inside the item loop
             const int q_ = tid_ & 3;
