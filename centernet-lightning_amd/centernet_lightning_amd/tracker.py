@@ -13,7 +13,7 @@ match list goes back.  The reference instead copies every frame's k x (6+E) dete
 KalmanFilter (third-party, absent) on the host, beside the life cycle; the filtered boxes are uploaded to the device table.
 Per frame: ONE kernel launch (cnl_track_frame_f32) writes the frame record — kept-detection indices, boxes / scores / labels, cost
 matrices — straight into mapped host memory, ONE stream synchronisation makes it readable; no copy operation in either direction.
-`reid_cost`: "cosine" / "euclidean" / "sqeuclidean" / "cityblock" / "chebyshev" / "canberra" / "braycurtis" have kernels; any other scipy
+`reid_cost`: "cosine" / "euclidean" / "sqeuclidean" / "cityblock" / "chebyshev" / "canberra" / "braycurtis" / "correlation" have kernels; any other scipy
 cdist name or a callable, and a callable `box_cost`
 (tracker.py:51, 62-64), are computed on the host from copies only with `allow_host_cost=True` (otherwise the constructor raises).
 There is no CPU fallback for the device path: without the HIP library or a GPU, `update` raises.
@@ -34,7 +34,7 @@ from .config import load_config
 
 _BOX_MODES = {None: 0, "iou": 1, "giou": 2}
 _LABEL_KINDS = {torch.int64: 1, torch.int32: 2, torch.float32: 3}     # det_label element types cnl_track_frame_f32 reads
-_REID_METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2, "cityblock": 3, "chebyshev": 4, "canberra": 5, "braycurtis": 6}
+_REID_METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2, "cityblock": 3, "chebyshev": 4, "canberra": 5, "braycurtis": 6, "correlation": 7}
 # ^ the scipy cdist metrics with a gfx950 kernel (float64, scipy's operation order); "manhattan" etc. are scipy aliases -> host path
 
 
@@ -193,7 +193,7 @@ class Tracker:
     def __init__(self, model=None, nms_kernel=3, num_detections=300, detection_threshold=0.3, reid_cost="cosine",
                  reid_threshold=0.2, box_cost="iou", box_threshold=0.5, smoothing_factor=0.5, use_kalman=False,
                  max_inactive_age=30, min_birth_age=2, device=None, allow_host_cost=False):
-        """reid_cost: "cosine" (default), "euclidean", "sqeuclidean", "cityblock", "chebyshev", "canberra", "braycurtis" run on the device.  The reference accepts ANY scipy cdist metric name or
+        """reid_cost: "cosine" (default), "euclidean", "sqeuclidean", "cityblock", "chebyshev", "canberra", "braycurtis", "correlation" run on the device.  The reference accepts ANY scipy cdist metric name or
         a callable (tracker.py:51, 62-64), and a callable box_cost: those are computed on the HOST from copies of the frame's kept embeddings /
         boxes and the track table (two more device -> host copies per frame) — only with allow_host_cost=True, otherwise they raise: a silent
         CPU detour is not what a caller of a gfx950 tracker expects."""

@@ -78,6 +78,32 @@ __device__ __forceinline__ int compact_scores(const float* __restrict__ det_scor
     return n;
 }
 
+// Row mean in float64 in numpy's order (np.add.reduce over a contiguous last axis = pairwise summation: eight strided partial sums per block of <= 128 elements,
+// combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the tail added sequentially; longer rows split in halves rounded down to a multiple of 8) — scipy's cdist
+// "correlation" centres both operands with XA.mean(axis=1) before its cosine kernel.
+__device__ double np_pairwise_sum(const float* a, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res = res + (double)a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (double)a[j];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = r[j] + (double)a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res = res + (double)a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
 __device__ __forceinline__ void pair_costs(const int* sel, const int n, const float* __restrict__ det_emb, const float* __restrict__ det_box, const int E,
                                            const float* __restrict__ trk_emb, const float* __restrict__ trk_box, const int T, const int box_mode,
                                            const int reid_metric, double* __restrict__ reid_cost, float* __restrict__ box_cost) {
@@ -91,6 +117,18 @@ __device__ __forceinline__ void pair_costs(const int* sel, const int n, const fl
         const float* v = trk_emb + (long)t * E;
         double uu, vv, uv;
         seq_dots(u, v, E, uu, vv, uv);
+        double c = uv / (sqrt(uu) * sqrt(vv));
+        if (fabs(c) > 1.0) c = copysign(1.0, c);
+        reid_cost[p] = (1.0 - c);
+    } else if (reid_metric == 7) {   // scipy cdist "correlation": both rows centred by their float64 mean (numpy's pairwise order), then the cosine kernel
+        const float* u = det_emb + (long)d * E;
+        const float* v = trk_emb + (long)t * E;
+        const double mu = np_pairwise_sum(u, E) / (double)E, mv = np_pairwise_sum(v, E) / (double)E;
+        double uu = 0.0, vv = 0.0, uv = 0.0;
+        for (int e = 0; e < E; ++e) {
+            const double x = (double)u[e] - mu, y = (double)v[e] - mv;
+            uu = uu + x * x; vv = vv + y * y; uv = uv + x * y;
+        }
         double c = uv / (sqrt(uu) * sqrt(vv));
         if (fabs(c) > 1.0) c = copysign(1.0, c);
         reid_cost[p] = (1.0 - c);
@@ -235,7 +273,7 @@ extern "C" int cnl_track_costs_metric_f32(const float* det_emb, const float* det
     CNL_REQUIRE(k > 0 && E > 0 && T >= 0, CNL_E_BAD_ARG, "cnl_track_costs_f32: bad k/E/T");
     CNL_REQUIRE(k <= MAXK, CNL_E_UNSUPPORTED, "cnl_track_costs_f32: k = %d > %d detections per frame", k, MAXK);
     CNL_REQUIRE(box_cost >= 0 && box_cost <= 2, CNL_E_BAD_ARG, "cnl_track_costs_f32: box_cost must be 0 (none), 1 (iou), 2 (giou)");
-    CNL_REQUIRE(reid_metric >= 0 && reid_metric <= 6, CNL_E_BAD_ARG, "cnl_track_costs_metric_f32: reid_metric must be 0 (cosine), 1 (euclidean), 2 (sqeuclidean), 3 (cityblock), 4 (chebyshev), 5 (canberra) or 6 (braycurtis)");
+    CNL_REQUIRE(reid_metric >= 0 && reid_metric <= 7, CNL_E_BAD_ARG, "cnl_track_costs_metric_f32: reid_metric must be 0 (cosine), 1 (euclidean), 2 (sqeuclidean), 3 (cityblock), 4 (chebyshev), 5 (canberra), 6 (braycurtis) or 7 (correlation)");
     CNL_REQUIRE(T == 0 || (trk_emb && reid_cost), CNL_E_BAD_ARG, "cnl_track_costs_f32: T > 0 without track table / reid_cost");
     CNL_REQUIRE(T == 0 || box_cost == 0 || (trk_box && box_cost_out), CNL_E_BAD_ARG,
                 "cnl_track_costs_f32: box cost requested without track boxes / output");
@@ -260,7 +298,7 @@ extern "C" int cnl_track_frame_f32(const float* det_emb, const float* det_box, c
     CNL_REQUIRE(k > 0 && E > 0 && T >= 0, CNL_E_BAD_ARG, "cnl_track_frame_f32: bad k/E/T");
     CNL_REQUIRE(k <= MAXK, CNL_E_UNSUPPORTED, "cnl_track_frame_f32: k = %d > %d detections per frame", k, MAXK);
     CNL_REQUIRE(box_cost >= 0 && box_cost <= 2, CNL_E_BAD_ARG, "cnl_track_frame_f32: box_cost must be 0 (none), 1 (iou), 2 (giou)");
-    CNL_REQUIRE(reid_metric >= 0 && reid_metric <= 6, CNL_E_BAD_ARG, "cnl_track_frame_f32: reid_metric must be 0 (cosine) .. 6 (braycurtis)");
+    CNL_REQUIRE(reid_metric >= 0 && reid_metric <= 7, CNL_E_BAD_ARG, "cnl_track_frame_f32: reid_metric must be 0 (cosine) .. 7 (correlation)");
     CNL_REQUIRE(label_kind >= 0 && label_kind <= 3 && (label_kind == 0 || det_label), CNL_E_BAD_ARG,
                 "cnl_track_frame_f32: label_kind must be 0 (none), 1 (int64), 2 (int32), 3 (float32) with det_label set");
     CNL_REQUIRE(T == 0 || trk_emb, CNL_E_BAD_ARG, "cnl_track_frame_f32: T > 0 without track table");

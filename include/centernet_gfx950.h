@@ -443,8 +443,8 @@ int cnl_track_costs_f32(const float* det_emb, const float* det_box, const float*
                         float detection_threshold, const float* trk_emb, const float* trk_box, int32_t T, int32_t box_cost,
                         int32_t* n_det, int32_t* det_index, double* reid_cost, float* box_cost_out, void* stream);
 /* the same with the re-ID metric as an argument (models/tracker.py:51, 150: any scipy cdist metric): 0 "cosine", 1 "euclidean",
- * 2 "sqeuclidean", 3 "cityblock", 4 "chebyshev", 5 "canberra", 6 "braycurtis" — each in float64 in scipy's operation order (bit for bit
- * scipy's matrix; cosine to 1e-12).  Other metrics / callables: host fallback in tracker.py (opt-in). */
+ * 2 "sqeuclidean", 3 "cityblock", 4 "chebyshev", 5 "canberra", 6 "braycurtis", 7 "correlation" (round 6: rows centred by their float64 mean in numpy's
+ * pairwise order, then the cosine kernel) — each in float64 in scipy's operation order (bit for bit scipy's matrix; cosine / correlation to 1e-12).  Other metrics / callables: host fallback in tracker.py (opt-in). */
 int cnl_track_costs_metric_f32(const float* det_emb, const float* det_box, const float* det_score, int32_t k, int32_t E,
                                float detection_threshold, const float* trk_emb, const float* trk_box, int32_t T, int32_t box_cost,
                                int32_t reid_metric, int32_t* n_det, int32_t* det_index, double* reid_cost, float* box_cost_out, void* stream);
