@@ -103,10 +103,10 @@ def test_product_tracker_host_surface(configs_dir):
         assert (t.smoothing_factor, t.max_inactive_age, t.min_birth_age, t.frame, t.next_track_id, t.tracks) == (0.5, 30, 2, 0, 0, [])
         assert cl.Tracker(use_kalman=True).use_kalman is True          # tracker.py:243-262: host-side filter (BoxKalman)
         with pytest.raises(ValueError):
-            cl.Tracker(reid_cost="correlation")                # no gfx950 kernel: needs allow_host_cost=True
+            cl.Tracker(reid_cost="minkowski")                # no gfx950 kernel: needs allow_host_cost=True
         for name in ("euclidean", "sqeuclidean", "cityblock", "chebyshev", "canberra", "braycurtis"):      # these have one
             assert cl.Tracker(reid_cost=name).reid_cost == name and cl.Tracker(reid_cost=name)._host_reid is None
-        assert cl.Tracker(reid_cost="correlation", allow_host_cost=True)._host_reid == "correlation"
+        assert cl.Tracker(reid_cost="minkowski", allow_host_cost=True)._host_reid == "minkowski"
         with pytest.raises(ValueError):
             cl.Tracker(box_cost="diou")
         import torch
