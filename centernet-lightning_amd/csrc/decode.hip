@@ -498,7 +498,30 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
             }
         }
     }
-    for (int i = tid; !in_regs && i < a.HW; i += 16 * TK_THREADS) {      // sixteen independent loads in flight per thread, then the bookkeeping
+    // Round 6: 16-byte loads where the image's pixel count allows (any partition of the pixels over the threads serves the bound: the m-th largest of a wave's 64
+    // thread maxima has m elements at or above it) — the 41 K-pixel maps of 608 x 1088 frames took three rounds of sixteen 4-byte loads per thread, now eleven
+    // 16-byte loads in two rounds.
+    const bool vec4 = !in_regs && (a.HW & 3) == 0;
+    for (int q = tid; vec4 && q < (a.HW >> 2); q += 8 * TK_THREADS) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = q + j * TK_THREADS < (a.HW >> 2) ? *reinterpret_cast<const f32x4*>(sc + 4 * (q + j * TK_THREADS)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int qq = q + j * TK_THREADS;
+            if (qq < (a.HW >> 2)) {
+                unsigned key[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    key[c] = score_key(v[j][c]);
+                    tmax = tmax > key[c] ? tmax : key[c];
+                }
+                if (klds) *reinterpret_cast<uint4*>(lds_keys + 4 * qq) = make_uint4(key[0], key[1], key[2], key[3]);
+                if (k16) *reinterpret_cast<uint2*>(lds_k16 + 4 * qq) = make_uint2((key[0] >> 16) | (key[1] & 0xFFFF0000u), (key[2] >> 16) | (key[3] & 0xFFFF0000u));
+            }
+        }
+    }
+    for (int i = tid; !in_regs && !vec4 && i < a.HW; i += 16 * TK_THREADS) {      // sixteen independent loads in flight per thread, then the bookkeeping
         float v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = i + j * TK_THREADS < a.HW ? sc[i + j * TK_THREADS] : 0.f;
@@ -577,6 +600,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                 for (int j = 0; j < 8; ++j)
                     if (tid + (c0 + j) * TK_THREADS < a.HW && score_key(vv[j]) >= Tlo) qual |= 1ull << (c0 + j);
             }
+            TK_STAMP(12);
+            TK_STAMP(13);
             for (;;) {                                       // most threads own no candidate at all: 1-3 rounds per wave
                 if (__ballot(qual != 0ull) == 0ull) break;
                 bool has = qual != 0ull;
@@ -614,6 +639,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                 }
             }
         }
+        TK_STAMP(14);
         __syncthreads();
         const unsigned total = sh_count;
         TK_STAMP(2);
@@ -801,9 +827,22 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         __syncthreads();
         const bool e_pow2 = (a.E & (a.E - 1)) == 0;
         const int e_sh = 31 - __builtin_clz((unsigned)a.E);
-        for (int t = tid; t < a.k * a.E; t += TK_THREADS) {
-            const int d = e_pow2 ? (t >> e_sh) : t / a.E, e = t - d * a.E;
-            a.emb[((long)n * a.k + d) * a.E + e] = a.reid[ebase[d] + (long)e * a.rsc];
+        const int total = a.k * a.E;
+        for (int t0 = tid; t0 < total; t0 += 8 * TK_THREADS) {      // eight independent gathers in flight per thread (one at a time, the loop was a chain of LDS read -> load -> store: 10-12 K cycles at k = 300, E = 64)
+            float g[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = t0 + j * TK_THREADS;
+                if (t < total) {
+                    const int d = e_pow2 ? (t >> e_sh) : t / a.E, e = t - d * a.E;
+                    g[j] = a.reid[ebase[d] + (long)e * a.rsc];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = t0 + j * TK_THREADS;
+                if (t < total) a.emb[(long)n * total + t] = g[j];
+            }
         }
     }
     TK_STAMP(6);

@@ -21,4 +21,4 @@ for b in range(3):
     line = f"block {b}: candidates {r[8]}: "
     for a_, b_ in zip(order[:-1], order[1:]):
         line += f"{names[b_]} {r[b_] - r[a_]} | "
-    print(line + f"total {r[6] - r[0]} cycles")
+    print(line + f"total {r[6] - r[0]} cycles; inside the compaction (thread 0): bound + prefilter scan {r[12] - r[1]} | exact re-reads + emits {r[13] - r[12]} | in-register rounds {r[14] - r[13]} | barrier {r[2] - r[14]}")
