@@ -450,6 +450,7 @@ __device__ __forceinline__ void block_sort_desc(unsigned long long* cand, int S,
     __syncthreads();
 }
 
+template <bool R48>      // R48: the instantiation for maps whose keys a thread keeps in 48 registers (below); the other one carries none of that
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     extern __shared__ unsigned lds_keys[];          // [HW] when a.keys_in_lds
     __shared__ unsigned hist[4096];
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     // Maps whose 32-bit keys do not fit the LDS budget (the 152 x 272 maps of 608 x 1088 frames: 165 KB) keep the UPPER HALVES of the keys there (round 6):
     // key >> 16 >= bound >> 16 is a superset test, so the second pass over the scores — six rounds of dependent loads, 12 of the kernel's 17 K compaction
     // cycles at that size — becomes 41 two-byte LDS reads per thread; the few elements that pass are re-read and tested exactly.
-    const bool k16 = a.keys16_in_lds && !in_regs && !klds;
+    const bool k16 = !R48 && a.keys16_in_lds && !in_regs && !klds;      // (maps with H * W % 4 == 0 of up to 48 K pixels run the R48 instantiation: keys in registers, below)
     unsigned short* lds_k16 = reinterpret_cast<unsigned short*>(lds_keys);
     unsigned kreg[16];
 #pragma unroll
@@ -502,7 +503,31 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     // thread maxima has m elements at or above it) — the 41 K-pixel maps of 608 x 1088 frames took three rounds of sixteen 4-byte loads per thread, now eleven
     // 16-byte loads in two rounds.
     const bool vec4 = !in_regs && (a.HW & 3) == 0;
-    for (int q = tid; vec4 && q < (a.HW >> 2); q += 8 * TK_THREADS) {
+    // ... and maps of up to 48 K pixels whose keys do not fit the LDS keep them in REGISTERS, twelve quads per thread (the kernel runs 1024 threads of at most 128 registers):
+    // the compaction's scan is then 48 register compares instead of 41 two-byte LDS reads behind per-element branches (7-8 K of its 12.7 K cycles, r6g)
+    const bool reg48 = R48 && vec4 && !klds && KCH <= 48;
+    unsigned kq[48];
+#pragma unroll
+    for (int j = 0; j < 48; ++j) kq[j] = 0u;
+    const int nquads = (a.HW >> 2) > tid ? ((a.HW >> 2) - tid + TK_THREADS - 1) / TK_THREADS : 0;      // quads tid, tid + 1024, ... this thread owns
+    if (reg48) {
+#pragma unroll
+        for (int b0 = 0; b0 < 12; b0 += 6) {
+            f32x4 v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v[j] = b0 + j < nquads ? *reinterpret_cast<const f32x4*>(sc + 4 * (tid + (b0 + j) * TK_THREADS)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (b0 + j < nquads) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        kq[4 * (b0 + j) + c] = score_key(v[j][c]);
+                        tmax = tmax > kq[4 * (b0 + j) + c] ? tmax : kq[4 * (b0 + j) + c];
+                    }
+                }
+        }
+    }
+    for (int q = tid; vec4 && !reg48 && q < (a.HW >> 2); q += 8 * TK_THREADS) {
         f32x4 v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = q + j * TK_THREADS < (a.HW >> 2) ? *reinterpret_cast<const f32x4*>(sc + 4 * (q + j * TK_THREADS)) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -580,7 +605,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                 for (int j = 0; j < 16; ++j)
                     if (tid + j * TK_THREADS < a.HW && kreg[j] >= Tlo) qual |= 1ull << j;
             }
-            for (int c0 = 0; strided && c0 < KCH; c0 += 8) {             // eight independent loads at a time
+            if (reg48) {
+#pragma unroll
+                for (int b = 0; b < 48; ++b) qual |= (unsigned long long)((b >> 2) < nquads && kq[b] >= Tlo) << b;
+            }
+            for (int c0 = 0; strided && !reg48 && c0 < KCH; c0 += 8) {             // eight independent loads at a time
                 if (klds) {          // the keys are in LDS (this thread wrote exactly these words): no second pass over memory (round 6: the 41 K-pixel maps of 608 x 1088 frames)
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
@@ -609,7 +638,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                 if (has) {
                     const int c = __builtin_ctzll(qual);
                     qual &= qual - 1;
-                    idx = (unsigned)(tid + c * TK_THREADS);
+                    idx = reg48 ? (unsigned)(4 * (tid + (c >> 2) * TK_THREADS) + (c & 3)) : (unsigned)(tid + c * TK_THREADS);
                     if (in_regs) {
                         key = kreg[0];
 #pragma unroll
@@ -828,7 +857,25 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         const bool e_pow2 = (a.E & (a.E - 1)) == 0;
         const int e_sh = 31 - __builtin_clz((unsigned)a.E);
         const int total = a.k * a.E;
-        for (int t0 = tid; t0 < total; t0 += 8 * TK_THREADS) {      // eight independent gathers in flight per thread (one at a time, the loop was a chain of LDS read -> load -> store: 10-12 K cycles at k = 300, E = 64)
+        // channel-minor embeddings (what the reid head emits) with E % 4 == 0: 16 bytes per thread and request
+        const bool e_vec4 = a.rsc == 1 && (a.E & 3) == 0 && ((a.rsn | a.rsh | a.rsw) & 3) == 0 && ((uintptr_t)a.reid & 15) == 0 && ((uintptr_t)a.emb & 15) == 0;
+        for (int t0 = tid * 4; e_vec4 && t0 < total; t0 += 16 * TK_THREADS) {
+            f32x4 g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = t0 + j * 4 * TK_THREADS;
+                if (t < total) {
+                    const int d = e_pow2 ? (t >> e_sh) : t / a.E, e = t - d * a.E;
+                    g[j] = *reinterpret_cast<const f32x4*>(a.reid + ebase[d] + e);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = t0 + j * 4 * TK_THREADS;
+                if (t < total) *reinterpret_cast<f32x4*>(a.emb + (long)n * total + t) = g[j];
+            }
+        }
+        for (int t0 = tid; !e_vec4 && t0 < total; t0 += 8 * TK_THREADS) {      // eight independent gathers in flight per thread (one at a time, the loop was a chain of LDS read -> load -> store: 10-12 K cycles at k = 300, E = 64)
             float g[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1007,10 +1054,13 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
     t.keys_in_lds = key_words * 4 <= 96 * 1024;
     t.keys16_in_lds = !t.keys_in_lds && key_words * 2 <= 96 * 1024;
     const size_t key_bytes = t.keys_in_lds ? key_words * 4 : (t.keys16_in_lds ? key_words * 2 : 0);
-    static cnl::DeviceOnce once;
-    rc = cnl::kernel_setup(once, reinterpret_cast<const void*>(&topk_kernel), 96 * 1024);
+    const int kch = (HW + TK_THREADS - 1) / TK_THREADS;
+    const bool r48 = (HW & 3) == 0 && !t.keys_in_lds && kch > 16 && kch <= 48;
+    static cnl::DeviceOnce once, once48;
+    rc = r48 ? cnl::kernel_setup(once48, reinterpret_cast<const void*>(&topk_kernel<true>), 96 * 1024) : cnl::kernel_setup(once, reinterpret_cast<const void*>(&topk_kernel<false>), 96 * 1024);
     if (rc != CNL_OK) return rc;
-    hipLaunchKernelGGL(topk_kernel, dim3(p->N), dim3(TK_THREADS), key_bytes, s, t);
+    if (r48) hipLaunchKernelGGL(topk_kernel<true>, dim3(p->N), dim3(TK_THREADS), 0, s, t);
+    else hipLaunchKernelGGL(topk_kernel<false>, dim3(p->N), dim3(TK_THREADS), key_bytes, s, t);
     return cnl::check_launch("topk_kernel");
 }
 
