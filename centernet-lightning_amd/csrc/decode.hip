@@ -407,6 +407,18 @@ __device__ __forceinline__ unsigned score_key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// inclusive prefix sum over the 64 lanes of a wave, six DPP adds: within the rows of 16 (row_shr 1 / 2 / 4 / 8, zeros shifted in), then row 0 -> 1 and 2 -> 3
+// (row_bcast:15), then rows 0 + 1 -> 2, 3 (row_bcast:31)
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
 constexpr int TK_THREADS = 1024;
 #ifdef TK_TIMING
 __device__ unsigned long long tk_stamps[64 * 16];
@@ -453,8 +465,8 @@ __device__ __forceinline__ void block_sort_desc(unsigned long long* cand, int S,
 template <bool R48>      // R48: the instantiation for maps whose keys a thread keeps in 48 registers (below); the other one carries none of that
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     extern __shared__ unsigned lds_keys[];          // [HW] when a.keys_in_lds
-    __shared__ unsigned hist[4096];
-    __shared__ unsigned wave_tot[TK_THREADS / 64];
+    __shared__ __align__(16) unsigned hist[4096];
+    __shared__ unsigned wave_tot[TK_THREADS / 64], wave_max[TK_THREADS / 64];
     __shared__ unsigned long long cand[1024 + 8];
     __shared__ unsigned sh_prefix, sh_need, sh_count;
 
@@ -472,12 +484,13 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     constexpr int FAST_CAP = 1024;                           // candidates the rank step takes (O(n^2 / threads)); more -> radix select
     unsigned long long* win = reinterpret_cast<unsigned long long*>(hist);      // [k] winners of the fast path (hist is unused there)
     for (int i = tid; i < FAST_CAP + 8; i += TK_THREADS) cand[i] = 0ull;        // zero padding: never greater than a candidate
+    hist[tid] = 0u;                                          // the bins of the bound's second step (below)
     if (tid == 0) sh_count = 0u;
     TK_STAMP(11);
     unsigned tmax = 0u;
     // Maps of at most 16 x 1024 pixels (128 x 128): the thread's 16 keys (indices tid + 1024 j) simply stay in registers — no LDS copy, no
     // index arithmetic; the fallback re-reads the scores from memory.  Larger maps: keys in LDS ([owner thread][odd pitch]) when they fit.
-    const bool in_regs = KCH <= 16;
+    const bool in_regs = !R48 && KCH <= 16;                 // (the launcher picks the R48 instantiation for 16 < KCH <= 48 only: it carries no kreg)
     const bool klds = a.keys_in_lds && !in_regs;
     // Maps whose 32-bit keys do not fit the LDS budget (the 152 x 272 maps of 608 x 1088 frames: 165 KB) keep the UPPER HALVES of the keys there (round 6):
     // key >> 16 >= bound >> 16 is a superset test, so the second pass over the scores — six rounds of dependent loads, 12 of the kernel's 17 K compaction
@@ -583,7 +596,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         }
 #undef TK_EXCH
         const unsigned vm = __shfl(v, (a.k + TK_THREADS / 64 - 1) / (TK_THREADS / 64) - 1);
-        if (lane == 0) wave_tot[wave] = vm;
+        if (lane == 0) { wave_tot[wave] = vm; wave_max[wave] = v; }
         TK_STAMP(10);
     }
     __syncthreads();                                         // + every key is in LDS, cand is zero, the counter is reset
@@ -591,7 +604,47 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
     unsigned Tlo = wave_tot[0];
 #pragma unroll
     for (int w = 1; w < TK_THREADS / 64; ++w) Tlo = Tlo < wave_tot[w] ? Tlo : wave_tot[w];
-    bool fast = false, sort_path = false;
+    // SECOND STEP of the bound (round 6).  T_lo is set by the weakest wave: 1.5-3 k elements pass it, and the rank step below costs n^2.  The k-th largest of the
+    // 1024 thread MAXIMA is a bound too (k threads hold an element at or above it) and lets ~1.1 k through; it is found to within one bin: the maxima >= T_lo
+    // (a few hundred) are counted into 512-1024 equal bins of key space between T_lo and the largest maximum (one LDS atomic per counted thread, one barrier);
+    // then wave 0 scans all the bins from the top — lane l sums the 16 bins of block 63 - l, a DPP prefix scan over the lanes finds the block that holds the k-th
+    // largest maximum, the lane's own 16 counts the bin — and a second barrier hands the lower edge of that bin, the new bound, to the others.
+    {
+        unsigned gmax = wave_max[0];
+#pragma unroll
+        for (int w = 1; w < TK_THREADS / 64; ++w) gmax = gmax > wave_max[w] ? gmax : wave_max[w];
+        const unsigned range = gmax - Tlo;
+        if (range != 0u) {                                   // (block-uniform)
+            const int bsh = range >= 1024u ? 22 - __clz(range) : 0;              // (range >> bsh) < 1024
+            if (tmax >= Tlo) atomicAdd(&hist[(tmax - Tlo) >> bsh], 1u);
+            __syncthreads();
+            if (wave == 0) {                                 // one wave scans (every instruction of a 16-wave block is paid 4 x: four waves share a SIMD); the others wait
+                const int blk = 63 - lane;
+                const uint4* hp = reinterpret_cast<const uint4*>(hist + 16 * blk);
+                const uint4 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3];
+                const unsigned hb[16] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
+                unsigned own = 0u;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) own += hb[j];
+                const unsigned P = wave_incl_scan(own);                              // maxima in this lane's block and the blocks above it
+                const unsigned long long bal = __ballot(P >= (unsigned)a.k);          // never empty: >= k maxima pass T_lo
+                const int L = __builtin_ctzll(bal);                                  // the lane whose block holds the k-th largest maximum
+                unsigned acc = P - own;                                              // maxima in the blocks above this lane's
+                int bin = 0;
+                bool found = false;
+#pragma unroll
+                for (int j = 15; j >= 0; --j) {
+                    acc += hb[j];
+                    if (!found && acc >= (unsigned)a.k) { found = true; bin = j; }
+                }
+                const unsigned binL = (unsigned)__shfl(16 * blk + bin, L);
+                if (lane == 0) sh_prefix = Tlo + (binL << bsh);
+            }
+            __syncthreads();
+            Tlo = sh_prefix;
+        }
+    }
+    bool fast = false;
     {
         // compaction of the elements >= T_lo into cand[] — in ANY order: the winners are placed by rank of the (key, ~index) pair below.
         // Thread t owns the contiguous index range [t*KCH, (t+1)*KCH); one LDS atomic per wave and round reserves the wave's slots.
@@ -630,6 +683,56 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                     if (tid + (c0 + j) * TK_THREADS < a.HW && score_key(vv[j]) >= Tlo) qual |= 1ull << (c0 + j);
             }
             TK_STAMP(12);
+            if (in_regs || reg48) {
+                // The keys are in registers: a prefix sum of the lanes' candidate counts and ONE LDS atomic per wave reserve the slots; every lane then walks its own
+                // bits and picks the key out of its registers with a binary tree of selects on the bits of the position (15 / 47 v_cndmask).  (The rounds below — a
+                // ballot, an atomic with its return and, for the 48-register maps, a re-read of the score per round — took 2.1-2.3 K cycles in the first wave and left
+                // it 1.3-4.7 K at the barrier behind the waves with a four-candidate lane; a statically unrolled walk over the 48 positions, 6-8 K.)
+                const unsigned cnt = (unsigned)__builtin_popcountll(qual);
+                const unsigned incl = wave_incl_scan(cnt);
+                const unsigned wtot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+                if (wtot != 0u) {                                                // (wave-uniform)
+                    unsigned base = 0u;
+                    if (lane == 63) base = atomicAdd(&sh_count, wtot);
+                    base = (unsigned)__builtin_amdgcn_readlane((int)base, 63);
+                    unsigned off = base + incl - cnt;
+                    while (qual != 0ull) {
+                        const int c = __builtin_ctzll(qual);
+                        qual &= qual - 1ull;
+                        unsigned key, idx;
+                        // (bit masks, v_bfi_b32, not ?: — the compiler turns a tree of selects back into a dynamically indexed array, and that into scratch memory)
+                        const unsigned m1 = 0u - (unsigned)(c & 1), m2 = 0u - (unsigned)((c >> 1) & 1), m4 = 0u - (unsigned)((c >> 2) & 1), m8 = 0u - (unsigned)((c >> 3) & 1);
+#define TK_SEL(m_, hi_, lo_) (((hi_) & (m_)) | ((lo_) & ~(m_)))
+                        if (in_regs) {
+                            unsigned t8[8], t4[4];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) t8[i] = TK_SEL(m1, kreg[2 * i + 1], kreg[2 * i]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) t4[i] = TK_SEL(m2, t8[2 * i + 1], t8[2 * i]);
+                            const unsigned u0 = TK_SEL(m4, t4[1], t4[0]), u1 = TK_SEL(m4, t4[3], t4[2]);
+                            key = TK_SEL(m8, u1, u0);
+                            idx = (unsigned)(tid + c * TK_THREADS);
+                        } else {
+                            unsigned t24[24], t12[12], t6[6], t3[3];
+#pragma unroll
+                            for (int i = 0; i < 24; ++i) t24[i] = TK_SEL(m1, kq[2 * i + 1], kq[2 * i]);
+#pragma unroll
+                            for (int i = 0; i < 12; ++i) t12[i] = TK_SEL(m2, t24[2 * i + 1], t24[2 * i]);
+#pragma unroll
+                            for (int i = 0; i < 6; ++i) t6[i] = TK_SEL(m4, t12[2 * i + 1], t12[2 * i]);
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) t3[i] = TK_SEL(m8, t6[2 * i + 1], t6[2 * i]);
+                            const unsigned m16 = 0u - (unsigned)((c >> 4) & 1), m32 = 0u - (unsigned)((c >> 5) & 1);
+                            key = TK_SEL(m32, t3[2], TK_SEL(m16, t3[1], t3[0]));
+                            idx = (unsigned)(4 * (tid + (c >> 2) * TK_THREADS) + (c & 3));
+                        }
+#undef TK_SEL
+                        if (off < (unsigned)FAST_CAP) cand[off] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - idx);
+                        ++off;
+                    }
+                }
+                qual = 0ull;
+            }
             TK_STAMP(13);
             for (;;) {                                       // most threads own no candidate at all: 1-3 rounds per wave
                 if (__ballot(qual != 0ull) == 0ull) break;
@@ -678,32 +781,38 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
         if (total <= (unsigned)FAST_CAP) {                   // else: ties / plateaus en masse -> radix select below
             fast = true;
             // rank of a candidate = how many candidates are greater ((key, ~index) pairs are distinct): the k winners land in canonical
-            // order (score desc, index asc) without a sort.  All lanes read the same 16 bytes (two candidates): LDS broadcasts.
-            // 1 .. 8 neighbouring lanes share a candidate (1024 threads, at most 1024 candidates) and scan interleaved slices of the array.
-            // More than 512 candidates (k = 300 on the large maps: 400-650): every lane then scans the whole array — 16 waves x n 8-byte LDS reads, 30-32 K cycles at
-            // n = 569-623 (tools/topk_trace.py; 12 K at n = 419, where two lanes share a candidate) — while a bitonic sort of the zero-padded 1024 (wave shuffles
-            // below distance 64) takes 26 K whatever n; the winners are then the first k of `cand` itself.  The pairs are distinct: both give the same order.
-            // (At n <= 512 the rank wins: a 512-wide sort measured 18.5 K against 12 K, and C1's 158-309 candidates went from 10.4 to 14.5 us.)
-            sort_path = total > 512u;
+            // order (score desc, index asc) without a sort.  All lanes read the same 16 bytes (two candidates): LDS broadcasts.  With ONE candidate per
+            // lane the LDS port bounds the step — a wave's 16-byte read occupies it for ~8 cycles whatever the addresses, n^2 / 64 pairs in all: 30-32 K
+            // cycles at n = 569-623 (tools/topk_trace.py; round 6 first tried a 1024-wide bitonic sort above 512 candidates, 26 K, then a radix select
+            // of the k-th key before the rank, 19 K).  Each lane therefore ranks FOUR candidates against every pair it reads — a quarter of the LDS
+            // traffic for the same compares, which the VALU now bounds (v_cmp_gt_u64 is half rate: 12 cycles per compare-and-count) — and 1 .. 8
+            // neighbouring lanes share a quad of candidates and scan interleaved slices of the array; lanes (and whole waves) without a quad skip the scan.
+            const unsigned nq = (total + 3u) >> 2;
             int psh = 0;
-            while (psh < 3 && (total << (psh + 1)) <= (unsigned)TK_THREADS) ++psh;
-            const int c = tid >> psh, part = tid & ((1 << psh) - 1);
-            if (sort_path) {
-                block_sort_desc(cand, 1024, tid);
-            } else {
-                const unsigned long long mine = c < (int)total ? cand[c] : ~0ull;
-                unsigned rank = 0;
+            while (psh < 3 && (nq << (psh + 1)) <= (unsigned)TK_THREADS) ++psh;
+            const unsigned cq = (unsigned)tid >> psh;
+            const int part = tid & ((1 << psh) - 1);
+            if (cq < nq) {
+                unsigned long long mine[4];
+                unsigned rank[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) mine[m] = cand[4u * cq + m];       // zero beyond total (the array is padded): never written below
                 for (unsigned j = (unsigned)part * 8u; j < total; j += 8u << psh) {
                     unsigned long long o[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) o[q] = cand[j + q];           // zero beyond total (the array is padded)
+                    for (int q = 0; q < 8; ++q) o[q] = cand[j + q];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) rank += o[q] > mine ? 1u : 0u;
+                    for (int q = 0; q < 8; ++q)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) rank[m] += o[q] > mine[m] ? 1u : 0u;
                 }
-                if (psh > 0) rank += (unsigned)__shfl_xor((int)rank, 1);
-                if (psh > 1) rank += (unsigned)__shfl_xor((int)rank, 2);
-                if (psh > 2) rank += (unsigned)__shfl_xor((int)rank, 4);
-                if (part == 0 && c < (int)total && rank < (unsigned)a.k) win[rank] = mine;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (psh > 0) rank[m] += (unsigned)__shfl_xor((int)rank[m], 1);
+                    if (psh > 1) rank[m] += (unsigned)__shfl_xor((int)rank[m], 2);
+                    if (psh > 2) rank[m] += (unsigned)__shfl_xor((int)rank[m], 4);
+                    if (part == 0 && 4u * cq + m < total && rank[m] < (unsigned)a.k) win[rank[m]] = mine[m];
+                }
             }
             __syncthreads();
             TK_STAMP(3);
@@ -835,7 +944,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
 
     TK_STAMP(5);
     // --- gathers + box decode for the k winners ---
-    const unsigned long long* winners = (fast && !sort_path) ? win : cand;
+    const unsigned long long* winners = fast ? win : cand;
     // the winners' offsets into the embedding map, once per detection (the gather below had two integer divisions per ELEMENT: 13 K cycles at k = 300, E = 64);
     // `hist` is free on both paths by now — but `win` aliases its first k * 8 bytes: the offsets live behind them
     long* ebase = reinterpret_cast<long*>(hist) + 1024;
