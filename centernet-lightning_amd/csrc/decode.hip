@@ -221,64 +221,140 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
         // row again (the ring is symmetric in the row order).
         const int dir = (by & 1) ? -1 : 1;
         const int rows = y_end - y0 + 2 * P;
-        for (int step = 0; step < rows; ++step) {
-            const int yy = dir > 0 ? y0 - P + step : y_end + P - 1 - step;
+        if constexpr (P == 1) {
+            // Round 6: no register shuffling.  The three rows of horizontal maxima are a ring written at step % 3 (their maximum does not care about the order), and
+            // the centre values of the previous row are simply the previous step's loads: two load buffers used alternately.  Six steps unrolled make every index
+            // static (80 v_mov of 340 VALU instructions per step gone); the class of the maximum is found after the fact (v_max3 tree + 7 compare / select
+            // pairs instead of 8 x compare + two selects).
+            float H[3][4][8], T[2][6][8];
 #pragma unroll
-            for (int i = 0; i < 2 * P; ++i)
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int v = 0; v < 8; ++v) hm[i][p][v] = hm[i + 1][p][v];
-#pragma unroll
-            for (int i = 0; i < P; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
 #pragma unroll
-                    for (int v = 0; v < 8; ++v) ct[i][p][v] = ct[i + 1][p][v];
-            float t[4 + 2 * P][8];
-            const bool row_ok = (unsigned)yy < (unsigned)a.H;
-            const float* row = base + (long)yy * a.sh;
+                    for (int v = 0; v < 8; ++v) H[i][p][v] = NINF;
 #pragma unroll
-            for (int j = 0; j < 4 + 2 * P; ++j) {
-                const int xx = x0 - P + j;
-                if (row_ok && (unsigned)xx < (unsigned)a.W) {
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int v = 0; v < 8; ++v) T[1][j][v] = NINF;
+            auto one = [&](const int step, float (&tc)[6][8], const float (&tp)[6][8], float (&hn)[4][8]) __attribute__((always_inline)) {
+                const int yy = dir > 0 ? y0 - 1 + step : y_end - step;
+                // The loads are UNCONDITIONAL, from clamped coordinates, and the pixels outside the image become -inf afterwards, behind a wave-uniform branch only
+                // the waves at an image border take: a load under a per-lane branch with a -inf fill on the other side makes the compiler wait for it at the
+                // join (s_waitcnt vmcnt(1) after every pair: two loads in flight instead of twelve).
+                const bool row_ok = (unsigned)yy < (unsigned)a.H;
+                const float* row = base + (long)min(max(yy, 0), a.H - 1) * a.sh;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int xx = min(max(x0 - 1 + j, 0), a.W - 1);
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (long)xx * a.sw);
                     const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (long)xx * a.sw + 4);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) { t[j][v] = lo[v]; t[j][4 + v] = hi[v]; }
-                } else {
-#pragma unroll
-                    for (int v = 0; v < 8; ++v) t[j][v] = NINF;
+                    for (int v = 0; v < 4; ++v) { tc[j][v] = lo[v]; tc[j][4 + v] = hi[v]; }
                 }
+                if (__ballot(!(row_ok && x0 >= 1 && x0 + 5 <= a.W)) != 0ull) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const bool ok = row_ok && (unsigned)(x0 - 1 + j) < (unsigned)a.W;
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) tc[j][v] = ok ? tc[j][v] : NINF;
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) hn[p][v] = fmaxf(fmaxf(tc[p][v], tc[p + 1][v]), tc[p + 2][v]);
+                const int yo = yy - dir;                  // row whose 3 x 3 windows are now complete; its centre values: the previous step's loads
+                if (step >= 2) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        float val[8];
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) {
+                            const float m = fmaxf(fmaxf(H[0][p][v], H[1][p][v]), H[2][p][v]);
+                            const float cv = tp[p + 1][v];
+                            val[v] = cv * (cv == m ? 1.0f : 0.0f);      // heatmap * nms_mask
+                        }
+                        // maximum over the 8 classes and the FIRST class that holds it (a strict '>' scan in class order, as torch.max(dim=1))
+                        float bv = val[0];
+                        int bc = 0;
+#pragma unroll
+                        for (int v = 1; v < 8; ++v)
+                            if (val[v] > bv) { bv = val[v]; bc = v; }
+                        if (x0 + p < a.W)            // larger key wins; equal keys: the smaller class
+                            atomicMax(&red[(yo - y0) * q.TW + run * 4 + p],
+                                      ((unsigned long long)score_key_fwd(bv) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(g * 8 + bc)));
+                    }
+                }
+            };
+            for (int step = 0; step < rows; step += 6) {
+                one(step, T[0], T[1], H[0]);
+                if (step + 1 < rows) one(step + 1, T[1], T[0], H[1]);
+                if (step + 2 < rows) one(step + 2, T[0], T[1], H[2]);
+                if (step + 3 < rows) one(step + 3, T[1], T[0], H[0]);
+                if (step + 4 < rows) one(step + 4, T[0], T[1], H[1]);
+                if (step + 5 < rows) one(step + 5, T[1], T[0], H[2]);
             }
+        } else {
+            for (int step = 0; step < rows; ++step) {
+                const int yy = dir > 0 ? y0 - P + step : y_end + P - 1 - step;
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+                for (int i = 0; i < 2 * P; ++i)
 #pragma unroll
-                for (int v = 0; v < 8; ++v) {
-                    float h = t[p][v];
+                    for (int p = 0; p < 4; ++p)
 #pragma unroll
-                    for (int d = 1; d <= 2 * P; ++d) h = fmaxf(h, t[p + d][v]);
-                    hm[2 * P][p][v] = h;
-                    ct[P][p][v] = t[p + P][v];
+                        for (int v = 0; v < 8; ++v) hm[i][p][v] = hm[i + 1][p][v];
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) ct[i][p][v] = ct[i + 1][p][v];
+                float t[4 + 2 * P][8];
+                const bool row_ok = (unsigned)yy < (unsigned)a.H;
+                const float* row = base + (long)yy * a.sh;
+#pragma unroll
+                for (int j = 0; j < 4 + 2 * P; ++j) {
+                    const int xx = x0 - P + j;
+                    if (row_ok && (unsigned)xx < (unsigned)a.W) {
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (long)xx * a.sw);
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (long)xx * a.sw + 4);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) { t[j][v] = lo[v]; t[j][4 + v] = hi[v]; }
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) t[j][v] = NINF;
+                    }
                 }
-            const int yo = yy - dir * P;              // row whose (2P+1)-window is now complete
-            if (step >= 2 * P) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    float bv = 0.f;
-                    int bc = 0;
+                for (int p = 0; p < 4; ++p)
 #pragma unroll
                     for (int v = 0; v < 8; ++v) {
-                        float m = hm[0][p][v];
+                        float h = t[p][v];
 #pragma unroll
-                        for (int i = 1; i < 2 * P + 1; ++i) m = fmaxf(m, hm[i][p][v]);
-                        const float cv = ct[0][p][v];
-                        const float val = cv * (cv == m ? 1.0f : 0.0f);      // heatmap * nms_mask
-                        if (v == 0 || val > bv) { bv = val; bc = g * 8 + v; }
+                        for (int d = 1; d <= 2 * P; ++d) h = fmaxf(h, t[p + d][v]);
+                        hm[2 * P][p][v] = h;
+                        ct[P][p][v] = t[p + P][v];
                     }
-                    if (x0 + p < a.W)            // larger key wins; equal keys: the smaller class (torch.max(dim=1) keeps the first)
-                        atomicMax(&red[(yo - y0) * q.TW + run * 4 + p],
-                                  ((unsigned long long)score_key_fwd(bv) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)bc));
+                const int yo = yy - dir * P;              // row whose (2P+1)-window is now complete
+                if (step >= 2 * P) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        float bv = 0.f;
+                        int bc = 0;
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) {
+                            float m = hm[0][p][v];
+#pragma unroll
+                            for (int i = 1; i < 2 * P + 1; ++i) m = fmaxf(m, hm[i][p][v]);
+                            const float cv = ct[0][p][v];
+                            const float val = cv * (cv == m ? 1.0f : 0.0f);      // heatmap * nms_mask
+                            if (v == 0 || val > bv) { bv = val; bc = g * 8 + v; }
+                        }
+                        if (x0 + p < a.W)            // larger key wins; equal keys: the smaller class (torch.max(dim=1) keeps the first)
+                            atomicMax(&red[(yo - y0) * q.TW + run * 4 + p],
+                                      ((unsigned long long)score_key_fwd(bv) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)bc));
+                    }
                 }
             }
         }
