@@ -142,6 +142,46 @@ def test_decode_topk_on_large_maps_with_ties(shape, k, kind):
         assert all((o[key] == outs[0][key]).all() for key in outs[0])
 
 
+def _bound_cases():
+    """Seeded random (shape, k, nms, score distribution) cases for stage 2's two-step pruning bound: every key storage (16 registers, 48 registers, LDS, 16-bit LDS
+    prefilter, neither) x k from 1 to 1024 x distributions that put the k-th largest thread maximum at either end of the bins, in one bin, or on a tie."""
+    rng = np.random.default_rng(606)
+    shapes = [(96, 96), (128, 128), (100, 131), (152, 272), (160, 256), (200, 200), (199, 201), (64, 700), (152, 300), (31, 33), (256, 256)]
+    kinds = ["uniform", "heavy_tail", "near_constant", "two_level", "wide_range", "few_distinct"]
+    cases = []
+    for i in range(36):
+        H, W = shapes[int(rng.integers(len(shapes)))]
+        cases.append((int(rng.choice([1, 2])), int(rng.choice([1, 2, 3])), H, W, int(min(rng.choice([1, 7, 100, 300, 511, 1024]), H * W)), int(rng.choice([1, 3])),
+                      kinds[i % len(kinds)], i))
+    return cases
+
+
+@pytest.mark.parametrize("case", _bound_cases(), ids=lambda c: "N{}C{}_{}x{}_k{}_nms{}_{}_{}".format(*c))
+def test_decode_topk_bound_random_distributions(case):
+    """Round 6's second step of the pruning bound (the k-th largest thread maximum to within one of 512-1024 bins between the first bound and the largest maximum) and the
+    four-candidates-per-lane rank: bit-exact against the oracle whatever the distribution does to the bins."""
+    N, C, H, W, k, nms, kind, seed = case
+    g = torch.Generator().manual_seed(1000 + seed)
+    u = torch.rand(N, C, H, W, generator=g)
+    if kind == "uniform":
+        heat = u
+    elif kind == "heavy_tail":
+        heat = u ** 12                                    # a handful of large scores, the k-th far below the maximum
+    elif kind == "near_constant":
+        heat = 0.5 + u * 1e-6                             # the whole range inside a few hundred float steps: bins of width 1
+    elif kind == "two_level":
+        heat = torch.where(u > 0.999, 0.5 + u, u * 1e-3)  # a few winners, then a cliff
+    elif kind == "wide_range":
+        heat = (u - 0.3) * torch.exp((torch.rand(N, C, H, W, generator=g) - 0.5) * 40)      # signs, zeros' neighbourhood, 17 decades
+    else:
+        heat = (u * 5).floor() / 5                        # five values: every bound lands on a tie
+    box = torch.rand(N, 4, H, W, generator=g) * 9
+    ref = decode_ref.decode_detections(heat.numpy(), box.numpy(), k, nms)
+    _check(_np(hip_decode.decode(_layouts(heat)[1], _layouts(box)[1], None, k, nms)), ref)
+    if seed % 3 == 0:
+        _check(_np(hip_decode.decode(_layouts(heat)[0], _layouts(box)[0], None, k, nms)), ref)
+
+
 def test_decode_full_size_properties():
     """BASELINE C1 size (32x80x128x128): properties that need no oracle run — sortedness, peak-ness, top-k-ness."""
     N, C, H, W, k = 32, 80, 128, 128, 100
