@@ -62,7 +62,7 @@ class KernelOptions:
                        (per image: the maximum over all channels of each 8 x 8-pixel tile; the smallest non-zero tile maximum against the image maximum) and a
                        SplitRangeError names the launch when the ratio exceeds 10^5 — the caller then uses algo="f32" for that model.  A full extra pass per launch
                        and a host synchronisation: a diagnostic, not a production setting
- for small batches (default off): launches whose output is too small to fill the chip (one image: the
+      split_small      for small batches (default off): launches whose output is too small to fill the chip (one image: the
                        16x16 .. 64x64 maps) run as direct convs with the reduction split over several workgroups per output tile and a
                        fixed-order reduce (cnl_conv_params.splitk).  The choice then depends on the batch size, so results are no longer
                        bit-identical between a shard and the full batch (they stay within the fp32-grade error bars)."""
