@@ -212,14 +212,13 @@ __global__ __launch_bounds__(256) void peaks_cminor_kernel(const PeakArgs a) {
     }
 }
 
-// ---- stage 1, channel-minor layout with C % 8 == 0 (the 80-class heads): thread = (run of 4 pixels, 8 channels) ----
-// A thread loads the 4 + 2P pixels its run needs per row as 2 x 16 bytes each (a pixel's C floats are contiguous: the 10 lanes of a pixel
-// read 320 contiguous bytes), so every input vector is loaded 1.5 x (P = 1) instead of 3 x, and a block spans 128 pixels of a row (no
-// column halo at W = 128).  The maximum / first arg-max over the channel groups is an LDS atomic max of (score key, ~class) pairs —
+// ---- stage 1, channel-minor layout with C % 8 == 0 (the 80-class heads): thread = (run of RP = 4 or 2 pixels, 8 channels) ----
+// A thread loads the RP + 2P pixels its run needs per row as 2 x 16 bytes each (a pixel's C floats are contiguous: the 10 lanes of a pixel
+// read 320 contiguous bytes), so every input vector is loaded 1.5 x (RP = 4, P = 1; 2 x at RP = 2: out of L1) instead of 3 x.  The maximum / first arg-max over the channel groups is an LDS atomic max of (score key, ~class) pairs —
 // 8 bytes per output pixel instead of a [pixel][group] array, no second reduction pass.
 struct Peak8Args {
     PeakArgs p;
-    int CG8, RUNS, TW;       // channel groups of 8 per pixel, pixel runs per block, block width in pixels (RUNS * 4)
+    int CG8, RUNS, TW;       // channel groups of 8 per pixel, pixel runs per block, block width in pixels (RUNS * RP)
 };
 
 __device__ __forceinline__ unsigned score_key_fwd(float f) {
@@ -233,10 +232,11 @@ __device__ __forceinline__ float score_key_inv(unsigned k) {
 
 // Block = 160 threads = 16 runs x 10 channel groups at C = 80 (64 pixels wide); strips of R = 16 rows: measured best at 32 x 128 x 128 x 80
 // (back-to-back decode, us: R 8 / 12 / 16 / 24 / 32 = 52 / 62 / 45 / 57 / 68; 80 / 160 / 320 threads = 46.7 / 45.0 / 46.0;
-// profiles/r02_decode_variants.txt); R = 4 when 16-row strips would leave most CUs without a block (small batches).
+// profiles/r02_decode_variants.txt; with two-pixel runs, round 6: R 8 / 16 / 32 = 30.2 / 28.5 / 33.8 us for stage 1 alone); R = 4 when 16-row strips would leave most CUs
+// without a block (small batches).
 constexpr int PK8_THREADS = 160;
 
-template <int P, int PK8_R>
+template <int P, int PK8_R, int RP = 4>      // RP: pixels per run (4; 2 in the P = 1 form: half the registers, twice the waves — the launcher's choice)
 __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q) {
     const PeakArgs& a = q.p;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
     const int n = b / a.strips;
     const int tid = threadIdx.x;
     const int run = tid / q.CG8, g = tid - run * q.CG8;
-    const int x0 = bx * q.TW + run * 4;
+    const int x0 = bx * q.TW + run * RP;
     const int y0 = by * PK8_R;
     const bool active = run < q.RUNS && x0 < a.W;
     const float NINF = -__builtin_inff();
@@ -281,18 +281,18 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
             // the centre values of the previous row are simply the previous step's loads: two load buffers used alternately.  Six steps unrolled make every index
             // static (80 v_mov of 340 VALU instructions per step gone); the class of the maximum is found after the fact (v_max3 tree + 7 compare / select
             // pairs instead of 8 x compare + two selects).
-            float H[3][4][8], T[2][6][8];
+            float H[3][RP][8], T[2][RP + 2][8];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < RP; ++p)
 #pragma unroll
                     for (int v = 0; v < 8; ++v) H[i][p][v] = NINF;
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
+            for (int j = 0; j < RP + 2; ++j)
 #pragma unroll
                 for (int v = 0; v < 8; ++v) T[1][j][v] = NINF;
-            auto one = [&](const int step, float (&tc)[6][8], const float (&tp)[6][8], float (&hn)[4][8]) __attribute__((always_inline)) {
+            auto one = [&](const int step, float (&tc)[RP + 2][8], const float (&tp)[RP + 2][8], float (&hn)[RP][8]) __attribute__((always_inline)) {
                 const int yy = dir > 0 ? y0 - 1 + step : y_end - step;
                 // The loads are UNCONDITIONAL, from clamped coordinates, and the pixels outside the image become -inf afterwards, behind a wave-uniform branch only
                 // the waves at an image border take: a load under a per-lane branch with a -inf fill on the other side makes the compiler wait for it at the
@@ -300,29 +300,29 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
                 const bool row_ok = (unsigned)yy < (unsigned)a.H;
                 const float* row = base + (long)min(max(yy, 0), a.H - 1) * a.sh;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
+                for (int j = 0; j < RP + 2; ++j) {
                     const int xx = min(max(x0 - 1 + j, 0), a.W - 1);
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (long)xx * a.sw);
                     const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (long)xx * a.sw + 4);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) { tc[j][v] = lo[v]; tc[j][4 + v] = hi[v]; }
                 }
-                if (__ballot(!(row_ok && x0 >= 1 && x0 + 5 <= a.W)) != 0ull) {
+                if (__ballot(!(row_ok && x0 >= 1 && x0 + RP + 1 <= a.W)) != 0ull) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
+                    for (int j = 0; j < RP + 2; ++j) {
                         const bool ok = row_ok && (unsigned)(x0 - 1 + j) < (unsigned)a.W;
 #pragma unroll
                         for (int v = 0; v < 8; ++v) tc[j][v] = ok ? tc[j][v] : NINF;
                     }
                 }
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < RP; ++p)
 #pragma unroll
                     for (int v = 0; v < 8; ++v) hn[p][v] = fmaxf(fmaxf(tc[p][v], tc[p + 1][v]), tc[p + 2][v]);
                 const int yo = yy - dir;                  // row whose 3 x 3 windows are now complete; its centre values: the previous step's loads
                 if (step >= 2) {
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
+                    for (int p = 0; p < RP; ++p) {
                         float val[8];
 #pragma unroll
                         for (int v = 0; v < 8; ++v) {
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
                         for (int v = 1; v < 8; ++v)
                             if (val[v] > bv) { bv = val[v]; bc = v; }
                         if (x0 + p < a.W)            // larger key wins; equal keys: the smaller class
-                            atomicMax(&red[(yo - y0) * q.TW + run * 4 + p],
+                            atomicMax(&red[(yo - y0) * q.TW + run * RP + p],
                                       ((unsigned long long)score_key_fwd(bv) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(g * 8 + bc)));
                     }
                 }
@@ -1228,11 +1228,14 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
         q.CG8 = p->C / 8;
         q.RUNS = PK8_THREADS / q.CG8;
         if (q.RUNS > 32) q.RUNS = 32;                      // blocks at most 128 pixels wide: R x TW x 8 bytes of LDS stays small for any C
-        const int runs_w = (p->W + 3) / 4;
-        if (q.RUNS > runs_w) q.RUNS = runs_w;
-        q.TW = q.RUNS * 4;
-        a.tiles_x = (p->W + q.TW - 1) / q.TW;
         int R8 = 16;
+        // pixels per run: 2 for the 3 x 3 pool (P = 1; r6q: 111 registers, four 160-thread workgroups per CU instead of two at 195, 32-pixel blocks: 30.4 -> 28.5 us at C1 =
+        // 5.9 TB/s, what a plain read-once stream of the same bytes gets), 4 otherwise
+        const int rp = P == 1 ? 2 : 4;
+        const int runs_w = (p->W + rp - 1) / rp;
+        if (q.RUNS > runs_w) q.RUNS = runs_w;
+        q.TW = q.RUNS * rp;
+        a.tiles_x = (p->W + q.TW - 1) / q.TW;
         if ((long long)p->N * a.tiles_x * ((p->H + 15) / 16) < 256) R8 = 4;      // few images: more, shorter strips (results are identical)
         a.strips = (p->H + R8 - 1) / R8;
         a.CG = q.CG8; a.PXB = q.TW; a.R = R8;
@@ -1242,9 +1245,9 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
         const size_t lds = (size_t)R8 * q.TW * 8;
 #define PK8_LAUNCH(P_, R_) hipLaunchKernelGGL((peaks_c8_kernel<P_, R_>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q)
         if (R8 == 16) {
-            if (P == 0) PK8_LAUNCH(0, 16); else if (P == 1) PK8_LAUNCH(1, 16); else PK8_LAUNCH(2, 16);
+            if (P == 0) PK8_LAUNCH(0, 16); else if (P == 1 && rp == 2) hipLaunchKernelGGL((peaks_c8_kernel<1, 16, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q); else if (P == 1) PK8_LAUNCH(1, 16); else PK8_LAUNCH(2, 16);
         } else {
-            if (P == 0) PK8_LAUNCH(0, 4); else if (P == 1) PK8_LAUNCH(1, 4); else PK8_LAUNCH(2, 4);
+            if (P == 0) PK8_LAUNCH(0, 4); else if (P == 1 && rp == 2) hipLaunchKernelGGL((peaks_c8_kernel<1, 4, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q); else if (P == 1) PK8_LAUNCH(1, 4); else PK8_LAUNCH(2, 4);
         }
 #undef PK8_LAUNCH
         rc = cnl::check_launch("peaks_c8_kernel");
