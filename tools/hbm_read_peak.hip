@@ -26,6 +26,45 @@ __global__ __launch_bounds__(256) void read_kernel(const u32x4* __restrict__ buf
     if (acc[0] == 0x12345678u) out[0] = acc[1] ^ acc[2] ^ acc[3];
 }
 
+// read-and-write mix: reads the slice, writes every FOURTH 16 bytes read (xor-reduced groups of four) to `dst`: 1 byte written per 4 read — the heatmap out_conv's
+// 537 MB in / 168 MB out is 3.2 : 1
+template <int INFLIGHT>
+__global__ __launch_bounds__(256) void rw_kernel(const u32x4* __restrict__ buf, u32x4* __restrict__ dst, long n16) {
+    const long per = (n16 + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
+    for (long i = lo + threadIdx.x; i < hi; i += 256 * INFLIGHT) {
+        u32x4 v[INFLIGHT];
+#pragma unroll
+        for (int k = 0; k < INFLIGHT; ++k) {
+            const long j = i + (long)k * 256;
+            v[k] = buf[j < hi ? j : lo];
+        }
+#pragma unroll
+        for (int k = 0; k < INFLIGHT; k += 4) {
+            const long j = i + (long)k * 256;
+            if (j < hi) dst[(j - (long)k * 256) / 4 + (k / 4) * 64 + 0] = v[k] ^ v[k + 1] ^ v[k + 2] ^ v[k + 3];
+        }
+    }
+}
+
+template <int INFLIGHT>
+static void run_rw(u32x4* const* bufs, int nbuf, u32x4* dst, long bytes, int blocks) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const long n16 = bytes / 16;
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(rw_kernel<INFLIGHT>, dim3(blocks), dim3(256), 0, 0, bufs[w % nbuf], dst, n16);
+    const int reps = 20;
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(rw_kernel<INFLIGHT>, dim3(blocks), dim3(256), 0, 0, bufs[r % nbuf], dst, n16);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double us = 1e3 * ms / reps;
+    printf("  read + 1/4 written  %5ld MB in  %5d workgroups  %2d x 16 B in flight / thread: %7.1f us  %6.3f TB/s (read + written bytes)\n", bytes >> 20, blocks, INFLIGHT, us, bytes * 1.25 / us * 1e-6);
+}
+
 template <int INFLIGHT>
 static void run(const char* tag, u32x4* const* bufs, int nbuf, long bytes, int blocks, unsigned* out) {
     hipEvent_t e0, e1;
@@ -64,6 +103,15 @@ int main() {
             run<16>("cold", bufs, NBUF, bytes, cus * per_cu, out);
         }
         run<8>("same", bufs, 1, bytes, cus * 8, out);
+        {
+            u32x4* dst;
+            hipMalloc(&dst, bytes / 2);
+            for (int per_cu : {4, 8, 16}) {
+                run_rw<8>(bufs, NBUF, dst, bytes, cus * per_cu);
+                run_rw<16>(bufs, NBUF, dst, bytes, cus * per_cu);
+            }
+            hipFree(dst);
+        }
         for (int i = 0; i < NBUF; ++i) hipFree(bufs[i]);
     }
     return 0;
