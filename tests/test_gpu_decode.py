@@ -182,6 +182,33 @@ def test_decode_topk_bound_random_distributions(case):
         _check(_np(hip_decode.decode(_layouts(heat)[0], _layouts(box)[0], None, k, nms)), ref)
 
 
+def _planes_cases():
+    """Contiguous NCHW maps (the reference's own layout) of >= 16 classes with W % 4 == 0 and the 3 x 3 pool run stage 1's class-planes kernel (round 6): strips of 8 rows x
+    64 pixels, 16 class groups.  Edge shapes: one row, partial strips, partial / several x tiles, class counts around the group count; a slice of a wider tensor (row pitch > W)."""
+    cases = []
+    for C in (16, 17, 31, 80, 100):
+        for H, W in ((1, 4), (7, 8), (8, 64), (9, 60), (33, 68), (16, 132)):
+            cases.append((1 + (C + H) % 2, C, H, W))
+    return cases
+
+
+@pytest.mark.parametrize("case", _planes_cases(), ids=lambda c: "N{}C{}_{}x{}".format(*c))
+def test_decode_class_planes_kernel_shapes(case):
+    N, C, H, W = case
+    g = torch.Generator().manual_seed(C * 1000 + H * 10 + W)
+    heat = torch.rand(N, C, H, W, generator=g)
+    if (C + W) % 3 == 0:
+        heat = (heat * 8).floor() / 8                     # ties across classes and pixels: first class / lowest index must win
+    box = torch.rand(N, 4, H, W, generator=g) * 6
+    k = min(50, H * W)
+    ref = decode_ref.decode_detections(heat.numpy(), box.numpy(), k, 3)
+    _check(_np(hip_decode.decode(heat.cuda(), box.cuda(), None, k, 3)), ref)
+    # the same maps as a window of a wider, taller buffer: row pitch and plane pitch no longer W and H * W (still multiples of 4)
+    big = torch.zeros(N, C, H + 3, W + 8)
+    big[:, :, 1:H + 1, 4:W + 4] = heat
+    _check(_np(hip_decode.decode(big.cuda()[:, :, 1:H + 1, 4:W + 4], box.cuda(), None, k, 3)), ref)
+
+
 def test_decode_full_size_properties():
     """BASELINE C1 size (32x80x128x128): properties that need no oracle run — sortedness, peak-ness, top-k-ness."""
     N, C, H, W, k = 32, 80, 128, 128, 100
