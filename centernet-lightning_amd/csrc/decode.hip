@@ -496,29 +496,32 @@ __global__ __launch_bounds__(256) void peaks_generic_kernel(const PeakArgs a) {
 // ---- stage 1, class planes: contiguous rows (sw == 1) of W % 4 == 0 pixels — NCHW tensors, the reference's own layout — and the 3 x 3 pool (round 6) ----
 // The generic kernel above walks class by class, row by row, three 4-byte loads per step behind per-lane branches: 410 us for C1's 168 MB (0.4 TB/s), 14 x the
 // channel-minor kernel.  Here a 256-thread workgroup takes a strip of PP_R rows x 64 pixels for ALL classes: thread = (run of 4 pixels, class group cg of 16), classes
-// cg, cg + 16, ...; per class the (PP_R + 2) x (16-byte run + left + right neighbour) loads of the strip are issued AT ONCE, unconditionally, from clamped coordinates
+// cg, cg + 16, ... (fewer than 16 classes: 8 or 4 groups and strips of 128 / 256 pixels); per class the (PP_R + 2) x (16-byte run + left + right neighbour) loads of the strip are issued AT ONCE, unconditionally, from clamped coordinates
 // (the pixels outside the image become -inf afterwards), then reduced; the running (maximum, first class) per pixel stays in registers over the thread's classes (strict
 // '>' in ascending class order) and the 16 class groups meet in an LDS atomic max of (score key, ~class) pairs, as in peaks_c8_kernel.
 constexpr int PP_R = 8;
+constexpr int PLANES_MIN_C = 4;          // with 2 classes half of the 4 class groups idle: 20.3 us for C4's maps, the generic kernel 18.6
 __global__ __launch_bounds__(256) void peaks_planes_kernel(const PeakArgs a) {
-    __shared__ unsigned long long red[PP_R * 64];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);       // [PP_R][PXB]
+    const int RUNS = a.PXB >> 2, CGN = a.CG;             // runs of 4 pixels x class groups = 256 threads (16 x 16 from 16 classes up; 32 x 8, 64 x 4 for fewer)
     int b = (int)cnl::xcd_remap(blockIdx.x, gridDim.x);
     const int bx = b % a.tiles_x; b /= a.tiles_x;
     const int by = b % a.strips;
     const int n = b / a.strips;
     const int tid = threadIdx.x;
-    const int run = tid & 15, cg = tid >> 4;
-    const int x0 = bx * 64 + run * 4;
+    const int run = tid % RUNS, cg = tid / RUNS;
+    const int x0 = bx * a.PXB + run * 4;
     const int y0 = by * PP_R;
     const float NINF = -__builtin_inff();
-    for (int i = tid; i < PP_R * 64; i += 256) red[i] = 0ull;
+    for (int i = tid; i < PP_R * a.PXB; i += 256) red[i] = 0ull;
     __syncthreads();
     if (x0 < a.W && cg < a.C) {
         float best[PP_R][4];
         int bcls[PP_R][4];
         const bool left_ok = x0 >= 1, right_ok = x0 + 4 < a.W;
         const int xl = max(x0 - 1, 0), xr = min(x0 + 4, a.W - 1);
-        for (int c = cg; c < a.C; c += 16) {
+        for (int c = cg; c < a.C; c += CGN) {
             const float* base = a.heat + (long)n * a.sn + (long)c * a.sc;
             float t[PP_R + 2][6];
 #pragma unroll
@@ -559,13 +562,13 @@ __global__ __launch_bounds__(256) void peaks_planes_kernel(const PeakArgs a) {
             if (y0 + r < a.H) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p)       // larger key wins; equal keys: the smaller class (torch.max(dim=1) keeps the first)
-                    atomicMax(&red[r * 64 + run * 4 + p], ((unsigned long long)score_key_fwd(best[r][p]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)bcls[r][p]));
+                    atomicMax(&red[r * a.PXB + run * 4 + p], ((unsigned long long)score_key_fwd(best[r][p]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)bcls[r][p]));
             }
     }
     __syncthreads();
-    for (int t = tid; t < PP_R * 64; t += 256) {
-        const int r = t >> 6, p = t & 63;
-        const int xo = bx * 64 + p, yo = y0 + r;
+    for (int t = tid; t < PP_R * a.PXB; t += 256) {
+        const int r = t / a.PXB, p = t - r * a.PXB;
+        const int xo = bx * a.PXB + p, yo = y0 + r;
         if (xo >= a.W || yo >= a.H) continue;
         const unsigned long long c = red[t];
         const long o = (long)n * a.H * a.W + (long)yo * a.W + xo;
@@ -1345,13 +1348,16 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
         if (vec == 4) rc = launch_cminor<4>(a, P, lds, (unsigned)blocks, s);
         else if (vec == 2) rc = launch_cminor<2>(a, P, lds, (unsigned)blocks, s);
         else rc = launch_cminor<1>(a, P, lds, (unsigned)blocks, s);
-    } else if (P == 1 && p->C >= 16 && p->heat_sw == 1 && (p->W & 3) == 0 && ((p->heat_sn | p->heat_sc | p->heat_sh) & 3) == 0 && ((uintptr_t)p->heat & 15) == 0) {
-        a.CG = 1; a.PXB = 64; a.R = PP_R;                  // contiguous rows (NCHW) of at least 16 classes (its 16 class groups; C = 2: 67 against the generic kernel's 60 us): class planes
-        a.tiles_x = (p->W + 63) / 64;
+    } else if (P == 1 && p->C >= PLANES_MIN_C && p->heat_sw == 1 && (p->W & 3) == 0 && ((p->heat_sn | p->heat_sc | p->heat_sh) & 3) == 0 && ((uintptr_t)p->heat & 15) == 0) {
+        a.CG = p->C >= 16 ? 16 : (p->C >= 8 ? 8 : 4);      // contiguous rows (NCHW): class planes; class groups x runs = 256 threads
+        a.PXB = 256 / a.CG * 4;
+        a.R = PP_R;
+        a.tiles_x = (p->W + a.PXB - 1) / a.PXB;
         a.strips = (p->H + PP_R - 1) / PP_R;
         const long long blocks = (long long)p->N * a.tiles_x * a.strips;
         CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_decode_f32: grid too large");
-        hipLaunchKernelGGL(peaks_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        const size_t lds = (size_t)PP_R * a.PXB * 8;
+        hipLaunchKernelGGL(peaks_planes_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a);
         rc = cnl::check_launch("peaks_planes_kernel");
     } else {
         constexpr int R = 8;

@@ -183,10 +183,10 @@ def test_decode_topk_bound_random_distributions(case):
 
 
 def _planes_cases():
-    """Contiguous NCHW maps (the reference's own layout) of >= 16 classes with W % 4 == 0 and the 3 x 3 pool run stage 1's class-planes kernel (round 6): strips of 8 rows x
-    64 pixels, 16 class groups.  Edge shapes: one row, partial strips, partial / several x tiles, class counts around the group count; a slice of a wider tensor (row pitch > W)."""
+    """Contiguous NCHW maps (the reference's own layout) of >= 4 classes with W % 4 == 0 and the 3 x 3 pool run stage 1's class-planes kernel (round 6): strips of 8 rows x
+    64 pixels and 16 class groups (128 / 256 pixels and 8 / 4 groups below 16 / 8 classes).  Edge shapes: one row, partial strips, partial / several x tiles, class counts around the group count; a slice of a wider tensor (row pitch > W)."""
     cases = []
-    for C in (16, 17, 31, 80, 100):
+    for C in (4, 7, 8, 15, 16, 17, 31, 80, 100):
         for H, W in ((1, 4), (7, 8), (8, 64), (9, 60), (33, 68), (16, 132)):
             cases.append((1 + (C + H) % 2, C, H, W))
     return cases
