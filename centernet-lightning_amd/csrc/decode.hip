@@ -1199,18 +1199,16 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const TopkArgs a) {
                 if (t < total) *reinterpret_cast<f32x4*>(a.emb + (long)n * total + t) = g[j];
             }
         }
-        for (int t0 = tid; !e_vec4 && t0 < total; t0 += 8 * TK_THREADS) {      // eight independent gathers in flight per thread (one at a time, the loop was a chain of LDS read -> load -> store: 10-12 K cycles at k = 300, E = 64)
-            float g[8];
+        for (int t0 = tid; !e_vec4 && t0 < total; t0 += 16 * TK_THREADS) {     // sixteen independent gathers in flight per thread, UNCONDITIONAL (the last round re-reads element total - 1: a load under a per-lane
+            float g[16];                                                        // branch is waited for at the join); one at a time the loop was a chain of LDS read -> load -> store: 10-12 K cycles at k = 300, E = 64
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int t = t0 + j * TK_THREADS;
-                if (t < total) {
-                    const int d = e_pow2 ? (t >> e_sh) : t / a.E, e = t - d * a.E;
-                    g[j] = a.reid[ebase[d] + (long)e * a.rsc];
-                }
+            for (int j = 0; j < 16; ++j) {
+                const int t = min(t0 + j * TK_THREADS, total - 1);
+                const int d = e_pow2 ? (t >> e_sh) : t / a.E, e = t - d * a.E;
+                g[j] = a.reid[ebase[d] + (long)e * a.rsc];
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 16; ++j) {
                 const int t = t0 + j * TK_THREADS;
                 if (t < total) a.emb[(long)n * total + t] = g[j];
             }
