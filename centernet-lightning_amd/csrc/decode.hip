@@ -498,9 +498,10 @@ __global__ __launch_bounds__(256) void peaks_generic_kernel(const PeakArgs a) {
 // channel-minor kernel.  Here a 256-thread workgroup takes a strip of PP_R rows x 64 pixels for ALL classes: thread = (run of 4 pixels, class group cg of 16), classes
 // cg, cg + 16, ... (fewer than 16 classes: 8 or 4 groups and strips of 128 / 256 pixels); per class the (PP_R + 2) x (16-byte run + left + right neighbour) loads of the strip are issued AT ONCE, unconditionally, from clamped coordinates
 // (the pixels outside the image become -inf afterwards), then reduced; the running (maximum, first class) per pixel stays in registers over the thread's classes (strict
-// '>' in ascending class order) and the 16 class groups meet in an LDS atomic max of (score key, ~class) pairs, as in peaks_c8_kernel.
-constexpr int PP_R = 8;
+// '>' in ascending class order) and the 16 class groups meet in an LDS atomic max of (score key, ~class) pairs, as in peaks_c8_kernel.  Pools other than 3 x 3 (P = 0, 2, 3:
+// 209 / 653 / 914 us on the generic kernel) are instantiations of the same code.
 constexpr int PLANES_MIN_C = 4;          // with 2 classes half of the 4 class groups idle: 20.3 us for C4's maps, the generic kernel 18.6
+template <int P, int PP_R>               // pool (2P + 1)^2; strips of PP_R rows (8 for P <= 1, 4 above: the strip's (PP_R + 2P) x (4 + 2P) values of a class live in registers)
 __global__ __launch_bounds__(256) void peaks_planes_kernel(const PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);       // [PP_R][PXB]
@@ -519,40 +520,52 @@ __global__ __launch_bounds__(256) void peaks_planes_kernel(const PeakArgs a) {
     if (x0 < a.W && cg < a.C) {
         float best[PP_R][4];
         int bcls[PP_R][4];
-        const bool left_ok = x0 >= 1, right_ok = x0 + 4 < a.W;
-        const int xl = max(x0 - 1, 0), xr = min(x0 + 4, a.W - 1);
         for (int c = cg; c < a.C; c += CGN) {
             const float* base = a.heat + (long)n * a.sn + (long)c * a.sc;
-            float t[PP_R + 2][6];
+            float t[PP_R + 2 * P][4 + 2 * P];
 #pragma unroll
-            for (int r = 0; r < PP_R + 2; ++r) {
-                const float* row = base + (long)min(max(y0 - 1 + r, 0), a.H - 1) * a.sh;
+            for (int r = 0; r < PP_R + 2 * P; ++r) {
+                const float* row = base + (long)min(max(y0 - P + r, 0), a.H - 1) * a.sh;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(row + x0);
-                t[r][0] = row[xl];
-                t[r][1] = v[0]; t[r][2] = v[1]; t[r][3] = v[2]; t[r][4] = v[3];
-                t[r][5] = row[xr];
-            }
 #pragma unroll
-            for (int r = 0; r < PP_R + 2; ++r) {
-                const bool row_ok = (unsigned)(y0 - 1 + r) < (unsigned)a.H;          // (block-uniform)
-                t[r][0] = row_ok && left_ok ? t[r][0] : NINF;
-                t[r][5] = row_ok && right_ok ? t[r][5] : NINF;
-                if (!row_ok) {
+                for (int j = 0; j < 4; ++j) t[r][P + j] = v[j];
 #pragma unroll
-                    for (int j = 1; j < 5; ++j) t[r][j] = NINF;
+                for (int d = 1; d <= P; ++d) {
+                    t[r][P - d] = row[max(x0 - d, 0)];
+                    t[r][P + 3 + d] = row[min(x0 + 3 + d, a.W - 1)];
                 }
             }
-            float h[PP_R + 2][4];
 #pragma unroll
-            for (int r = 0; r < PP_R + 2; ++r)
+            for (int r = 0; r < PP_R + 2 * P; ++r) {
+                const bool row_ok = (unsigned)(y0 - P + r) < (unsigned)a.H;          // (block-uniform)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) h[r][p] = fmaxf(fmaxf(t[r][p], t[r][p + 1]), t[r][p + 2]);
+                for (int d = 1; d <= P; ++d) {
+                    t[r][P - d] = row_ok && x0 - d >= 0 ? t[r][P - d] : NINF;
+                    t[r][P + 3 + d] = row_ok && x0 + 3 + d < a.W ? t[r][P + 3 + d] : NINF;
+                }
+                if (!row_ok) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[r][P + j] = NINF;
+                }
+            }
+            float h[PP_R + 2 * P][4];
+#pragma unroll
+            for (int r = 0; r < PP_R + 2 * P; ++r)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float m = t[r][p];
+#pragma unroll
+                    for (int j = 1; j <= 2 * P; ++j) m = fmaxf(m, t[r][p + j]);
+                    h[r][p] = m;
+                }
 #pragma unroll
             for (int r = 0; r < PP_R; ++r)
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    const float m = fmaxf(fmaxf(h[r][p], h[r + 1][p]), h[r + 2][p]);
-                    const float cv = t[r + 1][p + 1];
+                    float m = h[r][p];
+#pragma unroll
+                    for (int i = 1; i <= 2 * P; ++i) m = fmaxf(m, h[r + i][p]);
+                    const float cv = t[r + P][p + P];
                     const float val = cv * (cv == m ? 1.0f : 0.0f);      // heatmap * nms_mask
                     if (c == cg || val > best[r][p]) { best[r][p] = val; bcls[r][p] = c; }
                 }
@@ -1346,16 +1359,22 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
         if (vec == 4) rc = launch_cminor<4>(a, P, lds, (unsigned)blocks, s);
         else if (vec == 2) rc = launch_cminor<2>(a, P, lds, (unsigned)blocks, s);
         else rc = launch_cminor<1>(a, P, lds, (unsigned)blocks, s);
-    } else if (P == 1 && p->C >= PLANES_MIN_C && p->heat_sw == 1 && (p->W & 3) == 0 && ((p->heat_sn | p->heat_sc | p->heat_sh) & 3) == 0 && ((uintptr_t)p->heat & 15) == 0) {
+    } else if (P <= 3 && p->C >= PLANES_MIN_C && p->heat_sw == 1 && (p->W & 3) == 0 && ((p->heat_sn | p->heat_sc | p->heat_sh) & 3) == 0 && ((uintptr_t)p->heat & 15) == 0) {
         a.CG = p->C >= 16 ? 16 : (p->C >= 8 ? 8 : 4);      // contiguous rows (NCHW): class planes; class groups x runs = 256 threads
         a.PXB = 256 / a.CG * 4;
-        a.R = PP_R;
+        const int R = P <= 1 ? 8 : 4;
+        a.R = R;
         a.tiles_x = (p->W + a.PXB - 1) / a.PXB;
-        a.strips = (p->H + PP_R - 1) / PP_R;
+        a.strips = (p->H + R - 1) / R;
         const long long blocks = (long long)p->N * a.tiles_x * a.strips;
         CNL_REQUIRE(blocks < (1ll << 31), CNL_E_UNSUPPORTED, "cnl_decode_f32: grid too large");
-        const size_t lds = (size_t)PP_R * a.PXB * 8;
-        hipLaunchKernelGGL(peaks_planes_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a);
+        const size_t lds = (size_t)R * a.PXB * 8;
+        switch (P) {
+            case 0: hipLaunchKernelGGL((peaks_planes_kernel<0, 8>), dim3((unsigned)blocks), dim3(256), lds, s, a); break;
+            case 1: hipLaunchKernelGGL((peaks_planes_kernel<1, 8>), dim3((unsigned)blocks), dim3(256), lds, s, a); break;
+            case 2: hipLaunchKernelGGL((peaks_planes_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), lds, s, a); break;
+            default: hipLaunchKernelGGL((peaks_planes_kernel<3, 4>), dim3((unsigned)blocks), dim3(256), lds, s, a); break;
+        }
         rc = cnl::check_launch("peaks_planes_kernel");
     } else {
         constexpr int R = 8;

@@ -209,6 +209,21 @@ def test_decode_class_planes_kernel_shapes(case):
     _check(_np(hip_decode.decode(big.cuda()[:, :, 1:H + 1, 4:W + 4], box.cuda(), None, k, 3)), ref)
 
 
+@pytest.mark.parametrize("nms", [1, 5, 7])
+@pytest.mark.parametrize("shape", [(2, 16, 9, 60), (1, 80, 33, 68), (1, 7, 16, 132), (2, 100, 8, 64), (1, 31, 3, 8)], ids=lambda s: "N{}C{}_{}x{}".format(*s))
+def test_decode_class_planes_kernel_pools(shape, nms):
+    """The class-planes kernel's other instantiations: no pool, 5 x 5, 7 x 7 (strips of 4 rows from 5 x 5 up)."""
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(C * 100 + H + W + nms)
+    heat = torch.rand(N, C, H, W, generator=g)
+    if (H + nms) % 2 == 0:
+        heat = (heat * 6).floor() / 6
+    box = torch.rand(N, 4, H, W, generator=g) * 6
+    k = min(40, H * W)
+    ref = decode_ref.decode_detections(heat.numpy(), box.numpy(), k, nms)
+    _check(_np(hip_decode.decode(heat.cuda(), box.cuda(), None, k, nms)), ref)
+
+
 def test_decode_full_size_properties():
     """BASELINE C1 size (32x80x128x128): properties that need no oracle run — sortedness, peak-ness, top-k-ness."""
     N, C, H, W, k = 32, 80, 128, 128, 100
