@@ -256,18 +256,18 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
 
     if (active) {
         const float* base = a.heat + (long)n * a.sn + (long)g * 8;
-        float hm[2 * P + 1][4][8];    // horizontal maxima of the last 2P+1 rows
-        float ct[P + 1][4][8];        // centre values of the last P+1 rows
+        float hm[2 * P + 1][RP][8];    // horizontal maxima of the last 2P+1 rows
+        float ct[P + 1][RP][8];        // centre values of the last P+1 rows
 #pragma unroll
         for (int i = 0; i < 2 * P + 1; ++i)
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < RP; ++p)
 #pragma unroll
                 for (int v = 0; v < 8; ++v) hm[i][p][v] = NINF;
 #pragma unroll
         for (int i = 0; i < P + 1; ++i)
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < RP; ++p)
 #pragma unroll
                 for (int v = 0; v < 8; ++v) ct[i][p][v] = NINF;
         const int y_end = min(y0 + PK8_R, a.H);
@@ -356,33 +356,36 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
 #pragma unroll
                 for (int i = 0; i < 2 * P; ++i)
 #pragma unroll
-                    for (int p = 0; p < 4; ++p)
+                    for (int p = 0; p < RP; ++p)
 #pragma unroll
                         for (int v = 0; v < 8; ++v) hm[i][p][v] = hm[i + 1][p][v];
 #pragma unroll
                 for (int i = 0; i < P; ++i)
 #pragma unroll
-                    for (int p = 0; p < 4; ++p)
+                    for (int p = 0; p < RP; ++p)
 #pragma unroll
                         for (int v = 0; v < 8; ++v) ct[i][p][v] = ct[i + 1][p][v];
-                float t[4 + 2 * P][8];
+                float t[RP + 2 * P][8];
                 const bool row_ok = (unsigned)yy < (unsigned)a.H;
-                const float* row = base + (long)yy * a.sh;
+                const float* row = base + (long)min(max(yy, 0), a.H - 1) * a.sh;      // unconditional loads from clamped coordinates, as in the 3 x 3 form
 #pragma unroll
-                for (int j = 0; j < 4 + 2 * P; ++j) {
-                    const int xx = x0 - P + j;
-                    if (row_ok && (unsigned)xx < (unsigned)a.W) {
-                        const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (long)xx * a.sw);
-                        const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (long)xx * a.sw + 4);
+                for (int j = 0; j < RP + 2 * P; ++j) {
+                    const int xx = min(max(x0 - P + j, 0), a.W - 1);
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (long)xx * a.sw);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (long)xx * a.sw + 4);
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) { t[j][v] = lo[v]; t[j][4 + v] = hi[v]; }
-                    } else {
+                    for (int v = 0; v < 4; ++v) { t[j][v] = lo[v]; t[j][4 + v] = hi[v]; }
+                }
+                if (__ballot(!(row_ok && x0 >= P && x0 + RP + P <= a.W)) != 0ull) {
 #pragma unroll
-                        for (int v = 0; v < 8; ++v) t[j][v] = NINF;
+                    for (int j = 0; j < RP + 2 * P; ++j) {
+                        const bool ok = row_ok && (unsigned)(x0 - P + j) < (unsigned)a.W;
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) t[j][v] = ok ? t[j][v] : NINF;
                     }
                 }
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < RP; ++p)
 #pragma unroll
                     for (int v = 0; v < 8; ++v) {
                         float h = t[p][v];
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
                 const int yo = yy - dir * P;              // row whose (2P+1)-window is now complete
                 if (step >= 2 * P) {
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
+                    for (int p = 0; p < RP; ++p) {
                         float bv = 0.f;
                         int bc = 0;
 #pragma unroll
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(PK8_THREADS) void peaks_c8_kernel(const Peak8Args q
                             if (v == 0 || val > bv) { bv = val; bc = g * 8 + v; }
                         }
                         if (x0 + p < a.W)            // larger key wins; equal keys: the smaller class (torch.max(dim=1) keeps the first)
-                            atomicMax(&red[(yo - y0) * q.TW + run * 4 + p],
+                            atomicMax(&red[(yo - y0) * q.TW + run * RP + p],
                                       ((unsigned long long)score_key_fwd(bv) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)bc));
                     }
                 }
@@ -1326,7 +1329,7 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
         int R8 = 16;
         // pixels per run: 2 for the 3 x 3 pool (P = 1; r6q: 111 registers, four 160-thread workgroups per CU instead of two at 195, 32-pixel blocks: 30.4 -> 28.5 us at C1 =
         // 5.9 TB/s, what a plain read-once stream of the same bytes gets), 4 otherwise
-        const int rp = P == 1 ? 2 : 4;
+        const int rp = (P == 1 || P == 2) ? 2 : 4;      // (5 x 5: 176 registers at two-pixel runs; four-pixel runs spilled 424)
         const int runs_w = (p->W + rp - 1) / rp;
         if (q.RUNS > runs_w) q.RUNS = runs_w;
         q.TW = q.RUNS * rp;
@@ -1340,9 +1343,9 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
         const size_t lds = (size_t)R8 * q.TW * 8;
 #define PK8_LAUNCH(P_, R_) hipLaunchKernelGGL((peaks_c8_kernel<P_, R_>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q)
         if (R8 == 16) {
-            if (P == 0) PK8_LAUNCH(0, 16); else if (P == 1 && rp == 2) hipLaunchKernelGGL((peaks_c8_kernel<1, 16, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q); else if (P == 1) PK8_LAUNCH(1, 16); else PK8_LAUNCH(2, 16);
+            if (P == 0) PK8_LAUNCH(0, 16); else if (P == 1 && rp == 2) hipLaunchKernelGGL((peaks_c8_kernel<1, 16, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q); else if (P == 1) PK8_LAUNCH(1, 16); else hipLaunchKernelGGL((peaks_c8_kernel<2, 16, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q);
         } else {
-            if (P == 0) PK8_LAUNCH(0, 4); else if (P == 1 && rp == 2) hipLaunchKernelGGL((peaks_c8_kernel<1, 4, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q); else if (P == 1) PK8_LAUNCH(1, 4); else PK8_LAUNCH(2, 4);
+            if (P == 0) PK8_LAUNCH(0, 4); else if (P == 1 && rp == 2) hipLaunchKernelGGL((peaks_c8_kernel<1, 4, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q); else if (P == 1) PK8_LAUNCH(1, 4); else hipLaunchKernelGGL((peaks_c8_kernel<2, 4, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q);
         }
 #undef PK8_LAUNCH
         rc = cnl::check_launch("peaks_c8_kernel");
