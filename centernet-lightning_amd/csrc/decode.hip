@@ -1321,7 +1321,7 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
         };
         vec = ok(4) ? 4 : (ok(2) ? 2 : 1);
     }
-    if (cminor && vec == 4 && p->C % 8 == 0 && p->C / 8 <= PK8_THREADS && P <= 2 && p->W >= 8) {
+    if (cminor && vec == 4 && p->C % 8 == 0 && p->C / 8 <= PK8_THREADS && P <= 3 && p->W >= 8) {
         Peak8Args q;
         q.CG8 = p->C / 8;
         q.RUNS = PK8_THREADS / q.CG8;
@@ -1329,7 +1329,7 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
         int R8 = 16;
         // pixels per run: 2 for the 3 x 3 pool (P = 1; r6q: 111 registers, four 160-thread workgroups per CU instead of two at 195, 32-pixel blocks: 30.4 -> 28.5 us at C1 =
         // 5.9 TB/s, what a plain read-once stream of the same bytes gets), 4 otherwise
-        const int rp = (P == 1 || P == 2) ? 2 : 4;      // (5 x 5: 176 registers at two-pixel runs; four-pixel runs spilled 424)
+        const int rp = P >= 1 ? 2 : 4;      // (5 x 5: 176 registers at two-pixel runs; four-pixel runs spilled 424)
         const int runs_w = (p->W + rp - 1) / rp;
         if (q.RUNS > runs_w) q.RUNS = runs_w;
         q.TW = q.RUNS * rp;
@@ -1343,9 +1343,9 @@ extern "C" int cnl_decode_f32(const cnl_decode_params* p, void* stream) {
         const size_t lds = (size_t)R8 * q.TW * 8;
 #define PK8_LAUNCH(P_, R_) hipLaunchKernelGGL((peaks_c8_kernel<P_, R_>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q)
         if (R8 == 16) {
-            if (P == 0) PK8_LAUNCH(0, 16); else if (P == 1 && rp == 2) hipLaunchKernelGGL((peaks_c8_kernel<1, 16, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q); else if (P == 1) PK8_LAUNCH(1, 16); else hipLaunchKernelGGL((peaks_c8_kernel<2, 16, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q);
+            if (P == 0) PK8_LAUNCH(0, 16); else if (P == 1 && rp == 2) hipLaunchKernelGGL((peaks_c8_kernel<1, 16, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q); else if (P == 1) PK8_LAUNCH(1, 16); else if (P == 2) hipLaunchKernelGGL((peaks_c8_kernel<2, 16, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q); else hipLaunchKernelGGL((peaks_c8_kernel<3, 16, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q);
         } else {
-            if (P == 0) PK8_LAUNCH(0, 4); else if (P == 1 && rp == 2) hipLaunchKernelGGL((peaks_c8_kernel<1, 4, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q); else if (P == 1) PK8_LAUNCH(1, 4); else hipLaunchKernelGGL((peaks_c8_kernel<2, 4, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q);
+            if (P == 0) PK8_LAUNCH(0, 4); else if (P == 1 && rp == 2) hipLaunchKernelGGL((peaks_c8_kernel<1, 4, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q); else if (P == 1) PK8_LAUNCH(1, 4); else if (P == 2) hipLaunchKernelGGL((peaks_c8_kernel<2, 4, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q); else hipLaunchKernelGGL((peaks_c8_kernel<3, 4, 2>), dim3((unsigned)blocks), dim3(PK8_THREADS), lds, s, q);
         }
 #undef PK8_LAUNCH
         rc = cnl::check_launch("peaks_c8_kernel");

@@ -63,7 +63,7 @@ def test_decode_kats(name):
 
 @pytest.mark.parametrize("shape,k,nms,emb", [((3, 80, 128, 128), 100, 3, 0), ((2, 2, 152, 272), 300, 3, 64), ((2, 5, 33, 47), 77, 5, 3),
                                             ((1, 1, 8, 200), 9, 7, 0), ((2, 6, 16, 16), 256, 1, 0), ((1, 81, 20, 20), 50, 3, 0),
-                                            ((1, 130, 12, 12), 20, 3, 0)])
+                                            ((1, 130, 12, 12), 20, 3, 0), ((2, 16, 40, 36), 50, 7, 0), ((1, 80, 20, 24), 30, 7, 0), ((2, 8, 33, 66), 64, 5, 0)])
 def test_decode_random_vs_oracle(shape, k, nms, emb):
     ins = recipes.decode_inputs(sum(shape) + k, shape, emb)
     ref = decode_ref.decode_detections(ins[0].numpy(), ins[1].numpy(), k, nms, reid=ins[2].numpy() if emb else None)
