@@ -247,6 +247,12 @@ def test_decode_full_size_properties():
     # idempotence / determinism
     o2 = hip_decode.decode(heat, box, None, k, 3)
     assert all(torch.equal(o[key], o2[key]) for key in o)
+    # layout independence at full size: the same logical maps as contiguous NCHW tensors (the reference's layout: the class-planes stage 1) give the same bytes,
+    # for every pool size both layouts have a kernel of their own for
+    for nms in (3, 1, 5, 7):
+        a_ = hip_decode.decode(heat, box, None, k, nms)
+        b_ = hip_decode.decode(heat.contiguous(), box.contiguous(), None, k, nms)
+        assert all(torch.equal(a_[key], b_[key]) for key in a_), nms
 
 
 def test_standalone_gathers_and_model_surface():
