@@ -255,6 +255,24 @@ def test_decode_full_size_properties():
         assert all(torch.equal(a_[key], b_[key]) for key in a_), nms
 
 
+def test_decode_tracking_shape_layout_independence():
+    """BASELINE C4's maps (2 x 152 x 272 + 64-d embeddings, k = 300; 8 images): channel-minor and contiguous NCHW inputs — different stage-1 kernels, 16-byte against strided
+    embedding gathers — give the same bytes, run after run."""
+    N, C, H, W, k, E = 8, 2, 152, 272, 300, 64
+    g = torch.Generator(device="cuda").manual_seed(4)
+    heat = torch.randn(N, H, W, C, device="cuda", generator=g).sub_(2.19).sigmoid_().permute(0, 3, 1, 2)
+    box = (torch.rand(N, H, W, 4, device="cuda", generator=g) * 16).permute(0, 3, 1, 2)
+    emb = torch.randn(N, H, W, E, device="cuda", generator=g).permute(0, 3, 1, 2)
+    a_ = hip_decode.decode(heat, box, emb, k, 3)
+    b_ = hip_decode.decode(heat.contiguous(), box.contiguous(), emb.contiguous(), k, 3)
+    c_ = hip_decode.decode(heat, box, emb, k, 3)
+    for key in a_:
+        assert torch.equal(a_[key], b_[key]), key
+        assert torch.equal(a_[key], c_[key]), key
+    flat = emb.reshape(N, E, H * W)
+    assert torch.equal(a_["embeddings"], torch.gather(flat, 2, a_["indices"].unsqueeze(1).expand(-1, E, -1)).permute(0, 2, 1))
+
+
 def test_standalone_gathers_and_model_surface():
     ins = recipes.decode_inputs(8, (2, 3, 24, 32), 16)
     heat, box, reid = [t.cuda() for t in ins]
